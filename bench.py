@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""bench.py -- iLQR iterations/sec as trajectory-timesteps/sec on MI355X.
+
+A "step" is one full iLQR iteration of the hot path over one batch of synthetic acrobot
+problems: finite-difference derivatives -> backward Riccati pass with box-QP -> 11-alpha
+line-search rollouts -> accept/commit, for every trajectory (ILQR_FLAG_FIXED_WORK: no
+trajectory leaves its loop, so the work per step is exactly B*T trajectory-timesteps).
+
+Workload (BASELINE.json metric, configs[2]): acrobot n=4 m=1, T=499 transitions (500 knots),
+B=4096 per GPU, fp64, control limits +-1.5 (box-QP clamps active), x0 ~ (pi a, pi b, c, d),
+a..d ~ U(-1,1), u0 = 0.  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see README/DESIGN.md for the field contract).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
+
+
+def algorithmic_bytes_per_timestep(n, m):
+    """SURVEY.md 8(d) / BASELINE.md 4: fp64 bytes per trajectory-timestep of each kernel."""
+    s = 8
+    return {
+        "backward": (2 * n * n + 2 * n * m + m * m + n + 2 * m + m * n + m) * s,          # acrobot 416
+        "derivatives": (n + m + 2 * n * n + 2 * n * m + m * m + n + m) * s,              # acrobot 408
+        "rollout": 11 * (2 * m + m * n + n + n + m) * s,                                 # acrobot 11*120
+        "accept": 2 * (n + m) * s,                                                       # commit copy
+    }
+
+
+def cpu_baseline(B_total, T, dt, lim, budget_s=15.0):
+    """The CPU oracle (plain-C restatement of the reference, OpenMP over trajectories) on a
+    bounded sample of the same workload, on this box's host cores."""
+    from oracle import oracle as O
+    from tests.util import acrobot_x0
+    cores = os.cpu_count() or 1
+    om = O.Model("acrobot", u_lim=lim)
+    iters = 2
+    x0_all = acrobot_x0(B_total)
+
+    def run(nb):
+        x0 = x0_all[:nb]
+        u0 = np.zeros((nb, T, 1))
+        t0 = time.perf_counter()
+        O.batch_solve(om, x0, u0, dt, max_iters=iters, fixed_work=True, nthreads=cores)
+        return time.perf_counter() - t0
+
+    nb = cores
+    t = run(nb)
+    rate = nb * T * iters / t
+    nb2 = int(min(B_total, max(cores, (budget_s * rate) / (T * iters))))
+    nb2 = max(cores, (nb2 // cores) * cores)
+    t2 = run(nb2)
+    return {"value": nb2 * T * iters / t2, "unit": "trajectory-timesteps/s", "cores": cores, "kind": "port",
+            "sample": "%d trajectories x %d fixed-work iterations of the same acrobot workload, %.1f s, "
+                      "oracle/liboracle_ilqr.so with OpenMP over trajectories" % (nb2, iters, t2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU")
+    ap.add_argument("--T", type=int, default=499)
+    ap.add_argument("--limit", type=float, default=1.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flags", type=int, default=0, help="extra ilqr_flags (kernel variant selection)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ilqr_amd import BatchILQR, capi
+    from tests.util import acrobot_x0
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch one rank per GPU (torch.distributed.run)"
+
+    B, T, dt, lim, n, m = args.batch, args.T, 0.02, args.limit, 4, 1
+    # this rank's shard of the global synthetic batch (trajectory b of rank r = global r*B + b)
+    x0 = acrobot_x0(B * world)[rank * B:(rank + 1) * B]
+    u0 = np.zeros((B, T, m))
+    stream = torch.cuda.current_stream().cuda_stream
+    g = BatchILQR("acrobot", B, T, dt, u_min=-lim, u_max=lim, device=local_rank,
+                  flags=capi.FLAG_FIXED_WORK | args.flags, stream=stream)
+    g.init_traj(x0, u0)
+    g.iterate(args.warmup)
+    cost_dev = torch.empty(B, dtype=torch.float64, device="cuda")
+    gathered = torch.empty(B * world, dtype=torch.float64, device="cuda") if world > 1 else cost_dev
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    g.profile(True)
+    g.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    g.iterate(args.steps)
+    # the one exchange step of the path: gather of per-trajectory costs (RCCL over xGMI)
+    capi.check(g.lib.ilqr_copy_cost_to_device(g.h, cost_dev.data_ptr()))
+    if world > 1:
+        dist.all_gather_into_tensor(gathered, cost_dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    prof = g.profile_read()
+    g.profile(False)
+
+    if rank == 0:
+        costs = gathered.cpu().numpy()
+        assert np.all(np.isfinite(costs)), "non-finite cost in the gathered result"
+        steps = args.steps
+        value = world * B * T * steps / elapsed
+        bytes_ts = algorithmic_bytes_per_timestep(n, m)
+        stages = {}
+        for name, (ms, launches) in prof.items():
+            if launches:
+                stages[name] = {"ms_per_launch": ms / launches, "launches": launches,
+                                "algorithmic_GBps": bytes_ts[name] * B * T / (ms / launches * 1e-3) / 1e9}
+        dom = max(stages, key=lambda k: stages[k]["ms_per_launch"])
+        name_of = {i: g.lib.ilqr_stage_kernel_name(g.h, i).decode() for i in range(capi.NUM_STAGES)}
+        dom_kernel = name_of[capi.STAGE_NAMES.index(dom)]
+        achieved = stages[dom]["algorithmic_GBps"]
+        out = {
+            "metric": "iLQR iterations/sec (batch x T timesteps/sec), acrobot T=500 batch=4096",
+            "value": value, "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "acrobot n=4 m=1 T=499 transitions (500 knots) B=%d per GPU, u in [-%.1f,%.1f] "
+                                   "(box-QP clamps active), fp64, full iteration = FD derivatives + backward/box-QP "
+                                   "+ 11-alpha rollouts + accept, fixed work" % (B, lim, lim),
+                       "batch_per_gpu": B, "T": T, "parallelism": "batch-sharded x%d, no data-path collective; "
+                       "one all_gather of per-trajectory costs at the end" % world},
+            "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_ts[dom] * B * T,
+                         "avg_launch_ms": stages[dom]["ms_per_launch"]},
+            "stages": stages,
+            "backward_only_timesteps_per_s": (B * T / (stages["backward"]["ms_per_launch"] * 1e-3)) * world
+            if "backward" in stages else None,
+            "final_cost_mean": float(np.mean(costs)),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B, T, dt, lim)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,215 @@
+"""BatchILQR -- numpy-facing host mirror of the reference's iLQR class for B trajectories.
+
+Method names follow include/ilqr.h:28-107 (init_traj, generate_trajectory, its warm-start
+overload) plus the stage calls and accessors the reference keeps private (tests reach them
+through FRIEND_TEST there).  All arrays use the canonical layouts of include/ilqr_amd.h;
+matrices are returned as [..., rows, cols] numpy arrays (transposed views of the column-major
+memory), so K[b, t] is the nu x nx gain matrix and fx[b, t] the nx x nx Jacobian.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+ALPHAS = np.array([1.0000, 0.5012, 0.2512, 0.1259, 0.0631, 0.0316, 0.0158, 0.0079, 0.0040,
+                   0.0020, 0.0010])  # include/ilqr.h:24
+STATUS_NAMES = {0: "running", 1: "converged_grad", 2: "converged_cost", 3: "lambda_max", 4: "max_iter"}
+_MODELS = {"acrobot": (capi.MODEL_ACROBOT, 4, 1), "double_integrator": (capi.MODEL_DOUBLE_INTEGRATOR, 4, 2),
+           "integrator": (capi.MODEL_DOUBLE_INTEGRATOR, 4, 2)}
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+class BatchILQR:
+    def __init__(self, model, B, T, dt, u_min=None, u_max=None, goal=None, device=0, flags=0,
+                 stream=None, params=None):
+        self.lib = capi.load()
+        mid, nx, nu = _MODELS[model]
+        self.model, self.nx, self.nu, self.B, self.T, self.dt = model, nx, nu, int(B), int(T), float(dt)
+        self._keep = []
+        d = capi.Desc()
+        d.abi_version = capi.ABI_VERSION
+        d.model, d.nx, d.nu, d.T, d.B, d.dt = mid, nx, nu, self.T, self.B, self.dt
+        d.device, d.flags = device, flags
+        for name, val, n in (("u_min", u_min, nu), ("u_max", u_max, nu), ("goal", goal, nx)):
+            if val is not None:
+                arr = _c(np.broadcast_to(np.asarray(val, dtype=np.float64), (n,)))
+                self._keep.append(arr)
+                setattr(d, name, _p(arr))
+        d.stream = stream
+        if params is not None:
+            p = capi.Params()
+            self.lib.ilqr_default_params(C.byref(p))
+            for k, v in params.items():
+                setattr(p, k, v)
+            self._keep.append(p)
+            d.params = C.pointer(p)
+        self.h = C.c_void_p()
+        capi.check(self.lib.ilqr_create(C.byref(d), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ilqr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- solves (include/ilqr.h:49-54) ----
+    def init_traj(self, x0, u0):
+        x0, u0 = _c(x0), _c(u0)
+        assert x0.shape == (self.B, self.nx) and u0.shape == (self.B, self.T, self.nu)
+        cost = np.zeros(self.B)
+        capi.check(self.lib.ilqr_init_traj(self.h, _p(x0), _p(u0), _p(cost)))
+        return cost
+
+    def generate_trajectory(self, x0=None, u0=None):
+        if x0 is not None and u0 is not None:
+            x0, u0 = _c(x0), _c(u0)
+            capi.check(self.lib.ilqr_solve(self.h, _p(x0), _p(u0)))
+        elif x0 is not None:
+            x0 = _c(x0)
+            capi.check(self.lib.ilqr_warm_start(self.h, _p(x0)))
+        else:
+            capi.check(self.lib.ilqr_generate_trajectory(self.h))
+
+    solve = generate_trajectory  # BASELINE.json's "iLQR::solve()"
+
+    def iterate(self, n=1):
+        capi.check(self.lib.ilqr_iterate(self.h, int(n)))
+
+    def synchronize(self):
+        capi.check(self.lib.ilqr_synchronize(self.h))
+
+    # ---- stages ----
+    def compute_derivatives(self):
+        capi.check(self.lib.ilqr_compute_derivatives(self.h))
+
+    def backward_pass(self):
+        div = np.zeros(self.B, dtype=np.int32)
+        capi.check(self.lib.ilqr_backward_pass(self.h, div.ctypes.data_as(_ip)))
+        return div
+
+    def backward_step(self):
+        capi.check(self.lib.ilqr_backward_step(self.h))
+
+    def rollout_candidates(self):
+        cost = np.zeros((self.B, len(ALPHAS)))
+        capi.check(self.lib.ilqr_rollout_candidates(self.h, _p(cost)))
+        return cost
+
+    def line_search(self):
+        capi.check(self.lib.ilqr_line_search(self.h))
+
+    # ---- setters (canonical layouts; matrices given as [..., rows, cols]) ----
+    def set_trajectory(self, x0=None, xs=None, us=None, cost=None):
+        a = [None if v is None else _c(v) for v in (x0, xs, us, cost)]
+        capi.check(self.lib.ilqr_set_trajectory(self.h, *[_p(v) for v in a]))
+
+    def set_gains(self, k=None, K=None):
+        k = None if k is None else _c(k)
+        K = None if K is None else _c(np.swapaxes(np.asarray(K), -1, -2))
+        capi.check(self.lib.ilqr_set_gains(self.h, _p(k), _p(K)))
+
+    def set_derivatives(self, **d):
+        """fx, fu, cx, cu, cxx, cxu, cuu as [B][T+1][rows][cols] (vectors [B][T+1][n])."""
+        order = ("fx", "fu", "cx", "cu", "cxx", "cxu", "cuu")
+        arrs = []
+        for name in order:
+            v = d.get(name)
+            if v is None:
+                arrs.append(None)
+            elif name in ("cx", "cu"):
+                arrs.append(_c(v))
+            else:
+                arrs.append(_c(np.swapaxes(np.asarray(v), -1, -2)))
+        capi.check(self.lib.ilqr_set_derivatives(self.h, *[_p(v) for v in arrs]))
+
+    def set_lambda(self, lam=None, dlam=None):
+        lam = None if lam is None else _c(np.broadcast_to(lam, (self.B,)))
+        dlam = None if dlam is None else _c(np.broadcast_to(dlam, (self.B,)))
+        capi.check(self.lib.ilqr_set_lambda(self.h, _p(lam), _p(dlam)))
+
+    # ---- getters ----
+    def trajectory(self):
+        xs = np.zeros((self.B, self.T + 1, self.nx))
+        us = np.zeros((self.B, self.T, self.nu))
+        capi.check(self.lib.ilqr_get_trajectory(self.h, _p(xs), _p(us)))
+        return xs, us
+
+    def gains(self):
+        k = np.zeros((self.B, self.T, self.nu))
+        K = np.zeros((self.B, self.T, self.nx, self.nu))  # memory: column-major nu x nx
+        capi.check(self.lib.ilqr_get_gains(self.h, _p(k), _p(K)))
+        return k, np.swapaxes(K, -1, -2)
+
+    def derivatives(self):
+        n, m, B, T1 = self.nx, self.nu, self.B, self.T + 1
+        mem = dict(fx=np.zeros((B, T1, n, n)), fu=np.zeros((B, T1, m, n)), cx=np.zeros((B, T1, n)),
+                   cu=np.zeros((B, T1, m)), cxx=np.zeros((B, T1, n, n)), cxu=np.zeros((B, T1, m, n)),
+                   cuu=np.zeros((B, T1, m, m)))
+        order = ("fx", "fu", "cx", "cu", "cxx", "cxu", "cuu")
+        capi.check(self.lib.ilqr_get_derivatives(self.h, *[_p(mem[k]) for k in order]))
+        return {k: (v if k in ("cx", "cu") else np.swapaxes(v, -1, -2)) for k, v in mem.items()}
+
+    def cost(self):
+        c = np.zeros(self.B)
+        capi.check(self.lib.ilqr_get_cost(self.h, _p(c)))
+        return c
+
+    def lambdas(self):
+        lam, dlam = np.zeros(self.B), np.zeros(self.B)
+        capi.check(self.lib.ilqr_get_lambda(self.h, _p(lam), _p(dlam)))
+        return lam, dlam
+
+    def dV(self):
+        d = np.zeros((self.B, 2))
+        capi.check(self.lib.ilqr_get_dV(self.h, _p(d)))
+        return d
+
+    def gnorm(self):
+        g = np.zeros(self.B)
+        capi.check(self.lib.ilqr_get_gnorm(self.h, _p(g)))
+        return g
+
+    def status(self):
+        st, it, al = (np.zeros(self.B, dtype=np.int32) for _ in range(3))
+        capi.check(self.lib.ilqr_get_status(self.h, st.ctypes.data_as(_ip), it.ctypes.data_as(_ip),
+                                            al.ctypes.data_as(_ip)))
+        return st, it, al
+
+    def candidate(self, a):
+        xs = np.zeros((self.B, self.T + 1, self.nx))
+        us = np.zeros((self.B, self.T, self.nu))
+        capi.check(self.lib.ilqr_get_candidate(self.h, int(a), _p(xs), _p(us)))
+        return xs, us
+
+    def count_running(self):
+        n = C.c_int(0)
+        capi.check(self.lib.ilqr_count_running(self.h, C.byref(n)))
+        return n.value
+
+    # ---- measurement ----
+    def profile(self, enable=True):
+        capi.check(self.lib.ilqr_profile_enable(self.h, int(enable)))
+
+    def profile_reset(self):
+        capi.check(self.lib.ilqr_profile_reset(self.h))
+
+    def profile_read(self):
+        ms = (C.c_double * capi.NUM_STAGES)()
+        n = (C.c_int * capi.NUM_STAGES)()
+        capi.check(self.lib.ilqr_profile_read(self.h, ms, n))
+        return {capi.STAGE_NAMES[i]: (ms[i], n[i]) for i in range(capi.NUM_STAGES)}

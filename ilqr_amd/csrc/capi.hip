@@ -1,0 +1,736 @@
+// capi.hip -- implementation of the C ABI of include/ilqr_amd.h on top of the HIP kernels.
+//
+// One opaque handle (ilqr_batch) owns all device memory of a batch in the tiled layout of
+// common.hpp, a HIP stream, and the per-stage HIP-event timers.  No CPU compute path exists:
+// every entry point either launches kernels or moves bytes.
+#include "../../include/ilqr_amd.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace ilqr;
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIPCHK(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(ILQR_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define REQUIRE(cond, ...)                              \
+  do {                                                  \
+    if (!(cond)) return fail(ILQR_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------
+// the handle
+// ------------------------------------------------------------------------------------------
+struct StageTimer {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+  double ms = 0;
+  int launches = 0;
+};
+
+struct ilqr_batch {
+  int model, nx, nu, T, B, Bp, ntiles, device, flags;
+  double dt;
+  ilqr_params params;
+  AcrobotModel acrobot;
+  DoubleIntegratorModel dint;
+  BatchView v;
+  SolverParams sp;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int* commit_idx = nullptr;
+  double* staging = nullptr;  // device scratch for canonical <-> tiled conversion
+  size_t staging_elems = 0;
+  std::vector<void*> allocs;
+  bool initialised = false;  // init_traj / set_trajectory has run
+  bool profile = false;
+  StageTimer timers[ILQR_NUM_STAGES];
+};
+
+static int rec_of(const ilqr_batch* h) { return rec_size(h->nx, h->nu); }
+
+template <class T>
+static int dev_alloc(ilqr_batch* h, T** p, size_t n) {
+  void* q = nullptr;
+  HIPCHK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+  HIPCHK(hipMemsetAsync(q, 0, std::max<size_t>(n, 1) * sizeof(T), h->stream));
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+
+static int grid_for(size_t n, int block) { return (int)std::min<size_t>((n + block - 1) / block, 65535u * 16u); }
+
+// stage timing -------------------------------------------------------------------------------
+static int timer_begin(ilqr_batch* h, int stage, std::pair<hipEvent_t, hipEvent_t>* ev) {
+  if (!h->profile) return 0;
+  StageTimer& t = h->timers[stage];
+  if (!t.pool.empty()) {
+    *ev = t.pool.back();
+    t.pool.pop_back();
+  } else {
+    HIPCHK(hipEventCreate(&ev->first));
+    HIPCHK(hipEventCreate(&ev->second));
+  }
+  HIPCHK(hipEventRecord(ev->first, h->stream));
+  return 0;
+}
+static int timer_end(ilqr_batch* h, int stage, const std::pair<hipEvent_t, hipEvent_t>& ev) {
+  if (!h->profile) return 0;
+  HIPCHK(hipEventRecord(ev.second, h->stream));
+  h->timers[stage].pending.push_back(ev);
+  h->timers[stage].launches++;
+  return 0;
+}
+static int timers_drain(ilqr_batch* h) {
+  for (int s = 0; s < ILQR_NUM_STAGES; s++) {
+    StageTimer& t = h->timers[s];
+    for (auto& ev : t.pending) {
+      float ms = 0;
+      HIPCHK(hipEventSynchronize(ev.second));
+      HIPCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
+      t.ms += ms;
+      t.pool.push_back(ev);
+    }
+    t.pending.clear();
+  }
+  return 0;
+}
+
+// host <-> device helpers -----------------------------------------------------------------------
+static int ensure_staging(ilqr_batch* h, size_t elems) {
+  if (elems <= h->staging_elems) return 0;
+  if (h->staging) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipFree(h->staging));
+    h->staging = nullptr;
+    h->staging_elems = 0;
+  }
+  HIPCHK(hipMalloc((void**)&h->staging, elems * sizeof(double)));
+  h->staging_elems = elems;
+  return 0;
+}
+// canonical host [B][S][E] -> tiled device
+static int upload(ilqr_batch* h, const double* src, double* dst_tiled, int S, int E) {
+  const size_t n = (size_t)h->B * S * E;
+  if (int rc = ensure_staging(h, n)) return rc;
+  HIPCHK(hipMemcpyAsync(h->staging, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const size_t nt = (size_t)h->ntiles * S * E * TW;
+  hipLaunchKernelGGL(k_pack, dim3(grid_for(nt, 256)), dim3(256), 0, h->stream, h->staging, dst_tiled, h->B, h->ntiles, S, E);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));  // staging is reused by the next call
+  return 0;
+}
+static int download(ilqr_batch* h, const double* src_tiled, double* dst, int S, int E) {
+  const size_t n = (size_t)h->B * S * E;
+  if (int rc = ensure_staging(h, n)) return rc;
+  hipLaunchKernelGGL(k_unpack, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, src_tiled, h->staging, h->B, S, E);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(dst, h->staging, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+static int upload_rec(ilqr_batch* h, const double* src, int off, int E) {
+  const int S = h->T + 1;
+  const size_t n = (size_t)h->B * S * E;
+  if (int rc = ensure_staging(h, n)) return rc;
+  HIPCHK(hipMemcpyAsync(h->staging, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const size_t nt = (size_t)h->ntiles * S * E * TW;
+  hipLaunchKernelGGL(k_pack_rec, dim3(grid_for(nt, 256)), dim3(256), 0, h->stream, h->staging, h->v.D, h->B, h->ntiles, S,
+                     rec_of(h), off, E);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+static int download_rec(ilqr_batch* h, double* dst, int off, int E) {
+  const int S = h->T + 1;
+  const size_t n = (size_t)h->B * S * E;
+  if (int rc = ensure_staging(h, n)) return rc;
+  hipLaunchKernelGGL(k_unpack_rec, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, h->v.D, h->staging, h->B, S, rec_of(h), off, E);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(dst, h->staging, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+// per-trajectory scalar arrays [Bp] on device <-> [B] host
+template <class T>
+static int scalars_to_host(ilqr_batch* h, const T* dev, T* host) {
+  HIPCHK(hipMemcpyAsync(host, dev, (size_t)h->B * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+template <class T>
+static int scalars_to_dev(ilqr_batch* h, const T* host, T* dev) {
+  HIPCHK(hipMemcpyAsync(dev, host, (size_t)h->B * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel launchers (dispatch on the device model)
+// ------------------------------------------------------------------------------------------
+template <class M>
+static int launch_rollout_t(ilqr_batch* h, const M& m, bool gains, const AlphaSet& al, int n_alpha, double* xs_out,
+                            double* us_out, double* cost_out, size_t sx, size_t su, int mode) {
+  dim3 grid(h->Bp / 64, n_alpha), block(64);
+  if (gains)
+    hipLaunchKernelGGL((k_rollout<M, true>), grid, block, 0, h->stream, h->v, m, al, xs_out, us_out, cost_out, sx, su, mode);
+  else
+    hipLaunchKernelGGL((k_rollout<M, false>), grid, block, 0, h->stream, h->v, m, al, xs_out, us_out, cost_out, sx, su, mode);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int launch_rollout(ilqr_batch* h, bool gains, const AlphaSet& al, int n_alpha, double* xs_out, double* us_out,
+                          double* cost_out, size_t sx, size_t su, int mode) {
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (int rc = timer_begin(h, ILQR_STAGE_ROLLOUT, &ev)) return rc;
+  int rc;
+  switch (h->model) {
+    case ILQR_MODEL_ACROBOT: rc = launch_rollout_t(h, h->acrobot, gains, al, n_alpha, xs_out, us_out, cost_out, sx, su, mode); break;
+    case ILQR_MODEL_DOUBLE_INTEGRATOR: rc = launch_rollout_t(h, h->dint, gains, al, n_alpha, xs_out, us_out, cost_out, sx, su, mode); break;
+    default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device rollout", h->model);
+  }
+  if (rc) return rc;
+  return timer_end(h, ILQR_STAGE_ROLLOUT, ev);
+}
+
+static int launch_derivatives(ilqr_batch* h, int force) {
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (int rc = timer_begin(h, ILQR_STAGE_DERIVATIVES, &ev)) return rc;
+  dim3 grid((h->T + 1 + 15) / 16, h->ntiles), block(256);
+  switch (h->model) {
+    case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_derivatives<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, force); break;
+    case ILQR_MODEL_DOUBLE_INTEGRATOR: hipLaunchKernelGGL((k_derivatives<DoubleIntegratorModel>), grid, block, 0, h->stream, h->v, h->dint, force); break;
+    default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device derivatives", h->model);
+  }
+  HIPCHK(hipGetLastError());
+  return timer_end(h, ILQR_STAGE_DERIVATIVES, ev);
+}
+
+static int launch_backward(ilqr_batch* h, int mode) {
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (int rc = timer_begin(h, ILQR_STAGE_BACKWARD, &ev)) return rc;
+  dim3 grid(h->Bp / 64), block(64);
+  switch (h->model) {
+    case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_backward_t<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, h->sp, mode); break;
+    case ILQR_MODEL_DOUBLE_INTEGRATOR: hipLaunchKernelGGL((k_backward_t<DoubleIntegratorModel>), grid, block, 0, h->stream, h->v, h->dint, h->sp, mode); break;
+    default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device backward pass yet", h->model);
+  }
+  HIPCHK(hipGetLastError());
+  return timer_end(h, ILQR_STAGE_BACKWARD, ev);
+}
+
+static int launch_accept_commit(ilqr_batch* h) {
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (int rc = timer_begin(h, ILQR_STAGE_ACCEPT, &ev)) return rc;
+  HIPCHK(hipMemsetAsync(h->v.n_running, 0, sizeof(int), h->stream));
+  hipLaunchKernelGGL(k_accept, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->sp, h->commit_idx);
+  HIPCHK(hipGetLastError());
+  dim3 grid((h->T + 1 + 15) / 16, h->ntiles), block(256);
+  if (h->nx == 4 && h->nu == 1)
+    hipLaunchKernelGGL((k_commit<4, 1>), grid, block, 0, h->stream, h->v, h->commit_idx);
+  else if (h->nx == 4 && h->nu == 2)
+    hipLaunchKernelGGL((k_commit<4, 2>), grid, block, 0, h->stream, h->v, h->commit_idx);
+  else
+    return fail(ILQR_ERR_UNSUPPORTED, "no commit kernel for nx=%d nu=%d", h->nx, h->nu);
+  HIPCHK(hipGetLastError());
+  return timer_end(h, ILQR_STAGE_ACCEPT, ev);
+}
+
+static AlphaSet line_search_alphas() {
+  AlphaSet a;
+  for (int i = 0; i < NALPHA; i++) a.a[i] = kAlphaHost[i];
+  return a;
+}
+
+static int do_rollout_candidates(ilqr_batch* h, int mode) {
+  const size_t sx = (size_t)h->ntiles * (h->T + 1) * h->nx * TW, su = (size_t)h->ntiles * h->T * h->nu * TW;
+  return launch_rollout(h, true, line_search_alphas(), NALPHA, h->v.xs_c, h->v.us_c, h->v.cost_c, sx, su, mode);
+}
+
+// ------------------------------------------------------------------------------------------
+// public API
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* ilqr_last_error(void) { return g_err; }
+int ilqr_abi_version(void) { return ILQR_AMD_ABI_VERSION; }
+
+void ilqr_default_params(ilqr_params* p) {  // include/ilqr.h:14-24
+  p->max_iter = 100;
+  p->tol_fun = 1e-6;
+  p->tol_grad = 1e-6;
+  p->lambda_init = 1;
+  p->dlambda_init = 1;
+  p->lambda_factor = 1.6;
+  p->lambda_max = 1e11;
+  p->lambda_min = 1e-8;
+  p->z_min = 0;
+}
+
+void ilqr_destroy(ilqr_batch* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->staging) (void)hipFree(h->staging);
+  for (auto& t : h->timers) {
+    for (auto& ev : t.pending) {
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+    for (auto& ev : t.pool) {
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+  }
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(ILQR_ERR_NO_DEVICE, "no HIP device visible: libilqr_amd has no CPU path");
+  if (d->device < 0 || d->device >= ndev) return fail(ILQR_ERR_NO_DEVICE, "device %d out of range (%d visible)", d->device, ndev);
+  HIPCHK(hipSetDevice(d->device));
+  h->device = d->device;
+  if (d->stream) {
+    h->stream = (hipStream_t)d->stream;
+  } else {
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+  }
+  h->model = d->model;
+  h->nx = d->nx;
+  h->nu = d->nu;
+  h->T = d->T;
+  h->B = d->B;
+  h->dt = d->dt;
+  h->flags = d->flags;
+  h->Bp = ((d->B + 63) / 64) * 64;
+  h->ntiles = h->Bp / TW;
+  if (d->params)
+    h->params = *d->params;
+  else
+    ilqr_default_params(&h->params);
+
+  // model parameters (the constructor bodies of acrobot.h:14-40, double_integrator.h:14-27)
+  if (d->model == ILQR_MODEL_ACROBOT) {
+    REQUIRE(d->nx == 4 && d->nu == 1, "acrobot is nx=4 nu=1 (include/acrobot.h:27-28), got %d/%d", d->nx, d->nu);
+    AcrobotModel& m = h->acrobot;
+    m.goal[0] = 3.1415;
+    m.goal[1] = m.goal[2] = m.goal[3] = 0;
+    m.u_min[0] = d->u_min ? d->u_min[0] : -5.0;
+    m.u_max[0] = d->u_max ? d->u_max[0] : 5.0;
+  } else if (d->model == ILQR_MODEL_DOUBLE_INTEGRATOR) {
+    REQUIRE(d->nx == 4 && d->nu == 2, "double integrator is nx=4 nu=2 (include/double_integrator.h:16-17), got %d/%d", d->nx, d->nu);
+    DoubleIntegratorModel& m = h->dint;
+    const double g0[4] = {1.0, 0.5, 0.0, 0.0};
+    for (int i = 0; i < 4; i++) m.goal[i] = d->goal ? d->goal[i] : g0[i];
+    for (int j = 0; j < 2; j++) {
+      m.u_min[j] = d->u_min ? d->u_min[j] : -0.5;
+      m.u_max[j] = d->u_max ? d->u_max[j] : 0.5;
+    }
+  } else {
+    return fail(ILQR_ERR_UNSUPPORTED, "model id %d is not available in this build", d->model);
+  }
+
+  const size_t nt = h->ntiles, T = h->T, T1 = h->T + 1, nx = h->nx, nu = h->nu, REC = rec_of(h), Bp = h->Bp;
+  BatchView& v = h->v;
+  v.B = h->B;
+  v.Bp = h->Bp;
+  v.ntiles = h->ntiles;
+  v.T = h->T;
+  v.dt = h->dt;
+  int rc = 0;
+  rc |= dev_alloc(h, &v.x0, nt * nx * TW);
+  rc |= dev_alloc(h, &v.xs, nt * T1 * nx * TW);
+  rc |= dev_alloc(h, &v.us, nt * T * nu * TW);
+  rc |= dev_alloc(h, &v.kff, nt * T * nu * TW);
+  rc |= dev_alloc(h, &v.Kfb, nt * T * nu * nx * TW);
+  rc |= dev_alloc(h, &v.D, nt * T1 * REC * TW);
+  rc |= dev_alloc(h, &v.xs_c, (size_t)NALPHA * nt * T1 * nx * TW);
+  rc |= dev_alloc(h, &v.us_c, (size_t)NALPHA * nt * T * nu * TW);
+  rc |= dev_alloc(h, &v.cost_c, (size_t)NALPHA * Bp);
+  rc |= dev_alloc(h, &v.cost, Bp);
+  rc |= dev_alloc(h, &v.lambda, Bp);
+  rc |= dev_alloc(h, &v.dlambda, Bp);
+  rc |= dev_alloc(h, &v.dV, 2 * Bp);
+  rc |= dev_alloc(h, &v.gnorm, Bp);
+  rc |= dev_alloc(h, &v.status, Bp);
+  rc |= dev_alloc(h, &v.iters, Bp);
+  rc |= dev_alloc(h, &v.flg_change, Bp);
+  rc |= dev_alloc(h, &v.alpha_idx, Bp);
+  rc |= dev_alloc(h, &v.diverge, Bp);
+  rc |= dev_alloc(h, &v.backpass_done, Bp);
+  rc |= dev_alloc(h, &v.n_running, 1);
+  rc |= dev_alloc(h, &h->commit_idx, Bp);
+  if (rc) return ILQR_ERR_HIP;
+
+  h->sp.max_iter = h->params.max_iter;
+  h->sp.tol_fun = h->params.tol_fun;
+  h->sp.tol_grad = h->params.tol_grad;
+  h->sp.lambda_factor = h->params.lambda_factor;
+  h->sp.lambda_max = h->params.lambda_max;
+  h->sp.lambda_min = h->params.lambda_min;
+  h->sp.z_min = h->params.z_min;
+  h->sp.fixed_work = (h->flags & ILQR_FLAG_FIXED_WORK) ? 1 : 0;
+
+  hipLaunchKernelGGL(k_reset_state, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
+                     h->params.dlambda_init);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int ilqr_create(const ilqr_desc* d, ilqr_batch** out) {
+  if (!d || !out) return fail(ILQR_ERR_INVALID, "null argument");
+  *out = nullptr;
+  REQUIRE(d->abi_version == ILQR_AMD_ABI_VERSION, "ABI version %d, library is %d", d->abi_version, ILQR_AMD_ABI_VERSION);
+  REQUIRE(d->B >= 1 && d->T >= 1 && d->nx >= 1 && d->nu >= 1, "B, T, nx, nu must be positive");
+  REQUIRE(d->nx <= MAXN && d->nu <= MAXM, "nx <= %d and nu <= %d", MAXN, MAXM);
+  REQUIRE(d->dt > 0, "dt must be positive");
+  ilqr_batch* h = new ilqr_batch();
+  const int rc = create_impl(d, h);
+  if (rc) {
+    char keep[sizeof(g_err)];
+    memcpy(keep, g_err, sizeof(keep));
+    if (rc != ILQR_ERR_NO_DEVICE) ilqr_destroy(h); else delete h;
+    memcpy(g_err, keep, sizeof(keep));
+    return rc;
+  }
+  *out = h;
+  return 0;
+}
+
+int ilqr_set_stream(ilqr_batch* h, void* s) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->own_stream) {
+    HIPCHK(hipStreamDestroy(h->stream));
+    h->own_stream = false;
+  }
+  if (s) {
+    h->stream = (hipStream_t)s;
+  } else {
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+  }
+  return 0;
+}
+
+int ilqr_synchronize(ilqr_batch* h) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ---- whole-solve entry points --------------------------------------------------------------
+int ilqr_init_traj(ilqr_batch* h, const double* x0, const double* u0, double* cost_out) {
+  if (!h || !x0 || !u0) return fail(ILQR_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = upload(h, x0, h->v.x0, 1, h->nx)) return rc;
+  if (int rc = upload(h, u0, h->v.us, h->T, h->nu)) return rc;  // us = u_0, ilqr_core.cpp:17
+  // ilqr_core.cpp:23-48: zero derivative/gain arrays; statics lambda/dlambda as for a fresh process
+  const size_t nt = h->ntiles, T = h->T, T1 = h->T + 1;
+  HIPCHK(hipMemsetAsync(h->v.D, 0, nt * T1 * rec_of(h) * TW * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(h->v.kff, 0, nt * T * h->nu * TW * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(h->v.Kfb, 0, nt * T * h->nu * h->nx * TW * sizeof(double), h->stream));
+  hipLaunchKernelGGL(k_reset_state, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
+                     h->params.dlambda_init);
+  HIPCHK(hipGetLastError());
+  // ilqr_core.cpp:20: open-loop rollout (K is empty); writes xs, us, cost in place
+  AlphaSet al = line_search_alphas();
+  if (int rc = launch_rollout(h, false, al, 1, h->v.xs, h->v.us, h->v.cost, 0, 0, 0)) return rc;
+  h->initialised = true;
+  if (cost_out) return scalars_to_host(h, h->v.cost, cost_out);
+  return 0;
+}
+
+int ilqr_iterate(ilqr_batch* h, int n_iters) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  if (!h->initialised) return fail(ILQR_ERR_STATE, "ilqr_iterate before ilqr_init_traj/ilqr_set_trajectory");
+  HIPCHK(hipSetDevice(h->device));
+  for (int it = 0; it < n_iters; it++) {
+    if (int rc = launch_derivatives(h, h->sp.fixed_work)) return rc;  // STEP 1
+    if (int rc = launch_backward(h, 1)) return rc;                    // STEP 2
+    if (int rc = do_rollout_candidates(h, 1)) return rc;              // STEP 3
+    if (int rc = launch_accept_commit(h)) return rc;                  // STEP 3/4
+  }
+  return 0;
+}
+
+int ilqr_count_running(ilqr_batch* h, int* n) {
+  if (!h || !n) return fail(ILQR_ERR_INVALID, "null argument");
+  std::vector<int> st(h->B);
+  if (int rc = scalars_to_host(h, h->v.status, st.data())) return rc;
+  int c = 0;
+  for (int s : st) c += (s == 0);
+  *n = c;
+  return 0;
+}
+
+int ilqr_generate_trajectory(ilqr_batch* h) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  if (!h->initialised) return fail(ILQR_ERR_STATE, "generate_trajectory needs x0/xs/us (asserts of ilqr_core.cpp:80-82)");
+  int done_iters = 0;
+  const int chunk = 10;
+  while (done_iters < h->params.max_iter) {
+    const int n = std::min(chunk, h->params.max_iter - done_iters);
+    if (int rc = ilqr_iterate(h, n)) return rc;
+    done_iters += n;
+    int running = 0;
+    HIPCHK(hipMemcpyAsync(&running, h->v.n_running, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (running == 0) break;
+  }
+  return 0;
+}
+
+int ilqr_solve(ilqr_batch* h, const double* x0, const double* u0) {
+  if (int rc = ilqr_init_traj(h, x0, u0, nullptr)) return rc;
+  return ilqr_generate_trajectory(h);
+}
+
+int ilqr_warm_start(ilqr_batch* h, const double* x0) {
+  if (!h || !x0) return fail(ILQR_ERR_INVALID, "null argument");
+  if (!h->initialised) return fail(ILQR_ERR_STATE, "warm start needs a previous solve (assert us.size()>0, ilqr_core.cpp:66)");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = upload(h, x0, h->v.x0, 1, h->nx)) return rc;
+  // forward_pass(x_0, us) with the stored gains: u = us[t] + K[t](x - xs[t])  (alpha*k term = 0)
+  AlphaSet al;
+  for (int i = 0; i < NALPHA; i++) al.a[i] = 0.0;
+  const size_t sx = (size_t)h->ntiles * (h->T + 1) * h->nx * TW, su = (size_t)h->ntiles * h->T * h->nu * TW;
+  if (int rc = launch_rollout(h, true, al, 1, h->v.xs_c, h->v.us_c, h->v.cost, sx, su, 0)) return rc;
+  HIPCHK(hipMemsetAsync(h->commit_idx, 0, (size_t)h->Bp * sizeof(int), h->stream));  // slot 0 for everyone
+  dim3 grid((h->T + 1 + 15) / 16, h->ntiles), block(256);
+  if (h->nu == 1)
+    hipLaunchKernelGGL((k_commit<4, 1>), grid, block, 0, h->stream, h->v, h->commit_idx);
+  else
+    hipLaunchKernelGGL((k_commit<4, 2>), grid, block, 0, h->stream, h->v, h->commit_idx);
+  HIPCHK(hipGetLastError());
+  // a new outer loop starts: status/iters/flgChange reset, lambda & dlambda persist (file statics)
+  std::vector<double> lam(h->B), dlam(h->B);
+  if (int rc = scalars_to_host(h, h->v.lambda, lam.data())) return rc;
+  if (int rc = scalars_to_host(h, h->v.dlambda, dlam.data())) return rc;
+  hipLaunchKernelGGL(k_reset_state, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, 1.0, 1.0);
+  HIPCHK(hipGetLastError());
+  if (int rc = scalars_to_dev(h, lam.data(), h->v.lambda)) return rc;
+  if (int rc = scalars_to_dev(h, dlam.data(), h->v.dlambda)) return rc;
+  return ilqr_generate_trajectory(h);
+}
+
+// ---- stages --------------------------------------------------------------------------------
+int ilqr_compute_derivatives(ilqr_batch* h) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  return launch_derivatives(h, 1);
+}
+
+int ilqr_backward_pass(ilqr_batch* h, int* diverge_out) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = launch_backward(h, 0)) return rc;
+  if (diverge_out) return scalars_to_host(h, h->v.diverge, diverge_out);
+  return 0;
+}
+
+int ilqr_backward_step(ilqr_batch* h) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  return launch_backward(h, 1);
+}
+
+int ilqr_rollout_candidates(ilqr_batch* h, double* cost_out) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = do_rollout_candidates(h, 0)) return rc;
+  if (cost_out) {
+    std::vector<double> tmp((size_t)NALPHA * h->Bp);
+    HIPCHK(hipMemcpyAsync(tmp.data(), h->v.cost_c, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int b = 0; b < h->B; b++)
+      for (int a = 0; a < NALPHA; a++) cost_out[(size_t)b * NALPHA + a] = tmp[(size_t)a * h->Bp + b];
+  }
+  return 0;
+}
+
+int ilqr_line_search(ilqr_batch* h) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = do_rollout_candidates(h, 1)) return rc;
+  return launch_accept_commit(h);
+}
+
+// ---- state exchange --------------------------------------------------------------------------
+int ilqr_set_trajectory(ilqr_batch* h, const double* x0, const double* xs, const double* us, const double* cost) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (x0) if (int rc = upload(h, x0, h->v.x0, 1, h->nx)) return rc;
+  if (xs) if (int rc = upload(h, xs, h->v.xs, h->T + 1, h->nx)) return rc;
+  if (us) if (int rc = upload(h, us, h->v.us, h->T, h->nu)) return rc;
+  if (cost) if (int rc = scalars_to_dev(h, cost, h->v.cost)) return rc;
+  h->initialised = true;
+  return 0;
+}
+int ilqr_set_gains(ilqr_batch* h, const double* k, const double* K) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (k) if (int rc = upload(h, k, h->v.kff, h->T, h->nu)) return rc;
+  if (K) if (int rc = upload(h, K, h->v.Kfb, h->T, h->nu * h->nx)) return rc;
+  return 0;
+}
+int ilqr_set_derivatives(ilqr_batch* h, const double* fx, const double* fu, const double* cx, const double* cu,
+                         const double* cxx, const double* cxu, const double* cuu) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  const int n = h->nx, m = h->nu;
+  int off = 0;
+  const double* srcs[7] = {fx, fu, cx, cu, cxx, cxu, cuu};
+  const int sizes[7] = {n * n, n * m, n, m, n * n, n * m, m * m};
+  for (int i = 0; i < 7; i++) {
+    if (srcs[i]) if (int rc = upload_rec(h, srcs[i], off, sizes[i])) return rc;
+    off += sizes[i];
+  }
+  return 0;
+}
+int ilqr_set_lambda(ilqr_batch* h, const double* lambda, const double* dlambda) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (lambda) if (int rc = scalars_to_dev(h, lambda, h->v.lambda)) return rc;
+  if (dlambda) if (int rc = scalars_to_dev(h, dlambda, h->v.dlambda)) return rc;
+  return 0;
+}
+
+int ilqr_get_trajectory(ilqr_batch* h, double* xs, double* us) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (xs) if (int rc = download(h, h->v.xs, xs, h->T + 1, h->nx)) return rc;
+  if (us) if (int rc = download(h, h->v.us, us, h->T, h->nu)) return rc;
+  return 0;
+}
+int ilqr_get_gains(ilqr_batch* h, double* k, double* K) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (k) if (int rc = download(h, h->v.kff, k, h->T, h->nu)) return rc;
+  if (K) if (int rc = download(h, h->v.Kfb, K, h->T, h->nu * h->nx)) return rc;
+  return 0;
+}
+int ilqr_get_derivatives(ilqr_batch* h, double* fx, double* fu, double* cx, double* cu, double* cxx, double* cxu,
+                         double* cuu) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  const int n = h->nx, m = h->nu;
+  int off = 0;
+  double* dsts[7] = {fx, fu, cx, cu, cxx, cxu, cuu};
+  const int sizes[7] = {n * n, n * m, n, m, n * n, n * m, m * m};
+  for (int i = 0; i < 7; i++) {
+    if (dsts[i]) if (int rc = download_rec(h, dsts[i], off, sizes[i])) return rc;
+    off += sizes[i];
+  }
+  return 0;
+}
+int ilqr_get_cost(ilqr_batch* h, double* cost) {
+  if (!h || !cost) return fail(ILQR_ERR_INVALID, "null argument");
+  return scalars_to_host(h, h->v.cost, cost);
+}
+int ilqr_get_lambda(ilqr_batch* h, double* lambda, double* dlambda) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  if (lambda) if (int rc = scalars_to_host(h, h->v.lambda, lambda)) return rc;
+  if (dlambda) if (int rc = scalars_to_host(h, h->v.dlambda, dlambda)) return rc;
+  return 0;
+}
+int ilqr_get_dV(ilqr_batch* h, double* dV) {
+  if (!h || !dV) return fail(ILQR_ERR_INVALID, "null argument");
+  std::vector<double> tmp(2 * (size_t)h->Bp);
+  HIPCHK(hipMemcpyAsync(tmp.data(), h->v.dV, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < h->B; b++) {
+    dV[2 * b] = tmp[b];
+    dV[2 * b + 1] = tmp[h->Bp + b];
+  }
+  return 0;
+}
+int ilqr_get_gnorm(ilqr_batch* h, double* g) {
+  if (!h || !g) return fail(ILQR_ERR_INVALID, "null argument");
+  return scalars_to_host(h, h->v.gnorm, g);
+}
+int ilqr_get_status(ilqr_batch* h, int* status, int* iters, int* alpha_idx) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  if (status) if (int rc = scalars_to_host(h, h->v.status, status)) return rc;
+  if (iters) if (int rc = scalars_to_host(h, h->v.iters, iters)) return rc;
+  if (alpha_idx) if (int rc = scalars_to_host(h, h->v.alpha_idx, alpha_idx)) return rc;
+  return 0;
+}
+int ilqr_get_candidate(ilqr_batch* h, int a, double* xs, double* us) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  REQUIRE(a >= 0 && a < NALPHA, "alpha index %d out of range", a);
+  const size_t sx = (size_t)h->ntiles * (h->T + 1) * h->nx * TW, su = (size_t)h->ntiles * h->T * h->nu * TW;
+  if (xs) if (int rc = download(h, h->v.xs_c + a * sx, xs, h->T + 1, h->nx)) return rc;
+  if (us) if (int rc = download(h, h->v.us_c + a * su, us, h->T, h->nu)) return rc;
+  return 0;
+}
+int ilqr_copy_cost_to_device(ilqr_batch* h, void* dst) {
+  if (!h || !dst) return fail(ILQR_ERR_INVALID, "null argument");
+  HIPCHK(hipMemcpyAsync(dst, h->v.cost, (size_t)h->B * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  return 0;
+}
+
+// ---- measurement -----------------------------------------------------------------------------
+int ilqr_profile_enable(ilqr_batch* h, int enable) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  h->profile = enable != 0;
+  return 0;
+}
+int ilqr_profile_reset(ilqr_batch* h) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  if (int rc = timers_drain(h)) return rc;
+  for (auto& t : h->timers) {
+    t.ms = 0;
+    t.launches = 0;
+  }
+  return 0;
+}
+int ilqr_profile_read(ilqr_batch* h, double ms_out[ILQR_NUM_STAGES], int launches_out[ILQR_NUM_STAGES]) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  if (int rc = timers_drain(h)) return rc;
+  for (int s = 0; s < ILQR_NUM_STAGES; s++) {
+    if (ms_out) ms_out[s] = h->timers[s].ms;
+    if (launches_out) launches_out[s] = h->timers[s].launches;
+  }
+  return 0;
+}
+const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
+  (void)h;
+  switch (stage) {
+    case ILQR_STAGE_DERIVATIVES: return "k_derivatives";
+    case ILQR_STAGE_BACKWARD: return "k_backward_t";
+    case ILQR_STAGE_ROLLOUT: return "k_rollout";
+    case ILQR_STAGE_ACCEPT: return "k_accept+k_commit";
+    default: return "";
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// common.hpp -- shared device/host definitions of the MI355X-native batched iLQR engine.
+//
+// Device storage ("tiled" layout, private to a handle): trajectories are grouped in tiles of
+// TW = 16 consecutive batch indices; an array with S slots (time steps) of E doubles per
+// trajectory is stored as  [tile][S][E][TW]  -- the innermost 16 doubles are one 128-byte
+// line holding the same element of 16 neighbouring trajectories.  Every kernel maps
+// consecutive lanes to consecutive trajectories of a tile, so each vector memory instruction
+// touches whole 128-byte lines, and one tile's whole time series is one contiguous stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace ilqr {
+
+constexpr int TW = 16;       // trajectories per tile (16 x 8 B = one 128-B line)
+constexpr int NALPHA = 11;   // include/ilqr.h:24
+constexpr int MAXN = 32;
+constexpr int MAXM = 16;
+
+// include/ilqr.h:24 -- the rounded literals, not 10^linspace(0,-3,11)
+__device__ __constant__ const double kAlpha[NALPHA] = {1.0000, 0.5012, 0.2512, 0.1259, 0.0631, 0.0316,
+                                                       0.0158, 0.0079, 0.0040, 0.0020, 0.0010};
+static const double kAlphaHost[NALPHA] = {1.0000, 0.5012, 0.2512, 0.1259, 0.0631, 0.0316,
+                                          0.0158, 0.0079, 0.0040, 0.0020, 0.0010};
+
+// include/finite_diff.h:9, src/derivatives.cpp:10
+constexpr double kEps = 1e-3;
+
+// include/boxqp.h:19-24,63
+constexpr int kQpMaxIter = 100;
+constexpr double kMinGrad = 1e-8;
+constexpr double kMinRelImprove = 1e-8;
+constexpr double kStepDec = 0.6;
+constexpr double kMinStep = 1e-22;
+constexpr double kArmijo = 0.1;
+constexpr double kClampTol = 1e-4;
+
+__host__ __device__ inline size_t tidx(int tile, int s, int e, int l, int S, int E) {
+  return (((size_t)tile * S + s) * E + e) * TW + l;
+}
+
+// element offsets inside one derivative record (all matrices column-major)
+template <int NX, int NU>
+struct Rec {
+  static constexpr int FX = 0;
+  static constexpr int FU = FX + NX * NX;
+  static constexpr int CX = FU + NX * NU;
+  static constexpr int CU = CX + NX;
+  static constexpr int CXX = CU + NU;
+  static constexpr int CXU = CXX + NX * NX;
+  static constexpr int CUU = CXU + NX * NU;
+  static constexpr int SIZE = CUU + NU * NU;
+};
+inline int rec_size(int nx, int nu) { return 2 * nx * nx + 2 * nx * nu + nx + nu + nu * nu; }
+
+// Solver tunables (include/ilqr.h:14-24), passed by value to kernels.
+struct SolverParams {
+  int max_iter;
+  double tol_fun, tol_grad, lambda_factor, lambda_max, lambda_min, z_min;
+  int fixed_work;
+};
+
+// Raw views of a batch's device state, passed by value to kernels.
+struct BatchView {
+  int B, Bp, ntiles, T;
+  double dt;
+  // trajectories
+  double* x0;   // [tile][1][nx][TW]
+  double* xs;   // [tile][T+1][nx][TW]
+  double* us;   // [tile][T][nu][TW]
+  double* kff;  // [tile][T][nu][TW]
+  double* Kfb;  // [tile][T][nu*nx][TW]
+  double* D;    // [tile][T+1][REC][TW]
+  double* xs_c; // [NALPHA][tile][T+1][nx][TW]
+  double* us_c; // [NALPHA][tile][T][nu][TW]
+  double* cost_c; // [NALPHA][Bp]
+  // per-trajectory scalars [Bp]
+  double* cost;
+  double* lambda;
+  double* dlambda;
+  double* dV;     // [2][Bp]
+  double* gnorm;
+  int* status;    // ilqr_traj_status
+  int* iters;
+  int* flg_change;
+  int* alpha_idx;     // accepted alpha of the last line search, -1 = none
+  int* diverge;       // return value of the last backward_pass()
+  int* backpass_done; // ilqr_core.cpp:136
+  int* n_running;     // [1] device counter
+};
+
+}  // namespace ilqr

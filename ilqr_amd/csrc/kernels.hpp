@@ -1,0 +1,707 @@
+// kernels.hpp -- HIP kernels of the batched iLQR hot path (gfx950 / MI355X).
+//
+//   k_rollout      forward_pass (src/ilqr_core.cpp:305-337), all line-search alphas concurrently
+//   k_derivatives  finite-difference sweep (src/derivatives.cpp + include/finite_diff.h)
+//   k_backward_t   backward_pass + box-QP + lambda retry (ilqr_core.cpp:350-401, 136-159),
+//                  one THREAD per trajectory (everything in registers)
+//   k_accept       first-accept selection, lambda schedule, termination (ilqr_core.cpp:185-282)
+//   k_commit       copies the accepted candidate into the nominal trajectory
+//   k_pack/unpack  canonical [B][S][E] <-> tiled [tile][S][E][16]
+//
+// Lane mapping everywhere: consecutive lanes = consecutive trajectories of a tile, so each
+// vector load/store touches whole 128-byte lines of the tiled layout (common.hpp).
+#pragma once
+#include "boxqp.hpp"
+#include "common.hpp"
+#include "models.hpp"
+
+namespace ilqr {
+
+// ------------------------------------------------------------------------------------------
+// layout conversion
+// ------------------------------------------------------------------------------------------
+// canonical src[b][s][e]  ->  tiled dst[tile][s][e][l]      (one thread per tiled element)
+__global__ void k_pack(const double* __restrict__ src, double* __restrict__ dst, int B, int ntiles, int S, int E) {
+  const size_t n = (size_t)ntiles * S * E * TW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i % TW);
+    size_t r = i / TW;
+    const int e = (int)(r % E);
+    r /= E;
+    const int s = (int)(r % S);
+    const int tile = (int)(r / S);
+    const int b = tile * TW + l;
+    dst[i] = (b < B) ? src[((size_t)b * S + s) * E + e] : 0.0;
+  }
+}
+// tiled src -> canonical dst   (one thread per canonical element; reads are line-strided but
+// this path only serves getters)
+__global__ void k_unpack(const double* __restrict__ src, double* __restrict__ dst, int B, int S, int E) {
+  const size_t n = (size_t)B * S * E;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i % E);
+    size_t r = i / E;
+    const int s = (int)(r % S);
+    const int b = (int)(r / S);
+    dst[i] = src[tidx(b / TW, s, e, b % TW, S, E)];
+  }
+}
+// tiled record sub-range [off, off+E) of a record of size REC  <->  canonical [B][S][E]
+__global__ void k_pack_rec(const double* __restrict__ src, double* __restrict__ dst, int B, int ntiles, int S,
+                           int REC, int off, int E) {
+  const size_t n = (size_t)ntiles * S * E * TW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i % TW);
+    size_t r = i / TW;
+    const int e = (int)(r % E);
+    r /= E;
+    const int s = (int)(r % S);
+    const int tile = (int)(r / S);
+    const int b = tile * TW + l;
+    dst[tidx(tile, s, off + e, l, S, REC)] = (b < B) ? src[((size_t)b * S + s) * E + e] : 0.0;
+  }
+}
+__global__ void k_unpack_rec(const double* __restrict__ src, double* __restrict__ dst, int B, int S, int REC,
+                             int off, int E) {
+  const size_t n = (size_t)B * S * E;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i % E);
+    size_t r = i / E;
+    const int s = (int)(r % S);
+    const int b = (int)(r / S);
+    dst[i] = src[tidx(b / TW, s, off + e, b % TW, S, REC)];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-trajectory state reset (init_traj, ilqr_core.cpp:11-56; statics of ilqr.h:17-18)
+// ------------------------------------------------------------------------------------------
+__global__ void k_reset_state(BatchView v, double lambda0, double dlambda0) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= v.Bp) return;
+  v.lambda[b] = lambda0;
+  v.dlambda[b] = dlambda0;
+  v.dV[b] = 0;
+  v.dV[v.Bp + b] = 0;
+  v.gnorm[b] = 0;
+  v.status[b] = (b < v.B) ? 0 : 4;  // padding lanes never run
+  v.iters[b] = 0;
+  v.flg_change[b] = 1;
+  v.alpha_idx[b] = -1;
+  v.diverge[b] = 0;
+  v.backpass_done[b] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward rollout
+// ------------------------------------------------------------------------------------------
+struct AlphaSet {
+  double a[NALPHA];
+};
+
+// One thread per (trajectory, alpha).  grid = (Bp/64, n_alpha), block = 64.
+//   GAINS=false : u_t = us[t]                                   (init_traj: K empty, :316)
+//   GAINS=true  : u_t = us[t] + alpha k[t] + K[t] (x_t - xs[t]) (:188-190, :315-316)
+// Writes the new states/controls to (xs_out, us_out) + a * stride and the cost to cost_out[a][b].
+// mode: 0 = all trajectories, 1 = only running ones whose backward pass succeeded.
+template <class M, bool GAINS>
+__global__ __launch_bounds__(64) void k_rollout(BatchView v, M model, AlphaSet alphas, double* __restrict__ xs_out,
+                                                double* __restrict__ us_out, double* __restrict__ cost_out,
+                                                size_t stride_x, size_t stride_u, int mode) {
+  constexpr int NX = M::NX, NU = M::NU;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int a = blockIdx.y;
+  if (b >= v.B) return;
+  if (mode == 1 && !(v.status[b] == 0 && v.backpass_done[b])) return;
+  const int tile = b / TW, l = b % TW;
+  const int T = v.T;
+  const double alpha = alphas.a[a];
+  const double dt = v.dt;
+  double* xo = xs_out + (size_t)a * stride_x;
+  double* uo = us_out + (size_t)a * stride_u;
+
+  double x[NX];
+#pragma unroll
+  for (int i = 0; i < NX; i++) {
+    x[i] = v.x0[tidx(tile, 0, i, l, 1, NX)];
+    xo[tidx(tile, 0, i, l, T + 1, NX)] = x[i];
+  }
+  double total = 0;
+
+  // software prefetch of step t+1 while step t integrates (none of it depends on x)
+  double un[NU], kn[NU], Kn[NU * NX], xn[NX];
+  auto load_step = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < NU; j++) un[j] = v.us[tidx(tile, t, j, l, T, NU)];
+    if (GAINS) {
+#pragma unroll
+      for (int j = 0; j < NU; j++) kn[j] = v.kff[tidx(tile, t, j, l, T, NU)];
+#pragma unroll
+      for (int e = 0; e < NU * NX; e++) Kn[e] = v.Kfb[tidx(tile, t, e, l, T, NU * NX)];
+#pragma unroll
+      for (int i = 0; i < NX; i++) xn[i] = v.xs[tidx(tile, t, i, l, T + 1, NX)];
+    }
+  };
+  load_step(0);
+  for (int t = 0; t < T; t++) {
+    double u[NU], kk[NU], K[NU * NX], xnom[NX];
+#pragma unroll
+    for (int j = 0; j < NU; j++) u[j] = un[j];
+    if (GAINS) {
+#pragma unroll
+      for (int j = 0; j < NU; j++) kk[j] = kn[j];
+#pragma unroll
+      for (int e = 0; e < NU * NX; e++) K[e] = Kn[e];
+#pragma unroll
+      for (int i = 0; i < NX; i++) xnom[i] = xn[i];
+    }
+    if (t + 1 < T) load_step(t + 1);
+    if (GAINS) {
+#pragma unroll
+      for (int j = 0; j < NU; j++) {
+        u[j] += kk[j] * alpha;  // :190
+        double acc = 0;
+#pragma unroll
+        for (int i = 0; i < NX; i++) acc += K[j + NU * i] * (x[i] - xnom[i]);
+        u[j] += acc;  // :316
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NU; j++) uo[tidx(tile, t, j, l, T, NU)] = u[j];  // :323 (no clamping)
+    total += model.cost(x, u);                                           // :324
+    double x1[NX];
+    integrate_dynamics(model, x, u, dt, x1);  // :325
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+      x[i] = x1[i];
+      xo[tidx(tile, t + 1, i, l, T + 1, NX)] = x1[i];
+    }
+  }
+  total += model.final_cost(x);  // :335
+  cost_out[(size_t)a * v.Bp + b] = total;
+}
+
+// ------------------------------------------------------------------------------------------
+// finite-difference derivatives
+// ------------------------------------------------------------------------------------------
+// include/finite_diff.h:67-86 applied to a scalar functor of an N-vector.
+template <int N, class F>
+__device__ __forceinline__ void fd_hessian(const double* x, F f, double* out /* N x N col-major */) {
+#pragma unroll
+  for (int i = 0; i < N; i++)
+#pragma unroll
+    for (int j = i; j < N; j++) {
+      double pp[N], pm[N], mp[N], mm[N];
+#pragma unroll
+      for (int l = 0; l < N; l++) pp[l] = pm[l] = mp[l] = mm[l] = x[l];
+      pp[i] += kEps;
+      pp[j] += kEps;
+      pm[i] += kEps;
+      pm[j] -= kEps;
+      mp[i] -= kEps;
+      mp[j] += kEps;
+      mm[i] -= kEps;
+      mm[j] -= kEps;
+      const double v = (f(pp) - f(mp) - f(pm) + f(mm)) / (4 * kEps * kEps);
+      out[i + N * j] = v;
+      out[j + N * i] = v;
+    }
+}
+// include/finite_diff.h:22-33
+template <int N, class F>
+__device__ __forceinline__ void fd_gradient(const double* x, F f, double* out) {
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    double p[N], m[N];
+#pragma unroll
+    for (int l = 0; l < N; l++) p[l] = m[l] = x[l];
+    p[i] += kEps;
+    m[i] -= kEps;
+    out[i] = (f(p) - f(m)) / (2 * kEps);
+  }
+}
+
+// One thread per knot point (b, t), t = 0..T.  block = 256 = 16 trajectories x 16 time steps,
+// grid = (ceil((T+1)/16), ntiles).  force != 0: every trajectory (stage call / bench mode),
+// otherwise only running trajectories whose flgChange is set (ilqr_core.cpp:115).
+template <class M>
+__global__ __launch_bounds__(256) void k_derivatives(BatchView v, M model, int force) {
+  constexpr int NX = M::NX, NU = M::NU;
+  using R = Rec<NX, NU>;
+  const int l = threadIdx.x & (TW - 1);
+  const int t = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int tile = blockIdx.y;
+  const int b = tile * TW + l;
+  const int T = v.T;
+  if (t > T || b >= v.B) return;
+  if (!force && !(v.status[b] == 0 && v.flg_change[b])) return;
+  const double dt = v.dt;
+
+  double x[NX], u[NU];
+#pragma unroll
+  for (int i = 0; i < NX; i++) x[i] = v.xs[tidx(tile, t, i, l, T + 1, NX)];
+#pragma unroll
+  for (int j = 0; j < NU; j++) u[j] = (t < T) ? v.us[tidx(tile, t, j, l, T, NU)] : 0.0;  // derivatives.cpp:35-38
+
+  double* D = v.D + tidx(tile, t, 0, l, T + 1, R::SIZE);
+  auto put = [&](int e, double val) { D[(size_t)e * TW] = val; };
+
+  if (t < T) {
+    // fx, fu: central differences of the Euler map (derivatives.cpp:19-25, finite_diff.h:35-47)
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+      double p[NX], m[NX], fp[NX], fm[NX];
+#pragma unroll
+      for (int q = 0; q < NX; q++) p[q] = m[q] = x[q];
+      p[i] += kEps;
+      m[i] -= kEps;
+      integrate_dynamics(model, p, u, dt, fp);
+      integrate_dynamics(model, m, u, dt, fm);
+#pragma unroll
+      for (int r = 0; r < NX; r++) put(R::FX + r + NX * i, (fp[r] - fm[r]) / (2 * kEps));
+    }
+#pragma unroll
+    for (int i = 0; i < NU; i++) {
+      double p[NU], m[NU], fp[NX], fm[NX];
+#pragma unroll
+      for (int q = 0; q < NU; q++) p[q] = m[q] = u[q];
+      p[i] += kEps;
+      m[i] -= kEps;
+      integrate_dynamics(model, x, p, dt, fp);
+      integrate_dynamics(model, x, m, dt, fm);
+#pragma unroll
+      for (int r = 0; r < NX; r++) put(R::FU + r + NX * i, (fp[r] - fm[r]) / (2 * kEps));
+    }
+    // cx, cu (derivatives.cpp:44-47)
+    double g[NX > NU ? NX : NU];
+    fd_gradient<NX>(x, [&](const double* xx) { return model.cost(xx, u); }, g);
+#pragma unroll
+    for (int i = 0; i < NX; i++) put(R::CX + i, g[i]);
+    fd_gradient<NU>(u, [&](const double* uu) { return model.cost(x, uu); }, g);
+#pragma unroll
+    for (int i = 0; i < NU; i++) put(R::CU + i, g[i]);
+    // cxx (derivatives.cpp:76-96)
+    double H[NX * NX];
+    fd_hessian<NX>(x, [&](const double* xx) { return model.cost(xx, u); }, H);
+#pragma unroll
+    for (int e = 0; e < NX * NX; e++) put(R::CXX + e, H[e]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < NX * NX + NX * NU; e++) put(R::FX + e, 0.0);  // fx[T], fu[T] stay zero
+    double g[NX];
+    fd_gradient<NX>(x, [&](const double* xx) { return model.final_cost(xx); }, g);  // :49
+#pragma unroll
+    for (int i = 0; i < NX; i++) put(R::CX + i, g[i]);
+#pragma unroll
+    for (int i = 0; i < NU; i++) put(R::CU + i, 0.0);  // :50-51
+    double H[NX * NX];
+    fd_hessian<NX>(x, [&](const double* xx) { return model.final_cost(xx); }, H);  // :92
+#pragma unroll
+    for (int e = 0; e < NX * NX; e++) put(R::CXX + e, H[e]);
+  }
+  // cuu at every t, with u = 0 at t = T (derivatives.cpp:98-112)
+  {
+    double H[NU * NU];
+    fd_hessian<NU>(u, [&](const double* uu) { return model.cost(x, uu); }, H);
+#pragma unroll
+    for (int e = 0; e < NU * NU; e++) put(R::CUU + e, H[e]);
+  }
+  // cxu (derivatives.cpp:114-144)
+#pragma unroll
+  for (int i = 0; i < NX; i++)
+#pragma unroll
+    for (int j = 0; j < NU; j++) {
+      double px[NX], mx[NX], pu[NU], mu[NU];
+#pragma unroll
+      for (int q = 0; q < NX; q++) px[q] = mx[q] = x[q];
+#pragma unroll
+      for (int q = 0; q < NU; q++) pu[q] = mu[q] = u[q];
+      px[i] += kEps;
+      mx[i] -= kEps;
+      pu[j] += kEps;
+      mu[j] -= kEps;
+      double val;
+      if (t < T)
+        val = (model.cost(px, pu) - model.cost(mx, pu) - model.cost(px, mu) + model.cost(mx, mu)) / (4 * (kEps * kEps));
+      else  // :140 (the reference's own "TODO this is wrong"; value is never consumed)
+        val = (model.final_cost(px) - model.final_cost(mx) - model.final_cost(px) + model.final_cost(mx)) /
+              (4 * (kEps * kEps));
+      put(R::CXU + i + NX * j, val);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward pass, one thread per trajectory
+// ------------------------------------------------------------------------------------------
+// mode 0: exactly one backward_pass() at the current lambda for every trajectory (stage call)
+// mode 1: STEP 2 of the outer loop for running trajectories: retry with increased lambda while
+//         the pass diverges (ilqr_core.cpp:136-150), then the gradient-norm test (:153-159).
+template <class M>
+__global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverParams sp, int mode) {
+  constexpr int NX = M::NX, NU = M::NU;
+  using R = Rec<NX, NU>;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= v.B) return;
+  if (mode == 1 && v.status[b] != 0) return;
+  const int tile = b / TW, l = b % TW;
+  const int T = v.T;
+  double lambda = v.lambda[b], dlambda = v.dlambda[b];
+  const double* Dt = v.D + tidx(tile, 0, 0, l, T + 1, R::SIZE);
+  auto rec = [&](int t, int e) { return Dt[((size_t)t * R::SIZE + e) * TW]; };
+
+  int diverge = 0;
+  bool done = false;
+  double dV0 = 0, dV1 = 0;
+  while (true) {
+    double Vx[NX], Vxx[NX * NX], kprev[NU];
+#pragma unroll
+    for (int i = 0; i < NX; i++) Vx[i] = rec(T, R::CX + i);  // :353
+#pragma unroll
+    for (int e = 0; e < NX * NX; e++) Vxx[e] = rec(T, R::CXX + e);  // :354
+#pragma unroll
+    for (int j = 0; j < NU; j++) kprev[j] = v.kff[tidx(tile, T - 1, j, l, T, NU)];  // k[min(i+1,T-1)] at i=T-1
+    dV0 = dV1 = 0;  // :356
+    diverge = 0;
+
+    for (int i = T - 1; i >= 0; i--) {
+      double fx[NX * NX], fu[NX * NU], cx[NX], cu[NU], cxx[NX * NX], cxu[NX * NU], cuu[NU * NU], us[NU];
+#pragma unroll
+      for (int e = 0; e < NX * NX; e++) fx[e] = rec(i, R::FX + e);
+#pragma unroll
+      for (int e = 0; e < NX * NU; e++) fu[e] = rec(i, R::FU + e);
+#pragma unroll
+      for (int e = 0; e < NX; e++) cx[e] = rec(i, R::CX + e);
+#pragma unroll
+      for (int e = 0; e < NU; e++) cu[e] = rec(i, R::CU + e);
+#pragma unroll
+      for (int e = 0; e < NX * NX; e++) cxx[e] = rec(i, R::CXX + e);
+#pragma unroll
+      for (int e = 0; e < NX * NU; e++) cxu[e] = rec(i, R::CXU + e);
+#pragma unroll
+      for (int e = 0; e < NU * NU; e++) cuu[e] = rec(i, R::CUU + e);
+#pragma unroll
+      for (int j = 0; j < NU; j++) us[j] = v.us[tidx(tile, i, j, l, T, NU)];
+
+      double Qx[NX], Qu[NU], Qxx[NX * NX], Qux[NU * NX], Quu[NU * NU], QuuF[NU * NU];
+      double A1[NX * NX], A2[NU * NX];
+      // :359-360
+#pragma unroll
+      for (int a = 0; a < NX; a++) {
+        double acc = 0;
+#pragma unroll
+        for (int q = 0; q < NX; q++) acc += fx[q + NX * a] * Vx[q];
+        Qx[a] = cx[a] + acc;
+      }
+#pragma unroll
+      for (int a = 0; a < NU; a++) {
+        double acc = 0;
+#pragma unroll
+        for (int q = 0; q < NX; q++) acc += fu[q + NX * a] * Vx[q];
+        Qu[a] = cu[a] + acc;
+      }
+      // :361  Qxx = cxx + (fx'Vxx) fx
+#pragma unroll
+      for (int a = 0; a < NX; a++)
+#pragma unroll
+        for (int c = 0; c < NX; c++) {
+          double acc = 0;
+#pragma unroll
+          for (int q = 0; q < NX; q++) acc += fx[q + NX * a] * Vxx[q + NX * c];
+          A1[a + NX * c] = acc;
+        }
+#pragma unroll
+      for (int a = 0; a < NX; a++)
+#pragma unroll
+        for (int c = 0; c < NX; c++) {
+          double acc = 0;
+#pragma unroll
+          for (int q = 0; q < NX; q++) acc += A1[a + NX * q] * fx[q + NX * c];
+          Qxx[a + NX * c] = cxx[a + NX * c] + acc;
+        }
+      // :362/:366  Qux = cxu' + (fu'Vxx) fx
+#pragma unroll
+      for (int a = 0; a < NU; a++)
+#pragma unroll
+        for (int c = 0; c < NX; c++) {
+          double acc = 0;
+#pragma unroll
+          for (int q = 0; q < NX; q++) acc += fu[q + NX * a] * Vxx[q + NX * c];
+          A2[a + NU * c] = acc;
+        }
+#pragma unroll
+      for (int a = 0; a < NU; a++)
+#pragma unroll
+        for (int c = 0; c < NX; c++) {
+          double acc = 0;
+#pragma unroll
+          for (int q = 0; q < NX; q++) acc += A2[a + NU * q] * fx[q + NX * c];
+          Qux[a + NU * c] = cxu[c + NX * a] + acc;
+        }
+      // :363/:367  Quu = cuu + (fu'Vxx) fu ; QuuF = cuu + lambda I + (fu'Vxx) fu
+#pragma unroll
+      for (int a = 0; a < NU; a++)
+#pragma unroll
+        for (int c = 0; c < NU; c++) {
+          double acc = 0;
+#pragma unroll
+          for (int q = 0; q < NX; q++) acc += A2[a + NU * q] * fu[q + NX * c];
+          Quu[a + NU * c] = cuu[a + NU * c] + acc;
+          QuuF[a + NU * c] = (cuu[a + NU * c] + ((a == c) ? lambda : 0.0)) + acc;
+        }
+
+      // :369
+      double lo[NU], hi[NU];
+#pragma unroll
+      for (int j = 0; j < NU; j++) {
+        lo[j] = model.u_min[j] - us[j];
+        hi[j] = model.u_max[j] - us[j];
+      }
+      BoxQPResult<NU> qp;
+      box_qp<NU>(QuuF, Qu, kprev, lo, hi, qp);
+      if (qp.result < 1) {  // :371
+        diverge = i;
+        break;
+      }
+
+      // :373-385
+      double K[NU * NX];
+#pragma unroll
+      for (int e = 0; e < NU * NX; e++) K[e] = 0;
+      {
+        int rank[NU], nf = 0;
+#pragma unroll
+        for (int j = 0; j < NU; j++) {
+          rank[j] = nf;
+          nf += qp.v_free[j] ? 1 : 0;
+        }
+        if (nf > 0) {
+          double Minv[NU * NU];
+          rinv_rinvT<NU>(qp.nfR, qp.R, Minv);
+          const int nuse = (nf < qp.nfR) ? nf : qp.nfR;
+#pragma unroll
+          for (int c = 0; c < NX; c++) {
+            double qf[NU];  // rows_w_ind(Qux_reg, v_free)(:, c)
+#pragma unroll
+            for (int a = 0; a < NU; a++) {
+              double val = 0;
+#pragma unroll
+              for (int j = 0; j < NU; j++)
+                if (qp.v_free[j] && rank[j] == a) val = Qux[j + NU * c];
+              qf[a] = val;
+            }
+#pragma unroll
+            for (int j = 0; j < NU; j++) {
+              if (qp.v_free[j] && rank[j] < nuse) {
+                double acc = 0;
+#pragma unroll
+                for (int a = 0; a < NU; a++)
+                  if (a < nuse) {
+                    double mrow = 0;  // Minv[rank[j]][a]
+#pragma unroll
+                    for (int r = 0; r < NU; r++)
+                      if (r == rank[j]) mrow = Minv[r + NU * a];
+                    acc += -mrow * qf[a];
+                  }
+                K[j + NU * c] = acc;
+              }
+            }
+          }
+        }
+      }
+
+      // :388-389
+      {
+        double d0 = 0;
+#pragma unroll
+        for (int j = 0; j < NU; j++) d0 += qp.x[j] * Qu[j];
+        dV0 += d0;
+        double d1 = 0;
+#pragma unroll
+        for (int c = 0; c < NU; c++) {
+          double r = 0;
+#pragma unroll
+          for (int a = 0; a < NU; a++) r += (0.5 * qp.x[a]) * Quu[a + NU * c];
+          d1 += r * qp.x[c];
+        }
+        dV1 += d1;
+      }
+      // :391-393
+      {
+        double T1[NX * NU];  // K' Quu  (NX x NU)
+#pragma unroll
+        for (int a = 0; a < NX; a++)
+#pragma unroll
+          for (int c = 0; c < NU; c++) {
+            double acc = 0;
+#pragma unroll
+            for (int q = 0; q < NU; q++) acc += K[q + NU * a] * Quu[q + NU * c];
+            T1[a + NX * c] = acc;
+          }
+        double Vxn[NX], Vn[NX * NX];
+#pragma unroll
+        for (int a = 0; a < NX; a++) {
+          double t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+          for (int c = 0; c < NU; c++) {
+            t1 += T1[a + NX * c] * qp.x[c];
+            t2 += K[c + NU * a] * Qu[c];
+            t3 += Qux[c + NU * a] * qp.x[c];
+          }
+          Vxn[a] = ((Qx[a] + t1) + t2) + t3;
+        }
+#pragma unroll
+        for (int a = 0; a < NX; a++)
+#pragma unroll
+          for (int c = 0; c < NX; c++) {
+            double t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+            for (int q = 0; q < NU; q++) {
+              t1 += T1[a + NX * q] * K[q + NU * c];
+              t2 += K[q + NU * a] * Qux[q + NU * c];
+              t3 += Qux[q + NU * a] * K[q + NU * c];
+            }
+            Vn[a + NX * c] = ((Qxx[a + NX * c] + t1) + t2) + t3;
+          }
+#pragma unroll
+        for (int a = 0; a < NX; a++) {
+          Vx[a] = Vxn[a];
+#pragma unroll
+          for (int c = 0; c < NX; c++) Vxx[a + NX * c] = 0.5 * (Vn[a + NX * c] + Vn[c + NX * a]);
+        }
+      }
+      // :396-397
+#pragma unroll
+      for (int j = 0; j < NU; j++) {
+        v.kff[tidx(tile, i, j, l, T, NU)] = qp.x[j];
+        kprev[j] = qp.x[j];
+      }
+#pragma unroll
+      for (int e = 0; e < NU * NX; e++) v.Kfb[tidx(tile, i, e, l, T, NU * NX)] = K[e];
+    }  // for i
+
+    if (mode == 0) {
+      done = (diverge == 0);
+      break;
+    }
+    if (diverge != 0) {  // :142-148
+      dlambda = fmax(dlambda * sp.lambda_factor, sp.lambda_factor);
+      lambda = fmax(lambda * dlambda, sp.lambda_min);
+      if (lambda > sp.lambda_max) break;
+      continue;
+    }
+    done = true;
+    break;
+  }
+
+  v.dV[b] = dV0;
+  v.dV[v.Bp + b] = dV1;
+  v.diverge[b] = diverge;
+  v.backpass_done[b] = done ? 1 : 0;
+  if (mode == 1) {
+    v.lambda[b] = lambda;
+    v.dlambda[b] = dlambda;
+  }
+  // :153 / :405-412  gnorm = mean_t max_j |k_j| / (|u_j| + 1), ascending t like std::accumulate
+  double acc = 0;
+  for (int t = 0; t < T; t++) {
+    double mx = 0;
+#pragma unroll
+    for (int j = 0; j < NU; j++) {
+      const double val = fabs(v.kff[tidx(tile, t, j, l, T, NU)]) / (fabs(v.us[tidx(tile, t, j, l, T, NU)]) + 1);
+      mx = (j == 0 || val > mx) ? val : mx;
+    }
+    acc += mx;
+  }
+  const double gnorm = acc / T;
+  v.gnorm[b] = gnorm;
+  if (mode == 1 && !sp.fixed_work && gnorm < sp.tol_grad && lambda < 1e-5) {  // :154-159
+    v.status[b] = 1;
+    v.iters[b] += 1;  // this iteration was started
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// line-search selection + lambda schedule + termination (one thread per trajectory)
+// ------------------------------------------------------------------------------------------
+__global__ void k_accept(BatchView v, SolverParams sp, int* __restrict__ commit_idx) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= v.Bp) return;
+  int commit = -1;
+  if (b < v.B && v.status[b] == 0) {
+    double lambda = v.lambda[b], dlambda = v.dlambda[b];
+    const double cost_s = v.cost[b];
+    bool fwd = false;
+    double new_cost = 0, dcost = 0;
+    int acc = -1;
+    if (v.backpass_done[b]) {  // :184
+      const double dV0 = v.dV[b], dV1 = v.dV[v.Bp + b];
+      for (int a = 0; a < NALPHA; a++) {  // the serial order of :185-220, first z > zMin wins
+        const double alpha = kAlpha[a];
+        new_cost = v.cost_c[(size_t)a * v.Bp + b];
+        dcost = cost_s - new_cost;                          // :199
+        const double expected = -alpha * (dV0 + alpha * dV1);  // :200
+        double z;
+        if (expected > 0)
+          z = dcost / expected;
+        else
+          z = (double)((0.0 < dcost) - (dcost < 0.0));  // sgn, common.h:52
+        if (z > sp.z_min) {
+          fwd = true;
+          acc = a;
+          break;
+        }
+      }
+    }
+    int status = 0;
+    if (fwd) {  // :242-263
+      dlambda = fmin(dlambda / sp.lambda_factor, 1 / sp.lambda_factor);
+      lambda = lambda * dlambda * (lambda > sp.lambda_min ? 1.0 : 0.0);
+      v.cost[b] = new_cost;
+      v.flg_change[b] = 1;
+      commit = acc;
+      if (!sp.fixed_work && dcost < sp.tol_fun) status = 2;
+    } else {  // :264-282
+      dlambda = fmax(dlambda * sp.lambda_factor, sp.lambda_factor);
+      lambda = fmax(lambda * dlambda, sp.lambda_min);
+      v.flg_change[b] = 0;
+      if (!sp.fixed_work && lambda > sp.lambda_max) status = 3;
+    }
+    v.lambda[b] = lambda;
+    v.dlambda[b] = dlambda;
+    v.alpha_idx[b] = acc;
+    const int it = v.iters[b] + 1;
+    v.iters[b] = it;
+    if (status == 0 && it >= sp.max_iter) status = 4;  // :103
+    v.status[b] = status;
+    if (status == 0) atomicAdd(v.n_running, 1);
+  }
+  commit_idx[b] = commit;
+}
+
+// copy candidate commit_idx[b] into the nominal trajectory.  block 256 = 16 traj x 16 steps.
+template <int NX, int NU>
+__global__ __launch_bounds__(256) void k_commit(BatchView v, const int* __restrict__ commit_idx) {
+  const int l = threadIdx.x & (TW - 1);
+  const int t = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int tile = blockIdx.y;
+  const int b = tile * TW + l;
+  const int T = v.T;
+  if (t > T || b >= v.B) return;
+  const int a = commit_idx[b];
+  if (a < 0) return;
+  const size_t sx = (size_t)v.ntiles * (T + 1) * NX * TW, su = (size_t)v.ntiles * T * NU * TW;
+#pragma unroll
+  for (int i = 0; i < NX; i++) {
+    const size_t o = tidx(tile, t, i, l, T + 1, NX);
+    v.xs[o] = v.xs_c[(size_t)a * sx + o];
+  }
+  if (t < T) {
+#pragma unroll
+    for (int j = 0; j < NU; j++) {
+      const size_t o = tidx(tile, t, j, l, T, NU);
+      v.us[o] = v.us_c[(size_t)a * su + o];
+    }
+  }
+}
+
+}  // namespace ilqr

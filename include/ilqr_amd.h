@@ -1,0 +1,189 @@
+/*
+ * ilqr_amd.h -- C ABI of libilqr_amd.so, the MI355X-native batched iLQR hot path.
+ *
+ * This is the drop-in boundary for the hot path of kazuotani14/iLQR ("the reference"):
+ * forward rollout, finite-difference derivatives, backward Riccati recursion with the
+ * per-timestep box-QP, and the line search / lambda schedule that strings them together,
+ * for B independent trajectories at once.  Every entry point names the reference interface
+ * (file:line, relative to the reference repository) it replaces.  The reference has no FFI
+ * of its own (it is one C++ process); INTEGRATION.md shows the few-line binding that routes
+ * class iLQR through this library.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; nothing is thrown across the boundary.
+ *     Every function returns 0 on success or a negative ilqr_status_code; ilqr_last_error()
+ *     gives the message of the calling thread's last failure.
+ *   - T is the number of transitions (= u0.size(), src/ilqr_core.cpp:12); state arrays have
+ *     T+1 knot points.  "acrobot T=500" of BASELINE.json is T = 499 here (500 knots).
+ *   - Host-side array layouts ("canonical"), all double, row-major over the leading indices:
+ *         x0 [B][nx]          u0,us,k [B][T][nu]        xs [B][T+1][nx]
+ *         K  [B][T][nu*nx]    each K_t column-major nu x nx  (Eigen MatrixXd default)
+ *         fx,cxx [B][T+1][nx*nx]   fu,cxu [B][T+1][nx*nu]   cuu [B][T+1][nu*nu]   (column-major)
+ *         cx [B][T+1][nx]     cu [B][T+1][nu]
+ *     so that a dump of the reference's std::vector<VectorXd/MatrixXd> members compares
+ *     element for element.  Device-side storage is private to the handle.
+ *   - All work is enqueued on the handle's HIP stream; getters synchronise that stream.
+ *   - A handle is independent of every other handle (the reference's file-static
+ *     lambda/dlambda, include/ilqr.h:17-18, are per-trajectory state here, reset to (1,1) by
+ *     ilqr_init_traj -- i.e. each fresh solve behaves like a fresh reference process).
+ *   - There is no CPU fallback: without a HIP device ilqr_create fails with ILQR_ERR_NO_DEVICE.
+ */
+#ifndef ILQR_AMD_H_
+#define ILQR_AMD_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ILQR_AMD_ABI_VERSION 1
+
+typedef struct ilqr_batch ilqr_batch; /* opaque: owns all device memory of one batch */
+
+enum ilqr_status_code {
+  ILQR_OK = 0,
+  ILQR_ERR_INVALID = -1,   /* bad argument / size mismatch (the reference asserts: boxqp.cpp:29-33, ilqr_core.cpp:66,80-82) */
+  ILQR_ERR_NO_DEVICE = -2, /* no HIP device / runtime failure at create */
+  ILQR_ERR_HIP = -3,       /* a HIP call failed; see ilqr_last_error() */
+  ILQR_ERR_STATE = -4,     /* call order violated (e.g. warm start before any solve, ilqr_core.cpp:66) */
+  ILQR_ERR_UNSUPPORTED = -5
+};
+
+/* Device models: compile-time twins of the reference's Model subclasses (include/model.h:6-21).
+ * A Model whose dynamics/cost exist only as host virtuals uses ILQR_MODEL_HOST: its rollouts and
+ * finite differences stay on the host (C++ facade) and only the backward pass runs here. */
+enum ilqr_model_id {
+  ILQR_MODEL_ACROBOT = 0,           /* include/acrobot.h            nx=4 nu=1 */
+  ILQR_MODEL_DOUBLE_INTEGRATOR = 1, /* include/double_integrator.h  nx=4 nu=2 */
+  ILQR_MODEL_LQ = 2,                /* synthetic LQ (BASELINE.json configs[4]), nx<=32 nu<=16 */
+  ILQR_MODEL_HOST = 3               /* derivatives supplied through ilqr_set_derivatives */
+};
+
+/* where a trajectory's outer loop stands (src/ilqr_core.cpp:103-288) */
+enum ilqr_traj_status {
+  ILQR_RUNNING = 0,
+  ILQR_CONVERGED_GRAD = 1, /* "SUCCESS: gradient norm < tolGrad", ilqr_core.cpp:154-159 */
+  ILQR_CONVERGED_COST = 2, /* "SUCCESS: cost change < tolFun",   ilqr_core.cpp:257-262 */
+  ILQR_LAMBDA_MAX = 3,     /* "EXIT: lambda > lambdaMax",         ilqr_core.cpp:276-281 */
+  ILQR_MAX_ITER = 4        /* maxIter iterations done,            ilqr_core.cpp:103 */
+};
+
+enum ilqr_flags {
+  /* Bench mode: every iteration runs derivatives + backward + all line-search rollouts for
+   * every trajectory and the three termination tests are disabled, so B*T*iters is exactly the
+   * work done.  Accept/reject and the lambda schedule stay as in the reference. */
+  ILQR_FLAG_FIXED_WORK = 1,
+  /* Backward-pass kernel choice: default picks by batch size. */
+  ILQR_FLAG_BACKWARD_THREAD_PER_TRAJ = 2,
+  ILQR_FLAG_BACKWARD_LANE_GROUP = 4
+};
+
+/* Solver tunables = the compile-time constants of include/ilqr.h:14-24 (defaults shown). */
+typedef struct ilqr_params {
+  int max_iter;          /* 100   maxIter */
+  double tol_fun;        /* 1e-6  tolFun */
+  double tol_grad;       /* 1e-6  tolGrad */
+  double lambda_init;    /* 1     lambda */
+  double dlambda_init;   /* 1     dlambda */
+  double lambda_factor;  /* 1.6   lambdaFactor */
+  double lambda_max;     /* 1e11  lambdaMax */
+  double lambda_min;     /* 1e-8  lambdaMin */
+  double z_min;          /* 0     zMin */
+} ilqr_params;
+
+typedef struct ilqr_desc {
+  int abi_version; /* ILQR_AMD_ABI_VERSION */
+  int model;       /* enum ilqr_model_id */
+  int nx, nu;      /* Model::x_dims, Model::u_dims (include/model.h:19-20) */
+  int T;           /* transitions */
+  int B;           /* trajectories in this batch (this rank's shard) */
+  double dt;       /* iLQR::dt, include/ilqr.h:30 */
+  int device;      /* HIP device ordinal */
+  int flags;       /* enum ilqr_flags */
+  const double* u_min; /* [nu] Model::u_min (include/model.h:17); NULL = the model's default */
+  const double* u_max; /* [nu] */
+  const double* goal;  /* [nx] DoubleIntegrator(goal) (double_integrator.h:14); NULL = (1,.5,0,0); acrobot ignores it */
+  const double *lq_A, *lq_B, *lq_Q, *lq_R, *lq_Qf; /* ILQR_MODEL_LQ: row-major [nx][nx],[nx][nu],[nx][nx],[nu][nu],[nx][nx] */
+  void* stream;             /* hipStream_t to enqueue on; NULL = the library creates one */
+  const ilqr_params* params; /* NULL = reference defaults */
+} ilqr_desc;
+
+const char* ilqr_last_error(void);
+int ilqr_abi_version(void);
+void ilqr_default_params(ilqr_params* p);
+
+/* iLQR::iLQR(Model*, double), include/ilqr.h:30-44 */
+int ilqr_create(const ilqr_desc* desc, ilqr_batch** out);
+void ilqr_destroy(ilqr_batch* h);
+int ilqr_set_stream(ilqr_batch* h, void* hip_stream);
+int ilqr_synchronize(ilqr_batch* h);
+
+/* ---- whole-solve entry points ------------------------------------------------------------ */
+/* iLQR::init_traj(x0,u0), src/ilqr_core.cpp:11-56: open-loop rollout, zero all derivative and
+ * gain arrays, lambda=dlambda=initial.  cost_out [B] may be NULL. */
+int ilqr_init_traj(ilqr_batch* h, const double* x0, const double* u0, double* cost_out);
+/* iLQR::generate_trajectory(), src/ilqr_core.cpp:79-302, on the state left by init_traj /
+ * previous calls.  Runs until every trajectory has left its loop (max_iter each). */
+int ilqr_generate_trajectory(ilqr_batch* h);
+/* iLQR::generate_trajectory(x0,u0), src/ilqr_core.cpp:59-62 (= BASELINE.json's "iLQR::solve()") */
+int ilqr_solve(ilqr_batch* h, const double* x0, const double* u0);
+/* iLQR::generate_trajectory(x0) (warm start), src/ilqr_core.cpp:65-76: re-roll the stored
+ * controls with the stored gains from new x0 [B][nx]; lambda/dlambda persist as in the reference. */
+int ilqr_warm_start(ilqr_batch* h, const double* x0);
+/* n_iters bodies of the outer for-loop (src/ilqr_core.cpp:103-288) for every trajectory that
+ * is still running; asynchronous (no host synchronisation inside). */
+int ilqr_iterate(ilqr_batch* h, int n_iters);
+
+/* ---- single stages (teacher-forced parity tests, host-model fallback) --------------------- */
+/* STEP 1, src/ilqr_core.cpp:115-120 = src/derivatives.cpp:15-144 over t = 0..T, all trajectories */
+int ilqr_compute_derivatives(ilqr_batch* h);
+/* one iLQR::backward_pass(), src/ilqr_core.cpp:350-401, at the current lambda (no retry).
+ * diverge_out [B] (may be NULL) receives its return value. Also refreshes dV. */
+int ilqr_backward_pass(ilqr_batch* h, int* diverge_out);
+/* STEP 2 incl. the lambda-increase retry loop and the gradient-norm test, ilqr_core.cpp:136-159 */
+int ilqr_backward_step(ilqr_batch* h);
+/* iLQR::forward_pass(x0,u) for u = us + alpha*k, src/ilqr_core.cpp:305-337 with :188-190:
+ * all 11 alphas of include/ilqr.h:24 are rolled out concurrently; cost_out [B][11] may be NULL. */
+int ilqr_rollout_candidates(ilqr_batch* h, double* cost_out);
+/* STEP 3 + STEP 4, src/ilqr_core.cpp:175-282: candidates, first-accept selection in the
+ * reference's serial order, lambda update, termination tests, commit of the accepted one. */
+int ilqr_line_search(ilqr_batch* h);
+
+/* ---- state exchange (canonical host layouts, see top) -------------------------------------- */
+int ilqr_set_trajectory(ilqr_batch* h, const double* x0, const double* xs, const double* us, const double* cost);
+int ilqr_set_gains(ilqr_batch* h, const double* k, const double* K);
+int ilqr_set_derivatives(ilqr_batch* h, const double* fx, const double* fu, const double* cx,
+                         const double* cu, const double* cxx, const double* cxu, const double* cuu);
+int ilqr_set_lambda(ilqr_batch* h, const double* lambda, const double* dlambda); /* [B] each, NULL = keep */
+
+int ilqr_get_trajectory(ilqr_batch* h, double* xs, double* us); /* either may be NULL */
+int ilqr_get_gains(ilqr_batch* h, double* k, double* K);
+int ilqr_get_derivatives(ilqr_batch* h, double* fx, double* fu, double* cx, double* cu,
+                         double* cxx, double* cxu, double* cuu);
+int ilqr_get_cost(ilqr_batch* h, double* cost);                     /* [B] cost_s */
+int ilqr_get_lambda(ilqr_batch* h, double* lambda, double* dlambda); /* [B] */
+int ilqr_get_dV(ilqr_batch* h, double* dV);                         /* [B][2] */
+int ilqr_get_gnorm(ilqr_batch* h, double* gnorm);                   /* [B] */
+int ilqr_get_status(ilqr_batch* h, int* status, int* iters, int* alpha_idx); /* [B] each, any NULL */
+int ilqr_get_candidate(ilqr_batch* h, int alpha_idx, double* xs, double* us); /* one alpha's rollout */
+int ilqr_count_running(ilqr_batch* h, int* n_running);
+/* device-to-device copy of the per-trajectory costs [B] into caller-owned device memory
+ * (the payload of the multi-GPU gather) */
+int ilqr_copy_cost_to_device(ilqr_batch* h, void* dst_device);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+enum ilqr_stage { ILQR_STAGE_DERIVATIVES = 0, ILQR_STAGE_BACKWARD = 1, ILQR_STAGE_ROLLOUT = 2,
+                  ILQR_STAGE_ACCEPT = 3, ILQR_NUM_STAGES = 4 };
+/* HIP-event timing of every kernel launch of a stage, accumulated on the handle's stream. */
+int ilqr_profile_enable(ilqr_batch* h, int enable);
+int ilqr_profile_reset(ilqr_batch* h);
+/* total milliseconds and launch count per stage since the last reset (synchronises) */
+int ilqr_profile_read(ilqr_batch* h, double ms_out[ILQR_NUM_STAGES], int launches_out[ILQR_NUM_STAGES]);
+/* name of the kernel a stage launches (as rocprofv3 reports it), for bench.py's roofline line */
+const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ILQR_AMD_H_ */

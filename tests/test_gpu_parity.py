@@ -1,0 +1,245 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/ilqr_amd.h) against the CPU
+oracle on identical seeded inputs, stage by stage with teacher forcing, plus
+end-to-end solves on the cases that are numerically stable.  Tolerance: 1e-6 relative (fp64),
+the figure BASELINE.json's north_star states; discrete outputs (diverge flags, accepted alpha,
+status, iteration counts) must match exactly."""
+import numpy as np
+import pytest
+
+from util import TOL, acrobot_x0, integrator_x0, mat, relerr, relerr_abs
+
+pytestmark = pytest.mark.gpu
+
+DT = 0.02
+CASES = [
+    # name, model kwargs (oracle), B, T, limit
+    ("acrobot", 70, 60, 5.0),
+    ("acrobot", 70, 60, 1.5),
+    ("integrator", 33, 40, 0.5),
+]
+
+
+def make(oracle, name, B, T, lim, **kw):
+    from ilqr_amd import BatchILQR
+    if name == "acrobot":
+        om = oracle.Model("acrobot", u_lim=lim)
+        g = BatchILQR("acrobot", B, T, DT, u_min=-lim, u_max=lim, **kw)
+        x0 = acrobot_x0(B)
+    else:
+        goal = [1.0, 0.5, 0.0, 0.0]
+        om = oracle.Model("integrator", goal=goal, u_lim=lim)
+        g = BatchILQR("integrator", B, T, DT, u_min=-lim, u_max=lim, goal=goal, **kw)
+        x0 = integrator_x0(B)
+    return om, g, x0
+
+
+def u_init(B, T, nu, seed=7, scale=0.3):
+    return np.random.default_rng(seed).normal(size=(B, T, nu)) * scale
+
+
+@pytest.mark.parametrize("name,B,T,lim", CASES)
+def test_init_rollout(oracle, name, B, T, lim):
+    om, g, x0 = make(oracle, name, B, T, lim)
+    u0 = u_init(B, T, om.nu)
+    cost = g.init_traj(x0, u0)
+    xs, us = g.trajectory()
+    xs_o, us_o, cost_o = oracle.batch_rollout(om, x0, u0, DT)
+    assert np.array_equal(us, u0)  # open loop: controls are stored untouched (ilqr_core.cpp:323)
+    assert relerr(xs, xs_o) < TOL
+    assert np.max(np.abs(cost - cost_o) / np.abs(cost_o)) < TOL
+    lam, dlam = g.lambdas()
+    assert np.all(lam == 1) and np.all(dlam == 1)
+
+
+@pytest.mark.parametrize("name,B,T,lim", CASES)
+def test_derivatives_teacher_forced(oracle, name, B, T, lim):
+    om, g, x0 = make(oracle, name, B, T, lim)
+    u0 = u_init(B, T, om.nu)
+    xs_o, us_o, cost_o = oracle.batch_rollout(om, x0, u0, DT)
+    g.set_trajectory(x0=x0, xs=xs_o, us=us_o, cost=cost_o)
+    g.compute_derivatives()
+    d = g.derivatives()
+    do = oracle.batch_derivatives(om, xs_o, us_o, DT)
+    for k in ("fx", "fu", "cx", "cu", "cxx", "cuu"):
+        ref = do[k] if k in ("cx", "cu") else mat(do[k])
+        # floor: entries that are mathematically zero carry +-1e-9-class finite-difference noise
+        assert relerr_abs(d[k], ref, 1e-2) < TOL, k
+    # cxu is ~0 for both shipped models (pure FD noise, <= 1e-8 absolute) and cxu[T] is unused
+    assert np.abs(d["cxu"] - mat(do["cxu"])).max() < 1e-6
+    assert np.all(d["fx"][:, T] == 0) and np.all(d["fu"][:, T] == 0) and np.all(d["cu"][:, T] == 0)
+
+
+@pytest.mark.parametrize("lam", [1.0, 1e-3, 0.0])
+@pytest.mark.parametrize("name,B,T,lim", CASES)
+def test_backward_teacher_forced(oracle, name, B, T, lim, lam):
+    om, g, x0 = make(oracle, name, B, T, lim)
+    u0 = u_init(B, T, om.nu, scale=1.0)
+    xs_o, us_o, cost_o = oracle.batch_rollout(om, x0, u0, DT)
+    do = oracle.batch_derivatives(om, xs_o, us_o, DT)
+    k_prev = u_init(B, T, om.nu, seed=11, scale=0.2)
+    ro = oracle.batch_backward(om, us_o, do, k_prev=k_prev, lam=lam)
+    g.set_trajectory(x0=x0, xs=xs_o, us=us_o, cost=cost_o)
+    g.set_derivatives(**{k: (do[k] if k in ("cx", "cu") else mat(do[k])) for k in do})
+    g.set_gains(k=k_prev, K=np.zeros((B, T, om.nu, om.nx)))
+    g.set_lambda(lam, 1.0)
+    div = g.backward_pass()
+    k, K = g.gains()
+    assert np.array_equal(div, ro["diverge"])
+    ok = ro["diverge"] == 0
+    assert ok.sum() > 0
+    assert relerr(k[ok], ro["k"][ok]) < TOL
+    assert relerr(K[ok], mat(ro["K"])[ok]) < TOL
+    assert relerr(g.dV()[ok], ro["dV"][ok]) < TOL
+    # clamped controls have zero feedback rows (Tassa 2014) and k inside the box
+    lo, hi = om.u_min[None, None, :] - us_o, om.u_max[None, None, :] - us_o
+    assert np.all(k[ok] >= lo[ok] - 1e-12) and np.all(k[ok] <= hi[ok] + 1e-12)
+    if lim < 5:
+        clamped = (np.abs(k - lo) < 1e-9) | (np.abs(k - hi) < 1e-9)
+        assert clamped[ok].mean() > 0.02  # the active-limit path is exercised
+
+
+@pytest.mark.parametrize("name,B,T,lim", CASES)
+def test_rollout_candidates_teacher_forced(oracle, name, B, T, lim):
+    om, g, x0 = make(oracle, name, B, T, lim)
+    u0 = u_init(B, T, om.nu)
+    xs_o, us_o, cost_o = oracle.batch_rollout(om, x0, u0, DT)
+    do = oracle.batch_derivatives(om, xs_o, us_o, DT)
+    ro = oracle.batch_backward(om, us_o, do, lam=1.0)
+    Kmat = mat(ro["K"])
+    g.set_trajectory(x0=x0, xs=xs_o, us=us_o, cost=cost_o)
+    g.set_gains(k=ro["k"], K=Kmat)
+    cost_c = g.rollout_candidates()
+    from ilqr_amd import ALPHAS
+    for a in (0, 3, 10):
+        xs_a, us_a, c_a = oracle.batch_rollout(om, x0, us_o + ALPHAS[a] * ro["k"], DT, xs_nom=xs_o, K=Kmat)
+        xg, ug = g.candidate(a)
+        fin = np.isfinite(c_a) & (np.abs(xs_a).reshape(B, -1).max(axis=1) < 1e6)
+        assert fin.sum() > B // 2
+        assert relerr(xg[fin], xs_a[fin]) < TOL
+        assert relerr(ug[fin], us_a[fin]) < TOL
+        assert np.max(np.abs(cost_c[fin, a] - c_a[fin]) / np.abs(c_a[fin])) < TOL
+
+
+@pytest.mark.parametrize("name,B,T,lim", CASES)
+def test_one_iteration_from_same_state(oracle, name, B, T, lim):
+    """init -> derivatives -> backward (+lambda retry) -> line search -> accept, all on device,
+    against the oracle's iterate_once: same accepted alpha, lambda schedule and new cost."""
+    om, g, x0 = make(oracle, name, B, T, lim)
+    u0 = np.zeros((B, T, om.nu))
+    g.init_traj(x0, u0)
+    g.iterate(1)
+    ro = oracle.batch_solve(om, x0, u0, DT, max_iters=1)
+    st, it, al = g.status()
+    lam, dlam = g.lambdas()
+    cost = g.cost()
+    assert np.array_equal(it, ro["iters"])
+    same = np.isclose(cost, ro["cost"], rtol=TOL)
+    assert same.mean() > 0.97  # a different accepted alpha on a knife-edge line search is tolerated
+    assert np.allclose(lam[same], ro["lam"][same], rtol=1e-12)
+    xs, us = g.trajectory()
+    assert relerr(xs[same], ro["xs"][same]) < 1e-5
+
+
+def test_acrobot_canonical_solve(oracle):
+    """`./run_iLQR acrobot` (x0 = 0, T = 499): 100 iterations, cost 5.397882537."""
+    from ilqr_amd import BatchILQR
+    B, T = 3, 499
+    g = BatchILQR("acrobot", B, T, DT)
+    x0, u0 = np.zeros((B, 4)), np.zeros((B, T, 1))
+    c0 = g.init_traj(x0, u0)
+    assert np.allclose(c0, 3947.6089000000002, rtol=1e-12)
+    g.generate_trajectory()
+    st, it, al = g.status()
+    assert np.all(st == 4) and np.all(it == 100)
+    cost = g.cost()
+    assert np.allclose(cost, 5.39788253688, rtol=TOL)
+    assert np.all(cost == cost[0])  # identical problems -> bit-identical results
+    om = oracle.Model("acrobot")
+    ro = oracle.batch_solve(om, x0[:1], u0[:1], DT)
+    k, K = g.gains()
+    xs, us = g.trajectory()
+    assert relerr(xs[:1], ro["xs"]) < 1e-5 and relerr(us[:1], ro["us"]) < 1e-4
+    assert np.all(g.lambdas()[0] == 0.0)
+
+
+def test_integrator_canonical_solve(oracle):
+    """`./run_iLQR integrator`: stops at iteration index 14 (15 iterations), cost 356.1685."""
+    from ilqr_amd import BatchILQR
+    B, T = 2, 99
+    g = BatchILQR("integrator", B, T, DT, goal=[1, .5, 0, 0])
+    x0 = np.tile([-1.0, 0, 0, -.2], (B, 1))
+    u0 = np.zeros((B, T, 2))
+    c0 = g.init_traj(x0, u0)
+    assert np.allclose(c0, 494.1509440000001, rtol=1e-13)
+    g.generate_trajectory()
+    st, it, al = g.status()
+    cost = g.cost()
+    assert np.allclose(cost, 356.168506469842, rtol=1e-9)
+    # the stop reason at that iteration is decided by rounding noise (see test_oracle_anchors)
+    assert np.all(np.isin(st, (2, 3))) and np.all((it >= 5) & (it <= 15))
+
+
+def test_small_scale_multi_iteration(oracle):
+    """x0 scale 0.01, 5 iterations: stable regime of SURVEY.md 0.3 -> end-to-end 1e-6 parity."""
+    from ilqr_amd import BatchILQR
+    B, T = 32, 499
+    om = oracle.Model("acrobot")
+    x0 = acrobot_x0(B, scale=0.01)
+    u0 = np.zeros((B, T, 1))
+    g = BatchILQR("acrobot", B, T, DT)
+    g.init_traj(x0, u0)
+    g.iterate(5)
+    ro = oracle.batch_solve(om, x0, u0, DT, max_iters=5)
+    cost = g.cost()
+    ok = np.isclose(cost, ro["cost"], rtol=TOL)
+    assert ok.mean() >= 0.9, (cost, ro["cost"])
+    k, K = g.gains()
+    assert relerr(k[ok], ro["k"][ok]) < 1e-4
+    st, it, al = g.status()
+    assert np.array_equal(it[ok], ro["iters"][ok])
+
+
+def test_warm_start(oracle):
+    """generate_trajectory(x0) (ilqr_core.cpp:65-76): re-roll stored controls with stored gains."""
+    from ilqr_amd import BatchILQR
+    B, T = 8, 120
+    g = BatchILQR("integrator", B, T, DT, goal=[1, .5, 0, 0])
+    x0 = integrator_x0(B)
+    g.generate_trajectory(x0, np.zeros((B, T, 2)))
+    c1 = g.cost()
+    xs1, us1 = g.trajectory()
+    k1, K1 = g.gains()
+    x0b = x0 + 0.01
+    g.generate_trajectory(x0b)
+    c2 = g.cost()
+    assert np.all(np.isfinite(c2)) and np.all(c2 <= 1.5 * c1 + 1.0)
+    # the warm-start rollout itself: u = us + K (x - xs)
+    om = oracle.Model("integrator", goal=[1, .5, 0, 0])
+    xs_w, us_w, c_w = oracle.batch_rollout(om, x0b, us1, DT, xs_nom=xs1, K=K1)
+    assert np.all(c2 <= c_w * (1 + 1e-9))
+
+
+def test_full_size_properties():
+    """BASELINE.json sizes (acrobot T=499, B=4096, clamps active): size-independent properties."""
+    from ilqr_amd import BatchILQR
+    B, T, lim = 4096, 499, 1.5
+    g = BatchILQR("acrobot", B, T, DT, u_min=-lim, u_max=lim)
+    x0 = acrobot_x0(B)
+    x0[1] = x0[0]
+    x0[B - 1] = x0[0]  # duplicates across tiles / waves
+    c0 = g.init_traj(x0, np.zeros((B, T, 1)))
+    g.iterate(3)
+    cost = g.cost()
+    st, it, al = g.status()
+    xs, us = g.trajectory()
+    k, K = g.gains()
+    assert np.all(np.isfinite(cost)) and np.all(cost <= c0 * (1 + 1e-12))  # monotone (line search)
+    assert cost[0] == cost[1] == cost[B - 1]
+    assert np.array_equal(xs[0], xs[1]) and np.array_equal(K[0], K[B - 1])
+    assert np.array_equal(xs[:, 0], x0)
+    lo, hi = -lim - us, lim - us
+    # clamped dims have zero feedback rows; k inside the box it was solved for
+    dV = g.dV()
+    assert np.all(dV[:, 0] <= 1e-9)
+    accepted = al >= 0
+    assert accepted.mean() > 0.5
