@@ -15,10 +15,13 @@
 #pragma once
 #include "common.hpp"
 
+// host+device so the very same source can be unit-tested on the CPU (tests/native)
+#define ILQR_HD __host__ __device__ __forceinline__
+
 namespace ilqr {
 
 template <int M>
-__device__ __forceinline__ void clamp_to_limits(const double* x, const double* lo, const double* hi, double* out) {
+ILQR_HD void clamp_to_limits(const double* x, const double* lo, const double* hi, double* out) {
 #pragma unroll
   for (int i = 0; i < M; i++) {  // include/boxqp.h:48-51  upper.cwiseMin(x.cwiseMax(lower))
     const double a = (x[i] < lo[i]) ? lo[i] : x[i];
@@ -27,7 +30,7 @@ __device__ __forceinline__ void clamp_to_limits(const double* x, const double* l
 }
 
 template <int M>
-__device__ __forceinline__ double quad_cost(const double* Q, const double* c, const double* x) {
+ILQR_HD double quad_cost(const double* Q, const double* c, const double* x) {
   double quad = 0, lin = 0;  // include/boxqp.h:53-55   ((0.5 x')Q) x + x.c
 #pragma unroll
   for (int j = 0; j < M; j++) {
@@ -42,7 +45,7 @@ __device__ __forceinline__ double quad_cost(const double* Q, const double* c, co
 }
 
 template <int M>
-__device__ __forceinline__ void matvec(const double* Q, const double* x, double* y) {
+ILQR_HD void matvec(const double* Q, const double* x, double* y) {
 #pragma unroll
   for (int i = 0; i < M; i++) {
     double s = 0;
@@ -55,7 +58,7 @@ __device__ __forceinline__ void matvec(const double* Q, const double* x, double*
 // src/boxqp.cpp:143-178.  Returns failed; x_opt/v_opt are written unless the direction is not
 // a descent direction (:151-154).
 template <int M>
-__device__ __forceinline__ bool quadclamp_line_search(const double* x0, const double* dir, const double* Q,
+ILQR_HD bool quadclamp_line_search(const double* x0, const double* dir, const double* Q,
                                                       const double* c, const double* lo, const double* hi,
                                                       double* x_opt, double& v_opt) {
   double grad[M], xr[M], xc[M];
@@ -90,7 +93,7 @@ __device__ __forceinline__ bool quadclamp_line_search(const double* x0, const do
 
 // Eigen 3.3.4 llt_inplace<Lower>::unblocked on the leading nf x nf block (ld = M).
 template <int M>
-__device__ __forceinline__ void llt_lower(int nf, double* A) {
+ILQR_HD void llt_lower(int nf, double* A) {
   bool stop = false;
 #pragma unroll
   for (int k = 0; k < M; k++) {
@@ -125,7 +128,7 @@ __device__ __forceinline__ void llt_lower(int nf, double* A) {
 // Minv = R^-1 R^-T for the upper-triangular leading nf x nf block of R (ld = M).
 // (The reference: two PartialPivLU inverses and a product, boxqp.cpp:105-112, ilqr_core.cpp:379.)
 template <int M>
-__device__ __forceinline__ void rinv_rinvT(int nf, const double* R, double* Minv) {
+ILQR_HD void rinv_rinvT(int nf, const double* R, double* Minv) {
   double Ri[M * M];
 #pragma unroll
   for (int e = 0; e < M * M; e++) Ri[e] = 0;
@@ -169,7 +172,7 @@ struct BoxQPResult {
 
 // src/boxqp.cpp:26-139
 template <int M>
-__device__ __forceinline__ void box_qp(const double* Q, const double* c, const double* x0, const double* lo,
+ILQR_HD void box_qp(const double* Q, const double* c, const double* x0, const double* lo,
                                        const double* hi, BoxQPResult<M>& res) {
   double x[M], grad[M], gc[M], search[M], tmp[M];
   double clamped[M], old_clamped[M];

@@ -1,0 +1,29 @@
+// Host-side instantiation of the product's device functions (boxqp.hpp is __host__ __device__)
+// so their logic can be unit-tested on a machine without a GPU.  TEST INFRASTRUCTURE.
+#include "../../ilqr_amd/csrc/boxqp.hpp"
+using namespace ilqr;
+
+template <int M>
+static int run(const double* Q, const double* c, const double* x0, const double* lo, const double* hi, double* x,
+               int* vfree, double* R, int* nfR) {
+  BoxQPResult<M> r;
+  box_qp<M>(Q, c, x0, lo, hi, r);
+  for (int i = 0; i < M; i++) {
+    x[i] = r.x[i];
+    vfree[i] = r.v_free[i];
+  }
+  for (int e = 0; e < M * M; e++) R[e] = r.R[e];
+  *nfR = r.nfR;
+  return r.result;
+}
+
+extern "C" int devfn_box_qp(int m, const double* Q, const double* c, const double* x0, const double* lo,
+                            const double* hi, double* x, int* vfree, double* R, int* nfR) {
+  switch (m) {
+    case 1: return run<1>(Q, c, x0, lo, hi, x, vfree, R, nfR);
+    case 2: return run<2>(Q, c, x0, lo, hi, x, vfree, R, nfR);
+    case 3: return run<3>(Q, c, x0, lo, hi, x, vfree, R, nfR);
+    case 4: return run<4>(Q, c, x0, lo, hi, x, vfree, R, nfR);
+    default: return -100;
+  }
+}
