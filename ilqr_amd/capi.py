@@ -90,7 +90,8 @@ def load(build_if_missing=True):
         if not os.path.exists(_build.LIB):
             raise ILQRError("libilqr_amd.so is missing (%s): build it with "
                             "`python -m ilqr_amd._build`; there is no fallback path" % _build.LIB)
-        lib = C.CDLL(_build.LIB)
+        # ILQR_AMD_LIB selects an experiment build of the same sources (e.g. -DILQR_PHASE_TIMING)
+        lib = C.CDLL(os.environ.get("ILQR_AMD_LIB", _build.LIB))
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)
             fn.restype = res

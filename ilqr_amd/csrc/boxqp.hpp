@@ -322,4 +322,200 @@ ILQR_HD void box_qp(const double* Q, const double* c, const double* x0, const do
   res.nfR = nfR;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// M = 1 fast path (acrobot, the headline configuration): the same projected-Newton iteration as
+// box_qp<1>, written out for a scalar so that the dependent chain is short.  Differences from
+// the literal restatement are all at rounding level and documented here:
+//   - the factor R = sqrt(Q) is never formed: (R^-1 R^-T) = 1/Q for Q > 0, and 1/Q^2 for the
+//     unchecked-LLT-failure case Q <= 0 where the reference ends up with R = Q;
+//   - |g| < minGrad instead of sqrt(g*g) < minGrad;
+//   - the Armijo test (v - old_v)/(step*slope) < 0.1 is evaluated without the division as
+//     (v - old_v) > 0.1*(step*slope), valid because step*slope < 0 on that path;
+//   - grad_clamped = Q*(x*0) + c is taken as c.
+// Outputs: x (= k), free (v_free[0]), minv = (R^-1 R^-T) of the factor held at exit.
+// ------------------------------------------------------------------------------------------
+ILQR_HD int box_qp_scalar(double Q, double c, double x0, double lo, double hi, double& x_out, int& free_out,
+                          double& minv_out) {
+  double x = (x0 < lo) ? lo : x0;
+  x = (hi < x) ? hi : x;
+  double val = (x * Q) * x + x * c;  // boxqp.cpp:36 (no 1/2)
+  double oldvalue = 0;
+  const double minv = (Q > 0.0) ? 1.0 / Q : 1.0 / (Q * Q);
+  int result = 0;
+  int free_ = 0;
+  for (int iter = 0; iter <= kQpMaxIter; iter++) {
+    if (iter > 0 && (oldvalue - val) < kMinRelImprove * fabs(oldvalue)) {
+      result = 4;
+      break;
+    }
+    const double grad = Q * x + c;
+    oldvalue = val;
+    const bool cl = (fabs(x - lo) < kClampTol && grad > 0) || (fabs(x - hi) < kClampTol && grad < 0);
+    if (cl) {
+      free_ = 0;
+      result = 6;
+      break;
+    }
+    free_ = 1;
+    if (fabs(grad) < kMinGrad) {
+      result = 5;
+      break;
+    }
+    const double search = -minv * c - x;
+    const double slope = search * grad;
+    if (slope >= 0) {
+      result = 2;
+      break;
+    }
+    double step = 1;
+    double xc = x + step * search;
+    xc = (xc < lo) ? lo : xc;
+    xc = (hi < xc) ? hi : xc;
+    double v = ((0.5 * xc) * Q) * xc + xc * c;
+    const double old_v = ((0.5 * x) * Q) * x + x * c;
+    bool failed = false;
+    while ((v - old_v) > kArmijo * (step * slope)) {
+      step *= kStepDec;
+      xc = x + step * search;
+      xc = (xc < lo) ? lo : xc;
+      xc = (hi < xc) ? hi : xc;
+      v = ((0.5 * xc) * Q) * xc + xc * c;
+      if (step < kMinStep) {
+        failed = true;
+        break;
+      }
+    }
+    if (failed) {
+      result = 2;
+      break;
+    }
+    x = xc;
+    val = v;
+  }
+  x_out = x;
+  free_out = free_;
+  minv_out = minv;
+  return result;
+}
+
+
+// Mostly straight-line evaluation of the first two projected-Newton iterations of box_qp_scalar.
+// With one wavefront holding 16 trajectories, data-dependent loops cost every lane the worst
+// lane's trip count plus an exec-mask round trip per branch, while on the acrobot workload every
+// QP leaves within two iterations through one of:
+//   A  all clamped at iter 0 (result 6, ~85 % with u in [-1.5,1.5])
+//   B  |grad| < minGrad at iter 0 (5)       C  not a descent direction (2)
+//   D  no improvement at iter 1 (4)         E  clamped at iter 1 (6)       F  |grad| < minGrad at iter 1 (5)
+// The evaluation is split in three so that the kernel can replace the sequential Armijo
+// backtracking (a Newton step truncated by a bound to < ~10 % of its length fails the test at
+// step 1 -- ~10 % of the QPs, i.e. most wavefronts) by a quad-parallel search:
+//   qp1_begin  iteration 0 up to the unit-step trial point
+//   qp1_backtrack_seq  the loop of boxqp.cpp:161-173 as written
+//   qp1_finish iteration 1's exit tests and the result ladder
+// box_qp_scalar_fast composes them sequentially (host tests, fallback).  A result of -1 means a
+// third iteration would be needed: the caller then runs box_qp_scalar (same answer).
+struct QP1State {
+  double Q, c, lo, hi;
+  double x, val0, g0, minv, search, slope, old_v;
+  double x1, v1, step;
+  bool clA, exB, exC, early, ls_failed;
+};
+
+ILQR_HD double qp1_value(const QP1State& q, double xx) { return ((0.5 * xx) * q.Q) * xx + xx * q.c; }
+ILQR_HD double qp1_trial(const QP1State& q, double step) { return fmin(fmax(q.x + step * q.search, q.lo), q.hi); }
+// Armijo test of boxqp.cpp:161 without the division (step*slope < 0 on this path)
+ILQR_HD bool qp1_armijo_fails(const QP1State& q, double v, double step) {
+  return (v - q.old_v) > kArmijo * (step * q.slope);
+}
+
+ILQR_HD void qp1_begin(double Q, double c, double x0, double lo, double hi, QP1State& q) {
+  q.Q = Q;
+  q.c = c;
+  q.lo = lo;
+  q.hi = hi;
+  q.x = fmin(fmax(x0, lo), hi);  // == clamp_to_limits for non-NaN input
+  q.val0 = (q.x * Q) * q.x + q.x * c;  // boxqp.cpp:36 (no 1/2)
+  q.g0 = Q * q.x + c;
+  const double den = (Q > 0.0) ? Q : Q * Q;
+  q.minv = 1.0 / den;
+  q.clA = (fabs(q.x - lo) < kClampTol && q.g0 > 0) || (fabs(q.x - hi) < kClampTol && q.g0 < 0);
+  q.exB = fabs(q.g0) < kMinGrad;
+  q.search = -q.minv * c - q.x;
+  q.slope = q.search * q.g0;
+  q.exC = q.slope >= 0;
+  q.early = q.clA || q.exB || q.exC;
+  q.step = 1;
+  q.x1 = qp1_trial(q, 1.0);
+  q.v1 = qp1_value(q, q.x1);
+  q.old_v = qp1_value(q, q.x);
+  q.ls_failed = false;
+}
+
+ILQR_HD void qp1_backtrack_seq(QP1State& q) {  // boxqp.cpp:161-173
+  while (!q.early && qp1_armijo_fails(q, q.v1, q.step)) {
+    q.step *= kStepDec;
+    q.x1 = qp1_trial(q, q.step);
+    q.v1 = qp1_value(q, q.x1);
+    if (q.step < kMinStep) {
+      q.ls_failed = true;
+      break;
+    }
+  }
+}
+
+ILQR_HD int qp1_finish(const QP1State& q, double& x_out, int& free_out, double& minv_out) {
+  const bool exD = (q.val0 - q.v1) < kMinRelImprove * fabs(q.val0);
+  const double g1 = q.Q * q.x1 + q.c;
+  const bool clE = (fabs(q.x1 - q.lo) < kClampTol && g1 > 0) || (fabs(q.x1 - q.hi) < kClampTol && g1 < 0);
+  const bool exF = fabs(g1) < kMinGrad;
+  minv_out = q.minv;
+  int result;
+  double xo = q.x;
+  int fr = 1;
+  if (q.clA) {  // the reference's order of tests
+    result = 6;
+    fr = 0;
+  } else if (q.exB) {
+    result = 5;
+  } else if (q.exC || q.ls_failed) {
+    result = 2;
+  } else {
+    xo = q.x1;
+    if (exD) {
+      result = 4;
+    } else if (clE) {
+      result = 6;
+      fr = 0;
+    } else if (exF) {
+      result = 5;
+    } else {
+      result = -1;
+    }
+  }
+  x_out = xo;
+  free_out = fr;
+  return result;
+}
+
+ILQR_HD int box_qp_scalar_fast(double Q, double c, double x0, double lo, double hi, double& x_out, int& free_out,
+                               double& minv_out) {
+  QP1State q;
+  qp1_begin(Q, c, x0, lo, hi, q);
+  qp1_backtrack_seq(q);
+  return qp1_finish(q, x_out, free_out, minv_out);
+}
+
+// step sizes of the backtracking loop, exactly as it produces them: s[0] = 1, s[k+1] = s[k]*0.6
+struct StepTable {
+  double s[104];
+  constexpr StepTable() : s() {
+    double v = 1.0;
+    for (int k = 0; k < 104; k++) {
+      s[k] = v;
+      v = v * kStepDec;
+    }
+  }
+};
+
 }  // namespace ilqr

@@ -228,14 +228,29 @@ static int launch_derivatives(ilqr_batch* h, int force) {
   return timer_end(h, ILQR_STAGE_DERIVATIVES, ev);
 }
 
+static bool use_quad_backward(const ilqr_batch* h) {
+  if (h->nx != 4) return false;
+  if (h->flags & ILQR_FLAG_BACKWARD_THREAD_PER_TRAJ) return false;
+  return true;
+}
+
 static int launch_backward(ilqr_batch* h, int mode) {
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_BACKWARD, &ev)) return rc;
-  dim3 grid(h->Bp / 64), block(64);
-  switch (h->model) {
-    case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_backward_t<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, h->sp, mode); break;
-    case ILQR_MODEL_DOUBLE_INTEGRATOR: hipLaunchKernelGGL((k_backward_t<DoubleIntegratorModel>), grid, block, 0, h->stream, h->v, h->dint, h->sp, mode); break;
-    default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device backward pass yet", h->model);
+  if (use_quad_backward(h)) {
+    dim3 grid(h->ntiles), block(64);  // one wavefront = one tile of 16 trajectories x 4 lanes
+    switch (h->model) {
+      case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_backward_q<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, h->sp, mode); break;
+      case ILQR_MODEL_DOUBLE_INTEGRATOR: hipLaunchKernelGGL((k_backward_q<DoubleIntegratorModel>), grid, block, 0, h->stream, h->v, h->dint, h->sp, mode); break;
+      default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device backward pass yet", h->model);
+    }
+  } else {
+    dim3 grid(h->Bp / 64), block(64);
+    switch (h->model) {
+      case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_backward_t<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, h->sp, mode); break;
+      case ILQR_MODEL_DOUBLE_INTEGRATOR: hipLaunchKernelGGL((k_backward_t<DoubleIntegratorModel>), grid, block, 0, h->stream, h->v, h->dint, h->sp, mode); break;
+      default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device backward pass yet", h->model);
+    }
   }
   HIPCHK(hipGetLastError());
   return timer_end(h, ILQR_STAGE_BACKWARD, ev);
@@ -293,6 +308,19 @@ void ilqr_destroy(ilqr_batch* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+#ifdef ILQR_PHASE_TIMING
+  if (h->v.dbg) {
+    long long d[64 * 8];
+    if (hipMemcpy(d, h->v.dbg, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess) {
+      static const char* nm[8] = {"load-issue", "Q-products", "slowQP+K", "V-update+dpp", "vmcnt-wait", "stores", "fastQP", "slow-path steps/T"};
+      for (int t = 0; t < 3; t++) {
+        fprintf(stderr, "[phase timing, tile %d, last backward pass] ", t * 20);
+        for (int q = 0; q < 8; q++) fprintf(stderr, "%s %.2f  ", nm[q], (double)d[t * 20 * 8 + q] / h->T);
+        fprintf(stderr, "\n");
+      }
+    }
+  }
+#endif
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->staging) (void)hipFree(h->staging);
   for (auto& t : h->timers) {
@@ -387,6 +415,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   rc |= dev_alloc(h, &v.backpass_done, Bp);
   rc |= dev_alloc(h, &v.n_running, 1);
   rc |= dev_alloc(h, &h->commit_idx, Bp);
+  rc |= dev_alloc(h, &v.dbg, 64 * 8);
   if (rc) return ILQR_ERR_HIP;
 
   h->sp.max_iter = h->params.max_iter;
@@ -723,10 +752,9 @@ int ilqr_profile_read(ilqr_batch* h, double ms_out[ILQR_NUM_STAGES], int launche
   return 0;
 }
 const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
-  (void)h;
   switch (stage) {
     case ILQR_STAGE_DERIVATIVES: return "k_derivatives";
-    case ILQR_STAGE_BACKWARD: return "k_backward_t";
+    case ILQR_STAGE_BACKWARD: return (h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t";
     case ILQR_STAGE_ROLLOUT: return "k_rollout";
     case ILQR_STAGE_ACCEPT: return "k_accept+k_commit";
     default: return "";

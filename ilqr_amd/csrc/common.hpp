@@ -88,6 +88,7 @@ struct BatchView {
   int* diverge;       // return value of the last backward_pass()
   int* backpass_done; // ilqr_core.cpp:136
   int* n_running;     // [1] device counter
+  long long* dbg;     // phase-timing scratch (only used by -DILQR_PHASE_TIMING experiment builds)
 };
 
 }  // namespace ilqr

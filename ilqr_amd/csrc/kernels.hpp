@@ -621,6 +621,498 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
 }
 
 // ------------------------------------------------------------------------------------------
+// backward pass, one QUAD of lanes per trajectory (NX == 4): one wavefront = one tile of 16
+// trajectories.  Lane (l, s) = 4 l + s owns column s of every nx-by-nx quantity of trajectory l;
+// the small dense products are split by column, the box-QP (m x m, scalar-sized) is evaluated
+// redundantly by the four lanes, and columns are exchanged with DPP quad_perm broadcasts
+// (v_mov_b32 dpp, no LDS).  The derivative records of step i-1 are prefetched into a second
+// register set while step i computes: the recursion never waits on HBM.
+// ------------------------------------------------------------------------------------------
+template <int SRC>
+__device__ __forceinline__ double quad_bcast(double x) {
+  constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);  // quad_perm:[SRC,SRC,SRC,SRC]
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void quad_gather(double x, double out[4]) {
+  out[0] = quad_bcast<0>(x);
+  out[1] = quad_bcast<1>(x);
+  out[2] = quad_bcast<2>(x);
+  out[3] = quad_bcast<3>(x);
+}
+
+__device__ __constant__ const StepTable kStepTable{};
+
+// Quad-parallel Armijo backtracking for the scalar QP (all four lanes of a quad hold the same
+// QP1State).  The sequential loop tries step_k = 0.6^k for k = 1, 2, ... until the test passes;
+// a Newton step that a bound truncates to a tiny fraction needs 10+ trips, and a wavefront pays
+// for its slowest quad.  For Q > 0 the set of passing k is upward closed (while the trial point
+// sits on the bound the value is constant and the threshold shrinks with the step; once it is
+// inside the bound a Newton step always passes), so: estimate k from the two thresholds, let
+// lane s evaluate the exact test at k_g-2+s, and accept the first passing k if k_g-2 fails.
+// Anything else (estimate off, Q <= 0, k near the minStep cut-off) returns false and the caller
+// runs the sequential loop -- the result is the same either way.
+__device__ __forceinline__ bool qp1_backtrack_quad(QP1State& q, int s, int l, const double* __restrict__ lds_steps) {
+  const bool need = !q.early && qp1_armijo_fails(q, q.v1, 1.0);
+  bool handled = !need;
+  if (__any(need)) {
+    const double bound = (q.search > 0) ? q.hi : q.lo;
+    const double f = (bound - q.x) / q.search;                      // fraction of the step inside the box
+    const double r = (q.v1 - q.old_v) / (kArmijo * q.slope);        // Armijo threshold while on the bound
+    const float thr = (float)fmax(r, f);
+    int kg = (int)ceilf(__log2f(thr) * -1.35691545f);               // 1/log2(0.6)
+    const bool sane = need && (q.Q > 0.0) && (thr > 0.f) && (thr < 1.f) && (kg >= 1) && (kg <= 96);
+    kg = sane ? kg : 2;
+    const int my_k = kg - 2 + s;
+    const double my_step = lds_steps[my_k > 0 ? my_k : 0];
+    const double my_x1 = qp1_trial(q, my_step);
+    const double my_v1 = qp1_value(q, my_x1);
+    const bool my_pass = (my_k >= 1) && !qp1_armijo_fails(q, my_v1, my_step);
+    const unsigned long long bal = __ballot(my_pass);
+    const unsigned int m4 = (unsigned int)(bal >> (4 * l)) & 0xFu;
+    // k_g-2 must fail (or be k=0, which is known to fail); the first passing k of the window wins
+    const bool valid = sane && ((m4 & 1u) == 0u) && (m4 != 0u);
+    if (valid) {
+      const int first = __ffs(m4) - 1;
+      const double st = lds_steps[kg - 2 + first];
+      q.step = st;
+      q.x1 = qp1_trial(q, st);
+      q.v1 = qp1_value(q, q.x1);
+      handled = true;
+    }
+  }
+  return handled;
+}
+
+template <int NU>
+struct QuadStep {  // what lane (l, s) needs of one derivative record
+  double fx[16];     // full fx (replicated over s)
+  double fxc[4];     // fx[:, s] again, loaded by address so no register array is indexed by s
+  double fu[4 * NU]; // full fu
+  double cu[NU], cuu[NU * NU], us[NU];
+  double cx;         // cx[s]
+  double cxx[4];     // cxx[:, s]
+  double cxu[NU];    // cxu[s, :]
+};
+
+template <class M>
+__global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverParams sp, int mode) {
+  static_assert(M::NX == 4, "quad kernel: one lane per state dimension");
+  constexpr int NX = 4, NU = M::NU;
+  using R = Rec<NX, NU>;
+  __shared__ double lds_steps[104];  // backtracking step sizes (per-lane indexed -> LDS, not constant cache)
+  for (int k = threadIdx.x; k < 104; k += 64) lds_steps[k] = kStepTable.s[k];
+  __syncthreads();
+  const int lane = threadIdx.x;
+  const int l = lane >> 2, s = lane & 3;
+  const int tile = blockIdx.x;
+  const int b = tile * TW + l;
+  if (b >= v.B) return;                        // quad-uniform
+  if (mode == 1 && v.status[b] != 0) return;   // quad-uniform
+  const int T = v.T;
+  double lambda = v.lambda[b], dlambda = v.dlambda[b];
+  const double* __restrict__ Dt = v.D + tidx(tile, 0, 0, l, T + 1, R::SIZE);
+  const double* __restrict__ ust = v.us + tidx(tile, 0, 0, l, T, NU);
+  double* __restrict__ kt = v.kff + tidx(tile, 0, 0, l, T, NU);
+  double* __restrict__ Kt = v.Kfb + tidx(tile, 0, 0, l, T, NU * NX);
+
+  auto load = [&](int t, QuadStep<NU>& d) {
+    const double* r = Dt + (size_t)t * R::SIZE * TW;
+#pragma unroll
+    for (int e = 0; e < 16; e++) d.fx[e] = r[(R::FX + e) * TW];
+#pragma unroll
+    for (int q = 0; q < 4; q++) d.fxc[q] = r[(R::FX + q + 4 * s) * TW];
+#pragma unroll
+    for (int e = 0; e < 4 * NU; e++) d.fu[e] = r[(R::FU + e) * TW];
+#pragma unroll
+    for (int e = 0; e < NU; e++) d.cu[e] = r[(R::CU + e) * TW];
+#pragma unroll
+    for (int e = 0; e < NU * NU; e++) d.cuu[e] = r[(R::CUU + e) * TW];
+    d.cx = r[(R::CX + s) * TW];
+#pragma unroll
+    for (int i = 0; i < 4; i++) d.cxx[i] = r[(R::CXX + i + 4 * s) * TW];
+#pragma unroll
+    for (int a = 0; a < NU; a++) d.cxu[a] = r[(R::CXU + s + 4 * a) * TW];
+#pragma unroll
+    for (int a = 0; a < NU; a++) d.us[a] = ust[((size_t)t * NU + a) * TW];
+  };
+
+  constexpr int kWaitAll = (7 << 4) | (15 << 8);  // s_waitcnt vmcnt(0) only (expcnt/lgkmcnt untouched)
+  int diverge = 0;
+  bool done = false;
+  double dV0 = 0, dV1 = 0, gacc = 0;
+  while (true) {
+    // carried state: full Vxx / Vx in every lane
+    double Vx[4], Vxx[16], kprev[NU];
+    {
+      const double* r = Dt + (size_t)T * R::SIZE * TW;
+#pragma unroll
+      for (int i = 0; i < 4; i++) Vx[i] = r[(R::CX + i) * TW];  // :353
+#pragma unroll
+      for (int e = 0; e < 16; e++) Vxx[e] = r[(R::CXX + e) * TW];  // :354
+    }
+#pragma unroll
+    for (int a = 0; a < NU; a++) kprev[a] = kt[((size_t)(T - 1) * NU + a) * TW];
+    dV0 = dV1 = 0;
+    diverge = 0;
+    gacc = 0;
+
+#ifdef ILQR_PHASE_TIMING
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tmark = clock64();
+#define ILQR_MARK(k) { __builtin_amdgcn_sched_barrier(0); const long long tn_ = clock64(); ph[k] += tn_ - tmark; tmark = tn_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define ILQR_MARK(k)
+#endif
+    // one Riccati step; returns false if the box-QP reports failure (ilqr_core.cpp:371)
+    auto step = [&](int i, const QuadStep<NU>& d) -> bool {
+      ILQR_MARK(0)  // load issue + loop overhead
+      // W = Vxx' * fx[:, s]   (column s)
+      double W[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        double acc = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc += Vxx[r + 4 * q] * d.fxc[q];
+        W[r] = acc;
+      }
+      // Qxx[:, s] = cxx[:, s] + fx' W      :361
+      double Qxxc[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        double acc = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc += d.fx[q + 4 * r] * W[q];
+        Qxxc[r] = d.cxx[r] + acc;
+      }
+      // Qx[s] = cx[s] + fx[:, s]' Vx'      :359
+      double Qxs;
+      {
+        double acc = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc += d.fxc[q] * Vx[q];
+        Qxs = d.cx + acc;
+      }
+      // Qux[:, s] = cxu[s, :]' + fu' W     :362/:366
+      double Quxc[NU];
+#pragma unroll
+      for (int a = 0; a < NU; a++) {
+        double acc = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc += d.fu[q + 4 * a] * W[q];
+        Quxc[a] = d.cxu[a] + acc;
+      }
+      // replicated: Qu, wv = Vxx' fu, Quu, QuuF     :360, :363, :367
+      double Qu[NU], Quu[NU * NU], QuuF[NU * NU];
+#pragma unroll
+      for (int a = 0; a < NU; a++) {
+        double acc = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc += d.fu[q + 4 * a] * Vx[q];
+        Qu[a] = d.cu[a] + acc;
+      }
+#pragma unroll
+      for (int c = 0; c < NU; c++) {
+        double wv[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          double acc = 0;
+#pragma unroll
+          for (int q = 0; q < 4; q++) acc += Vxx[r + 4 * q] * d.fu[q + 4 * c];
+          wv[r] = acc;
+        }
+#pragma unroll
+        for (int a = 0; a < NU; a++) {
+          double acc = 0;
+#pragma unroll
+          for (int q = 0; q < 4; q++) acc += d.fu[q + 4 * a] * wv[q];
+          Quu[a + NU * c] = d.cuu[a + NU * c] + acc;
+          QuuF[a + NU * c] = (d.cuu[a + NU * c] + ((a == c) ? lambda : 0.0)) + acc;
+        }
+      }
+      ILQR_MARK(1)  // Q-function products
+      // :369  box-QP (replicated in the quad)
+      double lo[NU], hi[NU];
+#pragma unroll
+      for (int a = 0; a < NU; a++) {
+        lo[a] = model.u_min[a] - d.us[a];
+        hi[a] = model.u_max[a] - d.us[a];
+      }
+      // :371  a failed QP ends the pass.  No early return: the rest of the step is computed
+      // anyway (its results are discarded) so that the vmcnt wait below sits on every path.
+      struct { double x[NU]; } qp;
+      double Kc[NU];
+      bool ok;
+      if constexpr (NU == 1) {
+        int free0;
+        double minv;
+        QP1State q1;
+        qp1_begin(QuuF[0], Qu[0], kprev[0], lo[0], hi[0], q1);
+        if (!qp1_backtrack_quad(q1, s, l, lds_steps)) qp1_backtrack_seq(q1);  // fallback: rare
+        int result = qp1_finish(q1, qp.x[0], free0, minv);
+        ILQR_MARK(6)  // fast QP
+#ifdef ILQR_PHASE_TIMING
+        if (__any(result < 0)) ph[7] += 1;
+#endif
+        if (result < 0)  // rare: a third Newton iteration
+          result = box_qp_scalar(QuuF[0], Qu[0], kprev[0], lo[0], hi[0], qp.x[0], free0, minv);
+        ok = result >= 1;
+        Kc[0] = free0 ? -minv * Quxc[0] : 0.0;  // :373-385
+      } else {
+        BoxQPResult<NU> r;
+        box_qp<NU>(QuuF, Qu, kprev, lo, hi, r);
+        ok = r.result >= 1;
+#pragma unroll
+        for (int a = 0; a < NU; a++) {
+          qp.x[a] = r.x[a];
+          Kc[a] = 0;
+        }
+        // :373-385  K[:, s] = -(R^-1 R^-T) Qux[free, s] scattered to the free rows
+        int rank[NU], nf = 0;
+#pragma unroll
+        for (int a = 0; a < NU; a++) {
+          rank[a] = nf;
+          nf += r.v_free[a] ? 1 : 0;
+        }
+        if (nf > 0) {
+          double Minv[NU * NU], qf[NU];
+          rinv_rinvT<NU>(r.nfR, r.R, Minv);
+          const int nuse = (nf < r.nfR) ? nf : r.nfR;
+#pragma unroll
+          for (int a = 0; a < NU; a++) {
+            double val = 0;
+#pragma unroll
+            for (int j = 0; j < NU; j++)
+              if (r.v_free[j] && rank[j] == a) val = Quxc[j];
+            qf[a] = val;
+          }
+#pragma unroll
+          for (int j = 0; j < NU; j++)
+            if (r.v_free[j] && rank[j] < nuse) {
+              double acc = 0;
+#pragma unroll
+              for (int a = 0; a < NU; a++)
+                if (a < nuse) {
+                  double mrow = 0;
+#pragma unroll
+                  for (int rr = 0; rr < NU; rr++)
+                    if (rr == rank[j]) mrow = Minv[rr + NU * a];
+                  acc += -mrow * qf[a];
+                }
+              Kc[j] = acc;
+            }
+        }
+      }
+      if (!ok) diverge = i;
+      ILQR_MARK(2)  // box-QP + K
+      // :388-389
+      {
+        double d0 = 0;
+#pragma unroll
+        for (int a = 0; a < NU; a++) d0 += qp.x[a] * Qu[a];
+        if (ok) dV0 += d0;
+        double d1 = 0;
+#pragma unroll
+        for (int c = 0; c < NU; c++) {
+          double r = 0;
+#pragma unroll
+          for (int a = 0; a < NU; a++) r += (0.5 * qp.x[a]) * Quu[a + NU * c];
+          d1 += r * qp.x[c];
+        }
+        if (ok) dV1 += d1;
+      }
+      // T1s[c] = (K' Quu)[s, c]
+      double T1s[NU];
+#pragma unroll
+      for (int c = 0; c < NU; c++) {
+        double acc = 0;
+#pragma unroll
+        for (int q = 0; q < NU; q++) acc += Kc[q] * Quu[q + NU * c];
+        T1s[c] = acc;
+      }
+      // :391  Vx[s]
+      double Vxs;
+      {
+        double t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+        for (int c = 0; c < NU; c++) {
+          t1 += T1s[c] * qp.x[c];
+          t2 += Kc[c] * Qu[c];
+          t3 += Quxc[c] * qp.x[c];
+        }
+        Vxs = ((Qxs + t1) + t2) + t3;
+      }
+      // exchange K, Qux, K'Quu columns inside the quad
+      double Kall[NU][4], Qall[NU][4], T1all[NU][4];
+#pragma unroll
+      for (int a = 0; a < NU; a++) {
+        quad_gather(Kc[a], Kall[a]);
+        quad_gather(Quxc[a], Qall[a]);
+      }
+#pragma unroll
+      for (int c = 0; c < NU; c++)  // (K'Quu)[r, c] for every r, from the gathered K (no third exchange)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          double acc = 0;
+#pragma unroll
+          for (int q = 0; q < NU; q++) acc += Kall[q][r] * Quu[q + NU * c];
+          T1all[c][r] = acc;
+        }
+      // :392  Vn[r, s] = Qxx[r,s] + (K'Quu)[r,:] K[:,s] + K[:,r]' Qux[:,s] + Qux[:,r]' K[:,s]
+      double Vn[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        double t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+        for (int q = 0; q < NU; q++) {
+          t1 += T1all[q][r] * Kc[q];
+          t2 += Kall[q][r] * Quxc[q];
+          t3 += Qall[q][r] * Kc[q];
+        }
+        Vn[r] = ((Qxxc[r] + t1) + t2) + t3;
+      }
+      // all-gather, then :393 symmetrise (every lane keeps the full matrix)
+      double Vf[16];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        double col[4];
+        quad_gather(Vn[r], col);  // col[c] = Vn[r, c]
+#pragma unroll
+        for (int c = 0; c < 4; c++) Vf[r + 4 * c] = col[c];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) Vxx[r + 4 * c] = 0.5 * (Vf[r + 4 * c] + Vf[c + 4 * r]);
+      quad_gather(Vxs, Vx);
+      // :405-412 term of the gradient norm for this step (summed here in descending t)
+      {
+        double mx = 0;
+#pragma unroll
+        for (int a = 0; a < NU; a++) {
+          const double val = fabs(qp.x[a]) / (fabs(d.us[a]) + 1);
+          mx = (a == 0 || val > mx) ? val : mx;
+        }
+        gacc += mx;
+      }
+      ILQR_MARK(3)  // value-function update + quad exchanges
+      // the prefetch issued at the top of this step has had the whole step to land
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(kWaitAll);
+      __builtin_amdgcn_sched_barrier(0);
+      ILQR_MARK(4)  // wait for the prefetch
+      // :396-397
+      if (ok) {
+#pragma unroll
+        for (int a = 0; a < NU; a++) {
+          kprev[a] = qp.x[a];
+          Kt[((size_t)i * NU * NX + a + NU * s) * TW] = Kc[a];
+        }
+        if (s == 0) {
+#pragma unroll
+          for (int a = 0; a < NU; a++) kt[((size_t)i * NU + a) * TW] = qp.x[a];
+        }
+      }
+      ILQR_MARK(5)  // stores
+      return ok;
+    };
+
+    {
+      // Two register sets, ping-pong.  Order inside one half-iteration:
+      //   issue the loads of the NEXT step into the idle set
+      //   -> compute this step from the set that has already landed
+      //   -> s_waitcnt vmcnt(0): everything outstanding here was issued a whole step ago (the
+      //      prefetch above, the previous step's stores), so this wait is normally free
+      //   -> issue this step's stores (never waited for).
+      // The explicit wait + sched_barriers keep hipcc from parking its own vmcnt(0) right behind
+      // the freshly issued prefetch, which would expose one HBM round trip per step.
+      QuadStep<NU> A, Bd;
+      int i = T - 1;
+      load(i, A);
+      __builtin_amdgcn_s_waitcnt(kWaitAll);
+      while (true) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (i >= 1) load(i - 1, Bd);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!step(i, A)) break;
+        if (--i < 0) break;
+        __builtin_amdgcn_sched_barrier(0);
+        if (i >= 1) load(i - 1, A);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!step(i, Bd)) break;
+        if (--i < 0) break;
+      }
+    }
+
+#ifdef ILQR_PHASE_TIMING
+    if (v.dbg && lane == 0 && tile < 64)
+      for (int q = 0; q < 8; q++) v.dbg[tile * 8 + q] = ph[q];
+#endif
+    if (mode == 0) {
+      done = (diverge == 0);
+      break;
+    }
+    if (diverge != 0) {  // :142-148
+      dlambda = fmax(dlambda * sp.lambda_factor, sp.lambda_factor);
+      lambda = fmax(lambda * dlambda, sp.lambda_min);
+      if (lambda > sp.lambda_max) break;
+      continue;
+    }
+    done = true;
+    break;
+  }
+
+  // :153 / :405-412 gradient norm.  A completed pass has summed its terms on the fly (descending
+  // t; the reference sums ascending -- same value to rounding).  Only when the pass was abandoned
+  // (lambda > lambdaMax) do k[0..T) hold a mix of old and new gains; then re-read them.
+  double acc = gacc;
+  if (!done) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    acc = 0;
+    for (int t0 = 0; t0 < T; t0 += 8) {
+      double kv[8][NU], uv[8][NU];
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int a = 0; a < NU; a++) {
+          const int t = (t0 + j < T) ? t0 + j : T - 1;
+          kv[j][a] = kt[((size_t)t * NU + a) * TW];
+          uv[j][a] = ust[((size_t)t * NU + a) * TW];
+        }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        double mx = 0;
+#pragma unroll
+        for (int a = 0; a < NU; a++) {
+          const double val = fabs(kv[j][a]) / (fabs(uv[j][a]) + 1);
+          mx = (a == 0 || val > mx) ? val : mx;
+        }
+        if (t0 + j < T) acc += mx;
+      }
+    }
+  }
+  const double gnorm = acc / T;
+  if (s == 0) {
+    v.dV[b] = dV0;
+    v.dV[v.Bp + b] = dV1;
+    v.diverge[b] = diverge;
+    v.backpass_done[b] = done ? 1 : 0;
+    v.gnorm[b] = gnorm;
+    if (mode == 1) {
+      v.lambda[b] = lambda;
+      v.dlambda[b] = dlambda;
+      if (!sp.fixed_work && gnorm < sp.tol_grad && lambda < 1e-5) {  // :154-159
+        v.status[b] = 1;
+        v.iters[b] += 1;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // line-search selection + lambda schedule + termination (one thread per trajectory)
 // ------------------------------------------------------------------------------------------
 __global__ void k_accept(BatchView v, SolverParams sp, int* __restrict__ commit_idx) {

@@ -27,3 +27,10 @@ extern "C" int devfn_box_qp(int m, const double* Q, const double* c, const doubl
     default: return -100;
   }
 }
+
+extern "C" int devfn_box_qp_scalar(double Q, double c, double x0, double lo, double hi, double* x, int* fr, double* minv) {
+  return box_qp_scalar(Q, c, x0, lo, hi, *x, *fr, *minv);
+}
+extern "C" int devfn_box_qp_scalar_fast(double Q, double c, double x0, double lo, double hi, double* x, int* fr, double* minv) {
+  return box_qp_scalar_fast(Q, c, x0, lo, hi, *x, *fr, *minv);
+}
