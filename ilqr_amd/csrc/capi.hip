@@ -193,11 +193,12 @@ static int scalars_to_dev(ilqr_batch* h, const T* host, T* dev) {
 template <class M>
 static int launch_rollout_t(ilqr_batch* h, const M& m, bool gains, const AlphaSet& al, int n_alpha, double* xs_out,
                             double* us_out, double* cost_out, size_t sx, size_t su, int mode) {
-  dim3 grid(h->Bp / 64, n_alpha), block(64);
+  const int aw = (n_alpha + 3) / 4;  // wavefronts per tile: 4 alphas each
+  dim3 grid(h->ntiles), block(64 * aw);
   if (gains)
-    hipLaunchKernelGGL((k_rollout<M, true>), grid, block, 0, h->stream, h->v, m, al, xs_out, us_out, cost_out, sx, su, mode);
+    hipLaunchKernelGGL((k_rollout<M, true>), grid, block, 0, h->stream, h->v, m, al, n_alpha, xs_out, us_out, cost_out, sx, su, mode);
   else
-    hipLaunchKernelGGL((k_rollout<M, false>), grid, block, 0, h->stream, h->v, m, al, xs_out, us_out, cost_out, sx, su, mode);
+    hipLaunchKernelGGL((k_rollout<M, false>), grid, block, 0, h->stream, h->v, m, al, n_alpha, xs_out, us_out, cost_out, sx, su, mode);
   HIPCHK(hipGetLastError());
   return 0;
 }

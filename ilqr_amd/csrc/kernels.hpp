@@ -99,21 +99,27 @@ struct AlphaSet {
   double a[NALPHA];
 };
 
-// One thread per (trajectory, alpha).  grid = (Bp/64, n_alpha), block = 64.
+// One thread per (trajectory, alpha).  A wavefront = one tile of 16 trajectories x 4 alphas
+// (lane = 16*alpha_sub + l): the nominal controls, gains and states of the tile are fetched once
+// per wavefront and shared by its four alphas (one 128-byte line per load instruction), and each
+// alpha's candidate row is still written as a whole line.  AW wavefronts of the same tile (alphas
+// 4w..4w+3) form one block, i.e. sit on one CU and share its L1.  grid = ntiles, block = 64*AW.
 //   GAINS=false : u_t = us[t]                                   (init_traj: K empty, :316)
 //   GAINS=true  : u_t = us[t] + alpha k[t] + K[t] (x_t - xs[t]) (:188-190, :315-316)
 // Writes the new states/controls to (xs_out, us_out) + a * stride and the cost to cost_out[a][b].
 // mode: 0 = all trajectories, 1 = only running ones whose backward pass succeeded.
 template <class M, bool GAINS>
-__global__ __launch_bounds__(64) void k_rollout(BatchView v, M model, AlphaSet alphas, double* __restrict__ xs_out,
-                                                double* __restrict__ us_out, double* __restrict__ cost_out,
-                                                size_t stride_x, size_t stride_u, int mode) {
+__global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet alphas, int n_alpha, double* __restrict__ xs_out,
+                          double* __restrict__ us_out, double* __restrict__ cost_out, size_t stride_x,
+                          size_t stride_u, int mode) {
   constexpr int NX = M::NX, NU = M::NU;
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  const int a = blockIdx.y;
-  if (b >= v.B) return;
+  const int lane = threadIdx.x & 63;
+  const int l = lane & (TW - 1);
+  const int a = (threadIdx.x >> 6) * 4 + (lane >> 4);
+  const int tile = blockIdx.x;
+  const int b = tile * TW + l;
+  if (b >= v.B || a >= n_alpha) return;
   if (mode == 1 && !(v.status[b] == 0 && v.backpass_done[b])) return;
-  const int tile = b / TW, l = b % TW;
   const int T = v.T;
   const double alpha = alphas.a[a];
   const double dt = v.dt;
@@ -128,41 +134,38 @@ __global__ __launch_bounds__(64) void k_rollout(BatchView v, M model, AlphaSet a
   }
   double total = 0;
 
-  // software prefetch of step t+1 while step t integrates (none of it depends on x)
-  double un[NU], kn[NU], Kn[NU * NX], xn[NX];
-  auto load_step = [&](int t) {
+  // The nominal controls / gains / states of step t do not depend on the rollout's own state,
+  // and one step of arithmetic (~600 cycles) is far shorter than an HBM round trip under load
+  // (~2000+ cycles), so they are prefetched PD steps ahead into a ring of register sets; the
+  // main loop is unrolled by PD so that every set is statically indexed.
+  constexpr int PD = 4;
+  struct StepIn {
+    double u[NU], k[GAINS ? NU : 1], K[GAINS ? NU * NX : 1], xnom[GAINS ? NX : 1];
+  };
+  auto load_step = [&](int t, StepIn& d) {
+    t = (t < T) ? t : T - 1;  // tail: harmless re-load instead of a branch
 #pragma unroll
-    for (int j = 0; j < NU; j++) un[j] = v.us[tidx(tile, t, j, l, T, NU)];
+    for (int j = 0; j < NU; j++) d.u[j] = v.us[tidx(tile, t, j, l, T, NU)];
     if (GAINS) {
 #pragma unroll
-      for (int j = 0; j < NU; j++) kn[j] = v.kff[tidx(tile, t, j, l, T, NU)];
+      for (int j = 0; j < NU; j++) d.k[j] = v.kff[tidx(tile, t, j, l, T, NU)];
 #pragma unroll
-      for (int e = 0; e < NU * NX; e++) Kn[e] = v.Kfb[tidx(tile, t, e, l, T, NU * NX)];
+      for (int e = 0; e < NU * NX; e++) d.K[e] = v.Kfb[tidx(tile, t, e, l, T, NU * NX)];
 #pragma unroll
-      for (int i = 0; i < NX; i++) xn[i] = v.xs[tidx(tile, t, i, l, T + 1, NX)];
+      for (int i = 0; i < NX; i++) d.xnom[i] = v.xs[tidx(tile, t, i, l, T + 1, NX)];
     }
   };
-  load_step(0);
-  for (int t = 0; t < T; t++) {
-    double u[NU], kk[NU], K[NU * NX], xnom[NX];
+  auto do_step = [&](int t, const StepIn& d) {
+    double u[NU];
 #pragma unroll
-    for (int j = 0; j < NU; j++) u[j] = un[j];
-    if (GAINS) {
-#pragma unroll
-      for (int j = 0; j < NU; j++) kk[j] = kn[j];
-#pragma unroll
-      for (int e = 0; e < NU * NX; e++) K[e] = Kn[e];
-#pragma unroll
-      for (int i = 0; i < NX; i++) xnom[i] = xn[i];
-    }
-    if (t + 1 < T) load_step(t + 1);
+    for (int j = 0; j < NU; j++) u[j] = d.u[j];
     if (GAINS) {
 #pragma unroll
       for (int j = 0; j < NU; j++) {
-        u[j] += kk[j] * alpha;  // :190
+        u[j] += d.k[j] * alpha;  // :190
         double acc = 0;
 #pragma unroll
-        for (int i = 0; i < NX; i++) acc += K[j + NU * i] * (x[i] - xnom[i]);
+        for (int i = 0; i < NX; i++) acc += d.K[j + NU * i] * (x[i] - d.xnom[i]);
         u[j] += acc;  // :316
       }
     }
@@ -176,6 +179,23 @@ __global__ __launch_bounds__(64) void k_rollout(BatchView v, M model, AlphaSet a
       x[i] = x1[i];
       xo[tidx(tile, t + 1, i, l, T + 1, NX)] = x1[i];
     }
+  };
+  StepIn ring[PD];
+#pragma unroll
+  for (int d = 0; d < PD; d++) load_step(d, ring[d]);
+  int t = 0;
+  for (; t + PD <= T; t += PD) {
+#pragma unroll
+    for (int d = 0; d < PD; d++) {
+      const StepIn cur = ring[d];
+      load_step(t + d + PD, ring[d]);
+      do_step(t + d, cur);
+    }
+  }
+  for (; t < T; t++) {  // remainder (< PD steps): the ring still holds them in order
+    StepIn cur;
+    load_step(t, cur);
+    do_step(t, cur);
   }
   total += model.final_cost(x);  // :335
   cost_out[(size_t)a * v.Bp + b] = total;

@@ -9,6 +9,42 @@
 
 namespace ilqr {
 
+// sin and cos of one argument with ONE shared range reduction: ~35 fp64 instructions instead
+// of the ~2 x 100 of two library calls.  The rollout and finite-difference kernels are bound by
+// fp64 VALU issue, and four libm trig calls per dynamics evaluation were 60 % of it.
+//   reduction: j = rint(x 2/pi), r = x - j pi/2 in three FMAs (pi/2 split in three doubles)
+//   kernels  : the classic minimax polynomials on [-pi/4, pi/4] (fdlibm k_sin / k_cos)
+// Absolute error about 1.2e-16 for |x| <= 1e5 (measured against long double on 2e7 samples).
+// Deliberately branch-free: a library fallback for huge arguments put ~20 taken branches into
+// every rollout step.  NaN/Inf propagate to NaN as in libm; a finite |x| beyond ~1e9 (a rollout
+// that has already diverged -- the line search rejects it on cost) loses accuracy gracefully.
+__device__ __forceinline__ void sincos_shared(double x, double& s_out, double& c_out) {
+  const double j = __builtin_rint(x * 6.36619772367581382433e-01);  // 2/pi
+  double r = __builtin_fma(-j, 1.57079632679489655800e+00, x);      // pi/2, leading 53 bits
+  r = __builtin_fma(-j, 6.12323399573676603587e-17, r);             // next 53 bits
+  r = __builtin_fma(-j, -1.49738490485916983294e-33, r);            // and the rest
+  const double z = r * r;
+  // sin(r) = r + r^3 (S1 + z (S2 + ... ))
+  const double ps = 8.33333333332248946124e-03 +
+                    z * (-1.98412698298579493134e-04 +
+                         z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double sr = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+  // cos(r) = 1 - z/2 + z^2 (C1 + z (C2 + ... )), summed so that the 1 - z/2 rounding is compensated
+  const double pc = z * (4.16666666666666019037e-02 +
+                         z * (-1.38888888888741095749e-03 +
+                              z * (2.48015872894767294178e-05 +
+                                   z * (-2.75573143513906633035e-07 +
+                                        z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double cr = w + (((1.0 - w) - hz) + z * pc);
+  const int q = (int)(long long)j & 3;
+  const double sa = (q & 1) ? cr : sr;
+  const double ca = (q & 1) ? sr : cr;
+  s_out = (q & 2) ? -sa : sa;
+  c_out = ((q + 1) & 2) ? -ca : ca;
+}
+
 // include/acrobot.h  (n=4, m=1).  I1=I2=l1=l2=m1=m2=1, lc1=lc2=.5, g=9.81 (:19-25).
 struct AcrobotModel {
   static constexpr int NX = 4;
@@ -20,20 +56,22 @@ struct AcrobotModel {
     const double I1 = 1, I2 = 1, l1 = 1, l2 = 1, m1 = 1, m2 = 1, g = 9.81;
     const double lc1 = 0.5 * l1, lc2 = 0.5 * l2;
     const double q0 = x[0], q1 = x[1], qd0 = x[2], qd1 = x[3];
+    // the four trig values of acrobot.h:44,55,65,66 from two shared-reduction evaluations;
+    // sin(q0+q1) by the angle-sum identity (about 2e-16 absolute)
+    double s1, c1, s2, c2;
+    sincos_shared(q0, s1, c1);
+    sincos_shared(q1, s2, c2);
+    const double s12 = s1 * c2 + c1 * s2;
     // H(q), acrobot.h:43-51
-    const double c2 = cos(q1);
     const double H00 = I1 + I2 + m2 * l1 * l1 + 2 * m2 * l1 * lc2 * c2;
     const double H01 = I2 + m2 * l1 * lc2 * c2;
     const double H10 = H01;
     const double H11 = I2;
     // C(q,qd), acrobot.h:53-61
-    const double s2 = sin(q1);
     const double C00 = -2 * m2 * l1 * lc2 * s2 * qd1;
     const double C01 = -m2 * l2 * lc2 * s2 * qd1;
     const double C10 = m2 * l1 * lc2 * s2 * qd0;
     // G(q), acrobot.h:63-70
-    const double s1 = sin(q0);
-    const double s12 = sin(q0 + q1);
     const double G0 = m1 * g * lc1 * s1 + m2 * g * (l1 * s1 + lc2 * s12);
     const double G1 = m2 * g * lc2 * s12;
     // rhs = (0,u) - C*qd - G, acrobot.h:80
