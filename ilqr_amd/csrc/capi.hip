@@ -64,6 +64,7 @@ struct ilqr_batch {
   size_t staging_elems = 0;
   std::vector<void*> allocs;
   bool initialised = false;  // init_traj / set_trajectory has run
+  bool commit_pending = false;  // an accepted candidate is not yet copied into xs/us
   bool profile = false;
   StageTimer timers[ILQR_NUM_STAGES];
 };
@@ -216,16 +217,44 @@ static int launch_rollout(ilqr_batch* h, bool gains, const AlphaSet& al, int n_a
   return timer_end(h, ILQR_STAGE_ROLLOUT, ev);
 }
 
+static int launch_commit(ilqr_batch* h) {
+  dim3 grid((h->T + 1 + 15) / 16, h->ntiles), block(256);
+  if (h->nx == 4 && h->nu == 1)
+    hipLaunchKernelGGL((k_commit<4, 1>), grid, block, 0, h->stream, h->v, h->commit_idx);
+  else if (h->nx == 4 && h->nu == 2)
+    hipLaunchKernelGGL((k_commit<4, 2>), grid, block, 0, h->stream, h->v, h->commit_idx);
+  else
+    return fail(ILQR_ERR_UNSUPPORTED, "no commit kernel for nx=%d nu=%d", h->nx, h->nu);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// copy an accepted-but-not-yet-copied candidate into the nominal trajectory now
+static int flush_commit(ilqr_batch* h) {
+  if (!h->commit_pending) return 0;
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (int rc = timer_begin(h, ILQR_STAGE_ACCEPT, &ev)) return rc;
+  if (int rc = launch_commit(h)) return rc;
+  h->commit_pending = false;
+  HIPCHK(hipMemsetAsync(h->commit_idx, 0xFF, (size_t)h->Bp * sizeof(int), h->stream));  // all -1
+  return timer_end(h, ILQR_STAGE_ACCEPT, ev);
+}
+
 static int launch_derivatives(ilqr_batch* h, int force) {
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_DERIVATIVES, &ev)) return rc;
   dim3 grid((h->T + 1 + 15) / 16, h->ntiles), block(256);
+  const int* ci = h->commit_pending ? h->commit_idx : nullptr;
   switch (h->model) {
-    case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_derivatives<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, force); break;
-    case ILQR_MODEL_DOUBLE_INTEGRATOR: hipLaunchKernelGGL((k_derivatives<DoubleIntegratorModel>), grid, block, 0, h->stream, h->v, h->dint, force); break;
+    case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_derivatives<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, force, ci); break;
+    case ILQR_MODEL_DOUBLE_INTEGRATOR: hipLaunchKernelGGL((k_derivatives<DoubleIntegratorModel>), grid, block, 0, h->stream, h->v, h->dint, force, ci); break;
     default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device derivatives", h->model);
   }
   HIPCHK(hipGetLastError());
+  if (h->commit_pending) {  // the kernel above performed the copy on the way
+    h->commit_pending = false;
+    HIPCHK(hipMemsetAsync(h->commit_idx, 0xFF, (size_t)h->Bp * sizeof(int), h->stream));
+  }
   return timer_end(h, ILQR_STAGE_DERIVATIVES, ev);
 }
 
@@ -257,20 +286,15 @@ static int launch_backward(ilqr_batch* h, int mode) {
   return timer_end(h, ILQR_STAGE_BACKWARD, ev);
 }
 
-static int launch_accept_commit(ilqr_batch* h) {
+// selection + lambda schedule + termination; the copy of the accepted candidate is left pending
+// (fused into the next derivative sweep, or flushed by flush_commit)
+static int launch_accept(ilqr_batch* h) {
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_ACCEPT, &ev)) return rc;
   HIPCHK(hipMemsetAsync(h->v.n_running, 0, sizeof(int), h->stream));
   hipLaunchKernelGGL(k_accept, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->sp, h->commit_idx);
   HIPCHK(hipGetLastError());
-  dim3 grid((h->T + 1 + 15) / 16, h->ntiles), block(256);
-  if (h->nx == 4 && h->nu == 1)
-    hipLaunchKernelGGL((k_commit<4, 1>), grid, block, 0, h->stream, h->v, h->commit_idx);
-  else if (h->nx == 4 && h->nu == 2)
-    hipLaunchKernelGGL((k_commit<4, 2>), grid, block, 0, h->stream, h->v, h->commit_idx);
-  else
-    return fail(ILQR_ERR_UNSUPPORTED, "no commit kernel for nx=%d nu=%d", h->nx, h->nu);
-  HIPCHK(hipGetLastError());
+  h->commit_pending = true;
   return timer_end(h, ILQR_STAGE_ACCEPT, ev);
 }
 
@@ -319,6 +343,10 @@ void ilqr_destroy(ilqr_batch* h) {
         for (int q = 0; q < 8; q++) fprintf(stderr, "%s %.2f  ", nm[q], (double)d[t * 20 * 8 + q] / h->T);
         fprintf(stderr, "\n");
       }
+      for (int t = 0; t < 3; t++)
+        fprintf(stderr, "[rollout phase timing, tile %d] loop+prefetch %.1f  wait+feedback+ustore %.1f  cost+dynamics %.1f  xstores %.1f cyc/step\n", t,
+                (double)d[512 - 16 + t * 4 + 0] / h->T, (double)d[512 - 16 + t * 4 + 1] / h->T, (double)d[512 - 16 + t * 4 + 2] / h->T,
+                (double)d[512 - 16 + t * 4 + 3] / h->T);
     }
   }
 #endif
@@ -416,6 +444,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   rc |= dev_alloc(h, &v.backpass_done, Bp);
   rc |= dev_alloc(h, &v.n_running, 1);
   rc |= dev_alloc(h, &h->commit_idx, Bp);
+  if (!rc && hipMemsetAsync(h->commit_idx, 0xFF, Bp * sizeof(int), h->stream) != hipSuccess) rc = 1;
   rc |= dev_alloc(h, &v.dbg, 64 * 8);
   if (rc) return ILQR_ERR_HIP;
 
@@ -507,9 +536,9 @@ int ilqr_iterate(ilqr_batch* h, int n_iters) {
     if (int rc = launch_derivatives(h, h->sp.fixed_work)) return rc;  // STEP 1
     if (int rc = launch_backward(h, 1)) return rc;                    // STEP 2
     if (int rc = do_rollout_candidates(h, 1)) return rc;              // STEP 3
-    if (int rc = launch_accept_commit(h)) return rc;                  // STEP 3/4
+    if (int rc = launch_accept(h)) return rc;                         // STEP 3/4
   }
-  return 0;
+  return flush_commit(h);  // the last iteration's accepted trajectories
 }
 
 int ilqr_count_running(ilqr_batch* h, int* n) {
@@ -555,12 +584,8 @@ int ilqr_warm_start(ilqr_batch* h, const double* x0) {
   const size_t sx = (size_t)h->ntiles * (h->T + 1) * h->nx * TW, su = (size_t)h->ntiles * h->T * h->nu * TW;
   if (int rc = launch_rollout(h, true, al, 1, h->v.xs_c, h->v.us_c, h->v.cost, sx, su, 0)) return rc;
   HIPCHK(hipMemsetAsync(h->commit_idx, 0, (size_t)h->Bp * sizeof(int), h->stream));  // slot 0 for everyone
-  dim3 grid((h->T + 1 + 15) / 16, h->ntiles), block(256);
-  if (h->nu == 1)
-    hipLaunchKernelGGL((k_commit<4, 1>), grid, block, 0, h->stream, h->v, h->commit_idx);
-  else
-    hipLaunchKernelGGL((k_commit<4, 2>), grid, block, 0, h->stream, h->v, h->commit_idx);
-  HIPCHK(hipGetLastError());
+  if (int rc = launch_commit(h)) return rc;
+  HIPCHK(hipMemsetAsync(h->commit_idx, 0xFF, (size_t)h->Bp * sizeof(int), h->stream));
   // a new outer loop starts: status/iters/flgChange reset, lambda & dlambda persist (file statics)
   std::vector<double> lam(h->B), dlam(h->B);
   if (int rc = scalars_to_host(h, h->v.lambda, lam.data())) return rc;
@@ -610,8 +635,10 @@ int ilqr_rollout_candidates(ilqr_batch* h, double* cost_out) {
 int ilqr_line_search(ilqr_batch* h) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
   HIPCHK(hipSetDevice(h->device));
+  if (int rc = flush_commit(h)) return rc;
   if (int rc = do_rollout_candidates(h, 1)) return rc;
-  return launch_accept_commit(h);
+  if (int rc = launch_accept(h)) return rc;
+  return flush_commit(h);
 }
 
 // ---- state exchange --------------------------------------------------------------------------
@@ -757,7 +784,7 @@ const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
     case ILQR_STAGE_DERIVATIVES: return "k_derivatives";
     case ILQR_STAGE_BACKWARD: return (h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t";
     case ILQR_STAGE_ROLLOUT: return "k_rollout";
-    case ILQR_STAGE_ACCEPT: return "k_accept+k_commit";
+    case ILQR_STAGE_ACCEPT: return "k_accept";
     default: return "";
   }
 }

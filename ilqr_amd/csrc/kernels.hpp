@@ -138,7 +138,16 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
   // and one step of arithmetic (~600 cycles) is far shorter than an HBM round trip under load
   // (~2000+ cycles), so they are prefetched PD steps ahead into a ring of register sets; the
   // main loop is unrolled by PD so that every set is statically indexed.
+#ifdef ILQR_EXP_NOSTORE
+#define ILQR_EXP_STORE(dst, val) asm volatile("" ::"v"(val))
+#else
+#define ILQR_EXP_STORE(dst, val) dst = val
+#endif
+#ifdef ILQR_EXP_PD
+  constexpr int PD = ILQR_EXP_PD;
+#else
   constexpr int PD = 4;
+#endif
   struct StepIn {
     double u[NU], k[GAINS ? NU : 1], K[GAINS ? NU * NX : 1], xnom[GAINS ? NX : 1];
   };
@@ -155,7 +164,15 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
       for (int i = 0; i < NX; i++) d.xnom[i] = v.xs[tidx(tile, t, i, l, T + 1, NX)];
     }
   };
+#ifdef ILQR_PHASE_TIMING
+  long long rph[4] = {0, 0, 0, 0};
+  long long rmark = clock64();
+#define ILQR_RMARK(k) { __builtin_amdgcn_sched_barrier(0); const long long tn_ = clock64(); rph[k] += tn_ - rmark; rmark = tn_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define ILQR_RMARK(k)
+#endif
   auto do_step = [&](int t, const StepIn& d) {
+    ILQR_RMARK(0)  // loop control + prefetch issue
     double u[NU];
 #pragma unroll
     for (int j = 0; j < NU; j++) u[j] = d.u[j];
@@ -170,15 +187,18 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
       }
     }
 #pragma unroll
-    for (int j = 0; j < NU; j++) uo[tidx(tile, t, j, l, T, NU)] = u[j];  // :323 (no clamping)
+    for (int j = 0; j < NU; j++) ILQR_EXP_STORE(uo[tidx(tile, t, j, l, T, NU)], u[j]);  // :323 (no clamping)
+    ILQR_RMARK(1)  // wait for inputs + feedback + u store
     total += model.cost(x, u);                                           // :324
     double x1[NX];
     integrate_dynamics(model, x, u, dt, x1);  // :325
+    ILQR_RMARK(2)  // cost + dynamics
 #pragma unroll
     for (int i = 0; i < NX; i++) {
       x[i] = x1[i];
-      xo[tidx(tile, t + 1, i, l, T + 1, NX)] = x1[i];
+      ILQR_EXP_STORE(xo[tidx(tile, t + 1, i, l, T + 1, NX)], x1[i]);
     }
+    ILQR_RMARK(3)  // x stores
   };
   StepIn ring[PD];
 #pragma unroll
@@ -197,6 +217,10 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
     load_step(t, cur);
     do_step(t, cur);
   }
+#ifdef ILQR_PHASE_TIMING
+  if (v.dbg && threadIdx.x == 0 && tile < 3 && GAINS)
+    for (int q = 0; q < 4; q++) v.dbg[512 - 16 + tile * 4 + q] = rph[q];
+#endif
   total += model.final_cost(x);  // :335
   cost_out[(size_t)a * v.Bp + b] = total;
 }
@@ -244,8 +268,11 @@ __device__ __forceinline__ void fd_gradient(const double* x, F f, double* out) {
 // One thread per knot point (b, t), t = 0..T.  block = 256 = 16 trajectories x 16 time steps,
 // grid = (ceil((T+1)/16), ntiles).  force != 0: every trajectory (stage call / bench mode),
 // otherwise only running trajectories whose flgChange is set (ilqr_core.cpp:115).
+// commit_idx (may be null): a line search accepted candidate commit_idx[b] for trajectory b and
+// its copy into the nominal trajectory is still pending -- this kernel reads the knot from the
+// candidate and performs the copy on the way (the separate k_commit pass is only used to flush).
 template <class M>
-__global__ __launch_bounds__(256) void k_derivatives(BatchView v, M model, int force) {
+__global__ __launch_bounds__(256) void k_derivatives(BatchView v, M model, int force, const int* __restrict__ commit_idx) {
   constexpr int NX = M::NX, NU = M::NU;
   using R = Rec<NX, NU>;
   const int l = threadIdx.x & (TW - 1);
@@ -254,14 +281,30 @@ __global__ __launch_bounds__(256) void k_derivatives(BatchView v, M model, int f
   const int b = tile * TW + l;
   const int T = v.T;
   if (t > T || b >= v.B) return;
-  if (!force && !(v.status[b] == 0 && v.flg_change[b])) return;
+  const int ci = commit_idx ? commit_idx[b] : -1;
+  const bool want = force || (v.status[b] == 0 && v.flg_change[b]);
+  if (ci < 0 && !want) return;
   const double dt = v.dt;
 
   double x[NX], u[NU];
+  {
+    const size_t sx = (size_t)v.ntiles * (T + 1) * NX * TW, su = (size_t)v.ntiles * T * NU * TW;
+    const double* xsrc = (ci >= 0) ? v.xs_c + (size_t)ci * sx : v.xs;
+    const double* usrc = (ci >= 0) ? v.us_c + (size_t)ci * su : v.us;
 #pragma unroll
-  for (int i = 0; i < NX; i++) x[i] = v.xs[tidx(tile, t, i, l, T + 1, NX)];
+    for (int i = 0; i < NX; i++) x[i] = xsrc[tidx(tile, t, i, l, T + 1, NX)];
 #pragma unroll
-  for (int j = 0; j < NU; j++) u[j] = (t < T) ? v.us[tidx(tile, t, j, l, T, NU)] : 0.0;  // derivatives.cpp:35-38
+    for (int j = 0; j < NU; j++) u[j] = (t < T) ? usrc[tidx(tile, t, j, l, T, NU)] : 0.0;  // derivatives.cpp:35-38
+    if (ci >= 0) {  // the pending commit of ilqr_core.cpp:210-213 ("accept": xs, us keep the new rollout)
+#pragma unroll
+      for (int i = 0; i < NX; i++) v.xs[tidx(tile, t, i, l, T + 1, NX)] = x[i];
+      if (t < T) {
+#pragma unroll
+        for (int j = 0; j < NU; j++) v.us[tidx(tile, t, j, l, T, NU)] = u[j];
+      }
+    }
+  }
+  if (!want) return;
 
   double* D = v.D + tidx(tile, t, 0, l, T + 1, R::SIZE);
   auto put = [&](int e, double val) { D[(size_t)e * TW] = val; };
