@@ -84,6 +84,7 @@ def main():
     import torch
     import torch.distributed as dist
     from ilqr_amd import BatchILQR, capi
+    from ilqr_amd import dist as D
     from tests.util import acrobot_x0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,7 +100,8 @@ def main():
 
     B, T, dt, lim, n, m = args.batch, args.T, 0.02, args.limit, 4, 1
     # this rank's shard of the global synthetic batch (trajectory b of rank r = global r*B + b)
-    x0 = acrobot_x0(B * world)[rank * B:(rank + 1) * B]
+    lo, hi = D.shard(B * world, rank, world)
+    x0 = acrobot_x0(B * world)[lo:hi]
     u0 = np.zeros((B, T, m))
     stream = torch.cuda.current_stream().cuda_stream
     g = BatchILQR("acrobot", B, T, dt, u_min=-lim, u_max=lim, device=local_rank,
@@ -107,7 +109,6 @@ def main():
     g.init_traj(x0, u0)
     g.iterate(args.warmup)
     cost_dev = torch.empty(B, dtype=torch.float64, device="cuda")
-    gathered = torch.empty(B * world, dtype=torch.float64, device="cuda") if world > 1 else cost_dev
 
     def barrier():
         torch.cuda.synchronize()
@@ -122,14 +123,9 @@ def main():
     g.iterate(args.steps)
     # the one exchange step of the path: gather of per-trajectory costs (RCCL over xGMI)
     capi.check(g.lib.ilqr_copy_cost_to_device(g.h, cost_dev.data_ptr()))
-    if world > 1:
-        dist.all_gather_into_tensor(gathered, cost_dev)
+    gathered = D.gather_costs(cost_dev)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device="cuda")
     prof = g.profile_read()
     g.profile(False)
 

@@ -1,0 +1,425 @@
+// ilqr_amd.hpp -- C++ host facade over the C ABI (include/ilqr_amd.h).
+//
+// Mirrors the reference's plugin and solver interfaces so that code written against
+// kazuotani14/iLQR keeps compiling against the MI355X engine:
+//     class Model   <->  include/model.h:6-21      (same virtuals, same public fields)
+//     class iLQR    <->  include/ilqr.h:28-107     (same ctor/ownership, generate_trajectory x3,
+//                                                    init_traj, output_to_csv; + solve(), accessors)
+//     class BatchILQR    new: B independent problems sharing one model
+// Header-only; link with -lilqr_amd.  Vector/matrix types are Eigen's when <Eigen/Core> is on the
+// include path (the reference's users have it), otherwise the minimal dense types below.
+//
+// A Model subclass runs on the GPU only through a device twin: the subclass says which
+// one by overriding device_model_id().  The shipped Acrobot / DoubleIntegrator do; a host-only
+// Model makes the iLQR constructor throw (no silent CPU path).
+#ifndef ILQR_AMD_HPP_
+#define ILQR_AMD_HPP_
+
+#include <algorithm>
+#include <cmath>
+#include <initializer_list>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ilqr_amd.h"
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Core>) && !defined(ILQR_AMD_NO_EIGEN)
+#include <Eigen/Core>
+#include <Eigen/StdVector>
+#define ILQR_AMD_HAVE_EIGEN 1
+#endif
+#endif
+
+namespace ilqr_amd {
+
+#ifdef ILQR_AMD_HAVE_EIGEN
+using VectorXd = Eigen::VectorXd;
+using MatrixXd = Eigen::MatrixXd;
+typedef std::vector<VectorXd, Eigen::aligned_allocator<VectorXd>> VecOfVecXd;  // include/common.h:29
+typedef std::vector<MatrixXd, Eigen::aligned_allocator<MatrixXd>> VecOfMatXd;  // include/common.h:30
+#else
+// Minimal stand-ins with the subset of the Eigen API the reference's interface uses.
+class VectorXd {
+ public:
+  VectorXd() {}
+  explicit VectorXd(int n) : d_(n, 0.0) {}
+  VectorXd(std::initializer_list<double> v) : d_(v) {}
+  int size() const { return (int)d_.size(); }
+  void resize(int n) { d_.resize(n); }
+  void setZero() { std::fill(d_.begin(), d_.end(), 0.0); }
+  double& operator()(int i) { return d_[i]; }
+  double operator()(int i) const { return d_[i]; }
+  double& operator[](int i) { return d_[i]; }
+  double operator[](int i) const { return d_[i]; }
+  double* data() { return d_.data(); }
+  const double* data() const { return d_.data(); }
+  static VectorXd Zero(int n) { return VectorXd(n); }
+
+ private:
+  std::vector<double> d_;
+};
+class MatrixXd {  // column-major like Eigen's default
+ public:
+  MatrixXd() : r_(0), c_(0) {}
+  MatrixXd(int r, int c) : r_(r), c_(c), d_((size_t)r * c, 0.0) {}
+  int rows() const { return r_; }
+  int cols() const { return c_; }
+  void resize(int r, int c) { r_ = r; c_ = c; d_.assign((size_t)r * c, 0.0); }
+  double& operator()(int i, int j) { return d_[i + (size_t)r_ * j]; }
+  double operator()(int i, int j) const { return d_[i + (size_t)r_ * j]; }
+  double* data() { return d_.data(); }
+  const double* data() const { return d_.data(); }
+
+ private:
+  int r_, c_;
+  std::vector<double> d_;
+};
+typedef std::vector<VectorXd> VecOfVecXd;
+typedef std::vector<MatrixXd> VecOfMatXd;
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// include/model.h:6-21
+// ---------------------------------------------------------------------------------------------
+class Model {
+ public:
+  virtual ~Model() {}
+  virtual VectorXd dynamics(const VectorXd& x, const VectorXd& u) = 0;
+  virtual double cost(const VectorXd& x, const VectorXd& u) = 0;
+  virtual double final_cost(const VectorXd& x) = 0;
+
+  VectorXd integrate_dynamics(const VectorXd& x, const VectorXd& u, double dt) {  // model.h:12-15
+    VectorXd dx = dynamics(x, u);
+    VectorXd x1(x.size());
+    for (int i = 0; i < (int)x.size(); i++) x1(i) = x(i) + dx(i) * dt;
+    return x1;
+  }
+
+  VectorXd u_min, u_max;
+  int x_dims = 0;
+  int u_dims = 0;
+
+  // Which device twin evaluates this model inside the HIP kernels (enum ilqr_model_id).
+  virtual int device_model_id() const { return ILQR_MODEL_HOST; }
+  // Model-specific parameter block handed to the device twin (the goal for DoubleIntegrator).
+  virtual const double* device_goal() const { return nullptr; }
+};
+
+// include/acrobot.h (host evaluation; the kernels use ilqr::AcrobotModel)
+class Acrobot : public Model {
+ public:
+  Acrobot() {
+    x_dims = 4;
+    u_dims = 1;
+    u_min = VectorXd(1);
+    u_max = VectorXd(1);
+    u_min(0) = -5;  // acrobot.h:37
+    u_max(0) = 5;
+    goal_[0] = 3.1415;  // acrobot.h:21
+    goal_[1] = goal_[2] = goal_[3] = 0;
+  }
+  VectorXd dynamics(const VectorXd& x, const VectorXd& u) override {  // acrobot.h:72-81
+    const double g = 9.81;
+    const double c2 = std::cos(x(1)), s2 = std::sin(x(1)), s1 = std::sin(x(0)), s12 = std::sin(x(0) + x(1));
+    const double H00 = 3 + c2, H01 = 1 + 0.5 * c2, H11 = 1;
+    const double C00 = -s2 * x(3), C01 = -0.5 * s2 * x(3), C10 = 0.5 * s2 * x(2);
+    const double G0 = g * 0.5 * s1 + g * (s1 + 0.5 * s12), G1 = g * 0.5 * s12;
+    const double r0 = (0.0 - (C00 * x(2) + C01 * x(3))) - G0;
+    const double r1 = (u(0) - C10 * x(2)) - G1;
+    const double invdet = 1.0 / (H00 * H11 - H01 * H01);
+    VectorXd dx(4);
+    dx(0) = x(2);
+    dx(1) = x(3);
+    dx(2) = (H11 * invdet) * r0 + (-H01 * invdet) * r1;
+    dx(3) = (-H01 * invdet) * r0 + (H00 * invdet) * r1;
+    return dx;
+  }
+  double cost(const VectorXd&, const VectorXd& u) override { return 0.1 * 0.1 * (u(0) * u(0)); }  // :83-92
+  double final_cost(const VectorXd& x) override {  // :94-100
+    double q = 0, qd = 0;
+    for (int i = 0; i < 2; i++) q += (goal_[i] - x(i)) * (goal_[i] - x(i));
+    for (int i = 2; i < 4; i++) qd += (goal_[i] - x(i)) * (goal_[i] - x(i));
+    return 400.0 * q + 400.0 * qd;
+  }
+  int device_model_id() const override { return ILQR_MODEL_ACROBOT; }
+
+ private:
+  double goal_[4];
+};
+
+// include/double_integrator.h
+class DoubleIntegrator : public Model {
+ public:
+  explicit DoubleIntegrator(const VectorXd& xd) {
+    x_dims = 4;
+    u_dims = 2;
+    u_min = VectorXd(2);
+    u_max = VectorXd(2);
+    for (int j = 0; j < 2; j++) {
+      u_min(j) = -0.5;  // double_integrator.h:25-26
+      u_max(j) = 0.5;
+    }
+    for (int i = 0; i < 4; i++) goal_[i] = xd(i);
+  }
+  VectorXd dynamics(const VectorXd& x, const VectorXd& u) override {  // :29-37
+    VectorXd dx(4);
+    dx(0) = x(2);
+    dx(1) = x(3);
+    dx(2) = u(0);
+    dx(3) = u(1);
+    return dx;
+  }
+  double cost(const VectorXd& x, const VectorXd& u) override { return quad(x, 1.0) + u(0) * u(0) + u(1) * u(1); }
+  double final_cost(const VectorXd& x) override { return quad(x, 10.0); }
+  int device_model_id() const override { return ILQR_MODEL_DOUBLE_INTEGRATOR; }
+  const double* device_goal() const override { return goal_; }
+
+ private:
+  double quad(const VectorXd& x, double s) const {
+    const double hx[4] = {1, 1, 0.2, 0.2};
+    double c = 0;
+    for (int i = 0; i < 4; i++) c += s * hx[i] * (goal_[i] - x(i)) * (goal_[i] - x(i));
+    return c;
+  }
+  double goal_[4];
+};
+
+inline void check(int rc, const char* what) {
+  if (rc != ILQR_OK) throw std::runtime_error(std::string(what) + ": " + ilqr_last_error());
+}
+
+// ---------------------------------------------------------------------------------------------
+// B independent problems, one shared model.  Arrays in the canonical layouts of ilqr_amd.h.
+// ---------------------------------------------------------------------------------------------
+class BatchILQR {
+ public:
+  BatchILQR(std::shared_ptr<Model> model, int B, int T, double dt, int device = 0, int flags = 0)
+      : model_(model), B_(B), T_(T), n_(model->x_dims), m_(model->u_dims), h_(nullptr) {
+    if (model->device_model_id() == ILQR_MODEL_HOST)
+      throw std::runtime_error(
+          "ilqr_amd: this Model has no device twin (device_model_id() == ILQR_MODEL_HOST); the HIP rollout and "
+          "finite-difference kernels cannot call host virtuals and there is no CPU fallback");
+    std::vector<double> lo(m_), hi(m_);
+    for (int j = 0; j < m_; j++) {
+      lo[j] = model->u_min(j);
+      hi[j] = model->u_max(j);
+    }
+    ilqr_desc d = {};
+    d.abi_version = ILQR_AMD_ABI_VERSION;
+    d.model = model->device_model_id();
+    d.nx = n_;
+    d.nu = m_;
+    d.T = T;
+    d.B = B;
+    d.dt = dt;
+    d.device = device;
+    d.flags = flags;
+    d.u_min = lo.data();
+    d.u_max = hi.data();
+    d.goal = model->device_goal();
+    check(ilqr_create(&d, &h_), "ilqr_create");
+  }
+  ~BatchILQR() { ilqr_destroy(h_); }
+  BatchILQR(const BatchILQR&) = delete;
+  BatchILQR& operator=(const BatchILQR&) = delete;
+
+  ilqr_batch* handle() { return h_; }
+  int batch() const { return B_; }
+  int horizon() const { return T_; }
+
+  std::vector<double> init_traj(const std::vector<double>& x0, const std::vector<double>& u0) {
+    require(x0.size() == (size_t)B_ * n_ && u0.size() == (size_t)B_ * T_ * m_, "init_traj: x0 [B][nx], u0 [B][T][nu]");
+    std::vector<double> cost(B_);
+    check(ilqr_init_traj(h_, x0.data(), u0.data(), cost.data()), "ilqr_init_traj");
+    return cost;
+  }
+  void generate_trajectory() { check(ilqr_generate_trajectory(h_), "ilqr_generate_trajectory"); }
+  void generate_trajectory(const std::vector<double>& x0) { check(ilqr_warm_start(h_, x0.data()), "ilqr_warm_start"); }
+  void generate_trajectory(const std::vector<double>& x0, const std::vector<double>& u0) {
+    init_traj(x0, u0);
+    generate_trajectory();
+  }
+  void solve(const std::vector<double>& x0, const std::vector<double>& u0) { generate_trajectory(x0, u0); }
+  void iterate(int n) { check(ilqr_iterate(h_, n), "ilqr_iterate"); }
+
+  std::vector<double> states() {
+    std::vector<double> xs((size_t)B_ * (T_ + 1) * n_);
+    check(ilqr_get_trajectory(h_, xs.data(), nullptr), "ilqr_get_trajectory");
+    return xs;
+  }
+  std::vector<double> controls() {
+    std::vector<double> us((size_t)B_ * T_ * m_);
+    check(ilqr_get_trajectory(h_, nullptr, us.data()), "ilqr_get_trajectory");
+    return us;
+  }
+  std::vector<double> gains_k() {
+    std::vector<double> k((size_t)B_ * T_ * m_);
+    check(ilqr_get_gains(h_, k.data(), nullptr), "ilqr_get_gains");
+    return k;
+  }
+  std::vector<double> gains_K() {  // [B][T][nu*nx], each K_t column-major nu x nx
+    std::vector<double> K((size_t)B_ * T_ * m_ * n_);
+    check(ilqr_get_gains(h_, nullptr, K.data()), "ilqr_get_gains");
+    return K;
+  }
+  std::vector<double> cost() {
+    std::vector<double> c(B_);
+    check(ilqr_get_cost(h_, c.data()), "ilqr_get_cost");
+    return c;
+  }
+  std::vector<int> status() {
+    std::vector<int> s(B_);
+    check(ilqr_get_status(h_, s.data(), nullptr, nullptr), "ilqr_get_status");
+    return s;
+  }
+  std::vector<int> iterations() {
+    std::vector<int> s(B_);
+    check(ilqr_get_status(h_, nullptr, s.data(), nullptr), "ilqr_get_status");
+    return s;
+  }
+
+ private:
+  static void require(bool ok, const char* msg) {
+    if (!ok) throw std::invalid_argument(msg);  // the reference asserts (ilqr_core.cpp:66,80-82)
+  }
+  std::shared_ptr<Model> model_;
+  int B_, T_, n_, m_;
+  ilqr_batch* h_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// include/ilqr.h:28-107 -- the single-trajectory solver, B = 1 over the batch engine
+// ---------------------------------------------------------------------------------------------
+class iLQR {
+ public:
+  iLQR(Model* p_dyn, double timeDelta) : dt(timeDelta) { model.reset(p_dyn); }  // takes ownership, ilqr.h:31
+  iLQR() = default;
+
+  std::shared_ptr<Model> model;  // public in the reference too (ilqr.h:47)
+  bool verbose = true;           // SHOWPROGRESS / "Saved iLQR result" prints (ilqr_core.cpp:1)
+  bool write_csv = true;         // output_to_csv("ilqr_result.csv") at the end of every solve (:300)
+
+  void generate_trajectory() {  // ilqr_core.cpp:79-302
+    if (!engine_) throw std::logic_error("generate_trajectory(): no trajectory initialised (asserts of ilqr_core.cpp:80-82)");
+    int iter = 0;
+    for (;; iter++) {
+      int running = 0;
+      check(ilqr_count_running(engine_->handle(), &running), "ilqr_count_running");
+      if (!running) break;
+      const double cost_before = engine_->cost()[0];
+      engine_->iterate(1);
+      if (verbose) print_progress(iter, cost_before);
+    }
+    if (write_csv) output_to_csv("ilqr_result.csv");
+  }
+  void generate_trajectory(const VectorXd& x_0) {  // warm start, ilqr_core.cpp:65-76
+    if (!engine_) throw std::logic_error("warm start needs a previous solve (assert us.size()>0, ilqr_core.cpp:66)");
+    std::vector<double> x0(x_0.data(), x_0.data() + x_0.size());
+    engine_->generate_trajectory(x0);
+    if (write_csv) output_to_csv("ilqr_result.csv");
+  }
+  void generate_trajectory(const VectorXd& x_0, const VecOfVecXd& u0) {  // fresh start, :59-62
+    init_traj(x_0, u0);
+    generate_trajectory();
+  }
+  void solve(const VectorXd& x_0, const VecOfVecXd& u0) { generate_trajectory(x_0, u0); }  // BASELINE.json's name
+
+  double init_traj(const VectorXd& x_0, const VecOfVecXd& u_0) {  // ilqr_core.cpp:11-56
+    T = (int)u_0.size();
+    const int n = model->x_dims, m = model->u_dims;
+    if ((int)x_0.size() != n) throw std::invalid_argument("init_traj: x_0 has the wrong size");
+    engine_.reset(new BatchILQR(model, 1, T, dt));
+    std::vector<double> x0(x_0.data(), x_0.data() + n), u0((size_t)T * m);
+    for (int t = 0; t < T; t++)
+      for (int j = 0; j < m; j++) u0[(size_t)t * m + j] = u_0[t](j);
+    const double c = engine_->init_traj(x0, u0)[0];
+    if (verbose) std::printf("Initial cost: %g\n", c);
+    return c;
+  }
+
+  // ilqr_core.cpp:414-431, byte-compatible (including the one u column too many in the header
+  // and the unterminated last row) so plot_results.py-style consumers keep working
+  void output_to_csv(const std::string filename) {
+    const int n = model->x_dims, m = model->u_dims;
+    const std::vector<double> xs = engine_->states(), us = engine_->controls();
+    FILE* XU = std::fopen(filename.c_str(), "w");
+    if (!XU) throw std::runtime_error("output_to_csv: cannot open " + filename);
+    for (int i = 1; i <= n; i++) std::fprintf(XU, "x%d, ", i);
+    for (int j = 0; j < m; j++) std::fprintf(XU, "u%d, ", j);
+    std::fprintf(XU, "u%d\n", m);
+    for (int t = 0; t < T; t++) {
+      for (int i = 0; i < n; i++) std::fprintf(XU, "%f, ", xs[(size_t)t * n + i]);
+      for (int j = 0; j < m - 1; j++) std::fprintf(XU, "%f, ", us[(size_t)t * m + j]);
+      std::fprintf(XU, "%f\n", us[(size_t)t * m + m - 1]);
+    }
+    for (int i = 0; i < n; i++) std::fprintf(XU, "%f, ", xs[(size_t)T * n + i]);
+    std::fclose(XU);
+    if (verbose) std::printf("Saved iLQR result to %s\n", filename.c_str());
+  }
+
+  // accessors the reference keeps private (tests reach them through FRIEND_TEST, ilqr.h:103-106)
+  VecOfVecXd states() const { return unpack(engine_->states(), T + 1, model->x_dims); }
+  VecOfVecXd controls() const { return unpack(engine_->controls(), T, model->u_dims); }
+  VecOfVecXd gains_k() const { return unpack(engine_->gains_k(), T, model->u_dims); }
+  VecOfMatXd gains_K() const {
+    const int n = model->x_dims, m = model->u_dims;
+    const std::vector<double> K = engine_->gains_K();
+    VecOfMatXd out(T);
+    for (int t = 0; t < T; t++) {
+      out[t] = MatrixXd(m, n);
+      for (int j = 0; j < n; j++)
+        for (int a = 0; a < m; a++) out[t](a, j) = K[(size_t)t * m * n + a + (size_t)m * j];
+    }
+    return out;
+  }
+  double cost() const { return engine_->cost()[0]; }
+  int iterations() const { return engine_->iterations()[0]; }
+  int status() const { return engine_->status()[0]; }  // enum ilqr_traj_status
+
+ private:
+  double dt = 0;
+  int T = 0;
+  std::unique_ptr<BatchILQR> engine_;
+
+  static VecOfVecXd unpack(const std::vector<double>& a, int S, int E) {
+    VecOfVecXd out(S);
+    for (int s = 0; s < S; s++) {
+      out[s] = VectorXd(E);
+      for (int e = 0; e < E; e++) out[s](e) = a[(size_t)s * E + e];
+    }
+    return out;
+  }
+  // the table of ilqr_core.cpp:238-246 / :270-273
+  void print_progress(int iter, double cost_before) {
+    if (iter == 0) std::printf("iteration\tcost\t\treduction\texpect\t\tgrad\t\tlog10(lambda)\n");
+    int st = 0, it = 0, al = 0;
+    double lam = 0, gn = 0, c = 0, dV[2] = {0, 0};
+    ilqr_batch* h = engine_->handle();
+    check(ilqr_get_status(h, &st, &it, &al), "ilqr_get_status");
+    check(ilqr_get_lambda(h, &lam, nullptr), "ilqr_get_lambda");
+    check(ilqr_get_gnorm(h, &gn), "ilqr_get_gnorm");
+    check(ilqr_get_cost(h, &c), "ilqr_get_cost");
+    check(ilqr_get_dV(h, dV), "ilqr_get_dV");
+    static const double alphas[11] = {1.0000, 0.5012, 0.2512, 0.1259, 0.0631, 0.0316, 0.0158, 0.0079, 0.0040, 0.0020, 0.0010};
+    if (st == ILQR_CONVERGED_GRAD) {
+      std::printf("\nSUCCESS: gradient norm < tolGrad\n\n");
+      return;
+    }
+    if (al >= 0) {
+      const double a = alphas[al];
+      std::printf("%-12d\t%-12.3g\t%-12.3g\t%-12.3g\t%-12.3g\t%-12.1f\n", iter, c, cost_before - c, -a * (dV[0] + a * dV[1]), gn, std::log10(lam));
+      if (st == ILQR_CONVERGED_COST) std::printf("\nSUCCESS: cost change < tolFun\n");
+    } else {
+      std::printf("%-12d\t%-12s\t%-12.3g\t%-12.3g\t%-12.3g\t%-12.1f\n", iter, "NO STEP", 0.0, 0.0, gn, std::log10(lam));
+      if (st == ILQR_LAMBDA_MAX) std::printf("\nEXIT: lambda > lambdaMax\n");
+    }
+  }
+};
+
+}  // namespace ilqr_amd
+
+#endif  // ILQR_AMD_HPP_

@@ -1,0 +1,96 @@
+"""The C++ host facade (include/ilqr_amd.hpp): source compatibility with the reference's Model /
+iLQR interface, loud failure without a GPU, and -- on the GPU box -- the two canonical problems
+of the reference's driver (src/run_ilqr.cpp) end to end, including the CSV side effect."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "examples", "run_ilqr")
+EIGEN = "/root/reference/include/eigen"
+
+
+def build_example(out=EXE, extra=()):
+    from ilqr_amd import _build
+    _build.build()
+    cmd = ["g++", "-std=c++14", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), *extra,
+           os.path.join(ROOT, "examples", "run_ilqr.cpp"), "-o", out,
+           "-L" + os.path.join(ROOT, "ilqr_amd", "lib"), "-lilqr_amd", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + os.path.join(ROOT, "ilqr_amd", "lib"), "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return out
+
+
+def test_facade_builds_and_fails_loudly_without_gpu(tmp_path):
+    import torch
+    exe = build_example()
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([exe, "acrobot", "--quiet"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 2
+    assert "no HIP device" in r.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir(EIGEN), reason="vendored Eigen only exists in the build container")
+def test_facade_compiles_against_eigen_types(tmp_path):
+    """With <Eigen/Core> on the include path the facade's Model/iLQR use Eigen::VectorXd, i.e. a
+    user's Model subclass written for the reference compiles unchanged."""
+    src = tmp_path / "user_model.cpp"
+    src.write_text('''
+#include "ilqr_amd.hpp"
+#include <type_traits>
+static_assert(std::is_same<ilqr_amd::VectorXd, Eigen::VectorXd>::value, "Eigen types expected");
+// a Model written against include/model.h of the reference
+class Pendulum : public ilqr_amd::Model {
+ public:
+  Pendulum() { x_dims = 2; u_dims = 1; u_min = Eigen::VectorXd::Constant(1, -2.0); u_max = Eigen::VectorXd::Constant(1, 2.0); }
+  virtual Eigen::VectorXd dynamics(const Eigen::VectorXd& x, const Eigen::VectorXd& u) override {
+    Eigen::VectorXd dx(2); dx << x(1), u(0) - 9.81 * sin(x(0)); return dx; }
+  virtual double cost(const Eigen::VectorXd& x, const Eigen::VectorXd& u) override { return x.dot(x) + u.dot(u); }
+  virtual double final_cost(const Eigen::VectorXd& x) override { return 10 * x.dot(x); }
+};
+int main() {
+  Pendulum p; Eigen::VectorXd x(2); x << 0.1, 0.0; Eigen::VectorXd u(1); u << 0.5;
+  Eigen::VectorXd x1 = p.integrate_dynamics(x, u, 0.02);
+  if (std::abs(x1(0) - 0.1) > 1e-12) return 1;
+  try { ilqr_amd::iLQR s(new Pendulum(), 0.02); ilqr_amd::VecOfVecXd u0(5, u); s.verbose = false; s.init_traj(x, u0); }
+  catch (const std::runtime_error& e) { return std::string(e.what()).find("no device twin") != std::string::npos ? 0 : 2; }
+  return 3;
+}
+''')
+    exe = tmp_path / "user_model"
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-w", "-I" + os.path.join(ROOT, "include"), "-I" + EIGEN, str(src),
+                           "-o", str(exe), "-L" + os.path.join(ROOT, "ilqr_amd", "lib"), "-lilqr_amd", "-L/opt/rocm/lib",
+                           "-lamdhip64", "-Wl,-rpath," + os.path.join(ROOT, "ilqr_amd", "lib"), "-Wl,-rpath,/opt/rocm/lib"])
+    assert subprocess.run([str(exe)]).returncode == 0  # host-only model is rejected loudly
+
+
+@pytest.mark.gpu
+def test_run_ilqr_acrobot(tmp_path):
+    """`./run_iLQR acrobot`: 100 iterations, final cost 5.39788253688."""
+    exe = build_example()
+    r = subprocess.run([exe, "acrobot"], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert "Initial cost: 3947.61" in out
+    assert "iteration\tcost\t\treduction\texpect\t\tgrad\t\tlog10(lambda)" in out
+    last = [l for l in out.splitlines() if l.startswith("final cost")][0].split()
+    assert abs(float(last[2]) - 5.39788253688) < 1e-6 * 5.4 and int(last[4]) == 100 and int(last[6]) == 4
+    # CSV side effect of every solve (ilqr_core.cpp:300, format :414-431)
+    lines = (tmp_path / "ilqr_result.csv").read_text().split("\n")
+    assert lines[0] == "x1, x2, x3, x4, u0, u1"
+    assert len(lines) == 1 + 499 + 1 and lines[-1].endswith(", ") and lines[1].count(",") == 4
+    # second printed row of the reference's progress table: cost 2.66e3 at iteration 1
+    row1 = [l for l in out.splitlines() if l.startswith("1 ")][0].split()
+    assert row1[1] == "2.66e+03"
+
+
+@pytest.mark.gpu
+def test_run_ilqr_integrator(tmp_path):
+    exe = build_example()
+    r = subprocess.run([exe, "integrator", "--quiet"], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert r.returncode == 0, r.stderr
+    last = [l for l in r.stdout.splitlines() if l.startswith("final cost")][0].split()
+    assert abs(float(last[2]) - 356.168506469842) < 1e-6 * 356
+    assert 5 <= int(last[4]) <= 15
