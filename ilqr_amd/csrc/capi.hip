@@ -191,26 +191,28 @@ static int scalars_to_dev(ilqr_batch* h, const T* host, T* dev) {
 // ------------------------------------------------------------------------------------------
 // kernel launchers (dispatch on the device model)
 // ------------------------------------------------------------------------------------------
+// cand = true: knots go to the time-chunked candidate buffer; false: straight into xs/us (init)
 template <class M>
-static int launch_rollout_t(ilqr_batch* h, const M& m, bool gains, const AlphaSet& al, int n_alpha, double* xs_out,
-                            double* us_out, double* cost_out, size_t sx, size_t su, int mode) {
+static int launch_rollout_t(ilqr_batch* h, const M& m, bool gains, bool cand, const AlphaSet& al, int n_alpha,
+                            double* cost_out, int mode) {
   const int aw = (n_alpha + 3) / 4;  // wavefronts per tile: 4 alphas each
   dim3 grid(h->ntiles), block(64 * aw);
-  if (gains)
-    hipLaunchKernelGGL((k_rollout<M, true>), grid, block, 0, h->stream, h->v, m, al, n_alpha, xs_out, us_out, cost_out, sx, su, mode);
+  if (gains && cand)
+    hipLaunchKernelGGL((k_rollout<M, true, true>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode);
+  else if (!gains && !cand)
+    hipLaunchKernelGGL((k_rollout<M, false, false>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode);
   else
-    hipLaunchKernelGGL((k_rollout<M, false>), grid, block, 0, h->stream, h->v, m, al, n_alpha, xs_out, us_out, cost_out, sx, su, mode);
+    return fail(ILQR_ERR_INVALID, "unsupported rollout variant");
   HIPCHK(hipGetLastError());
   return 0;
 }
-static int launch_rollout(ilqr_batch* h, bool gains, const AlphaSet& al, int n_alpha, double* xs_out, double* us_out,
-                          double* cost_out, size_t sx, size_t su, int mode) {
+static int launch_rollout(ilqr_batch* h, bool gains, bool cand, const AlphaSet& al, int n_alpha, double* cost_out, int mode) {
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_ROLLOUT, &ev)) return rc;
   int rc;
   switch (h->model) {
-    case ILQR_MODEL_ACROBOT: rc = launch_rollout_t(h, h->acrobot, gains, al, n_alpha, xs_out, us_out, cost_out, sx, su, mode); break;
-    case ILQR_MODEL_DOUBLE_INTEGRATOR: rc = launch_rollout_t(h, h->dint, gains, al, n_alpha, xs_out, us_out, cost_out, sx, su, mode); break;
+    case ILQR_MODEL_ACROBOT: rc = launch_rollout_t(h, h->acrobot, gains, cand, al, n_alpha, cost_out, mode); break;
+    case ILQR_MODEL_DOUBLE_INTEGRATOR: rc = launch_rollout_t(h, h->dint, gains, cand, al, n_alpha, cost_out, mode); break;
     default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device rollout", h->model);
   }
   if (rc) return rc;
@@ -305,8 +307,7 @@ static AlphaSet line_search_alphas() {
 }
 
 static int do_rollout_candidates(ilqr_batch* h, int mode) {
-  const size_t sx = (size_t)h->ntiles * (h->T + 1) * h->nx * TW, su = (size_t)h->ntiles * h->T * h->nu * TW;
-  return launch_rollout(h, true, line_search_alphas(), NALPHA, h->v.xs_c, h->v.us_c, h->v.cost_c, sx, su, mode);
+  return launch_rollout(h, true, true, line_search_alphas(), NALPHA, h->v.cost_c, mode);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -428,8 +429,8 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   rc |= dev_alloc(h, &v.kff, nt * T * nu * TW);
   rc |= dev_alloc(h, &v.Kfb, nt * T * nu * nx * TW);
   rc |= dev_alloc(h, &v.D, nt * T1 * REC * TW);
-  rc |= dev_alloc(h, &v.xs_c, (size_t)NALPHA * nt * T1 * nx * TW);
-  rc |= dev_alloc(h, &v.us_c, (size_t)NALPHA * nt * T * nu * TW);
+  v.nch = (h->T + 1 + CT - 1) / CT;
+  rc |= dev_alloc(h, &v.cand, (size_t)NALPHA * nt * v.nch * TW * CT * (nx + nu));
   rc |= dev_alloc(h, &v.cost_c, (size_t)NALPHA * Bp);
   rc |= dev_alloc(h, &v.cost, Bp);
   rc |= dev_alloc(h, &v.lambda, Bp);
@@ -522,7 +523,7 @@ int ilqr_init_traj(ilqr_batch* h, const double* x0, const double* u0, double* co
   HIPCHK(hipGetLastError());
   // ilqr_core.cpp:20: open-loop rollout (K is empty); writes xs, us, cost in place
   AlphaSet al = line_search_alphas();
-  if (int rc = launch_rollout(h, false, al, 1, h->v.xs, h->v.us, h->v.cost, 0, 0, 0)) return rc;
+  if (int rc = launch_rollout(h, false, false, al, 1, h->v.cost, 0)) return rc;
   h->initialised = true;
   if (cost_out) return scalars_to_host(h, h->v.cost, cost_out);
   return 0;
@@ -581,8 +582,7 @@ int ilqr_warm_start(ilqr_batch* h, const double* x0) {
   // forward_pass(x_0, us) with the stored gains: u = us[t] + K[t](x - xs[t])  (alpha*k term = 0)
   AlphaSet al;
   for (int i = 0; i < NALPHA; i++) al.a[i] = 0.0;
-  const size_t sx = (size_t)h->ntiles * (h->T + 1) * h->nx * TW, su = (size_t)h->ntiles * h->T * h->nu * TW;
-  if (int rc = launch_rollout(h, true, al, 1, h->v.xs_c, h->v.us_c, h->v.cost, sx, su, 0)) return rc;
+  if (int rc = launch_rollout(h, true, true, al, 1, h->v.cost, 0)) return rc;
   HIPCHK(hipMemsetAsync(h->commit_idx, 0, (size_t)h->Bp * sizeof(int), h->stream));  // slot 0 for everyone
   if (int rc = launch_commit(h)) return rc;
   HIPCHK(hipMemsetAsync(h->commit_idx, 0xFF, (size_t)h->Bp * sizeof(int), h->stream));
@@ -744,9 +744,17 @@ int ilqr_get_status(ilqr_batch* h, int* status, int* iters, int* alpha_idx) {
 int ilqr_get_candidate(ilqr_batch* h, int a, double* xs, double* us) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
   REQUIRE(a >= 0 && a < NALPHA, "alpha index %d out of range", a);
-  const size_t sx = (size_t)h->ntiles * (h->T + 1) * h->nx * TW, su = (size_t)h->ntiles * h->T * h->nu * TW;
-  if (xs) if (int rc = download(h, h->v.xs_c + a * sx, xs, h->T + 1, h->nx)) return rc;
-  if (us) if (int rc = download(h, h->v.us_c + a * su, us, h->T, h->nu)) return rc;
+  HIPCHK(hipSetDevice(h->device));
+  const size_t nx_el = (size_t)h->B * (h->T + 1) * h->nx, nu_el = (size_t)h->B * h->T * h->nu;
+  if (int rc = ensure_staging(h, nx_el + nu_el)) return rc;
+  double* dxs = h->staging;
+  double* dus = h->staging + nx_el;
+  hipLaunchKernelGGL(k_unpack_cand, dim3(grid_for((size_t)h->B * (h->T + 1), 256)), dim3(256), 0, h->stream, h->v, a, h->nx,
+                     h->nu, dxs, dus);
+  HIPCHK(hipGetLastError());
+  if (xs) HIPCHK(hipMemcpyAsync(xs, dxs, nx_el * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (us) HIPCHK(hipMemcpyAsync(us, dus, nu_el * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 int ilqr_copy_cost_to_device(ilqr_batch* h, void* dst) {

@@ -36,6 +36,17 @@ constexpr double kMinStep = 1e-22;
 constexpr double kArmijo = 0.1;
 constexpr double kClampTol = 1e-4;
 
+// Candidate trajectories use a different layout from everything else: a line search accepts a
+// different alpha for every trajectory, so the accepted candidate is GATHERED per lane.  With the
+// tiled layout that costs one 128-byte line per 8 useful bytes (8x read amplification measured);
+// here CT consecutive knots (x_t, u_t) of one (alpha, trajectory) are contiguous (CT*(nx+nu)
+// doubles = 320 B for the acrobot), so the gather reads whole chunks.  The rollout kernel
+// transposes through LDS to write these chunks with fully contiguous 512-byte stores.
+constexpr int CT = 8;
+__host__ __device__ inline size_t cidx(int a, int tile, int c, int l, int j, int e, int ntiles, int nch, int KR) {
+  return (((((size_t)a * ntiles + tile) * nch + c) * TW + l) * CT + j) * KR + e;
+}
+
 __host__ __device__ inline size_t tidx(int tile, int s, int e, int l, int S, int E) {
   return (((size_t)tile * S + s) * E + e) * TW + l;
 }
@@ -72,8 +83,8 @@ struct BatchView {
   double* kff;  // [tile][T][nu][TW]
   double* Kfb;  // [tile][T][nu*nx][TW]
   double* D;    // [tile][T+1][REC][TW]
-  double* xs_c; // [NALPHA][tile][T+1][nx][TW]
-  double* us_c; // [NALPHA][tile][T][nu][TW]
+  double* cand; // line-search candidates, time-chunked: [NALPHA][tile][NCH][TW][CT][nx+nu]  (cidx)
+  int nch;      // NCH = ceil((T+1)/CT) chunks of CT knots
   double* cost_c; // [NALPHA][Bp]
   // per-trajectory scalars [Bp]
   double* cost;

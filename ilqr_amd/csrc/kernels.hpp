@@ -101,53 +101,69 @@ struct AlphaSet {
 
 // One thread per (trajectory, alpha).  A wavefront = one tile of 16 trajectories x 4 alphas
 // (lane = 16*alpha_sub + l): the nominal controls, gains and states of the tile are fetched once
-// per wavefront and shared by its four alphas (one 128-byte line per load instruction), and each
-// alpha's candidate row is still written as a whole line.  AW wavefronts of the same tile (alphas
-// 4w..4w+3) form one block, i.e. sit on one CU and share its L1.  grid = ntiles, block = 64*AW.
+// per wavefront and shared by its four alphas (one 128-byte line per load instruction).  AW
+// wavefronts of the same tile (alphas 4w..4w+3) form one block, i.e. sit on one CU and share its
+// L1.  grid = ntiles, block = 64*AW.
 //   GAINS=false : u_t = us[t]                                   (init_traj: K empty, :316)
 //   GAINS=true  : u_t = us[t] + alpha k[t] + K[t] (x_t - xs[t]) (:188-190, :315-316)
-// Writes the new states/controls to (xs_out, us_out) + a * stride and the cost to cost_out[a][b].
-// mode: 0 = all trajectories, 1 = only running ones whose backward pass succeeded.
-template <class M, bool GAINS>
-__global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet alphas, int n_alpha, double* __restrict__ xs_out,
-                          double* __restrict__ us_out, double* __restrict__ cost_out, size_t stride_x,
-                          size_t stride_u, int mode) {
-  constexpr int NX = M::NX, NU = M::NU;
+//   CAND=false  : knots (x_t, u_t) go straight into the nominal tiled xs/us (init_traj)
+//   CAND=true   : knots go to candidate `a` in the time-chunked layout (common.hpp cidx): each
+//                 wavefront stages CT knots in LDS ([knot*KR+e][lane], padded rows) and flushes
+//                 them as 512-byte contiguous stores
+// The cost goes to cost_out[a][b].  mode: 0 = all trajectories, 1 = only running ones whose
+// backward pass succeeded.
+template <class M, bool GAINS, bool CAND>
+__global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet alphas, int n_alpha,
+                                                 double* __restrict__ cost_out, int mode) {
+  constexpr int NX = M::NX, NU = M::NU, KR = NX + NU;
+  constexpr int SROW = 65;  // padded LDS row (64 lanes + 1): conflict-free transposed reads
+  __shared__ double stage_all[CAND ? 3 * CT * KR * SROW : 1];
+  const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int l = lane & (TW - 1);
-  const int a = (threadIdx.x >> 6) * 4 + (lane >> 4);
+  const int a_sub = lane >> 4;
+  const int a = wave * 4 + a_sub;
   const int tile = blockIdx.x;
   const int b = tile * TW + l;
-  if (b >= v.B || a >= n_alpha) return;
-  if (mode == 1 && !(v.status[b] == 0 && v.backpass_done[b])) return;
+  bool active = (b < v.B) && (a < n_alpha);
+  if (active && mode == 1) active = (v.status[b] == 0 && v.backpass_done[b]);
+  if (!CAND && !active) return;
+  const unsigned long long act_mask = __ballot(active);
+  if (CAND && act_mask == 0ull) return;  // wave-uniform
+  double* stage = stage_all + (CAND ? wave * CT * KR * SROW : 0);
   const int T = v.T;
-  const double alpha = alphas.a[a];
+  const double alpha = alphas.a[a < NALPHA ? a : NALPHA - 1];
   const double dt = v.dt;
-  double* xo = xs_out + (size_t)a * stride_x;
-  double* uo = us_out + (size_t)a * stride_u;
 
   double x[NX];
 #pragma unroll
-  for (int i = 0; i < NX; i++) {
-    x[i] = v.x0[tidx(tile, 0, i, l, 1, NX)];
-    xo[tidx(tile, 0, i, l, T + 1, NX)] = x[i];
-  }
+  for (int i = 0; i < NX; i++) x[i] = v.x0[tidx(tile, 0, i, l, 1, NX)];
   double total = 0;
+
+  // cooperative flush of the knots staged for chunk c (all 64 lanes; inactive (alpha, l) pairs skipped)
+  auto flush = [&](int c) {
+    if (!CAND) return;
+    constexpr int PER = CT * KR;  // doubles per (alpha, trajectory) chunk
+#pragma unroll
+    for (int as = 0; as < 4; as++) {
+      const int aa = wave * 4 + as;
+      double* base = v.cand + cidx(aa < NALPHA ? aa : 0, tile, c, 0, 0, 0, v.ntiles, v.nch, KR);
+#pragma unroll
+      for (int m = 0; m < (TW * PER) / 64; m++) {
+        const int p = m * 64 + lane;
+        const int ll = p / PER, q = p % PER;
+        const double val = stage[q * SROW + as * 16 + ll];
+        if ((act_mask >> (as * 16 + ll)) & 1ull) base[p] = val;
+      }
+    }
+  };
 
   // The nominal controls / gains / states of step t do not depend on the rollout's own state,
   // and one step of arithmetic (~600 cycles) is far shorter than an HBM round trip under load
   // (~2000+ cycles), so they are prefetched PD steps ahead into a ring of register sets; the
   // main loop is unrolled by PD so that every set is statically indexed.
-#ifdef ILQR_EXP_NOSTORE
-#define ILQR_EXP_STORE(dst, val) asm volatile("" ::"v"(val))
-#else
-#define ILQR_EXP_STORE(dst, val) dst = val
-#endif
-#ifdef ILQR_EXP_PD
-  constexpr int PD = ILQR_EXP_PD;
-#else
   constexpr int PD = 4;
-#endif
+  static_assert(CT % PD == 0, "a chunk is a whole number of unrolled groups");
   struct StepIn {
     double u[NU], k[GAINS ? NU : 1], K[GAINS ? NU * NX : 1], xnom[GAINS ? NX : 1];
   };
@@ -171,6 +187,22 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
 #else
 #define ILQR_RMARK(k)
 #endif
+  auto emit_knot = [&](int t, const double* xx, const double* uu) {  // knot t = (x_t, u_t)
+    if (CAND) {
+      const int j = t & (CT - 1);
+#pragma unroll
+      for (int i = 0; i < NX; i++) stage[(j * KR + i) * SROW + lane] = xx[i];
+#pragma unroll
+      for (int q = 0; q < NU; q++) stage[(j * KR + NX + q) * SROW + lane] = uu[q];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NX; i++) v.xs[tidx(tile, t, i, l, T + 1, NX)] = xx[i];
+      if (t < T) {
+#pragma unroll
+        for (int q = 0; q < NU; q++) v.us[tidx(tile, t, q, l, T, NU)] = uu[q];  // :323 (no clamping)
+      }
+    }
+  };
   auto do_step = [&](int t, const StepIn& d) {
     ILQR_RMARK(0)  // loop control + prefetch issue
     double u[NU];
@@ -186,19 +218,16 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
         u[j] += acc;  // :316
       }
     }
-#pragma unroll
-    for (int j = 0; j < NU; j++) ILQR_EXP_STORE(uo[tidx(tile, t, j, l, T, NU)], u[j]);  // :323 (no clamping)
-    ILQR_RMARK(1)  // wait for inputs + feedback + u store
-    total += model.cost(x, u);                                           // :324
+    emit_knot(t, x, u);
+    ILQR_RMARK(1)  // wait for inputs + feedback + knot store
+    total += model.cost(x, u);  // :324
     double x1[NX];
     integrate_dynamics(model, x, u, dt, x1);  // :325
     ILQR_RMARK(2)  // cost + dynamics
 #pragma unroll
-    for (int i = 0; i < NX; i++) {
-      x[i] = x1[i];
-      ILQR_EXP_STORE(xo[tidx(tile, t + 1, i, l, T + 1, NX)], x1[i]);
-    }
-    ILQR_RMARK(3)  // x stores
+    for (int i = 0; i < NX; i++) x[i] = x1[i];
+    if ((t & (CT - 1)) == CT - 1) flush(t / CT);
+    ILQR_RMARK(3)  // chunk flush
   };
   StepIn ring[PD];
 #pragma unroll
@@ -212,17 +241,39 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
       do_step(t + d, cur);
     }
   }
-  for (; t < T; t++) {  // remainder (< PD steps): the ring still holds them in order
+  for (; t < T; t++) {  // remainder (< PD steps)
     StepIn cur;
     load_step(t, cur);
     do_step(t, cur);
+  }
+  {  // knot T: the final state (no control)
+    double uz[NU];
+#pragma unroll
+    for (int q = 0; q < NU; q++) uz[q] = 0;
+    emit_knot(T, x, uz);
+    flush(T / CT);
   }
 #ifdef ILQR_PHASE_TIMING
   if (v.dbg && threadIdx.x == 0 && tile < 3 && GAINS)
     for (int q = 0; q < 4; q++) v.dbg[512 - 16 + tile * 4 + q] = rph[q];
 #endif
   total += model.final_cost(x);  // :335
-  cost_out[(size_t)a * v.Bp + b] = total;
+  if (active) cost_out[(size_t)a * v.Bp + b] = total;
+}
+
+// candidate `a` (time-chunked) -> canonical xs [B][T+1][nx], us [B][T][nu]   (getter only)
+__global__ void k_unpack_cand(BatchView v, int a, int NX, int NU, double* __restrict__ xs, double* __restrict__ us) {
+  const int KR = NX + NU, T = v.T;
+  const size_t n = (size_t)v.B * (T + 1);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i % (T + 1));
+    const int b = (int)(i / (T + 1));
+    const double* r = v.cand + cidx(a, b / TW, t / CT, b % TW, t % CT, 0, v.ntiles, v.nch, KR);
+    if (xs)
+      for (int e = 0; e < NX; e++) xs[((size_t)b * (T + 1) + t) * NX + e] = r[e];
+    if (us && t < T)
+      for (int e = 0; e < NU; e++) us[((size_t)b * T + t) * NU + e] = r[NX + e];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -288,13 +339,18 @@ __global__ __launch_bounds__(256) void k_derivatives(BatchView v, M model, int f
 
   double x[NX], u[NU];
   {
-    const size_t sx = (size_t)v.ntiles * (T + 1) * NX * TW, su = (size_t)v.ntiles * T * NU * TW;
-    const double* xsrc = (ci >= 0) ? v.xs_c + (size_t)ci * sx : v.xs;
-    const double* usrc = (ci >= 0) ? v.us_c + (size_t)ci * su : v.us;
+    if (ci >= 0) {  // knot t of the accepted candidate: KR contiguous doubles
+      const double* r = v.cand + cidx(ci, tile, t / CT, l, t % CT, 0, v.ntiles, v.nch, NX + NU);
 #pragma unroll
-    for (int i = 0; i < NX; i++) x[i] = xsrc[tidx(tile, t, i, l, T + 1, NX)];
+      for (int i = 0; i < NX; i++) x[i] = r[i];
 #pragma unroll
-    for (int j = 0; j < NU; j++) u[j] = (t < T) ? usrc[tidx(tile, t, j, l, T, NU)] : 0.0;  // derivatives.cpp:35-38
+      for (int j = 0; j < NU; j++) u[j] = (t < T) ? r[NX + j] : 0.0;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NX; i++) x[i] = v.xs[tidx(tile, t, i, l, T + 1, NX)];
+#pragma unroll
+      for (int j = 0; j < NU; j++) u[j] = (t < T) ? v.us[tidx(tile, t, j, l, T, NU)] : 0.0;  // derivatives.cpp:35-38
+    }
     if (ci >= 0) {  // the pending commit of ilqr_core.cpp:210-213 ("accept": xs, us keep the new rollout)
 #pragma unroll
       for (int i = 0; i < NX; i++) v.xs[tidx(tile, t, i, l, T + 1, NX)] = x[i];
@@ -1244,18 +1300,12 @@ __global__ __launch_bounds__(256) void k_commit(BatchView v, const int* __restri
   if (t > T || b >= v.B) return;
   const int a = commit_idx[b];
   if (a < 0) return;
-  const size_t sx = (size_t)v.ntiles * (T + 1) * NX * TW, su = (size_t)v.ntiles * T * NU * TW;
+  const double* r = v.cand + cidx(a, tile, t / CT, l, t % CT, 0, v.ntiles, v.nch, NX + NU);
 #pragma unroll
-  for (int i = 0; i < NX; i++) {
-    const size_t o = tidx(tile, t, i, l, T + 1, NX);
-    v.xs[o] = v.xs_c[(size_t)a * sx + o];
-  }
+  for (int i = 0; i < NX; i++) v.xs[tidx(tile, t, i, l, T + 1, NX)] = r[i];
   if (t < T) {
 #pragma unroll
-    for (int j = 0; j < NU; j++) {
-      const size_t o = tidx(tile, t, j, l, T, NU);
-      v.us[o] = v.us_c[(size_t)a * su + o];
-    }
+    for (int j = 0; j < NU; j++) v.us[tidx(tile, t, j, l, T, NU)] = r[NX + j];
   }
 }
 
