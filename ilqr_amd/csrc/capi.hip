@@ -663,14 +663,11 @@ int ilqr_set_derivatives(ilqr_batch* h, const double* fx, const double* fu, cons
                          const double* cxx, const double* cxu, const double* cuu) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
   HIPCHK(hipSetDevice(h->device));
-  const int n = h->nx, m = h->nu;
-  int off = 0;
+  int off[7], len[7];
+  rec_offsets(h->nx, h->nu, off, len);
   const double* srcs[7] = {fx, fu, cx, cu, cxx, cxu, cuu};
-  const int sizes[7] = {n * n, n * m, n, m, n * n, n * m, m * m};
-  for (int i = 0; i < 7; i++) {
-    if (srcs[i]) if (int rc = upload_rec(h, srcs[i], off, sizes[i])) return rc;
-    off += sizes[i];
-  }
+  for (int i = 0; i < 7; i++)
+    if (srcs[i]) if (int rc = upload_rec(h, srcs[i], off[i], len[i])) return rc;
   return 0;
 }
 int ilqr_set_lambda(ilqr_batch* h, const double* lambda, const double* dlambda) {
@@ -699,14 +696,11 @@ int ilqr_get_derivatives(ilqr_batch* h, double* fx, double* fu, double* cx, doub
                          double* cuu) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
   HIPCHK(hipSetDevice(h->device));
-  const int n = h->nx, m = h->nu;
-  int off = 0;
+  int off[7], len[7];
+  rec_offsets(h->nx, h->nu, off, len);
   double* dsts[7] = {fx, fu, cx, cu, cxx, cxu, cuu};
-  const int sizes[7] = {n * n, n * m, n, m, n * n, n * m, m * m};
-  for (int i = 0; i < 7; i++) {
-    if (dsts[i]) if (int rc = download_rec(h, dsts[i], off, sizes[i])) return rc;
-    off += sizes[i];
-  }
+  for (int i = 0; i < 7; i++)
+    if (dsts[i]) if (int rc = download_rec(h, dsts[i], off[i], len[i])) return rc;
   return 0;
 }
 int ilqr_get_cost(ilqr_batch* h, double* cost) {

@@ -51,19 +51,39 @@ __host__ __device__ inline size_t tidx(int tile, int s, int e, int l, int S, int
   return (((size_t)tile * S + s) * E + e) * TW + l;
 }
 
-// element offsets inside one derivative record (all matrices column-major)
+// Element offsets inside one derivative record (all matrices column-major).  The order puts the
+// two odd-sized blocks (cu, cuu; together nu(nu+1) doubles) last, so every block starts at an even
+// offset and the record can be stored as PAIRS of doubles.
 template <int NX, int NU>
 struct Rec {
   static constexpr int FX = 0;
   static constexpr int FU = FX + NX * NX;
   static constexpr int CX = FU + NX * NU;
-  static constexpr int CU = CX + NX;
-  static constexpr int CXX = CU + NU;
+  static constexpr int CXX = CX + NX;
   static constexpr int CXU = CXX + NX * NX;
-  static constexpr int CUU = CXU + NX * NU;
+  static constexpr int CU = CXU + NX * NU;
+  static constexpr int CUU = CU + NU;
   static constexpr int SIZE = CUU + NU * NU;
+  static_assert(NX % 2 == 0, "pair layout assumes an even state dimension");
+  static_assert(SIZE % 2 == 0, "record must be a whole number of pairs");
 };
 inline int rec_size(int nx, int nu) { return 2 * nx * nx + 2 * nx * nu + nx + nu + nu * nu; }
+// runtime offsets in the ABI's order fx, fu, cx, cu, cxx, cxu, cuu
+inline void rec_offsets(int nx, int nu, int off[7], int len[7]) {
+  const int FX = 0, FU = FX + nx * nx, CX = FU + nx * nu, CXX = CX + nx, CXU = CXX + nx * nx, CU = CXU + nx * nu, CUU = CU + nu;
+  const int o[7] = {FX, FU, CX, CU, CXX, CXU, CUU};
+  const int n[7] = {nx * nx, nx * nu, nx, nu, nx * nx, nx * nu, nu * nu};
+  for (int i = 0; i < 7; i++) {
+    off[i] = o[i];
+    len[i] = n[i];
+  }
+}
+// Derivative records are stored pair-interleaved: [tile][knot][REC/2][TW][2] -- element e of lane
+// l sits next to element e^1 of the same trajectory, so one 16-byte access per lane moves two
+// elements (the backward kernel needs 37 elements per lane and step: 18 loads instead of 37).
+__host__ __device__ inline size_t didx(int tile, int t, int e, int l, int T1, int REC) {
+  return ((((size_t)tile * T1 + t) * (REC / 2) + (e >> 1)) * TW + l) * 2 + (e & 1);
+}
 
 // Solver tunables (include/ilqr.h:14-24), passed by value to kernels.
 struct SolverParams {
@@ -82,7 +102,7 @@ struct BatchView {
   double* us;   // [tile][T][nu][TW]
   double* kff;  // [tile][T][nu][TW]
   double* Kfb;  // [tile][T][nu*nx][TW]
-  double* D;    // [tile][T+1][REC][TW]
+  double* D;    // derivative records, pair-interleaved [tile][T+1][REC/2][TW][2]  (didx)
   double* cand; // line-search candidates, time-chunked: [NALPHA][tile][NCH][TW][CT][nx+nu]  (cidx)
   int nch;      // NCH = ceil((T+1)/CT) chunks of CT knots
   double* cost_c; // [NALPHA][Bp]

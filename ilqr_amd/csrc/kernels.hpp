@@ -58,7 +58,7 @@ __global__ void k_pack_rec(const double* __restrict__ src, double* __restrict__ 
     const int s = (int)(r % S);
     const int tile = (int)(r / S);
     const int b = tile * TW + l;
-    dst[tidx(tile, s, off + e, l, S, REC)] = (b < B) ? src[((size_t)b * S + s) * E + e] : 0.0;
+    dst[didx(tile, s, off + e, l, S, REC)] = (b < B) ? src[((size_t)b * S + s) * E + e] : 0.0;
   }
 }
 __global__ void k_unpack_rec(const double* __restrict__ src, double* __restrict__ dst, int B, int S, int REC,
@@ -69,7 +69,7 @@ __global__ void k_unpack_rec(const double* __restrict__ src, double* __restrict_
     size_t r = i / E;
     const int s = (int)(r % S);
     const int b = (int)(r / S);
-    dst[i] = src[tidx(b / TW, s, off + e, b % TW, S, REC)];
+    dst[i] = src[didx(b / TW, s, off + e, b % TW, S, REC)];
   }
 }
 
@@ -362,8 +362,15 @@ __global__ __launch_bounds__(256) void k_derivatives(BatchView v, M model, int f
   }
   if (!want) return;
 
-  double* D = v.D + tidx(tile, t, 0, l, T + 1, R::SIZE);
-  auto put = [&](int e, double val) { D[(size_t)e * TW] = val; };
+  typedef double double2_t __attribute__((ext_vector_type(2)));
+  double* D = v.D + didx(tile, t, 0, l, T + 1, R::SIZE);
+  auto put = [&](int e, double val) { D[(size_t)(e >> 1) * (2 * TW) + (e & 1)] = val; };
+  auto put2 = [&](int e, double v0, double v1) {  // e even: one 16-byte store
+    double2_t w;
+    w.x = v0;
+    w.y = v1;
+    *reinterpret_cast<double2_t*>(D + (size_t)(e >> 1) * (2 * TW)) = w;
+  };
 
   if (t < T) {
     // fx, fu: central differences of the Euler map (derivatives.cpp:19-25, finite_diff.h:35-47)
@@ -377,7 +384,8 @@ __global__ __launch_bounds__(256) void k_derivatives(BatchView v, M model, int f
       integrate_dynamics(model, p, u, dt, fp);
       integrate_dynamics(model, m, u, dt, fm);
 #pragma unroll
-      for (int r = 0; r < NX; r++) put(R::FX + r + NX * i, (fp[r] - fm[r]) / (2 * kEps));
+      for (int r = 0; r < NX; r += 2)
+        put2(R::FX + r + NX * i, (fp[r] - fm[r]) / (2 * kEps), (fp[r + 1] - fm[r + 1]) / (2 * kEps));
     }
 #pragma unroll
     for (int i = 0; i < NU; i++) {
@@ -389,13 +397,14 @@ __global__ __launch_bounds__(256) void k_derivatives(BatchView v, M model, int f
       integrate_dynamics(model, x, p, dt, fp);
       integrate_dynamics(model, x, m, dt, fm);
 #pragma unroll
-      for (int r = 0; r < NX; r++) put(R::FU + r + NX * i, (fp[r] - fm[r]) / (2 * kEps));
+      for (int r = 0; r < NX; r += 2)
+        put2(R::FU + r + NX * i, (fp[r] - fm[r]) / (2 * kEps), (fp[r + 1] - fm[r + 1]) / (2 * kEps));
     }
     // cx, cu (derivatives.cpp:44-47)
     double g[NX > NU ? NX : NU];
     fd_gradient<NX>(x, [&](const double* xx) { return model.cost(xx, u); }, g);
 #pragma unroll
-    for (int i = 0; i < NX; i++) put(R::CX + i, g[i]);
+    for (int i = 0; i < NX; i += 2) put2(R::CX + i, g[i], g[i + 1]);
     fd_gradient<NU>(u, [&](const double* uu) { return model.cost(x, uu); }, g);
 #pragma unroll
     for (int i = 0; i < NU; i++) put(R::CU + i, g[i]);
@@ -403,20 +412,20 @@ __global__ __launch_bounds__(256) void k_derivatives(BatchView v, M model, int f
     double H[NX * NX];
     fd_hessian<NX>(x, [&](const double* xx) { return model.cost(xx, u); }, H);
 #pragma unroll
-    for (int e = 0; e < NX * NX; e++) put(R::CXX + e, H[e]);
+    for (int e = 0; e < NX * NX; e += 2) put2(R::CXX + e, H[e], H[e + 1]);
   } else {
 #pragma unroll
-    for (int e = 0; e < NX * NX + NX * NU; e++) put(R::FX + e, 0.0);  // fx[T], fu[T] stay zero
+    for (int e = 0; e < NX * NX + NX * NU; e += 2) put2(R::FX + e, 0.0, 0.0);  // fx[T], fu[T] stay zero
     double g[NX];
     fd_gradient<NX>(x, [&](const double* xx) { return model.final_cost(xx); }, g);  // :49
 #pragma unroll
-    for (int i = 0; i < NX; i++) put(R::CX + i, g[i]);
+    for (int i = 0; i < NX; i += 2) put2(R::CX + i, g[i], g[i + 1]);
 #pragma unroll
     for (int i = 0; i < NU; i++) put(R::CU + i, 0.0);  // :50-51
     double H[NX * NX];
     fd_hessian<NX>(x, [&](const double* xx) { return model.final_cost(xx); }, H);  // :92
 #pragma unroll
-    for (int e = 0; e < NX * NX; e++) put(R::CXX + e, H[e]);
+    for (int e = 0; e < NX * NX; e += 2) put2(R::CXX + e, H[e], H[e + 1]);
   }
   // cuu at every t, with u = 0 at t = T (derivatives.cpp:98-112)
   {
@@ -465,8 +474,8 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
   const int tile = b / TW, l = b % TW;
   const int T = v.T;
   double lambda = v.lambda[b], dlambda = v.dlambda[b];
-  const double* Dt = v.D + tidx(tile, 0, 0, l, T + 1, R::SIZE);
-  auto rec = [&](int t, int e) { return Dt[((size_t)t * R::SIZE + e) * TW]; };
+  const double* Dt = v.D + didx(tile, 0, 0, l, T + 1, R::SIZE);
+  auto rec = [&](int t, int e) { return Dt[((size_t)t * (R::SIZE / 2) + (e >> 1)) * (2 * TW) + (e & 1)]; };
 
   int diverge = 0;
   bool done = false;
@@ -832,28 +841,57 @@ __global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverP
   if (mode == 1 && v.status[b] != 0) return;   // quad-uniform
   const int T = v.T;
   double lambda = v.lambda[b], dlambda = v.dlambda[b];
-  const double* __restrict__ Dt = v.D + tidx(tile, 0, 0, l, T + 1, R::SIZE);
+  typedef double double2_t __attribute__((ext_vector_type(2)));
+  const double* __restrict__ Dt = v.D + didx(tile, 0, 0, l, T + 1, R::SIZE);
   const double* __restrict__ ust = v.us + tidx(tile, 0, 0, l, T, NU);
   double* __restrict__ kt = v.kff + tidx(tile, 0, 0, l, T, NU);
   double* __restrict__ Kt = v.Kfb + tidx(tile, 0, 0, l, T, NU * NX);
 
+  // 16-byte loads of element pairs (e even) and 8-byte loads of single elements of a record
   auto load = [&](int t, QuadStep<NU>& d) {
-    const double* r = Dt + (size_t)t * R::SIZE * TW;
+    const double* r = Dt + (size_t)t * (R::SIZE / 2) * (2 * TW);
+    auto pair = [&](int e) { return *reinterpret_cast<const double2_t*>(r + (size_t)(e >> 1) * (2 * TW)); };
+    auto one = [&](int e) { return r[(size_t)(e >> 1) * (2 * TW) + (e & 1)]; };
 #pragma unroll
-    for (int e = 0; e < 16; e++) d.fx[e] = r[(R::FX + e) * TW];
+    for (int e = 0; e < 16; e += 2) {
+      const double2_t w = pair(R::FX + e);
+      d.fx[e] = w.x;
+      d.fx[e + 1] = w.y;
+    }
 #pragma unroll
-    for (int q = 0; q < 4; q++) d.fxc[q] = r[(R::FX + q + 4 * s) * TW];
+    for (int q = 0; q < 4; q += 2) {
+      const double2_t w = pair(R::FX + q + 4 * s);
+      d.fxc[q] = w.x;
+      d.fxc[q + 1] = w.y;
+    }
 #pragma unroll
-    for (int e = 0; e < 4 * NU; e++) d.fu[e] = r[(R::FU + e) * TW];
+    for (int e = 0; e < 4 * NU; e += 2) {
+      const double2_t w = pair(R::FU + e);
+      d.fu[e] = w.x;
+      d.fu[e + 1] = w.y;
+    }
+    {  // cu and cuu are adjacent: nu(nu+1) doubles, an even count at an even offset
+      double tail[NU + NU * NU];
 #pragma unroll
-    for (int e = 0; e < NU; e++) d.cu[e] = r[(R::CU + e) * TW];
+      for (int e = 0; e < NU + NU * NU; e += 2) {
+        const double2_t w = pair(R::CU + e);
+        tail[e] = w.x;
+        tail[e + 1] = w.y;
+      }
 #pragma unroll
-    for (int e = 0; e < NU * NU; e++) d.cuu[e] = r[(R::CUU + e) * TW];
-    d.cx = r[(R::CX + s) * TW];
+      for (int e = 0; e < NU; e++) d.cu[e] = tail[e];
 #pragma unroll
-    for (int i = 0; i < 4; i++) d.cxx[i] = r[(R::CXX + i + 4 * s) * TW];
+      for (int e = 0; e < NU * NU; e++) d.cuu[e] = tail[NU + e];
+    }
+    d.cx = one(R::CX + s);
 #pragma unroll
-    for (int a = 0; a < NU; a++) d.cxu[a] = r[(R::CXU + s + 4 * a) * TW];
+    for (int i = 0; i < 4; i += 2) {
+      const double2_t w = pair(R::CXX + i + 4 * s);
+      d.cxx[i] = w.x;
+      d.cxx[i + 1] = w.y;
+    }
+#pragma unroll
+    for (int a = 0; a < NU; a++) d.cxu[a] = one(R::CXU + s + 4 * a);
 #pragma unroll
     for (int a = 0; a < NU; a++) d.us[a] = ust[((size_t)t * NU + a) * TW];
   };
@@ -866,11 +904,11 @@ __global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverP
     // carried state: full Vxx / Vx in every lane
     double Vx[4], Vxx[16], kprev[NU];
     {
-      const double* r = Dt + (size_t)T * R::SIZE * TW;
+      const double* r = Dt + (size_t)T * (R::SIZE / 2) * (2 * TW);
 #pragma unroll
-      for (int i = 0; i < 4; i++) Vx[i] = r[(R::CX + i) * TW];  // :353
+      for (int i = 0; i < 4; i++) Vx[i] = r[(size_t)((R::CX + i) >> 1) * (2 * TW) + ((R::CX + i) & 1)];  // :353
 #pragma unroll
-      for (int e = 0; e < 16; e++) Vxx[e] = r[(R::CXX + e) * TW];  // :354
+      for (int e = 0; e < 16; e++) Vxx[e] = r[(size_t)((R::CXX + e) >> 1) * (2 * TW) + ((R::CXX + e) & 1)];  // :354
     }
 #pragma unroll
     for (int a = 0; a < NU; a++) kprev[a] = kt[((size_t)(T - 1) * NU + a) * TW];
