@@ -429,6 +429,7 @@ ILQR_HD bool qp1_armijo_fails(const QP1State& q, double v, double step) {
   return (v - q.old_v) > kArmijo * (step * q.slope);
 }
 
+template <bool EVAL_UNIT = true>
 ILQR_HD void qp1_begin(double Q, double c, double x0, double lo, double hi, QP1State& q) {
   q.Q = Q;
   q.c = c;
@@ -439,15 +440,21 @@ ILQR_HD void qp1_begin(double Q, double c, double x0, double lo, double hi, QP1S
   q.g0 = Q * q.x + c;
   const double den = (Q > 0.0) ? Q : Q * Q;
   q.minv = 1.0 / den;
-  q.clA = (fabs(q.x - lo) < kClampTol && q.g0 > 0) || (fabs(q.x - hi) < kClampTol && q.g0 < 0);
+  // (bitwise & | on purpose: no short-circuit branches in the wavefront's instruction stream)
+  q.clA = ((fabs(q.x - lo) < kClampTol) & (q.g0 > 0)) | ((fabs(q.x - hi) < kClampTol) & (q.g0 < 0));
   q.exB = fabs(q.g0) < kMinGrad;
   q.search = -q.minv * c - q.x;
   q.slope = q.search * q.g0;
   q.exC = q.slope >= 0;
-  q.early = q.clA || q.exB || q.exC;
+  q.early = q.clA | q.exB | q.exC;
   q.step = 1;
-  q.x1 = qp1_trial(q, 1.0);
-  q.v1 = qp1_value(q, q.x1);
+  if (EVAL_UNIT) {
+    q.x1 = qp1_trial(q, 1.0);
+    q.v1 = qp1_value(q, q.x1);
+  } else {
+    q.x1 = q.x;
+    q.v1 = 0;
+  }
   q.old_v = qp1_value(q, q.x);
   q.ls_failed = false;
 }
@@ -467,35 +474,16 @@ ILQR_HD void qp1_backtrack_seq(QP1State& q) {  // boxqp.cpp:161-173
 ILQR_HD int qp1_finish(const QP1State& q, double& x_out, int& free_out, double& minv_out) {
   const bool exD = (q.val0 - q.v1) < kMinRelImprove * fabs(q.val0);
   const double g1 = q.Q * q.x1 + q.c;
-  const bool clE = (fabs(q.x1 - q.lo) < kClampTol && g1 > 0) || (fabs(q.x1 - q.hi) < kClampTol && g1 < 0);
+  const bool clE = ((fabs(q.x1 - q.lo) < kClampTol) & (g1 > 0)) | ((fabs(q.x1 - q.hi) < kClampTol) & (g1 < 0));
   const bool exF = fabs(g1) < kMinGrad;
   minv_out = q.minv;
-  int result;
-  double xo = q.x;
-  int fr = 1;
-  if (q.clA) {  // the reference's order of tests
-    result = 6;
-    fr = 0;
-  } else if (q.exB) {
-    result = 5;
-  } else if (q.exC || q.ls_failed) {
-    result = 2;
-  } else {
-    xo = q.x1;
-    if (exD) {
-      result = 4;
-    } else if (clE) {
-      result = 6;
-      fr = 0;
-    } else if (exF) {
-      result = 5;
-    } else {
-      result = -1;
-    }
-  }
-  x_out = xo;
-  free_out = fr;
-  return result;
+  // the reference's order of tests, as selects (no branches)
+  const bool stay = q.clA | q.exB | q.exC | q.ls_failed;  // x is not updated
+  const int inner = exD ? 4 : (clE ? 6 : (exF ? 5 : -1));
+  const int outer = q.clA ? 6 : (q.exB ? 5 : 2);
+  x_out = stay ? q.x : q.x1;
+  free_out = (q.clA | (!stay & !exD & clE)) ? 0 : 1;
+  return stay ? outer : inner;
 }
 
 ILQR_HD int box_qp_scalar_fast(double Q, double c, double x0, double lo, double hi, double& x_out, int& free_out,

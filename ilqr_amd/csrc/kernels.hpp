@@ -773,45 +773,47 @@ __device__ __forceinline__ void quad_gather(double x, double out[4]) {
 
 __device__ __constant__ const StepTable kStepTable{};
 
-// Quad-parallel Armijo backtracking for the scalar QP (all four lanes of a quad hold the same
-// QP1State).  The sequential loop tries step_k = 0.6^k for k = 1, 2, ... until the test passes;
-// a Newton step that a bound truncates to a tiny fraction needs 10+ trips, and a wavefront pays
-// for its slowest quad.  For Q > 0 the set of passing k is upward closed (while the trial point
-// sits on the bound the value is constant and the threshold shrinks with the step; once it is
-// inside the bound a Newton step always passes), so: estimate k from the two thresholds, let
-// lane s evaluate the exact test at k_g-2+s, and accept the first passing k if k_g-2 fails.
-// Anything else (estimate off, Q <= 0, k near the minStep cut-off) returns false and the caller
-// runs the sequential loop -- the result is the same either way.
-__device__ __forceinline__ bool qp1_backtrack_quad(QP1State& q, int s, int l, const double* __restrict__ lds_steps) {
-  const bool need = !q.early && qp1_armijo_fails(q, q.v1, 1.0);
-  bool handled = !need;
-  if (__any(need)) {
-    const double bound = (q.search > 0) ? q.hi : q.lo;
-    const double f = (bound - q.x) / q.search;                      // fraction of the step inside the box
-    const double r = (q.v1 - q.old_v) / (kArmijo * q.slope);        // Armijo threshold while on the bound
-    const float thr = (float)fmax(r, f);
-    int kg = (int)ceilf(__log2f(thr) * -1.35691545f);               // 1/log2(0.6)
-    const bool sane = need && (q.Q > 0.0) && (thr > 0.f) && (thr < 1.f) && (kg >= 1) && (kg <= 96);
-    kg = sane ? kg : 2;
-    const int my_k = kg - 2 + s;
-    const double my_step = lds_steps[my_k > 0 ? my_k : 0];
-    const double my_x1 = qp1_trial(q, my_step);
-    const double my_v1 = qp1_value(q, my_x1);
-    const bool my_pass = (my_k >= 1) && !qp1_armijo_fails(q, my_v1, my_step);
-    const unsigned long long bal = __ballot(my_pass);
-    const unsigned int m4 = (unsigned int)(bal >> (4 * l)) & 0xFu;
-    // k_g-2 must fail (or be k=0, which is known to fail); the first passing k of the window wins
-    const bool valid = sane && ((m4 & 1u) == 0u) && (m4 != 0u);
-    if (valid) {
-      const int first = __ffs(m4) - 1;
-      const double st = lds_steps[kg - 2 + first];
-      q.step = st;
-      q.x1 = qp1_trial(q, st);
-      q.v1 = qp1_value(q, q.x1);
-      handled = true;
-    }
-  }
-  return handled;
+// Quad-parallel Armijo line search for the scalar QP (all four lanes of a quad hold the same
+// QP1State).  The reference's loop (boxqp.cpp:156-173) tries step_k = 0.6^k for k = 0, 1, 2, ...
+// until the Armijo test passes; a Newton step that a bound truncates to a tiny fraction needs
+// 10+ trips, and a wavefront pays for its slowest quad.  For Q > 0 the set of passing k is upward
+// closed (while the trial point sits on the bound the value is constant and the threshold shrinks
+// with the step; once it is inside the bound a Newton step always passes).  So the four lanes
+// evaluate four candidates in ONE instruction stream -- lane 0 the unit step, lanes 1..3 a window
+// k1, k1+1, k1+2 around an fp32 estimate of the answer -- with the exact test and the exact step
+// table, and the first passing candidate whose predecessor is known to fail is taken.  Anything
+// else (estimate off, Q <= 0, k near the minStep cut-off) returns false and the caller runs the
+// sequential loop: the result is the reference's either way.
+__device__ __forceinline__ bool qp1_search_quad(QP1State& q, int s, int lane, const double* __restrict__ lds_steps) {
+  const double bound = (q.search > 0) ? q.hi : q.lo;
+  const double v_b = qp1_value(q, bound);
+  // fp32 estimates: f = fraction of the step inside the box, r = Armijo threshold on the bound
+  const float f = (float)(bound - q.x) * __frcp_rn((float)q.search);
+  const float r = (float)(v_b - q.old_v) * __frcp_rn((float)(kArmijo * q.slope));
+  const float thr = fmaxf(f, r);
+  int kg = (int)ceilf(__log2f(thr) * -1.35691545f);  // log(thr)/log(0.6)
+  const bool sane = (q.Q > 0.0) & (thr > 0.f) & (thr < 1.f) & (kg >= 1) & (kg <= 96);
+  const int k1 = (sane & (kg > 2)) ? kg - 1 : 1;
+  const int my_k = (s == 0) ? 0 : k1 + s - 1;
+  const double my_step = lds_steps[my_k];
+  const double my_x1 = qp1_trial(q, my_step);
+  const double my_v1 = qp1_value(q, my_x1);
+  const bool my_pass = !qp1_armijo_fails(q, my_v1, my_step);
+  const unsigned long long bal = __ballot(my_pass);
+  const unsigned int m4 = (unsigned int)(bal >> (lane & ~3)) & 0xFu;
+  // which candidate wins: lane 0 if the unit step passes, else the first passing window lane,
+  // provided its predecessor failed (in the window, or k = 0 when the window starts at k = 1)
+  const bool unit = (m4 & 1u) != 0u;
+  const unsigned int w = m4 >> 1;
+  const int wwin = __ffs(w);  // 1..3, 0 if none
+  const bool wok = (w != 0u) & ((wwin > 1) | (k1 == 1)) & (sane | (k1 == 1));
+  const bool ok = unit | wok;
+  const int win = unit ? 0 : wwin;
+  const int src = (lane & ~3) + (ok ? win : 0);
+  q.x1 = __shfl(my_x1, src, 64);
+  q.v1 = __shfl(my_v1, src, 64);
+  q.step = __shfl(my_step, src, 64);
+  return ok | q.early;
 }
 
 template <int NU>
@@ -1006,8 +1008,13 @@ __global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverP
         int free0;
         double minv;
         QP1State q1;
-        qp1_begin(QuuF[0], Qu[0], kprev[0], lo[0], hi[0], q1);
-        if (!qp1_backtrack_quad(q1, s, l, lds_steps)) qp1_backtrack_seq(q1);  // fallback: rare
+        qp1_begin<false>(QuuF[0], Qu[0], kprev[0], lo[0], hi[0], q1);
+        if (!qp1_search_quad(q1, s, lane, lds_steps)) {  // fallback: rare
+          q1.step = 1;
+          q1.x1 = qp1_trial(q1, 1.0);
+          q1.v1 = qp1_value(q1, q1.x1);
+          qp1_backtrack_seq(q1);
+        }
         int result = qp1_finish(q1, qp.x[0], free0, minv);
         ILQR_MARK(6)  // fast QP
 #ifdef ILQR_PHASE_TIMING
