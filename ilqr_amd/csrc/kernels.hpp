@@ -141,7 +141,7 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
   double total = 0;
 
   // cooperative flush of the knots staged for chunk c (all 64 lanes; inactive (alpha, l) pairs skipped)
-  auto flush = [&](int c) {
+  auto flush = [&](int c) __attribute__((always_inline)) {
     if (!CAND) return;
     constexpr int PER = CT * KR;  // doubles per (alpha, trajectory) chunk
 #pragma unroll
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
   struct StepIn {
     double u[NU], k[GAINS ? NU : 1], K[GAINS ? NU * NX : 1], xnom[GAINS ? NX : 1];
   };
-  auto load_step = [&](int t, StepIn& d) {
+  auto load_step = [&](int t, StepIn& d) __attribute__((always_inline)) {
     t = (t < T) ? t : T - 1;  // tail: harmless re-load instead of a branch
 #pragma unroll
     for (int j = 0; j < NU; j++) d.u[j] = v.us[tidx(tile, t, j, l, T, NU)];
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
 #else
 #define ILQR_RMARK(k)
 #endif
-  auto emit_knot = [&](int t, const double* xx, const double* uu) {  // knot t = (x_t, u_t)
+  auto emit_knot = [&](int t, const double* xx, const double* uu) __attribute__((always_inline)) {  // knot t = (x_t, u_t)
     if (CAND) {
       const int j = t & (CT - 1);
 #pragma unroll
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
       }
     }
   };
-  auto do_step = [&](int t, const StepIn& d) {
+  auto do_step = [&](int t, const StepIn& d) __attribute__((always_inline)) {
     ILQR_RMARK(0)  // loop control + prefetch issue
     double u[NU];
 #pragma unroll
@@ -851,9 +851,9 @@ __global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverP
 
   // 16-byte loads of element pairs (e even) and 8-byte loads of single elements of a record
   auto load = [&](int t, QuadStep<NU>& d) {
-    const double* r = Dt + (size_t)t * (R::SIZE / 2) * (2 * TW);
-    auto pair = [&](int e) { return *reinterpret_cast<const double2_t*>(r + (size_t)(e >> 1) * (2 * TW)); };
-    auto one = [&](int e) { return r[(size_t)(e >> 1) * (2 * TW) + (e & 1)]; };
+    const double* r = Dt + (unsigned)(t * ((R::SIZE / 2) * 2 * TW));  // in-tile offsets fit 32 bits
+    auto pair = [&](int e) { return *reinterpret_cast<const double2_t*>(r + (unsigned)((e >> 1) * (2 * TW))); };
+    auto one = [&](int e) { return r[(unsigned)((e >> 1) * (2 * TW) + (e & 1))]; };
 #pragma unroll
     for (int e = 0; e < 16; e += 2) {
       const double2_t w = pair(R::FX + e);
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverP
 #pragma unroll
     for (int a = 0; a < NU; a++) d.cxu[a] = one(R::CXU + s + 4 * a);
 #pragma unroll
-    for (int a = 0; a < NU; a++) d.us[a] = ust[((size_t)t * NU + a) * TW];
+    for (int a = 0; a < NU; a++) d.us[a] = ust[(unsigned)((t * NU + a) * TW)];
   };
 
   constexpr int kWaitAll = (7 << 4) | (15 << 8);  // s_waitcnt vmcnt(0) only (expcnt/lgkmcnt untouched)
@@ -1159,7 +1159,7 @@ __global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverP
           const double val = fabs(qp.x[a]) / (fabs(d.us[a]) + 1);
           mx = (a == 0 || val > mx) ? val : mx;
         }
-        gacc += mx;
+        if (ok) gacc += mx;
       }
       ILQR_MARK(3)  // value-function update + quad exchanges
       // the prefetch issued at the top of this step has had the whole step to land
@@ -1172,11 +1172,11 @@ __global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverP
 #pragma unroll
         for (int a = 0; a < NU; a++) {
           kprev[a] = qp.x[a];
-          Kt[((size_t)i * NU * NX + a + NU * s) * TW] = Kc[a];
+          Kt[(unsigned)((i * NU * NX + a + NU * s) * TW)] = Kc[a];
         }
         if (s == 0) {
 #pragma unroll
-          for (int a = 0; a < NU; a++) kt[((size_t)i * NU + a) * TW] = qp.x[a];
+          for (int a = 0; a < NU; a++) kt[(unsigned)((i * NU + a) * TW)] = qp.x[a];
         }
       }
       ILQR_MARK(5)  // stores
