@@ -16,7 +16,9 @@ ALPHAS = np.array([1.0000, 0.5012, 0.2512, 0.1259, 0.0631, 0.0316, 0.0158, 0.007
                    0.0020, 0.0010])  # include/ilqr.h:24
 STATUS_NAMES = {0: "running", 1: "converged_grad", 2: "converged_cost", 3: "lambda_max", 4: "max_iter"}
 _MODELS = {"acrobot": (capi.MODEL_ACROBOT, 4, 1), "double_integrator": (capi.MODEL_DOUBLE_INTEGRATOR, 4, 2),
-           "integrator": (capi.MODEL_DOUBLE_INTEGRATOR, 4, 2)}
+           "integrator": (capi.MODEL_DOUBLE_INTEGRATOR, 4, 2),
+           # host-evaluated model: only the backward pass runs on the device (nx, nu given by the caller)
+           "host": (capi.MODEL_HOST, None, None)}
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 
@@ -31,9 +33,10 @@ def _p(a):
 
 class BatchILQR:
     def __init__(self, model, B, T, dt, u_min=None, u_max=None, goal=None, device=0, flags=0,
-                 stream=None, params=None):
+                 stream=None, params=None, nx=None, nu=None):
         self.lib = capi.load()
-        mid, nx, nu = _MODELS[model]
+        mid, mnx, mnu = _MODELS[model]
+        nx, nu = (mnx or nx), (mnu or nu)
         self.model, self.nx, self.nu, self.B, self.T, self.dt = model, nx, nu, int(B), int(T), float(dt)
         self._keep = []
         d = capi.Desc()

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "backward_wave.hpp"
 #include "kernels.hpp"
 
 using namespace ilqr;
@@ -65,6 +66,9 @@ struct ilqr_batch {
   std::vector<void*> allocs;
   bool initialised = false;  // init_traj / set_trajectory has run
   bool commit_pending = false;  // an accepted candidate is not yet copied into xs/us
+  bool aos = false;             // host-model / generic handles: trajectory-contiguous layout, wave-per-trajectory backward
+  double* d_umin = nullptr;     // [nu] device copies of the limits (generic kernel)
+  double* d_umax = nullptr;
   bool profile = false;
   StageTimer timers[ILQR_NUM_STAGES];
 };
@@ -132,9 +136,14 @@ static int ensure_staging(ilqr_batch* h, size_t elems) {
   h->staging_elems = elems;
   return 0;
 }
-// canonical host [B][S][E] -> tiled device
+// canonical host [B][S][E] -> tiled device  (AoS handles: the canonical layout IS the device layout)
 static int upload(ilqr_batch* h, const double* src, double* dst_tiled, int S, int E) {
   const size_t n = (size_t)h->B * S * E;
+  if (h->aos) {
+    HIPCHK(hipMemcpyAsync(dst_tiled, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+  }
   if (int rc = ensure_staging(h, n)) return rc;
   HIPCHK(hipMemcpyAsync(h->staging, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   const size_t nt = (size_t)h->ntiles * S * E * TW;
@@ -145,6 +154,11 @@ static int upload(ilqr_batch* h, const double* src, double* dst_tiled, int S, in
 }
 static int download(ilqr_batch* h, const double* src_tiled, double* dst, int S, int E) {
   const size_t n = (size_t)h->B * S * E;
+  if (h->aos) {
+    HIPCHK(hipMemcpyAsync(dst, src_tiled, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+  }
   if (int rc = ensure_staging(h, n)) return rc;
   hipLaunchKernelGGL(k_unpack, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, src_tiled, h->staging, h->B, S, E);
   HIPCHK(hipGetLastError());
@@ -157,6 +171,12 @@ static int upload_rec(ilqr_batch* h, const double* src, int off, int E) {
   const size_t n = (size_t)h->B * S * E;
   if (int rc = ensure_staging(h, n)) return rc;
   HIPCHK(hipMemcpyAsync(h->staging, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (h->aos) {
+    hipLaunchKernelGGL(k_rec_aos, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, h->v.D, h->staging, h->B, S, rec_of(h), off, E, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+  }
   const size_t nt = (size_t)h->ntiles * S * E * TW;
   hipLaunchKernelGGL(k_pack_rec, dim3(grid_for(nt, 256)), dim3(256), 0, h->stream, h->staging, h->v.D, h->B, h->ntiles, S,
                      rec_of(h), off, E);
@@ -168,6 +188,13 @@ static int download_rec(ilqr_batch* h, double* dst, int off, int E) {
   const int S = h->T + 1;
   const size_t n = (size_t)h->B * S * E;
   if (int rc = ensure_staging(h, n)) return rc;
+  if (h->aos) {
+    hipLaunchKernelGGL(k_rec_aos, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, h->v.D, h->staging, h->B, S, rec_of(h), off, E, 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(dst, h->staging, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+  }
   hipLaunchKernelGGL(k_unpack_rec, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, h->v.D, h->staging, h->B, S, rec_of(h), off, E);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(dst, h->staging, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -269,7 +296,9 @@ static bool use_quad_backward(const ilqr_batch* h) {
 static int launch_backward(ilqr_batch* h, int mode) {
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_BACKWARD, &ev)) return rc;
-  if (use_quad_backward(h)) {
+  if (h->aos) {
+    hipLaunchKernelGGL(k_backward_w, dim3(h->B), dim3(64), 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode);
+  } else if (use_quad_backward(h)) {
     dim3 grid(h->ntiles), block(64);  // one wavefront = one tile of 16 trajectories x 4 lanes
     switch (h->model) {
       case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_backward_q<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, h->sp, mode); break;
@@ -411,6 +440,12 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
       m.u_min[j] = d->u_min ? d->u_min[j] : -0.5;
       m.u_max[j] = d->u_max ? d->u_max[j] : 0.5;
     }
+  } else if (d->model == ILQR_MODEL_HOST || d->model == ILQR_MODEL_LQ) {
+    // Host-evaluated models (and, for now, the synthetic LQ model): derivatives arrive through
+    // ilqr_set_derivatives, the device runs the backward pass (one wavefront per trajectory).
+    REQUIRE(d->nx <= WN && d->nu <= WM, "generic backward kernel: nx <= %d, nu <= %d", WN, WM);
+    REQUIRE(d->u_min && d->u_max, "host-model handles need u_min/u_max (Model::u_min/u_max, include/model.h:17)");
+    h->aos = true;
   } else {
     return fail(ILQR_ERR_UNSUPPORTED, "model id %d is not available in this build", d->model);
   }
@@ -423,6 +458,24 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   v.T = h->T;
   v.dt = h->dt;
   int rc = 0;
+  if (h->aos) {
+    const size_t Bn = h->B;
+    v.nch = 0;
+    rc |= dev_alloc(h, &v.x0, Bn * nx);
+    rc |= dev_alloc(h, &v.xs, Bn * T1 * nx);
+    rc |= dev_alloc(h, &v.us, Bn * T * nu);
+    rc |= dev_alloc(h, &v.kff, Bn * T * nu);
+    rc |= dev_alloc(h, &v.Kfb, Bn * T * nu * nx);
+    rc |= dev_alloc(h, &v.D, Bn * T1 * REC);
+    rc |= dev_alloc(h, &h->d_umin, nu);
+    rc |= dev_alloc(h, &h->d_umax, nu);
+    v.cand = nullptr;
+    v.cost_c = nullptr;
+    if (!rc) {
+      if (hipMemcpyAsync(h->d_umin, d->u_min, nu * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = 1;
+      if (hipMemcpyAsync(h->d_umax, d->u_max, nu * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = 1;
+    }
+  } else {
   rc |= dev_alloc(h, &v.x0, nt * nx * TW);
   rc |= dev_alloc(h, &v.xs, nt * T1 * nx * TW);
   rc |= dev_alloc(h, &v.us, nt * T * nu * TW);
@@ -432,6 +485,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   v.nch = (h->T + 1 + CT - 1) / CT;
   rc |= dev_alloc(h, &v.cand, (size_t)NALPHA * nt * v.nch * TW * CT * (nx + nu));
   rc |= dev_alloc(h, &v.cost_c, (size_t)NALPHA * Bp);
+  }
   rc |= dev_alloc(h, &v.cost, Bp);
   rc |= dev_alloc(h, &v.lambda, Bp);
   rc |= dev_alloc(h, &v.dlambda, Bp);
@@ -510,6 +564,7 @@ int ilqr_synchronize(ilqr_batch* h) {
 // ---- whole-solve entry points --------------------------------------------------------------
 int ilqr_init_traj(ilqr_batch* h, const double* x0, const double* u0, double* cost_out) {
   if (!h || !x0 || !u0) return fail(ILQR_ERR_INVALID, "null argument");
+  if (h->aos) return fail(ILQR_ERR_UNSUPPORTED, "host-evaluated model: rollouts and finite differences stay on the host; only the backward pass (ilqr_set_derivatives + ilqr_backward_pass/_step) runs on the device");
   HIPCHK(hipSetDevice(h->device));
   if (int rc = upload(h, x0, h->v.x0, 1, h->nx)) return rc;
   if (int rc = upload(h, u0, h->v.us, h->T, h->nu)) return rc;  // us = u_0, ilqr_core.cpp:17
@@ -531,6 +586,7 @@ int ilqr_init_traj(ilqr_batch* h, const double* x0, const double* u0, double* co
 
 int ilqr_iterate(ilqr_batch* h, int n_iters) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  if (h->aos) return fail(ILQR_ERR_UNSUPPORTED, "host-evaluated model: rollouts and finite differences stay on the host; only the backward pass (ilqr_set_derivatives + ilqr_backward_pass/_step) runs on the device");
   if (!h->initialised) return fail(ILQR_ERR_STATE, "ilqr_iterate before ilqr_init_traj/ilqr_set_trajectory");
   HIPCHK(hipSetDevice(h->device));
   for (int it = 0; it < n_iters; it++) {
@@ -576,6 +632,7 @@ int ilqr_solve(ilqr_batch* h, const double* x0, const double* u0) {
 
 int ilqr_warm_start(ilqr_batch* h, const double* x0) {
   if (!h || !x0) return fail(ILQR_ERR_INVALID, "null argument");
+  if (h->aos) return fail(ILQR_ERR_UNSUPPORTED, "host-evaluated model: rollouts and finite differences stay on the host; only the backward pass (ilqr_set_derivatives + ilqr_backward_pass/_step) runs on the device");
   if (!h->initialised) return fail(ILQR_ERR_STATE, "warm start needs a previous solve (assert us.size()>0, ilqr_core.cpp:66)");
   HIPCHK(hipSetDevice(h->device));
   if (int rc = upload(h, x0, h->v.x0, 1, h->nx)) return rc;
@@ -600,6 +657,7 @@ int ilqr_warm_start(ilqr_batch* h, const double* x0) {
 // ---- stages --------------------------------------------------------------------------------
 int ilqr_compute_derivatives(ilqr_batch* h) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  if (h->aos) return fail(ILQR_ERR_UNSUPPORTED, "host-evaluated model: rollouts and finite differences stay on the host; only the backward pass (ilqr_set_derivatives + ilqr_backward_pass/_step) runs on the device");
   HIPCHK(hipSetDevice(h->device));
   return launch_derivatives(h, 1);
 }
@@ -620,6 +678,7 @@ int ilqr_backward_step(ilqr_batch* h) {
 
 int ilqr_rollout_candidates(ilqr_batch* h, double* cost_out) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  if (h->aos) return fail(ILQR_ERR_UNSUPPORTED, "host-evaluated model: rollouts and finite differences stay on the host; only the backward pass (ilqr_set_derivatives + ilqr_backward_pass/_step) runs on the device");
   HIPCHK(hipSetDevice(h->device));
   if (int rc = do_rollout_candidates(h, 0)) return rc;
   if (cost_out) {
@@ -634,6 +693,7 @@ int ilqr_rollout_candidates(ilqr_batch* h, double* cost_out) {
 
 int ilqr_line_search(ilqr_batch* h) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  if (h->aos) return fail(ILQR_ERR_UNSUPPORTED, "host-evaluated model: rollouts and finite differences stay on the host; only the backward pass (ilqr_set_derivatives + ilqr_backward_pass/_step) runs on the device");
   HIPCHK(hipSetDevice(h->device));
   if (int rc = flush_commit(h)) return rc;
   if (int rc = do_rollout_candidates(h, 1)) return rc;
@@ -737,6 +797,7 @@ int ilqr_get_status(ilqr_batch* h, int* status, int* iters, int* alpha_idx) {
 }
 int ilqr_get_candidate(ilqr_batch* h, int a, double* xs, double* us) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  if (h->aos) return fail(ILQR_ERR_UNSUPPORTED, "host-evaluated model: rollouts and finite differences stay on the host; only the backward pass (ilqr_set_derivatives + ilqr_backward_pass/_step) runs on the device");
   REQUIRE(a >= 0 && a < NALPHA, "alpha index %d out of range", a);
   HIPCHK(hipSetDevice(h->device));
   const size_t nx_el = (size_t)h->B * (h->T + 1) * h->nx, nu_el = (size_t)h->B * h->T * h->nu;
@@ -784,7 +845,7 @@ int ilqr_profile_read(ilqr_batch* h, double ms_out[ILQR_NUM_STAGES], int launche
 const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
   switch (stage) {
     case ILQR_STAGE_DERIVATIVES: return "k_derivatives";
-    case ILQR_STAGE_BACKWARD: return (h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t";
+    case ILQR_STAGE_BACKWARD: return (h && h->aos) ? "k_backward_w" : ((h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t");
     case ILQR_STAGE_ROLLOUT: return "k_rollout";
     case ILQR_STAGE_ACCEPT: return "k_accept";
     default: return "";

@@ -1,0 +1,84 @@
+"""The generic backward kernel (one wavefront per trajectory, nx <= 32, nu <= 16, LDS tiles) used
+for host-evaluated models and the synthetic LQ configuration (BASELINE.json configs[4]):
+teacher-forced parity against the oracle's backward_pass, through the C ABI (ILQR_MODEL_HOST)."""
+import numpy as np
+import pytest
+
+from tests.util import TOL, mat
+from tests.test_gpu_parity import _is_clamp_knife_edge, _per_traj_err
+
+pytestmark = pytest.mark.gpu
+DT = 0.02
+
+
+def lq_model(oracle, n, m, seed=7, lim=1.0):
+    rng = np.random.default_rng(seed)
+    A = -np.eye(n) + 0.1 * rng.normal(size=(n, n)) / np.sqrt(n)
+    Bm = rng.normal(size=(n, m)) / np.sqrt(n)
+    Q, R = np.eye(n), 0.1 * np.eye(m)
+    return oracle.Model("lq", lq=(A, Bm, Q, R, Q), u_lim=lim)
+
+
+def run_case(oracle, om, B, T, lam, x_scale=1.0, u_scale=0.5):
+    from ilqr_amd import BatchILQR
+    n, m = om.nx, om.nu
+    rng = np.random.default_rng(3)
+    x0 = rng.uniform(-1, 1, (B, n)) * x_scale
+    u0 = rng.normal(size=(B, T, m)) * u_scale
+    xs, us, cost = oracle.batch_rollout(om, x0, u0, DT)
+    dv = oracle.batch_derivatives(om, xs, us, DT)
+    k_prev = rng.normal(size=(B, T, m)) * 0.1
+    ro = oracle.batch_backward(om, us, dv, k_prev=k_prev, lam=lam)
+    g = BatchILQR("host", B, T, DT, nx=n, nu=m, u_min=om.u_min, u_max=om.u_max)
+    g.set_trajectory(x0=x0, xs=xs, us=us, cost=cost)
+    g.set_derivatives(**{k: (dv[k] if k in ("cx", "cu") else mat(dv[k])) for k in dv})
+    g.set_gains(k=k_prev, K=np.zeros((B, T, m, n)))
+    g.set_lambda(lam, 1.0)
+    # the records survive the round trip through the device layout
+    back = g.derivatives()
+    for kk in ("fx", "cxx", "cuu", "cxu"):
+        assert np.array_equal(back[kk], mat(dv[kk])), kk
+    div = g.backward_pass()
+    k, K = g.gains()
+    dV = g.dV()
+    Ko = mat(ro["K"])
+    lo, hi = om.u_min[None, None, :] - us, om.u_max[None, None, :] - us
+    conv = ro["diverge"] == 0
+    assert conv.sum() > 0
+    err = np.maximum.reduce([_per_traj_err(k, ro["k"]), _per_traj_err(K, Ko), _per_traj_err(dV, ro["dV"])])
+    good = (err < TOL) & (div == ro["diverge"])
+    ties = 0
+    for b in np.flatnonzero(conv & ~good):
+        assert _is_clamp_knife_edge(k[b], K[b], ro["k"][b], Ko[b], lo[b], hi[b]), (b, err[b])
+        ties += 1
+    assert ties <= max(1, B // 8), ties
+    ok = conv & good
+    clamped = (np.abs(k - lo) < 1e-9) | (np.abs(k - hi) < 1e-9)
+    return clamped[ok].mean(), g
+
+
+@pytest.mark.parametrize("lam", [1.0, 1e-3])
+def test_lq_32x16(oracle, lam):
+    """n = 32, m = 16 (the LDS-tile configuration), limits +-1 with part of the controls clamped."""
+    om = lq_model(oracle, 32, 16, lim=0.2)
+    frac, g = run_case(oracle, om, B=6, T=12, lam=lam, x_scale=1.0)
+    assert 0.02 < frac < 0.98  # mixed free / clamped sets: compaction + partial K rows exercised
+    # STEP 2 with the gradient-norm reduction on the same state
+    g.backward_step()
+    assert np.all(np.isfinite(g.gnorm()))
+
+
+def test_lq_odd_dims(oracle):
+    om = lq_model(oracle, 6, 3, seed=11, lim=0.3)
+    frac, _ = run_case(oracle, om, B=9, T=15, lam=1.0)
+    assert frac > 0.0
+
+
+def test_host_path_equals_device_model_path(oracle):
+    """Acrobot derivatives pushed through the host-model path give the same gains as the quad kernel."""
+    from ilqr_amd import BatchILQR
+    om = oracle.Model("acrobot", u_lim=1.5)
+    frac, g = run_case(oracle, om, B=20, T=40, lam=1.0, x_scale=1.0, u_scale=1.0)
+    assert frac > 0.02
+    with pytest.raises(Exception, match="host-evaluated model"):
+        g.iterate(1)
