@@ -13,7 +13,7 @@
 // n = 32, m = 16).
 //
 // Work split: the O(n^3) products are spread over the 64 lanes by output element with the inner
-// sum in index order (the oracle's order); LDS matrices use odd leading dimensions (33 / 17) so
+// sum in index order (the order of the reference's loops); LDS matrices use odd leading dimensions (33 / 17) so
 // that lanes walking different columns hit different banks.  One trajectory per wavefront makes
 // all control flow of the box-QP (src/boxqp.cpp:26-178) wave-uniform: projected-Newton
 // iterations, the factor-on-count-change rule, the Armijo loop run exactly as written, with
