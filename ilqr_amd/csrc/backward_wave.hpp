@@ -12,13 +12,18 @@
 // so a wavefront streams its own trajectory with 512-byte coalesced accesses (27 KB per step at
 // n = 32, m = 16).
 //
-// Work split: the O(n^3) products are spread over the 64 lanes by output element with the inner
-// sum in index order (the order of the reference's loops); LDS matrices use odd leading dimensions (33 / 17) so
-// that lanes walking different columns hit different banks.  One trajectory per wavefront makes
+// Work split: the O(n^3) products run on the matrix cores, v_mfma_f64_16x16x4_f64 on 16x16 output
+// tiles with operands read from LDS (one double per lane and k-step; fp64 MFMA has the VALU's
+// flop rate on gfx950, what it buys is 1 LDS read per 32 flops instead of per flop and a k-ordered
+// FMA chain = the order of the reference's loops).  LDS matrices are zero-padded to whole tiles
+// and use odd leading dimensions (33 / 17) so that lanes walking different columns hit different
+// banks.  One trajectory per wavefront makes
 // all control flow of the box-QP (src/boxqp.cpp:26-178) wave-uniform: projected-Newton
 // iterations, the factor-on-count-change rule, the Armijo loop run exactly as written, with
 // per-dimension work on lanes 0..m-1 and wave reductions for the scalars.
 #pragma once
+#include <stddef.h>
+
 #include "common.hpp"
 
 namespace ilqr {
@@ -38,14 +43,40 @@ struct WaveLds {
   int vfree[WM], idx[WM];
 };
 
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// One 16x16 output tile: acc += sum_k A(i,k) B(k,j) over `ksteps` k-steps of 4.  Lane l feeds
+// A(i = l&15, k = 4 ks + (l>>4)) and B(k, j = l&15); it ends with D(row = (l>>4) + 4 r, col = l&15),
+// r = 0..3 (the f64 C/D map of v_mfma_f64_16x16x4_f64).
+template <int KSTEPS, class FA, class FB>
+__device__ __forceinline__ double4_t mfma_tile(FA a_at, FB b_at, int lane) {
+  // compile-time trip count (operands are zero-padded to whole tiles): all 2*KSTEPS LDS reads are
+  // issued before the first MFMA, so the chain of dependent MFMAs runs back to back
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const int ij = lane & 15, kq = lane >> 4;
+  double av[KSTEPS], bv[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ks++) {
+    av[ks] = a_at(ij, ks * 4 + kq);
+    bv[ks] = b_at(ks * 4 + kq, ij);
+  }
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], acc, 0, 0, 0);
+  return acc;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {  // sum over the 64 lanes (result in all lanes)
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
-__device__ __forceinline__ void lds_sync() {  // one wavefront per block: LDS ops are in order, only drain them
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+__device__ __forceinline__ void lds_sync() {
+  // One wavefront per block: the LDS pipeline executes a wavefront's DS instructions in issue
+  // order, so a ds_read after a ds_write sees it whichever lane wrote.  Only the COMPILER has to be
+  // kept from reordering LDS accesses across this point: a wavefront-scope fence (no hardware
+  // wait).  A workgroup-scope release fence here would drain vmcnt -- i.e. every outstanding
+  // global load/store -- at each of the ~40 sync points of a step.
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -282,6 +313,56 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
   double* __restrict__ kb = v.kff + (size_t)b * T * m;
   double* __restrict__ Kb = v.Kfb + (size_t)b * T * m * n;
   double lambda = v.lambda[b], dlambda = v.dlambda[b];
+  const int NT = (n + 15) / 16;              // 16-row tiles covering n
+  const int KN = (n + 3) / 4, KM = (m + 3) / 4;  // MFMA k-steps covering n, m
+  const int orow = lane >> 4, ocol = lane & 15;  // this lane's rows (orow + 4 r) and column in an output tile
+  // zero every LDS matrix once: the padding up to whole tiles must read as 0 in the products
+  {
+    double* z = reinterpret_cast<double*>(&L);
+    const int nz = (int)((offsetof(WaveLds, Vx)) / sizeof(double));
+    for (int e = lane; e < nz; e += 64) z[e] = 0.0;
+  }
+  lds_sync();
+
+  // One step's record in registers, every load of it issued back to back (a single HBM round
+  // trip instead of one per loop iteration) and one step AHEAD of its use.  fx/fu are fetched
+  // row-contiguous for the copy into LDS; cxx/cxu/cuu are fetched directly in the MFMA output
+  // mapping (this lane's rows orow+4r, column ocol of each tile) where they are added.
+  struct RecRegs {
+    double fx[16], fu[8], cxx[16], cxu[8], cuu[4], cx, cu, us;
+  };
+  auto load_rec = [&](int i, RecRegs& q) __attribute__((always_inline)) {
+    const double* r = Db + (size_t)i * REC;
+    const int a32 = lane & 31, chalf = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int c = 2 * j + chalf;
+      q.fx[j] = (a32 < n && c < n) ? r[oFX + a32 + n * c] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int c = 2 * j + chalf;
+      q.fu[j] = (a32 < n && c < m) ? r[oFU + a32 + n * c] : 0.0;
+    }
+#pragma unroll
+    for (int t2 = 0; t2 < 16; t2++) {
+      const int a = (t2 >> 3) * 16 + orow + 4 * (t2 & 3), c = ((t2 >> 2) & 1) * 16 + ocol;
+      q.cxx[t2] = (a < n && c < n) ? r[oCXX + a + n * c] : 0.0;
+    }
+#pragma unroll
+    for (int t2 = 0; t2 < 8; t2++) {
+      const int a = orow + 4 * (t2 & 3), c = (t2 >> 2) * 16 + ocol;
+      q.cxu[t2] = (a < m && c < n) ? r[oCXU + c + n * a] : 0.0;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      const int a = orow + 4 * rr;
+      q.cuu[rr] = (a < m && ocol < m) ? r[oCUU + a + m * ocol] : 0.0;
+    }
+    q.cx = (lane < n) ? r[oCX + lane] : 0.0;
+    q.cu = (lane < m) ? r[oCU + lane] : 0.0;
+    q.us = (lane < m) ? usb[(size_t)i * m + lane] : 0.0;
+  };
 
   int diverge = 0;
   bool done = false;
@@ -291,77 +372,123 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
     {
       const double* r = Db + (size_t)T * REC;
       for (int e = lane; e < n; e += 64) L.Vx[e] = r[oCX + e];
-      for (int e = lane; e < n * n; e += 64) L.Vxx[(e % n) + LDN * (e / n)] = r[oCXX + e];
+      for (int c = 0; c < n; c++)
+        for (int a = lane; a < n; a += 64) L.Vxx[a + LDN * c] = r[oCXX + a + n * c];
       if (lane < m) L.kprev[lane] = kb[(size_t)(T - 1) * m + lane];
     }
     dV0 = dV1 = 0;
     diverge = 0;
     lds_sync();
+#ifdef ILQR_PHASE_TIMING
+    long long wph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long wmark = clock64();
+#define ILQR_WMARK(k) { __builtin_amdgcn_sched_barrier(0); const long long tn_ = clock64(); wph[k] += tn_ - wmark; wmark = tn_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define ILQR_WMARK(k)
+#endif
+    RecRegs cur;
+    load_rec(T - 1, cur);
     for (int i = T - 1; i >= 0; i--) {
-      const double* r = Db + (size_t)i * REC;
-      for (int e = lane; e < n * n; e += 64) L.fx[(e % n) + LDN * (e / n)] = r[oFX + e];
-      for (int e = lane; e < n * m; e += 64) L.fu[(e % n) + LDN * (e / n)] = r[oFU + e];
-      if (lane < m) {
-        const double us = usb[(size_t)i * m + lane];
-        L.lo[lane] = u_min[lane] - us;  // :369
-        L.hi[lane] = u_max[lane] - us;
+      ILQR_WMARK(7)
+      {  // fx, fu -> LDS (rows along lanes 0..31, two columns per pass)
+        const int a32 = lane & 31, chalf = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < 16; j++) L.fx[a32 + LDN * (2 * j + chalf)] = cur.fx[j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) L.fu[a32 + LDN * (2 * j + chalf)] = cur.fu[j];
       }
+      if (lane < m) {
+        L.lo[lane] = u_min[lane] - cur.us;  // :369
+        L.hi[lane] = u_max[lane] - cur.us;
+      }
+      const RecRegs rec = cur;           // this step's addends stay in registers
+      if (i > 0) load_rec(i - 1, cur);   // next step's record: in flight during this step
+      ILQR_WMARK(0)
       lds_sync();
       // :359-360
       for (int a = lane; a < n; a += 64) {
         double acc = 0;
         for (int q = 0; q < n; q++) acc += L.fx[q + LDN * a] * L.Vx[q];
-        L.Qx[a] = r[oCX + a] + acc;
+        L.Qx[a] = rec.cx + acc;  // n <= 32: a == lane
       }
       if (lane < m) {
         double acc = 0;
         for (int q = 0; q < n; q++) acc += L.fu[q + LDN * lane] * L.Vx[q];
-        L.Qu[lane] = r[oCU + lane] + acc;
+        L.Qu[lane] = rec.cu + acc;
       }
-      // A1 = fx' Vxx ; A2 = fu' Vxx
-      for (int e = lane; e < n * n; e += 64) {
-        const int a = e % n, c = e / n;
-        double acc = 0;
-        for (int q = 0; q < n; q++) acc += L.fx[q + LDN * a] * L.Vxx[q + LDN * c];
-        L.A1[a + LDN * c] = acc;
-      }
-      for (int e = lane; e < m * n; e += 64) {
-        const int a = e % m, c = e / m;
-        double acc = 0;
-        for (int q = 0; q < n; q++) acc += L.fu[q + LDN * a] * L.Vxx[q + LDN * c];
-        L.A2[a + LDM * c] = acc;
-      }
-      lds_sync();
-      // :361 Qxx ; :362 Qux ; :363/:367 Quu, QuuF
-      for (int e = lane; e < n * n; e += 64) {
-        const int a = e % n, c = e / n;
-        double acc = 0;
-        for (int q = 0; q < n; q++) acc += L.A1[a + LDN * q] * L.fx[q + LDN * c];
-        L.Qxx[a + LDN * c] = r[oCXX + e] + acc;
-      }
-      for (int e = lane; e < m * n; e += 64) {
-        const int a = e % m, c = e / m;
-        double acc = 0;
-        for (int q = 0; q < n; q++) acc += L.A2[a + LDM * q] * L.fx[q + LDN * c];
-        L.Qux[a + LDM * c] = r[oCXU + c + n * a] + acc;
-      }
-      for (int e = lane; e < m * m; e += 64) {
-        const int a = e % m, c = e / m;
-        double acc = 0;
-        for (int q = 0; q < n; q++) acc += L.A2[a + LDM * q] * L.fu[q + LDN * c];
-        const double cuu = r[oCUU + e];
-        L.Quu[a + LDM * c] = cuu + acc;
-        L.QuuF[a + LDM * c] = (cuu + ((a == c) ? lambda : 0.0)) + acc;
+      // A1 = fx' Vxx ; A2 = fu' Vxx      (matrix cores; LDS operands are zero-padded to whole tiles)
+#pragma unroll
+      for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++) {
+          if (ti >= NT || tj >= NT) continue;
+          const double4_t acc = mfma_tile<WN / 4>(
+              [&](int i2, int k) { return L.fx[k + LDN * (ti * 16 + i2)]; },
+              [&](int k, int j) { return L.Vxx[k + LDN * (tj * 16 + j)]; }, lane);
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) L.A1[(ti * 16 + orow + 4 * rr) + LDN * (tj * 16 + ocol)] = acc[rr];
+        }
+#pragma unroll
+      for (int tj = 0; tj < 2; tj++) {
+        if (tj >= NT) continue;
+        const double4_t acc = mfma_tile<WN / 4>(
+            [&](int i2, int k) { return L.fu[k + LDN * i2]; },
+            [&](int k, int j) { return L.Vxx[k + LDN * (tj * 16 + j)]; }, lane);
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) L.A2[(orow + 4 * rr) + LDM * (tj * 16 + ocol)] = acc[rr];
       }
       lds_sync();
+      ILQR_WMARK(1)
+      // :361 Qxx = cxx + A1 fx ; :362 Qux = cxu' + A2 fx ; :363/:367 Quu, QuuF = cuu (+ lambda I) + A2 fu
+#pragma unroll
+      for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++) {
+          if (ti >= NT || tj >= NT) continue;
+          const double4_t acc = mfma_tile<WN / 4>(
+              [&](int i2, int k) { return L.A1[(ti * 16 + i2) + LDN * k]; },
+              [&](int k, int j) { return L.fx[k + LDN * (tj * 16 + j)]; }, lane);
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            const int a = ti * 16 + orow + 4 * rr, c = tj * 16 + ocol;
+            L.Qxx[a + LDN * c] = (a < n && c < n) ? rec.cxx[(ti * 2 + tj) * 4 + rr] + acc[rr] : 0.0;
+          }
+        }
+#pragma unroll
+      for (int tj = 0; tj < 2; tj++) {
+        if (tj >= NT) continue;
+        const double4_t acc = mfma_tile<WN / 4>(
+            [&](int i2, int k) { return L.A2[i2 + LDM * k]; },
+            [&](int k, int j) { return L.fx[k + LDN * (tj * 16 + j)]; }, lane);
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int a = orow + 4 * rr, c = tj * 16 + ocol;
+          L.Qux[a + LDM * c] = (a < m && c < n) ? rec.cxu[tj * 4 + rr] + acc[rr] : 0.0;
+        }
+      }
+      {
+        const double4_t acc = mfma_tile<WN / 4>(
+            [&](int i2, int k) { return L.A2[i2 + LDM * k]; }, [&](int k, int j) { return L.fu[k + LDN * j]; }, lane);
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int a = orow + 4 * rr, c = ocol;
+          const bool in = (a < m && c < m);
+          const double cuu = in ? rec.cuu[rr] : 0.0;
+          L.Quu[a + LDM * c] = in ? cuu + acc[rr] : 0.0;
+          L.QuuF[a + LDM * c] = in ? (cuu + ((a == c) ? lambda : 0.0)) + acc[rr] : 0.0;
+        }
+      }
+      lds_sync();
+      ILQR_WMARK(2)
       int nfR = 0;
       const int result = w_box_qp(m, L, lane, nfR);
+      ILQR_WMARK(3)
       if (result < 1) {  // :371
         diverge = i;
         break;
       }
       // :373-385  K rows of free dims
-      for (int e = lane; e < m * n; e += 64) L.K[(e % m) + LDM * (e / m)] = 0;
+      for (int c = lane >> 4; c < n; c += 4) L.K[(lane & 15) + LDM * c] = 0;
       const unsigned long long free_mask = __ballot(lane < m && L.vfree[lane]);
       const int nf = __popcll(free_mask);
       if (lane < m && L.vfree[lane]) L.idx[__popcll(free_mask & ((1ull << lane) - 1ull))] = lane;
@@ -394,6 +521,7 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
         }
       }
       lds_sync();
+      ILQR_WMARK(4)
       // :388-389
       {
         const double d0 = wave_sum(lane < m ? L.x[lane] * L.Qu[lane] : 0.0);
@@ -407,14 +535,17 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
         dV1 += wave_sum(part);
       }
       // T1 = K' Quu (n x m)
-      for (int e = lane; e < n * m; e += 64) {
-        const int a = e % n, c = e / n;
-        double acc = 0;
-        for (int q = 0; q < m; q++) acc += L.K[q + LDM * a] * L.Quu[q + LDM * c];
-        L.T1[a + LDN * c] = acc;
+#pragma unroll
+      for (int ti = 0; ti < 2; ti++) {
+        if (ti >= NT) continue;
+        const double4_t acc = mfma_tile<WM / 4>(
+            [&](int i2, int k) { return L.K[k + LDM * (ti * 16 + i2)]; }, [&](int k, int j) { return L.Quu[k + LDM * j]; },
+            lane);
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) L.T1[(ti * 16 + orow + 4 * rr) + LDN * ocol] = acc[rr];
       }
       lds_sync();
-      // :391 Vx ; :392 Vn into A1 ; :393 symmetrise into Vxx
+      // :391 Vx ; :392 Vn = ((Qxx + T1 K) + K'Qux) + Qux'K into A1 ; :393 symmetrise into Vxx
       for (int a = lane; a < n; a += 64) {
         double t1 = 0, t2 = 0, t3 = 0;
         for (int c = 0; c < m; c++) t1 += L.T1[a + LDN * c] * L.x[c];
@@ -422,28 +553,52 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
         for (int c = 0; c < m; c++) t3 += L.Qux[c + LDM * a] * L.x[c];
         L.Vxn[a] = ((L.Qx[a] + t1) + t2) + t3;
       }
-      for (int e = lane; e < n * n; e += 64) {
-        const int a = e % n, c = e / n;
-        double t1 = 0, t2 = 0, t3 = 0;
-        for (int q = 0; q < m; q++) t1 += L.T1[a + LDN * q] * L.K[q + LDM * c];
-        for (int q = 0; q < m; q++) t2 += L.K[q + LDM * a] * L.Qux[q + LDM * c];
-        for (int q = 0; q < m; q++) t3 += L.Qux[q + LDM * a] * L.K[q + LDM * c];
-        L.A1[a + LDN * c] = ((L.Qxx[a + LDN * c] + t1) + t2) + t3;
-      }
+#pragma unroll
+      for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++) {
+          if (ti >= NT || tj >= NT) continue;
+          const double4_t t1 = mfma_tile<WM / 4>(
+              [&](int i2, int k) { return L.T1[(ti * 16 + i2) + LDN * k]; },
+              [&](int k, int j) { return L.K[k + LDM * (tj * 16 + j)]; }, lane);
+          const double4_t t2 = mfma_tile<WM / 4>(
+              [&](int i2, int k) { return L.K[k + LDM * (ti * 16 + i2)]; },
+              [&](int k, int j) { return L.Qux[k + LDM * (tj * 16 + j)]; }, lane);
+          const double4_t t3 = mfma_tile<WM / 4>(
+              [&](int i2, int k) { return L.Qux[k + LDM * (ti * 16 + i2)]; },
+              [&](int k, int j) { return L.K[k + LDM * (tj * 16 + j)]; }, lane);
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            const int a = ti * 16 + orow + 4 * rr, c = tj * 16 + ocol;
+            L.A1[a + LDN * c] = ((L.Qxx[a + LDN * c] + t1[rr]) + t2[rr]) + t3[rr];
+          }
+        }
       lds_sync();
-      for (int e = lane; e < n * n; e += 64) {
-        const int a = e % n, c = e / n;
-        L.Vxx[a + LDN * c] = 0.5 * (L.A1[a + LDN * c] + L.A1[c + LDN * a]);
-      }
+      ILQR_WMARK(5)
+#pragma unroll
+      for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            if (ti >= NT || tj >= NT) continue;
+            const int a = ti * 16 + orow + 4 * rr, c = tj * 16 + ocol;
+            L.Vxx[a + LDN * c] = 0.5 * (L.A1[a + LDN * c] + L.A1[c + LDN * a]);
+          }
       for (int a = lane; a < n; a += 64) L.Vx[a] = L.Vxn[a];
       // :396-397
       if (lane < m) {
         kb[(size_t)i * m + lane] = L.x[lane];
         L.kprev[lane] = L.x[lane];
       }
-      for (int e = lane; e < m * n; e += 64) Kb[(size_t)i * m * n + e] = L.K[(e % m) + LDM * (e / m)];
+      for (int c = lane >> 4; c < n; c += 4)
+        if ((lane & 15) < m) Kb[(size_t)i * m * n + (lane & 15) + m * c] = L.K[(lane & 15) + LDM * c];
       lds_sync();
     }
+#ifdef ILQR_PHASE_TIMING
+    if (v.dbg && lane == 0 && b == 0)
+      for (int q = 0; q < 8; q++) v.dbg[256 + q] = wph[q];
+#endif
     if (mode == 0) {
       done = (diverge == 0);
       break;

@@ -373,6 +373,10 @@ void ilqr_destroy(ilqr_batch* h) {
         for (int q = 0; q < 8; q++) fprintf(stderr, "%s %.2f  ", nm[q], (double)d[t * 20 * 8 + q] / h->T);
         fprintf(stderr, "\n");
       }
+      if (h->aos)
+        fprintf(stderr, "[wave backward phase timing, cyc/step] lds-fill+prefetch %.0f  Qx,A1,A2 %.0f  Qxx,Qux,Quu %.0f  boxQP %.0f  K %.0f  dV,T1,Vx,Vn %.0f  sym+stores(+loop) %.0f\n",
+                (double)d[256 + 0] / h->T, (double)d[256 + 1] / h->T, (double)d[256 + 2] / h->T, (double)d[256 + 3] / h->T,
+                (double)d[256 + 4] / h->T, (double)d[256 + 5] / h->T, (double)d[256 + 7] / h->T);
       for (int t = 0; t < 3; t++)
         fprintf(stderr, "[rollout phase timing, tile %d] loop+prefetch %.1f  wait+feedback+ustore %.1f  cost+dynamics %.1f  xstores %.1f cyc/step\n", t,
                 (double)d[512 - 16 + t * 4 + 0] / h->T, (double)d[512 - 16 + t * 4 + 1] / h->T, (double)d[512 - 16 + t * 4 + 2] / h->T,
