@@ -41,32 +41,50 @@ def algorithmic_bytes_per_timestep(n, m):
     }
 
 
-def cpu_baseline(B_total, T, dt, lim, budget_s=15.0):
+def cpu_baseline(B_total, T, dt, lim, target_wall_s=4.0):
     """The CPU oracle (plain-C restatement of the reference, OpenMP over trajectories) on a
-    bounded sample of the same workload, on this box's host cores."""
+    bounded sample of the same workload, on this box's host cores: the same fixed-work
+    iterations over as many of the bench's own trajectories as fit the time budget."""
     from oracle import oracle as O
     from tests.util import acrobot_x0
     cores = os.cpu_count() or 1
     om = O.Model("acrobot", u_lim=lim)
-    iters = 2
     x0_all = acrobot_x0(B_total)
 
-    def run(nb):
+    def run(nb, iters):
         x0 = x0_all[:nb]
         u0 = np.zeros((nb, T, 1))
         t0 = time.perf_counter()
         O.batch_solve(om, x0, u0, dt, max_iters=iters, fixed_work=True, nthreads=cores)
         return time.perf_counter() - t0
 
-    nb = cores
-    t = run(nb)
-    rate = nb * T * iters / t
-    nb2 = int(min(B_total, max(cores, (budget_s * rate) / (T * iters))))
-    nb2 = max(cores, (nb2 // cores) * cores)
-    t2 = run(nb2)
+    nb = min(B_total, 4 * cores)
+    t = run(nb, 1)                      # calibration
+    rate = nb * T / t
+    iters = 4
+    nb2 = int(min(B_total, max(cores, target_wall_s * rate / (T * iters))))
+    nb2 = max(cores, (nb2 // cores) * cores) if nb2 >= cores else nb2
+    if nb2 == B_total:                  # the whole batch is still too quick: run more iterations
+        iters = int(min(40, max(iters, target_wall_s * rate / (T * nb2))))
+    t2 = run(nb2, iters)
     return {"value": nb2 * T * iters / t2, "unit": "trajectory-timesteps/s", "cores": cores, "kind": "port",
-            "sample": "%d trajectories x %d fixed-work iterations of the same acrobot workload, %.1f s, "
-                      "oracle/liboracle_ilqr.so with OpenMP over trajectories" % (nb2, iters, t2)}
+            "sample": "%d trajectories x %d fixed-work iterations of the same acrobot workload, %.1f s wall "
+                      "(%.0f core-seconds), oracle/liboracle_ilqr.so with OpenMP over trajectories on all host "
+                      "threads" % (nb2, iters, t2, t2 * cores)}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/): the
+    bench cannot run rocprofv3 on itself, so it quotes the last collected figures when present."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    try:
+        d = json.load(open(path))
+        e = d["kernels"].get(kernel)
+        return (e["hbm_bytes_per_launch"], d.get("source")) if e else (None, None)
+    except Exception:
+        return None, None
 
 
 def main():
@@ -144,6 +162,7 @@ def main():
         name_of = {i: g.lib.ilqr_stage_kernel_name(g.h, i).decode() for i in range(capi.NUM_STAGES)}
         dom_kernel = name_of[capi.STAGE_NAMES.index(dom)]
         achieved = stages[dom]["algorithmic_GBps"]
+        traffic, traffic_src = pmc_traffic(dom_kernel)
         out = {
             "metric": "iLQR iterations/sec (batch x T timesteps/sec), acrobot T=500 batch=4096",
             "value": value, "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": steps,
@@ -155,7 +174,8 @@ def main():
                        "batch_per_gpu": B, "T": T, "parallelism": "batch-sharded x%d, no data-path collective; "
                        "one all_gather of per-trajectory costs at the end" % world},
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_ts[dom] * B * T,
                          "avg_launch_ms": stages[dom]["ms_per_launch"]},
             "stages": stages,

@@ -1,0 +1,87 @@
+"""Edge cases through the C ABI: ragged batch sizes (B not a multiple of the 16-trajectory tile or
+the 64-lane wavefront, B = 1), horizons around the candidate-chunk size (T = 1, 7, 8, 9, 16, 17:
+the time-chunked candidate layout has a tail path for each), and both backward kernels agreeing."""
+import numpy as np
+import pytest
+
+from tests.util import TOL, acrobot_x0, integrator_x0, mat, relerr
+
+pytestmark = pytest.mark.gpu
+DT = 0.02
+
+
+@pytest.mark.parametrize("T", [1, 2, 7, 8, 9, 16, 17, 33])
+@pytest.mark.parametrize("name,B", [("acrobot", 19), ("integrator", 5)])
+def test_horizons_around_chunk_size(oracle, name, B, T):
+    from ilqr_amd import ALPHAS, BatchILQR
+    if name == "acrobot":
+        om = oracle.Model("acrobot", u_lim=1.5)
+        g = BatchILQR("acrobot", B, T, DT, u_min=-1.5, u_max=1.5)
+        x0 = acrobot_x0(B, seed=T)
+    else:
+        om = oracle.Model("integrator", goal=[1, .5, 0, 0])
+        g = BatchILQR("integrator", B, T, DT, goal=[1, .5, 0, 0])
+        x0 = integrator_x0(B, seed=T)
+    u0 = np.random.default_rng(T).normal(size=(B, T, om.nu)) * 0.3
+    c0 = g.init_traj(x0, u0)
+    xs_o, us_o, c_o = oracle.batch_rollout(om, x0, u0, DT)
+    xs, us = g.trajectory()
+    assert relerr(xs, xs_o) < TOL and np.allclose(c0, c_o, rtol=TOL)
+    # candidates: every alpha's trajectory must come back intact through the chunked layout
+    g.compute_derivatives()
+    g.backward_step()
+    k, K = g.gains()
+    cc = g.rollout_candidates()
+    for a in (0, 5, 10):
+        xa, ua, ca = oracle.batch_rollout(om, x0, us_o + ALPHAS[a] * k, DT, xs_nom=xs_o, K=K)
+        xg, ug = g.candidate(a)
+        assert relerr(xg, xa) < 1e-5 and relerr(ug + 1.0, ua + 1.0) < 1e-5, (a, T)
+        assert np.allclose(cc[:, a], ca, rtol=1e-5)
+    # full iterations (exercise accept + fused commit + flush) stay in step with the oracle
+    g.init_traj(x0, u0)
+    g.iterate(2)
+    ro = oracle.batch_solve(om, x0, u0, DT, max_iters=2)
+    ok = np.isclose(g.cost(), ro["cost"], rtol=TOL)
+    assert ok.mean() >= 0.8
+    xs2, us2 = g.trajectory()
+    assert relerr(xs2[ok], ro["xs"][ok]) < 1e-5
+    st, it, al = g.status()
+    assert np.array_equal(it[ok], ro["iters"][ok])
+
+
+@pytest.mark.parametrize("B", [1, 15, 16, 17, 63, 64, 65, 130])
+def test_ragged_batches(oracle, B):
+    from ilqr_amd import BatchILQR
+    T = 40
+    om = oracle.Model("acrobot", u_lim=1.5)
+    x0 = acrobot_x0(max(B, 2), seed=B)[:B] * 0.3
+    u0 = np.zeros((B, T, 1))
+    g = BatchILQR("acrobot", B, T, DT, u_min=-1.5, u_max=1.5)
+    g.init_traj(x0, u0)
+    g.iterate(3)
+    ro = oracle.batch_solve(om, x0, u0, DT, max_iters=3)
+    ok = np.isclose(g.cost(), ro["cost"], rtol=TOL)
+    assert ok.mean() >= 0.85, (g.cost(), ro["cost"])
+    k, K = g.gains()
+    assert relerr(k[ok] + 1.0, ro["k"][ok] + 1.0) < 1e-5
+
+
+def test_backward_kernel_variants_agree(oracle):
+    """quad-per-trajectory (default) vs thread-per-trajectory backward kernels on the same state."""
+    from ilqr_amd import BatchILQR, capi
+    B, T = 70, 80
+    x0 = acrobot_x0(B)
+    res = []
+    for flags in (0, capi.FLAG_BACKWARD_THREAD_PER_TRAJ):
+        g = BatchILQR("acrobot", B, T, DT, u_min=-1.5, u_max=1.5, flags=flags)
+        g.init_traj(x0, np.zeros((B, T, 1)))
+        g.iterate(2)
+        g.compute_derivatives()
+        g.backward_step()
+        res.append((g.gains(), g.dV(), g.lambdas()[0], g.gnorm()))
+    (k0, K0), dV0, l0, gn0 = res[0]
+    (k1, K1), dV1, l1, gn1 = res[1]
+    same = np.isclose(l0, l1)
+    assert same.mean() > 0.9
+    assert relerr(k0[same] + 1, k1[same] + 1) < 1e-6 and relerr(K0[same] + 1, K1[same] + 1) < 1e-5
+    assert np.allclose(gn0[same], gn1[same], rtol=1e-9)
