@@ -280,10 +280,9 @@ static int launch_derivatives(ilqr_batch* h, int force) {
     default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device derivatives", h->model);
   }
   HIPCHK(hipGetLastError());
-  if (h->commit_pending) {  // the kernel above performed the copy on the way
-    h->commit_pending = false;
-    HIPCHK(hipMemsetAsync(h->commit_idx, 0xFF, (size_t)h->Bp * sizeof(int), h->stream));
-  }
+  // the kernel above performed the copy on the way; commit_idx is rewritten for every trajectory
+  // by the next k_accept and only read while commit_pending is set, so it needs no reset here
+  h->commit_pending = false;
   return timer_end(h, ILQR_STAGE_DERIVATIVES, ev);
 }
 
@@ -322,7 +321,6 @@ static int launch_backward(ilqr_batch* h, int mode) {
 static int launch_accept(ilqr_batch* h) {
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_ACCEPT, &ev)) return rc;
-  HIPCHK(hipMemsetAsync(h->v.n_running, 0, sizeof(int), h->stream));
   hipLaunchKernelGGL(k_accept, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->sp, h->commit_idx);
   HIPCHK(hipGetLastError());
   h->commit_pending = true;

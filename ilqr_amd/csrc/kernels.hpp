@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256) void k_derivatives(BatchView v, M model, int f
   const int b = tile * TW + l;
   const int T = v.T;
   if (t > T || b >= v.B) return;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *v.n_running = 0;  // k_accept of this iteration recounts
   const int ci = commit_idx ? commit_idx[b] : -1;
   const bool want = force || (v.status[b] == 0 && v.flg_change[b]);
   if (ci < 0 && !want) return;
