@@ -6,27 +6,46 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib", "libilqr_amd.so")
 SOURCES = [os.path.join(CSRC, "capi.hip")]
-HEADERS = [os.path.join(CSRC, f) for f in ("common.hpp", "models.hpp", "boxqp.hpp", "kernels.hpp")] + \
+HEADERS = [os.path.join(CSRC, f) for f in ("common.hpp", "models.hpp", "boxqp.hpp", "kernels.hpp", "backward_wave.hpp")] + \
           [os.path.join(os.path.dirname(PKG), "include", "ilqr_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
 
 
+HASHFILE = LIB + ".srchash"
+
+
+def _source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        if os.path.exists(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def stale():
-    if not os.path.exists(LIB):
+    """True when the library is missing or was built from different sources (content hash, not
+    mtimes: the tree is copied to the GPU box and 8 ranks may import it at once)."""
+    if not os.path.exists(LIB) or not os.path.exists(HASHFILE):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in SOURCES + HEADERS)
+    return open(HASHFILE).read().strip() != _source_hash()
 
 
 def build(force=False, verbose=False):
-    """Compile the extension if missing or older than its sources. Returns the .so path."""
+    """Compile the extension if missing or built from other sources. Returns the .so path."""
     if force or stale():
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        cmd = [HIPCC] + FLAGS + ["-o", LIB] + SOURCES
+        tmp = LIB + ".tmp.%d" % os.getpid()
+        cmd = [HIPCC] + FLAGS + ["-o", tmp] + SOURCES
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        os.replace(tmp, LIB)  # atomic: concurrent importers never see a half-written library
+        with open(HASHFILE, "w") as f:
+            f.write(_source_hash())
     return LIB
 
 
