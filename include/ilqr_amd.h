@@ -56,8 +56,11 @@ enum ilqr_status_code {
 enum ilqr_model_id {
   ILQR_MODEL_ACROBOT = 0,           /* include/acrobot.h            nx=4 nu=1 */
   ILQR_MODEL_DOUBLE_INTEGRATOR = 1, /* include/double_integrator.h  nx=4 nu=2 */
-  ILQR_MODEL_LQ = 2,                /* synthetic LQ (BASELINE.json configs[4]), nx<=32 nu<=16 */
-  ILQR_MODEL_HOST = 3               /* derivatives supplied through ilqr_set_derivatives */
+  ILQR_MODEL_LQ = 2,                /* synthetic LQ (BASELINE.json configs[4]), nx<=32 nu<=16; this build: backward pass only, like HOST */
+  ILQR_MODEL_HOST = 3               /* host-evaluated model, nx<=32 nu<=16: derivatives supplied through
+                                       ilqr_set_derivatives, ilqr_backward_pass/_step run on the device
+                                       (one wavefront per trajectory); rollout / FD entry points return
+                                       ILQR_ERR_UNSUPPORTED */
 };
 
 /* where a trajectory's outer loop stands (src/ilqr_core.cpp:103-288) */
