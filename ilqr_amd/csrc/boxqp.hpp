@@ -20,6 +20,20 @@
 
 namespace ilqr {
 
+// 1/a for a normal-range a: v_rcp_f64 + two Newton steps (5 dependent instructions, <= 1 ulp)
+// instead of the 11-instruction IEEE division sequence; the host build (unit tests) divides.
+ILQR_HD double recip(double a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(a);
+  double e = __builtin_fma(-a, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-a, r, 1.0);
+  return __builtin_fma(r, e, r);
+#else
+  return 1.0 / a;
+#endif
+}
+
 template <int M>
 ILQR_HD void clamp_to_limits(const double* x, const double* lo, const double* hi, double* out) {
 #pragma unroll
@@ -439,7 +453,7 @@ ILQR_HD void qp1_begin(double Q, double c, double x0, double lo, double hi, QP1S
   q.val0 = (q.x * Q) * q.x + q.x * c;  // boxqp.cpp:36 (no 1/2)
   q.g0 = Q * q.x + c;
   const double den = (Q > 0.0) ? Q : Q * Q;
-  q.minv = 1.0 / den;
+  q.minv = recip(den);
   // (bitwise & | on purpose: no short-circuit branches in the wavefront's instruction stream)
   q.clA = ((fabs(q.x - lo) < kClampTol) & (q.g0 > 0)) | ((fabs(q.x - hi) < kClampTol) & (q.g0 < 0));
   q.exB = fabs(q.g0) < kMinGrad;

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -316,6 +317,26 @@ static int launch_backward(ilqr_batch* h, int mode) {
   return timer_end(h, ILQR_STAGE_BACKWARD, ev);
 }
 
+// STEP 1 + STEP 2 in one launch (k_sweep_backward): the tile's derivative sweep runs on the three
+// SIMDs the quad backward pass leaves idle.  Timed as ILQR_STAGE_BACKWARD.
+static bool use_fused_sweep(const ilqr_batch* h) {
+  return use_quad_backward(h) && !h->aos && !(h->flags & ILQR_FLAG_UNFUSED) && !getenv("ILQR_AMD_UNFUSED");
+}
+static int launch_sweep_backward(ilqr_batch* h, int mode, int force) {
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (int rc = timer_begin(h, ILQR_STAGE_BACKWARD, &ev)) return rc;
+  dim3 grid(h->ntiles), block(64 * (1 + kProducers));
+  const int* ci = h->commit_pending ? h->commit_idx : nullptr;
+  switch (h->model) {
+    case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_sweep_backward<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, h->sp, mode, force, ci); break;
+    case ILQR_MODEL_DOUBLE_INTEGRATOR: hipLaunchKernelGGL((k_sweep_backward<DoubleIntegratorModel>), grid, block, 0, h->stream, h->v, h->dint, h->sp, mode, force, ci); break;
+    default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device backward pass yet", h->model);
+  }
+  HIPCHK(hipGetLastError());
+  h->commit_pending = false;  // the producers performed the copy on the way (see launch_derivatives)
+  return timer_end(h, ILQR_STAGE_BACKWARD, ev);
+}
+
 // selection + lambda schedule + termination; the copy of the accepted candidate is left pending
 // (fused into the next derivative sweep, or flushed by flush_commit)
 static int launch_accept(ilqr_batch* h) {
@@ -592,8 +613,12 @@ int ilqr_iterate(ilqr_batch* h, int n_iters) {
   if (!h->initialised) return fail(ILQR_ERR_STATE, "ilqr_iterate before ilqr_init_traj/ilqr_set_trajectory");
   HIPCHK(hipSetDevice(h->device));
   for (int it = 0; it < n_iters; it++) {
-    if (int rc = launch_derivatives(h, h->sp.fixed_work)) return rc;  // STEP 1
-    if (int rc = launch_backward(h, 1)) return rc;                    // STEP 2
+    if (use_fused_sweep(h)) {
+      if (int rc = launch_sweep_backward(h, 1, h->sp.fixed_work)) return rc;  // STEP 1 + STEP 2
+    } else {
+      if (int rc = launch_derivatives(h, h->sp.fixed_work)) return rc;  // STEP 1
+      if (int rc = launch_backward(h, 1)) return rc;                    // STEP 2
+    }
     if (int rc = do_rollout_candidates(h, 1)) return rc;              // STEP 3
     if (int rc = launch_accept(h)) return rc;                         // STEP 3/4
   }
@@ -847,7 +872,10 @@ int ilqr_profile_read(ilqr_batch* h, double ms_out[ILQR_NUM_STAGES], int launche
 const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
   switch (stage) {
     case ILQR_STAGE_DERIVATIVES: return "k_derivatives";
-    case ILQR_STAGE_BACKWARD: return (h && h->aos) ? "k_backward_w" : ((h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t");
+    case ILQR_STAGE_BACKWARD:
+      if (h && h->aos) return "k_backward_w";
+      if (h && use_fused_sweep(h)) return "k_sweep_backward";  // what ilqr_iterate launches
+      return (h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t";
     case ILQR_STAGE_ROLLOUT: return "k_rollout";
     case ILQR_STAGE_ACCEPT: return "k_accept";
     default: return "";

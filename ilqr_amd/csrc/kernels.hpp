@@ -323,16 +323,13 @@ __device__ __forceinline__ void fd_gradient(const double* x, F f, double* out) {
 // its copy into the nominal trajectory is still pending -- this kernel reads the knot from the
 // candidate and performs the copy on the way (the separate k_commit pass is only used to flush).
 template <class M>
-__global__ __launch_bounds__(256) void k_derivatives(BatchView v, M model, int force, const int* __restrict__ commit_idx) {
+__device__ __forceinline__ void derivatives_of_knot(const BatchView& v, const M& model, int force,
+                                                    const int* __restrict__ commit_idx, int tile, int t, int l) {
   constexpr int NX = M::NX, NU = M::NU;
   using R = Rec<NX, NU>;
-  const int l = threadIdx.x & (TW - 1);
-  const int t = blockIdx.x * 16 + (threadIdx.x >> 4);
-  const int tile = blockIdx.y;
   const int b = tile * TW + l;
   const int T = v.T;
   if (t > T || b >= v.B) return;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *v.n_running = 0;  // k_accept of this iteration recounts
   const int ci = commit_idx ? commit_idx[b] : -1;
   const bool want = force || (v.status[b] == 0 && v.flg_change[b]);
   if (ci < 0 && !want) return;
@@ -457,6 +454,15 @@ __global__ __launch_bounds__(256) void k_derivatives(BatchView v, M model, int f
               (4 * (kEps * kEps));
       put(R::CXU + i + NX * j, val);
     }
+}
+
+// grid = (ceil((T+1)/16), ntiles), block = 256 = 16 time steps x 16 trajectories
+template <class M>
+__global__ __launch_bounds__(256) void k_derivatives(BatchView v, M model, int force, const int* __restrict__ commit_idx) {
+  const int l = threadIdx.x & (TW - 1);
+  const int t = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *v.n_running = 0;  // k_accept of this iteration recounts
+  derivatives_of_knot(v, model, force, commit_idx, (int)blockIdx.y, t, l);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -789,8 +795,8 @@ __device__ __forceinline__ bool qp1_search_quad(QP1State& q, int s, int lane, co
   const double bound = (q.search > 0) ? q.hi : q.lo;
   const double v_b = qp1_value(q, bound);
   // fp32 estimates: f = fraction of the step inside the box, r = Armijo threshold on the bound
-  const float f = (float)(bound - q.x) * __frcp_rn((float)q.search);
-  const float r = (float)(v_b - q.old_v) * __frcp_rn((float)(kArmijo * q.slope));
+  const float f = (float)(bound - q.x) * __builtin_amdgcn_rcpf((float)q.search);  // 1-ulp v_rcp_f32: only an estimate
+  const float r = (float)(v_b - q.old_v) * __builtin_amdgcn_rcpf((float)(kArmijo * q.slope));
   const float thr = fmaxf(f, r);
   int kg = (int)ceilf(__log2f(thr) * -1.35691545f);  // log(thr)/log(0.6)
   const bool sane = (q.Q > 0.0) & (thr > 0.f) & (thr < 1.f) & (kg >= 1) & (kg <= 96);
@@ -828,17 +834,17 @@ struct QuadStep {  // what lane (l, s) needs of one derivative record
   double cxu[NU];    // cxu[s, :]
 };
 
-template <class M>
-__global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverParams sp, int mode) {
+// The body of the quad backward pass for one tile, run by ONE wavefront (lane = 4*l + s).
+// gate(t) returns once the derivative record and the nominal control of knot t may be read: a
+// no-op when the records were written by an earlier kernel (k_backward_q), a wait on the
+// co-resident producer wavefronts in k_sweep_backward.
+template <class M, class Gate>
+__device__ __forceinline__ void backward_quad(const BatchView& v, const M& model, const SolverParams& sp, int mode,
+                                              int tile, int lane, const double* __restrict__ lds_steps, Gate gate) {
   static_assert(M::NX == 4, "quad kernel: one lane per state dimension");
   constexpr int NX = 4, NU = M::NU;
   using R = Rec<NX, NU>;
-  __shared__ double lds_steps[104];  // backtracking step sizes (per-lane indexed -> LDS, not constant cache)
-  for (int k = threadIdx.x; k < 104; k += 64) lds_steps[k] = kStepTable.s[k];
-  __syncthreads();
-  const int lane = threadIdx.x;
   const int l = lane >> 2, s = lane & 3;
-  const int tile = blockIdx.x;
   const int b = tile * TW + l;
   if (b >= v.B) return;                        // quad-uniform
   if (mode == 1 && v.status[b] != 0) return;   // quad-uniform
@@ -852,6 +858,7 @@ __global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverP
 
   // 16-byte loads of element pairs (e even) and 8-byte loads of single elements of a record
   auto load = [&](int t, QuadStep<NU>& d) {
+    gate(t);
     const double* r = Dt + (unsigned)(t * ((R::SIZE / 2) * 2 * TW));  // in-tile offsets fit 32 bits
     auto pair = [&](int e) { return *reinterpret_cast<const double2_t*>(r + (unsigned)((e >> 1) * (2 * TW))); };
     auto one = [&](int e) { return r[(unsigned)((e >> 1) * (2 * TW) + (e & 1))]; };
@@ -907,6 +914,7 @@ __global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverP
     // carried state: full Vxx / Vx in every lane
     double Vx[4], Vxx[16], kprev[NU];
     {
+      gate(T);
       const double* r = Dt + (size_t)T * (R::SIZE / 2) * (2 * TW);
 #pragma unroll
       for (int i = 0; i < 4; i++) Vx[i] = r[(size_t)((R::CX + i) >> 1) * (2 * TW) + ((R::CX + i) & 1)];  // :353
@@ -1157,7 +1165,7 @@ __global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverP
         double mx = 0;
 #pragma unroll
         for (int a = 0; a < NU; a++) {
-          const double val = fabs(qp.x[a]) / (fabs(d.us[a]) + 1);
+          const double val = fabs(qp.x[a]) * recip(fabs(d.us[a]) + 1);
           mx = (a == 0 || val > mx) ? val : mx;
         }
         if (ok) gacc += mx;
@@ -1273,6 +1281,89 @@ __global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverP
         v.status[b] = 1;
         v.iters[b] += 1;
       }
+    }
+  }
+}
+
+__device__ __forceinline__ void load_step_table(double* lds_steps) {
+  for (int k = threadIdx.x; k < 104; k += blockDim.x) lds_steps[k] = kStepTable.s[k];
+  __syncthreads();
+}
+
+// stage call / records already in HBM: grid = ntiles, block = 64
+template <class M>
+__global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverParams sp, int mode) {
+  __shared__ double lds_steps[104];  // backtracking step sizes (per-lane indexed -> LDS, not constant cache)
+  load_step_table(lds_steps);
+  backward_quad(v, model, sp, mode, (int)blockIdx.x, (int)threadIdx.x, lds_steps, [](int) {});
+}
+
+// STEP 1 + STEP 2 of one iteration in ONE kernel (ilqr_iterate).  The quad backward pass keeps a
+// single wavefront per tile busy with one long dependent chain, i.e. one of the four SIMDs of a
+// CU; the finite-difference sweep is independent per knot.  So a block is one tile with four
+// wavefronts: wavefront 0 runs backward_quad, wavefronts 1..3 are PRODUCERS that compute the
+// derivative records of the tile's knots in descending t (4 knots x 16 trajectories per
+// wavefront and round), perform the pending commit of the accepted candidate on the way
+// (derivatives_of_knot), and publish their progress in LDS.  The consumer follows a few hundred
+// cycles behind the first round and never waits again (a producer round of 4 time steps costs
+// about as much as ONE backward step).  Producer and consumer share the CU, hence its L1 and L2:
+// workgroup-scope release/acquire is all the ordering needed, no device-wide cache maintenance.
+// Records still go through HBM in the didx layout, so a lambda retry (mode 1) and the getters
+// find them where the stand-alone kernels put them.    grid = ntiles, block = 256
+#ifndef ILQR_PRODUCERS
+#define ILQR_PRODUCERS 3
+#endif
+constexpr int kProducers = ILQR_PRODUCERS;
+constexpr int kKnotsPerRound = 4 * kProducers;  // 4 knots per producer wavefront
+#ifndef ILQR_LEAD_ROUNDS
+#define ILQR_LEAD_ROUNDS 1
+#endif
+constexpr int kLeadKnots = ILQR_LEAD_ROUNDS * kKnotsPerRound;  // producers stay at most this far ahead of the consumer
+template <class M>
+__global__ __launch_bounds__(64 * (1 + kProducers)) void k_sweep_backward(BatchView v, M model, SolverParams sp, int mode, int force,
+                                                        const int* __restrict__ commit_idx) {
+  __shared__ double lds_steps[104];
+  __shared__ int rounds_done[kProducers];
+  __shared__ int consumer_at;  // highest knot index j = T - t the backward pass has asked for
+  if (threadIdx.x < kProducers) rounds_done[threadIdx.x] = 0;
+  if (threadIdx.x == kProducers) consumer_at = 0;
+  load_step_table(lds_steps);  // (barrier)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tile = blockIdx.x;
+  const int T = v.T;
+  if (wave == 0) {
+    __builtin_amdgcn_s_setprio(3);
+    int have = 0;  // knots j < have are known to be produced
+    auto gate = [&](int t) __attribute__((always_inline)) {  // wave-uniform
+      const int j = T - t;
+      if (j < have) return;
+      const int round = j / kKnotsPerRound, w = (j % kKnotsPerRound) / 4;
+      __hip_atomic_store(&consumer_at, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (__hip_atomic_load(&rounds_done[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= round)
+        __builtin_amdgcn_s_sleep(2);
+      have = round * kKnotsPerRound + (w + 1) * 4;
+    };
+    backward_quad(v, model, sp, mode, tile, lane, lds_steps, gate);
+    // (a pass abandoned at lambdaMax never asks for the remaining knots: release the producers)
+    __hip_atomic_store(&consumer_at, 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else {
+    // Producers pace themselves to the consumer: running flat out they would saturate the CU's
+    // store path for the first third of the kernel (the sweep alone is HBM-write-bound) and the
+    // backward wavefront's own loads and stores would queue behind theirs; a bounded lead spreads
+    // the writes over the whole pass and leaves the records in L2 for the consumer.
+    const int w = wave - 1;
+    const int l = lane & (TW - 1), sub = lane >> 4;
+    if (tile == 0 && threadIdx.x == 64) *v.n_running = 0;  // k_accept of this iteration recounts
+    const int nrounds = (T + 1 + kKnotsPerRound - 1) / kKnotsPerRound;
+    for (int r = 0; r < nrounds; r++) {
+      const int j0 = r * kKnotsPerRound + w * 4;
+      while (j0 > __hip_atomic_load(&consumer_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + kLeadKnots)
+        __builtin_amdgcn_s_sleep(8);
+      const int t = T - (j0 + sub);
+      if (t >= 0) derivatives_of_knot(v, model, force, commit_idx, tile, t, l);
+      // all stores of this wavefront have reached the L2 before the round is published
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(&rounds_done[w], r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
 }

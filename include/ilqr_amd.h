@@ -79,7 +79,11 @@ enum ilqr_flags {
   ILQR_FLAG_FIXED_WORK = 1,
   /* Backward-pass kernel choice: default picks by batch size. */
   ILQR_FLAG_BACKWARD_THREAD_PER_TRAJ = 2,
-  ILQR_FLAG_BACKWARD_LANE_GROUP = 4
+  ILQR_FLAG_BACKWARD_LANE_GROUP = 4,
+  /* ilqr_iterate / ilqr_solve normally run the derivative sweep and the backward pass of an
+   * iteration in one kernel (nx = 4 models: the sweep uses the SIMDs the backward pass leaves
+   * idle).  This flag launches them as two kernels, as the stage calls do.  Same results. */
+  ILQR_FLAG_UNFUSED = 8
 };
 
 /* Solver tunables = the compile-time constants of include/ilqr.h:14-24 (defaults shown). */

@@ -1,0 +1,72 @@
+"""ilqr_iterate runs the derivative sweep and the backward pass of an iteration in one kernel
+(k_sweep_backward: producer wavefronts + the quad backward wavefront of a tile share a CU); the
+stage calls, and ILQR_FLAG_UNFUSED, run them as two kernels.  Both routes execute the same device
+functions on the same data, so everything they leave behind must be bit-identical."""
+import numpy as np
+import pytest
+
+from tests.util import acrobot_x0, integrator_x0
+
+pytestmark = pytest.mark.gpu
+DT = 0.02
+
+
+def _state(g):
+    xs, us = g.trajectory()
+    k, K = g.gains()
+    d = g.derivatives()
+    st, it, al = g.status()
+    lam, dlam = g.lambdas()
+    return dict(xs=xs, us=us, k=k, K=K, cost=g.cost(), st=st, it=it, al=al, lam=lam, dlam=dlam,
+                gnorm=g.gnorm(), **{"d_" + n: a for n, a in d.items()})
+
+
+def _same(a, b):
+    for n in a:
+        assert np.array_equal(a[n], b[n], equal_nan=True), n
+
+
+@pytest.mark.parametrize("fixed", [False, True])
+@pytest.mark.parametrize("B", [5, 48, 200])  # partial tile, whole tiles, many tiles
+def test_acrobot_fused_equals_unfused(B, fixed):
+    from ilqr_amd import BatchILQR, capi
+    T = 120
+    x0 = acrobot_x0(B, scale=0.3, seed=5)
+    u0 = np.zeros((B, T, 1))
+    base = capi.FLAG_FIXED_WORK if fixed else 0
+    out = []
+    for fl in (0, capi.FLAG_UNFUSED):
+        g = BatchILQR("acrobot", B, T, DT, u_min=-1.5, u_max=1.5, flags=base | fl)
+        g.init_traj(x0, u0)
+        g.iterate(6)
+        out.append(_state(g))
+        g.close()
+    _same(out[0], out[1])
+
+
+def test_integrator_fused_equals_unfused_through_termination():
+    """Normal mode until every trajectory has left its loop: covers wavefronts whose trajectories
+    are all finished (the consumer returns at once and must still release its producers) and the
+    lambda-retry passes that re-read records produced earlier in the same launch."""
+    from ilqr_amd import BatchILQR, capi
+    B, T = 40, 99
+    x0 = integrator_x0(B)
+    u0 = np.zeros((B, T, 2))
+    out = []
+    for fl in (0, capi.FLAG_UNFUSED):
+        g = BatchILQR("integrator", B, T, DT, goal=[1.0, 0.5, 0.0, 0.0], flags=fl)
+        g.generate_trajectory(x0, u0)
+        assert g.count_running() == 0
+        out.append(_state(g))
+        g.close()
+    _same(out[0], out[1])
+
+
+def test_stage_kernel_name_reports_the_fused_kernel():
+    from ilqr_amd import BatchILQR, capi
+    g = BatchILQR("acrobot", 16, 10, DT)
+    assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("backward")) == b"k_sweep_backward"
+    g.close()
+    g = BatchILQR("acrobot", 16, 10, DT, flags=capi.FLAG_UNFUSED)
+    assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("backward")) == b"k_backward_q"
+    g.close()
