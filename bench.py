@@ -36,7 +36,8 @@ def algorithmic_bytes_per_timestep(n, m):
     return {
         "backward": (2 * n * n + 2 * n * m + m * m + n + 2 * m + m * n + m) * s,          # acrobot 416
         "derivatives": (n + m + 2 * n * n + 2 * n * m + m * m + n + m) * s,              # acrobot 408
-        "rollout": 11 * (2 * m + m * n + n + n + m) * s,                                 # acrobot 11*120
+        # per alpha: reads us,k (2m), K (mn), xs (n); writes u_t (m) and one checkpoint state per 8 knots
+        "rollout": 11 * (2 * m + m * n + n + m + n / 8.0) * s,                            # acrobot 11*92
         "accept": 2 * (n + m) * s,                                                       # commit copy
     }
 

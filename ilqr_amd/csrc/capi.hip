@@ -219,7 +219,7 @@ static int scalars_to_dev(ilqr_batch* h, const T* host, T* dev) {
 // ------------------------------------------------------------------------------------------
 // kernel launchers (dispatch on the device model)
 // ------------------------------------------------------------------------------------------
-// cand = true: knots go to the time-chunked candidate buffer; false: straight into xs/us (init)
+// cand = true: controls + checkpoint states go to the candidate buffers; false: straight into xs/us (init)
 template <class M>
 static int launch_rollout_t(ilqr_batch* h, const M& m, bool gains, bool cand, const AlphaSet& al, int n_alpha,
                             double* cost_out, int mode) {
@@ -249,12 +249,11 @@ static int launch_rollout(ilqr_batch* h, bool gains, bool cand, const AlphaSet& 
 
 static int launch_commit(ilqr_batch* h) {
   dim3 grid((h->T + 1 + 15) / 16, h->ntiles), block(256);
-  if (h->nx == 4 && h->nu == 1)
-    hipLaunchKernelGGL((k_commit<4, 1>), grid, block, 0, h->stream, h->v, h->commit_idx);
-  else if (h->nx == 4 && h->nu == 2)
-    hipLaunchKernelGGL((k_commit<4, 2>), grid, block, 0, h->stream, h->v, h->commit_idx);
-  else
-    return fail(ILQR_ERR_UNSUPPORTED, "no commit kernel for nx=%d nu=%d", h->nx, h->nu);
+  switch (h->model) {
+    case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_commit<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, h->commit_idx); break;
+    case ILQR_MODEL_DOUBLE_INTEGRATOR: hipLaunchKernelGGL((k_commit<DoubleIntegratorModel>), grid, block, 0, h->stream, h->v, h->dint, h->commit_idx); break;
+    default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device rollout", h->model);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -492,7 +491,8 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     rc |= dev_alloc(h, &v.D, Bn * T1 * REC);
     rc |= dev_alloc(h, &h->d_umin, nu);
     rc |= dev_alloc(h, &h->d_umax, nu);
-    v.cand = nullptr;
+    v.cand_u = nullptr;
+    v.cand_x = nullptr;
     v.cost_c = nullptr;
     if (!rc) {
       if (hipMemcpyAsync(h->d_umin, d->u_min, nu * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = 1;
@@ -505,8 +505,9 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   rc |= dev_alloc(h, &v.kff, nt * T * nu * TW);
   rc |= dev_alloc(h, &v.Kfb, nt * T * nu * nx * TW);
   rc |= dev_alloc(h, &v.D, nt * T1 * REC * TW);
-  v.nch = (h->T + 1 + CT - 1) / CT;
-  rc |= dev_alloc(h, &v.cand, (size_t)NALPHA * nt * v.nch * TW * CT * (nx + nu));
+  v.nch = h->T / CT + 1;
+  rc |= dev_alloc(h, &v.cand_u, (size_t)NALPHA * nt * T * nu * TW);
+  rc |= dev_alloc(h, &v.cand_x, (size_t)NALPHA * nt * v.nch * nx * TW);
   rc |= dev_alloc(h, &v.cost_c, (size_t)NALPHA * Bp);
   }
   rc |= dev_alloc(h, &v.cost, Bp);
@@ -831,8 +832,12 @@ int ilqr_get_candidate(ilqr_batch* h, int a, double* xs, double* us) {
   if (int rc = ensure_staging(h, nx_el + nu_el)) return rc;
   double* dxs = h->staging;
   double* dus = h->staging + nx_el;
-  hipLaunchKernelGGL(k_unpack_cand, dim3(grid_for((size_t)h->B * (h->T + 1), 256)), dim3(256), 0, h->stream, h->v, a, h->nx,
-                     h->nu, dxs, dus);
+  const dim3 grid(grid_for((size_t)h->B * (h->T + 1), 256)), block(256);
+  switch (h->model) {
+    case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_unpack_cand<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, a, dxs, dus); break;
+    case ILQR_MODEL_DOUBLE_INTEGRATOR: hipLaunchKernelGGL((k_unpack_cand<DoubleIntegratorModel>), grid, block, 0, h->stream, h->v, h->dint, a, dxs, dus); break;
+    default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device rollout", h->model);
+  }
   HIPCHK(hipGetLastError());
   if (xs) HIPCHK(hipMemcpyAsync(xs, dxs, nx_el * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (us) HIPCHK(hipMemcpyAsync(us, dus, nu_el * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -36,16 +36,14 @@ constexpr double kMinStep = 1e-22;
 constexpr double kArmijo = 0.1;
 constexpr double kClampTol = 1e-4;
 
-// Candidate trajectories use a different layout from everything else: a line search accepts a
-// different alpha for every trajectory, so the accepted candidate is GATHERED per lane.  With the
-// tiled layout that costs one 128-byte line per 8 useful bytes (8x read amplification measured);
-// here CT consecutive knots (x_t, u_t) of one (alpha, trajectory) are contiguous (CT*(nx+nu)
-// doubles = 320 B for the acrobot), so the gather reads whole chunks.  The rollout kernel
-// transposes through LDS to write these chunks with fully contiguous 512-byte stores.
+// Line-search candidates are stored as CHECKPOINTS: every control u_t (the rollout's own output)
+// but the state only at every CT-th knot.  Whoever needs knot t of an accepted candidate (the
+// derivative sweep, the commit copy, the getter) re-integrates at most CT-1 Euler steps from the
+// checkpoint with the same device function the rollout used.  11 full candidate trajectories
+// per iteration were 909 MB of stores and bound the rollout kernel; checkpoints are 273 MB.
+//   cand_u  [NALPHA][tile][T][nu][TW]       (tidx with tile' = alpha*ntiles + tile)
+//   cand_x  [NALPHA][tile][NCH][nx][TW]     NCH = T/CT + 1, entry c = state at knot c*CT
 constexpr int CT = 8;
-__host__ __device__ inline size_t cidx(int a, int tile, int c, int l, int j, int e, int ntiles, int nch, int KR) {
-  return (((((size_t)a * ntiles + tile) * nch + c) * TW + l) * CT + j) * KR + e;
-}
 
 __host__ __device__ inline size_t tidx(int tile, int s, int e, int l, int S, int E) {
   return (((size_t)tile * S + s) * E + e) * TW + l;
@@ -103,8 +101,9 @@ struct BatchView {
   double* kff;  // [tile][T][nu][TW]
   double* Kfb;  // [tile][T][nu*nx][TW]
   double* D;    // derivative records, pair-interleaved [tile][T+1][REC/2][TW][2]  (didx)
-  double* cand; // line-search candidates, time-chunked: [NALPHA][tile][NCH][TW][CT][nx+nu]  (cidx)
-  int nch;      // NCH = ceil((T+1)/CT) chunks of CT knots
+  double* cand_u; // line-search candidates: every control      [NALPHA][tile][T][nu][TW]
+  double* cand_x; //                         checkpoint states  [NALPHA][tile][NCH][nx][TW]
+  int nch;        // NCH = T/CT + 1
   double* cost_c; // [NALPHA][Bp]
   // per-trajectory scalars [Bp]
   double* cost;

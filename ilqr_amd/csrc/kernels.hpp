@@ -5,7 +5,7 @@
 //   k_backward_t   backward_pass + box-QP + lambda retry (ilqr_core.cpp:350-401, 136-159),
 //                  one THREAD per trajectory (everything in registers)
 //   k_accept       first-accept selection, lambda schedule, termination (ilqr_core.cpp:185-282)
-//   k_commit       copies the accepted candidate into the nominal trajectory
+//   k_commit       rebuilds the accepted candidate from its checkpoints into the nominal trajectory
 //   k_pack/unpack  canonical [B][S][E] <-> tiled [tile][S][E][16]
 //
 // Lane mapping everywhere: consecutive lanes = consecutive trajectories of a tile, so each
@@ -107,17 +107,13 @@ struct AlphaSet {
 //   GAINS=false : u_t = us[t]                                   (init_traj: K empty, :316)
 //   GAINS=true  : u_t = us[t] + alpha k[t] + K[t] (x_t - xs[t]) (:188-190, :315-316)
 //   CAND=false  : knots (x_t, u_t) go straight into the nominal tiled xs/us (init_traj)
-//   CAND=true   : knots go to candidate `a` in the time-chunked layout (common.hpp cidx): each
-//                 wavefront stages CT knots in LDS ([knot*KR+e][lane], padded rows) and flushes
-//                 them as 512-byte contiguous stores
+//   CAND=true   : candidate `a` keeps every u_t and the state at every CT-th knot (common.hpp)
 // The cost goes to cost_out[a][b].  mode: 0 = all trajectories, 1 = only running ones whose
 // backward pass succeeded.
 template <class M, bool GAINS, bool CAND>
 __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet alphas, int n_alpha,
                                                  double* __restrict__ cost_out, int mode) {
-  constexpr int NX = M::NX, NU = M::NU, KR = NX + NU;
-  constexpr int SROW = 65;  // padded LDS row (64 lanes + 1): conflict-free transposed reads
-  __shared__ double stage_all[CAND ? 3 * CT * KR * SROW : 1];
+  constexpr int NX = M::NX, NU = M::NU;
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int l = lane & (TW - 1);
@@ -127,10 +123,7 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
   const int b = tile * TW + l;
   bool active = (b < v.B) && (a < n_alpha);
   if (active && mode == 1) active = (v.status[b] == 0 && v.backpass_done[b]);
-  if (!CAND && !active) return;
-  const unsigned long long act_mask = __ballot(active);
-  if (CAND && act_mask == 0ull) return;  // wave-uniform
-  double* stage = stage_all + (CAND ? wave * CT * KR * SROW : 0);
+  if (!active) return;
   const int T = v.T;
   const double alpha = alphas.a[a < NALPHA ? a : NALPHA - 1];
   const double dt = v.dt;
@@ -140,30 +133,11 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
   for (int i = 0; i < NX; i++) x[i] = v.x0[tidx(tile, 0, i, l, 1, NX)];
   double total = 0;
 
-  // cooperative flush of the knots staged for chunk c (all 64 lanes; inactive (alpha, l) pairs skipped)
-  auto flush = [&](int c) __attribute__((always_inline)) {
-    if (!CAND) return;
-    constexpr int PER = CT * KR;  // doubles per (alpha, trajectory) chunk
-#pragma unroll
-    for (int as = 0; as < 4; as++) {
-      const int aa = wave * 4 + as;
-      double* base = v.cand + cidx(aa < NALPHA ? aa : 0, tile, c, 0, 0, 0, v.ntiles, v.nch, KR);
-#pragma unroll
-      for (int m = 0; m < (TW * PER) / 64; m++) {
-        const int p = m * 64 + lane;
-        const int ll = p / PER, q = p % PER;
-        const double val = stage[q * SROW + as * 16 + ll];
-        if ((act_mask >> (as * 16 + ll)) & 1ull) base[p] = val;
-      }
-    }
-  };
-
   // The nominal controls / gains / states of step t do not depend on the rollout's own state,
   // and one step of arithmetic (~600 cycles) is far shorter than an HBM round trip under load
   // (~2000+ cycles), so they are prefetched PD steps ahead into a ring of register sets; the
   // main loop is unrolled by PD so that every set is statically indexed.
   constexpr int PD = 4;
-  static_assert(CT % PD == 0, "a chunk is a whole number of unrolled groups");
   struct StepIn {
     double u[NU], k[GAINS ? NU : 1], K[GAINS ? NU * NX : 1], xnom[GAINS ? NX : 1];
   };
@@ -189,11 +163,15 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
 #endif
   auto emit_knot = [&](int t, const double* xx, const double* uu) __attribute__((always_inline)) {  // knot t = (x_t, u_t)
     if (CAND) {
-      const int j = t & (CT - 1);
+      const int ta = a * v.ntiles + tile;
+      if (t < T) {
 #pragma unroll
-      for (int i = 0; i < NX; i++) stage[(j * KR + i) * SROW + lane] = xx[i];
+        for (int q = 0; q < NU; q++) v.cand_u[tidx(ta, t, q, l, T, NU)] = uu[q];
+      }
+      if ((t & (CT - 1)) == 0) {
 #pragma unroll
-      for (int q = 0; q < NU; q++) stage[(j * KR + NX + q) * SROW + lane] = uu[q];
+        for (int i = 0; i < NX; i++) v.cand_x[tidx(ta, t / CT, i, l, v.nch, NX)] = xx[i];
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < NX; i++) v.xs[tidx(tile, t, i, l, T + 1, NX)] = xx[i];
@@ -226,8 +204,7 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
     ILQR_RMARK(2)  // cost + dynamics
 #pragma unroll
     for (int i = 0; i < NX; i++) x[i] = x1[i];
-    if ((t & (CT - 1)) == CT - 1) flush(t / CT);
-    ILQR_RMARK(3)  // chunk flush
+    ILQR_RMARK(3)
   };
   StepIn ring[PD];
 #pragma unroll
@@ -251,28 +228,64 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
 #pragma unroll
     for (int q = 0; q < NU; q++) uz[q] = 0;
     emit_knot(T, x, uz);
-    flush(T / CT);
   }
 #ifdef ILQR_PHASE_TIMING
   if (v.dbg && threadIdx.x == 0 && tile < 3 && GAINS)
     for (int q = 0; q < 4; q++) v.dbg[512 - 16 + tile * 4 + q] = rph[q];
 #endif
   total += model.final_cost(x);  // :335
-  if (active) cost_out[(size_t)a * v.Bp + b] = total;
+  cost_out[(size_t)a * v.Bp + b] = total;
 }
 
-// candidate `a` (time-chunked) -> canonical xs [B][T+1][nx], us [B][T][nu]   (getter only)
-__global__ void k_unpack_cand(BatchView v, int a, int NX, int NU, double* __restrict__ xs, double* __restrict__ us) {
-  const int KR = NX + NU, T = v.T;
+// Knot t of candidate `a` of trajectory (tile, l): the control as stored, the state re-integrated
+// from the checkpoint at knot (t/CT)*CT with the rollout's own step (include/model.h:12-15).  The
+// CT-1 controls of the chunk are fetched up front (one memory round trip), the steps run predicated.
+template <class M>
+__device__ __forceinline__ void candidate_knot(const BatchView& v, const M& model, int a, int tile, int t, int l,
+                                               double* x, double* u) {
+  constexpr int NX = M::NX, NU = M::NU;
+  const int T = v.T, ta = a * v.ntiles + tile, c = t / CT, off = t - c * CT;
+#pragma unroll
+  for (int i = 0; i < NX; i++) x[i] = v.cand_x[tidx(ta, c, i, l, v.nch, NX)];
+  double uq[CT][NU];
+#pragma unroll
+  for (int q = 0; q < CT; q++) {
+    const int tq = (c * CT + q < T) ? c * CT + q : T - 1;
+#pragma unroll
+    for (int j = 0; j < NU; j++) uq[q][j] = v.cand_u[tidx(ta, tq, j, l, T, NU)];
+  }
+#pragma unroll
+  for (int j = 0; j < NU; j++) u[j] = 0.0;  // knot T has no control
+#pragma unroll
+  for (int q = 0; q < CT; q++) {
+    if (q < off) {
+      double x1[NX];
+      integrate_dynamics(model, x, uq[q], v.dt, x1);
+#pragma unroll
+      for (int i = 0; i < NX; i++) x[i] = x1[i];
+    }
+    if (q == off && t < T) {
+#pragma unroll
+      for (int j = 0; j < NU; j++) u[j] = uq[q][j];
+    }
+  }
+}
+
+// candidate `a` -> canonical xs [B][T+1][nx], us [B][T][nu]   (getter only)
+template <class M>
+__global__ void k_unpack_cand(BatchView v, M model, int a, double* __restrict__ xs, double* __restrict__ us) {
+  constexpr int NX = M::NX, NU = M::NU;
+  const int T = v.T;
   const size_t n = (size_t)v.B * (T + 1);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int t = (int)(i % (T + 1));
     const int b = (int)(i / (T + 1));
-    const double* r = v.cand + cidx(a, b / TW, t / CT, b % TW, t % CT, 0, v.ntiles, v.nch, KR);
+    double x[NX], u[NU];
+    candidate_knot(v, model, a, b / TW, t, b % TW, x, u);
     if (xs)
-      for (int e = 0; e < NX; e++) xs[((size_t)b * (T + 1) + t) * NX + e] = r[e];
+      for (int e = 0; e < NX; e++) xs[((size_t)b * (T + 1) + t) * NX + e] = x[e];
     if (us && t < T)
-      for (int e = 0; e < NU; e++) us[((size_t)b * T + t) * NU + e] = r[NX + e];
+      for (int e = 0; e < NU; e++) us[((size_t)b * T + t) * NU + e] = u[e];
   }
 }
 
@@ -337,12 +350,8 @@ __device__ __forceinline__ void derivatives_of_knot(const BatchView& v, const M&
 
   double x[NX], u[NU];
   {
-    if (ci >= 0) {  // knot t of the accepted candidate: KR contiguous doubles
-      const double* r = v.cand + cidx(ci, tile, t / CT, l, t % CT, 0, v.ntiles, v.nch, NX + NU);
-#pragma unroll
-      for (int i = 0; i < NX; i++) x[i] = r[i];
-#pragma unroll
-      for (int j = 0; j < NU; j++) u[j] = (t < T) ? r[NX + j] : 0.0;
+    if (ci >= 0) {  // knot t of the accepted candidate
+      candidate_knot(v, model, ci, tile, t, l, x, u);
     } else {
 #pragma unroll
       for (int i = 0; i < NX; i++) x[i] = v.xs[tidx(tile, t, i, l, T + 1, NX)];
@@ -1427,8 +1436,9 @@ __global__ void k_accept(BatchView v, SolverParams sp, int* __restrict__ commit_
 }
 
 // copy candidate commit_idx[b] into the nominal trajectory.  block 256 = 16 traj x 16 steps.
-template <int NX, int NU>
-__global__ __launch_bounds__(256) void k_commit(BatchView v, const int* __restrict__ commit_idx) {
+template <class M>
+__global__ __launch_bounds__(256) void k_commit(BatchView v, M model, const int* __restrict__ commit_idx) {
+  constexpr int NX = M::NX, NU = M::NU;
   const int l = threadIdx.x & (TW - 1);
   const int t = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int tile = blockIdx.y;
@@ -1437,12 +1447,13 @@ __global__ __launch_bounds__(256) void k_commit(BatchView v, const int* __restri
   if (t > T || b >= v.B) return;
   const int a = commit_idx[b];
   if (a < 0) return;
-  const double* r = v.cand + cidx(a, tile, t / CT, l, t % CT, 0, v.ntiles, v.nch, NX + NU);
+  double x[NX], u[NU];
+  candidate_knot(v, model, a, tile, t, l, x, u);
 #pragma unroll
-  for (int i = 0; i < NX; i++) v.xs[tidx(tile, t, i, l, T + 1, NX)] = r[i];
+  for (int i = 0; i < NX; i++) v.xs[tidx(tile, t, i, l, T + 1, NX)] = x[i];
   if (t < T) {
 #pragma unroll
-    for (int j = 0; j < NU; j++) v.us[tidx(tile, t, j, l, T, NU)] = r[NX + j];
+    for (int j = 0; j < NU; j++) v.us[tidx(tile, t, j, l, T, NU)] = u[j];
   }
 }
 
