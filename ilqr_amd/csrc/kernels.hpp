@@ -11,6 +11,8 @@
 // Lane mapping everywhere: consecutive lanes = consecutive trajectories of a tile, so each
 // vector load/store touches whole 128-byte lines of the tiled layout (common.hpp).
 #pragma once
+#include <type_traits>
+
 #include "boxqp.hpp"
 #include "common.hpp"
 #include "models.hpp"
@@ -335,17 +337,43 @@ __device__ __forceinline__ void fd_gradient(const double* x, F f, double* out) {
 // commit_idx (may be null): a line search accepted candidate commit_idx[b] for trajectory b and
 // its copy into the nominal trajectory is still pending -- this kernel reads the knot from the
 // candidate and performs the copy on the way (the separate k_commit pass is only used to flush).
-template <class M>
+// RING (k_sweep_backward): the record and the knot's nominal control are ALSO written to the LDS
+// slot `rs` (this lane's pair column of the slot: element e at rs[(e>>1)*2*TW + (e&1)], the
+// control behind the record), where the backward wavefront of the same block reads them.
+template <int NX, int NU>
+struct RingSlot {
+  static constexpr int US = Rec<NX, NU>::SIZE;               // controls follow the record
+  static constexpr int PAIRS = (Rec<NX, NU>::SIZE + NU + 1) / 2;
+  static constexpr int DOUBLES = PAIRS * 2 * TW;             // per slot
+  static constexpr int SLOTS = ((150 * 1024 / 8) / DOUBLES) / 4 * 4;  // ring size: what fits in ~150 KB of LDS
+};
+
+template <class M, bool RING = false>
 __device__ __forceinline__ void derivatives_of_knot(const BatchView& v, const M& model, int force,
-                                                    const int* __restrict__ commit_idx, int tile, int t, int l) {
+                                                    const int* __restrict__ commit_idx, int tile, int t, int l,
+                                                    double* rs = nullptr) {
   constexpr int NX = M::NX, NU = M::NU;
   using R = Rec<NX, NU>;
+  typedef double double2_t __attribute__((ext_vector_type(2)));
   const int b = tile * TW + l;
   const int T = v.T;
   if (t > T || b >= v.B) return;
   const int ci = commit_idx ? commit_idx[b] : -1;
   const bool want = force || (v.status[b] == 0 && v.flg_change[b]);
-  if (ci < 0 && !want) return;
+  if (ci < 0 && !want) {
+    // A running trajectory whose last line search failed keeps its derivatives (flgChange = 0,
+    // ilqr_core.cpp:115): the backward pass still wants them, so the ring gets a copy.
+    if (RING && v.status[b] == 0) {
+      const double* D0 = v.D + didx(tile, t, 0, l, T + 1, R::SIZE);
+#pragma unroll
+      for (int e = 0; e < R::SIZE; e += 2)
+        *reinterpret_cast<double2_t*>(rs + (e >> 1) * (2 * TW)) = *reinterpret_cast<const double2_t*>(D0 + (size_t)(e >> 1) * (2 * TW));
+#pragma unroll
+      for (int j = 0; j < NU; j++)
+        rs[((RingSlot<NX, NU>::US + j) >> 1) * (2 * TW) + ((RingSlot<NX, NU>::US + j) & 1)] = (t < T) ? v.us[tidx(tile, t, j, l, T, NU)] : 0.0;
+    }
+    return;
+  }
   const double dt = v.dt;
 
   double x[NX], u[NU];
@@ -367,17 +395,24 @@ __device__ __forceinline__ void derivatives_of_knot(const BatchView& v, const M&
       }
     }
   }
-  if (!want) return;
+  if (!want) return;  // (finished trajectory whose last candidate was committed above)
 
-  typedef double double2_t __attribute__((ext_vector_type(2)));
   double* D = v.D + didx(tile, t, 0, l, T + 1, R::SIZE);
-  auto put = [&](int e, double val) { D[(size_t)(e >> 1) * (2 * TW) + (e & 1)] = val; };
+  auto put = [&](int e, double val) {
+    D[(size_t)(e >> 1) * (2 * TW) + (e & 1)] = val;
+    if (RING) rs[(e >> 1) * (2 * TW) + (e & 1)] = val;
+  };
   auto put2 = [&](int e, double v0, double v1) {  // e even: one 16-byte store
     double2_t w;
     w.x = v0;
     w.y = v1;
     *reinterpret_cast<double2_t*>(D + (size_t)(e >> 1) * (2 * TW)) = w;
+    if (RING) *reinterpret_cast<double2_t*>(rs + (e >> 1) * (2 * TW)) = w;
   };
+  if (RING) {
+#pragma unroll
+    for (int j = 0; j < NU; j++) rs[((RingSlot<NX, NU>::US + j) >> 1) * (2 * TW) + ((RingSlot<NX, NU>::US + j) & 1)] = u[j];
+  }
 
   if (t < T) {
     // fx, fu: central differences of the Euler map (derivatives.cpp:19-25, finite_diff.h:35-47)
@@ -847,9 +882,12 @@ struct QuadStep {  // what lane (l, s) needs of one derivative record
 // gate(t) returns once the derivative record and the nominal control of knot t may be read: a
 // no-op when the records were written by an earlier kernel (k_backward_q), a wait on the
 // co-resident producer wavefronts in k_sweep_backward.
+// ring != nullptr: the FIRST pass reads each knot from LDS slot (T - t) % SLOTS, where the producers
+// put it; lambda-retry passes (and ring == nullptr) read the records from HBM.
 template <class M, class Gate>
 __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model, const SolverParams& sp, int mode,
-                                              int tile, int lane, const double* __restrict__ lds_steps, Gate gate) {
+                                              int tile, int lane, const double* __restrict__ lds_steps, Gate gate,
+                                              const double* ring = nullptr) {
   static_assert(M::NX == 4, "quad kernel: one lane per state dimension");
   constexpr int NX = 4, NU = M::NU;
   using R = Rec<NX, NU>;
@@ -865,12 +903,10 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
   double* __restrict__ kt = v.kff + tidx(tile, 0, 0, l, T, NU);
   double* __restrict__ Kt = v.Kfb + tidx(tile, 0, 0, l, T, NU * NX);
 
-  // 16-byte loads of element pairs (e even) and 8-byte loads of single elements of a record
-  auto load = [&](int t, QuadStep<NU>& d) {
-    gate(t);
-    const double* r = Dt + (unsigned)(t * ((R::SIZE / 2) * 2 * TW));  // in-tile offsets fit 32 bits
-    auto pair = [&](int e) { return *reinterpret_cast<const double2_t*>(r + (unsigned)((e >> 1) * (2 * TW))); };
-    auto one = [&](int e) { return r[(unsigned)((e >> 1) * (2 * TW) + (e & 1))]; };
+  using RS = RingSlot<NX, NU>;
+  bool from_ring = (ring != nullptr);  // cleared when a pass has to be repeated
+  // what lane (l, s) needs of knot t, given accessors for element pairs (e even) / single elements
+  auto fill = [&](auto pair, auto one, QuadStep<NU>& d) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = 0; e < 16; e += 2) {
       const double2_t w = pair(R::FX + e);
@@ -911,24 +947,56 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
     }
 #pragma unroll
     for (int a = 0; a < NU; a++) d.cxu[a] = one(R::CXU + s + 4 * a);
+  };
+  // (explicit address spaces: with generic pointers hipcc merges the two sources' loads into flat
+  // instructions, which wait on vmcnt and lgkmcnt alike)
+  typedef const __attribute__((address_space(3))) double lds_cd;
+  typedef const __attribute__((address_space(3))) double2_t lds_cd2;
+  auto load = [&](auto tag, int t, QuadStep<NU>& d) __attribute__((always_inline)) {
+    constexpr bool RP = decltype(tag)::value;
+    gate(t, RP);
+    if constexpr (RP) {  // ds_read_b128 / b64 from the producers' slot
+      lds_cd* r = (lds_cd*)(ring + ((T - t) % RS::SLOTS) * RS::DOUBLES + l * 2);
+      auto pair = [&](int e) { return *(lds_cd2*)(r + (e >> 1) * (2 * TW)); };
+      auto one = [&](int e) { return r[(e >> 1) * (2 * TW) + (e & 1)]; };
+      fill(pair, one, d);
 #pragma unroll
-    for (int a = 0; a < NU; a++) d.us[a] = ust[(unsigned)((t * NU + a) * TW)];
+      for (int a = 0; a < NU; a++) d.us[a] = one(RS::US + a);
+    } else {  // 16-byte / 8-byte global loads of the record in HBM
+      const double* r = Dt + (unsigned)(t * ((R::SIZE / 2) * 2 * TW));  // in-tile offsets fit 32 bits
+      auto pair = [&](int e) { return *reinterpret_cast<const double2_t*>(r + (unsigned)((e >> 1) * (2 * TW))); };
+      auto one = [&](int e) { return r[(unsigned)((e >> 1) * (2 * TW) + (e & 1))]; };
+      fill(pair, one, d);
+#pragma unroll
+      for (int a = 0; a < NU; a++) d.us[a] = ust[(unsigned)((t * NU + a) * TW)];
+    }
   };
 
   constexpr int kWaitAll = (7 << 4) | (15 << 8);  // s_waitcnt vmcnt(0) only (expcnt/lgkmcnt untouched)
+  constexpr int kWaitLds = 0xC07F;                // s_waitcnt lgkmcnt(0) only (vmcnt = 63, expcnt = 7)
   int diverge = 0;
   bool done = false;
   double dV0 = 0, dV1 = 0, gacc = 0;
-  while (true) {
+  // one backward_pass() at the current lambda; tag = std::true_type: knots come from the ring
+  auto one_pass = [&](auto tag) __attribute__((always_inline)) {
+    constexpr bool RP = decltype(tag)::value;
     // carried state: full Vxx / Vx in every lane
     double Vx[4], Vxx[16], kprev[NU];
     {
-      gate(T);
-      const double* r = Dt + (size_t)T * (R::SIZE / 2) * (2 * TW);
+      gate(T, RP);
+      if constexpr (RP) {
+        lds_cd* r = (lds_cd*)(ring + l * 2);  // knot T sits in slot 0
 #pragma unroll
-      for (int i = 0; i < 4; i++) Vx[i] = r[(size_t)((R::CX + i) >> 1) * (2 * TW) + ((R::CX + i) & 1)];  // :353
+        for (int i = 0; i < 4; i++) Vx[i] = r[((R::CX + i) >> 1) * (2 * TW) + ((R::CX + i) & 1)];  // :353
 #pragma unroll
-      for (int e = 0; e < 16; e++) Vxx[e] = r[(size_t)((R::CXX + e) >> 1) * (2 * TW) + ((R::CXX + e) & 1)];  // :354
+        for (int e = 0; e < 16; e++) Vxx[e] = r[((R::CXX + e) >> 1) * (2 * TW) + ((R::CXX + e) & 1)];  // :354
+      } else {
+        const double* r = Dt + (size_t)T * (R::SIZE / 2) * (2 * TW);
+#pragma unroll
+        for (int i = 0; i < 4; i++) Vx[i] = r[(size_t)((R::CX + i) >> 1) * (2 * TW) + ((R::CX + i) & 1)];  // :353
+#pragma unroll
+        for (int e = 0; e < 16; e++) Vxx[e] = r[(size_t)((R::CXX + e) >> 1) * (2 * TW) + ((R::CXX + e) & 1)];  // :354
+      }
     }
 #pragma unroll
     for (int a = 0; a < NU; a++) kprev[a] = kt[((size_t)(T - 1) * NU + a) * TW];
@@ -1180,9 +1248,15 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
         if (ok) gacc += mx;
       }
       ILQR_MARK(3)  // value-function update + quad exchanges
-      // the prefetch issued at the top of this step has had the whole step to land
+      // the prefetch issued at the top of this step has had the whole step to land.  From HBM:
+      // vmcnt(0) (this also drains the previous step's stores).  From the ring: only the LDS
+      // reads are waited for -- they must have landed before the next gate() frees the slot --
+      // and the stores are never waited for.
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(kWaitAll);
+      if constexpr (RP)
+        __builtin_amdgcn_s_waitcnt(kWaitLds);
+      else
+        __builtin_amdgcn_s_waitcnt(kWaitAll);
       __builtin_amdgcn_sched_barrier(0);
       ILQR_MARK(4)  // wait for the prefetch
       // :396-397
@@ -1212,16 +1286,16 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
       // the freshly issued prefetch, which would expose one HBM round trip per step.
       QuadStep<NU> A, Bd;
       int i = T - 1;
-      load(i, A);
-      __builtin_amdgcn_s_waitcnt(kWaitAll);
+      load(tag, i, A);
+      __builtin_amdgcn_s_waitcnt(kWaitAll & kWaitLds);
       while (true) {
         __builtin_amdgcn_sched_barrier(0);
-        if (i >= 1) load(i - 1, Bd);
+        if (i >= 1) load(tag, i - 1, Bd);
         __builtin_amdgcn_sched_barrier(0);
         if (!step(i, A)) break;
         if (--i < 0) break;
         __builtin_amdgcn_sched_barrier(0);
-        if (i >= 1) load(i - 1, A);
+        if (i >= 1) load(tag, i - 1, A);
         __builtin_amdgcn_sched_barrier(0);
         if (!step(i, Bd)) break;
         if (--i < 0) break;
@@ -1232,6 +1306,13 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
     if (v.dbg && lane == 0 && tile < 64)
       for (int q = 0; q < 8; q++) v.dbg[tile * 8 + q] = ph[q];
 #endif
+  };
+
+  while (true) {
+    if (from_ring)
+      one_pass(std::true_type{});
+    else
+      one_pass(std::false_type{});
     if (mode == 0) {
       done = (diverge == 0);
       break;
@@ -1240,6 +1321,7 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
       dlambda = fmax(dlambda * sp.lambda_factor, sp.lambda_factor);
       lambda = fmax(lambda * dlambda, sp.lambda_min);
       if (lambda > sp.lambda_max) break;
+      from_ring = false;  // the ring has moved on: the repeated pass reads the records from HBM
       continue;
     }
     done = true;
@@ -1304,7 +1386,7 @@ template <class M>
 __global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverParams sp, int mode) {
   __shared__ double lds_steps[104];  // backtracking step sizes (per-lane indexed -> LDS, not constant cache)
   load_step_table(lds_steps);
-  backward_quad(v, model, sp, mode, (int)blockIdx.x, (int)threadIdx.x, lds_steps, [](int) {});
+  backward_quad(v, model, sp, mode, (int)blockIdx.x, (int)threadIdx.x, lds_steps, [](int, bool) {});
 }
 
 // STEP 1 + STEP 2 of one iteration in ONE kernel (ilqr_iterate).  The quad backward pass keeps a
@@ -1315,10 +1397,11 @@ __global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverP
 // wavefront and round), perform the pending commit of the accepted candidate on the way
 // (derivatives_of_knot), and publish their progress in LDS.  The consumer follows a few hundred
 // cycles behind the first round and never waits again (a producer round of 4 time steps costs
-// about as much as ONE backward step).  Producer and consumer share the CU, hence its L1 and L2:
-// workgroup-scope release/acquire is all the ordering needed, no device-wide cache maintenance.
-// Records still go through HBM in the didx layout, so a lambda retry (mode 1) and the getters
-// find them where the stand-alone kernels put them.    grid = ntiles, block = 256
+// about as much as ONE backward step).  Each record goes into an LDS ring slot, from where the
+// backward wavefront reads it (ds_read: no HBM round trip, no vmcnt wait in its loop), AND to HBM
+// in the didx layout, where a lambda-retry pass and the getters find it as the stand-alone
+// kernels would have left it.  Workgroup-scope release/acquire is all the ordering needed.
+//   grid = ntiles, block = 64 * (1 + kProducers), LDS ~150 KB (one block per CU)
 #ifndef ILQR_PRODUCERS
 #define ILQR_PRODUCERS 3
 #endif
@@ -1331,10 +1414,14 @@ constexpr int kLeadKnots = ILQR_LEAD_ROUNDS * kKnotsPerRound;  // producers stay
 template <class M>
 __global__ __launch_bounds__(64 * (1 + kProducers)) void k_sweep_backward(BatchView v, M model, SolverParams sp, int mode, int force,
                                                         const int* __restrict__ commit_idx) {
+  using RS = RingSlot<M::NX, M::NU>;
+  static_assert(RS::SLOTS >= kLeadKnots + 4 && RS::SLOTS >= 16, "the ring must hold the producers' lead");
   __shared__ double lds_steps[104];
-  __shared__ int rounds_done[kProducers];
-  __shared__ int consumer_at;  // highest knot index j = T - t the backward pass has asked for
-  if (threadIdx.x < kProducers) rounds_done[threadIdx.x] = 0;
+  __shared__ double ring[RS::SLOTS * RS::DOUBLES];  // knot j = T - t lives in slot j % SLOTS
+  __shared__ int rounds_done[kProducers];    // rounds whose records are in the ring
+  __shared__ int rounds_stored[kProducers];  // rounds whose records (and committed knots) have reached HBM
+  __shared__ int consumer_at;  // knots j < consumer_at are in the backward pass's registers (slots free)
+  if (threadIdx.x < kProducers) rounds_done[threadIdx.x] = rounds_stored[threadIdx.x] = 0;
   if (threadIdx.x == kProducers) consumer_at = 0;
   load_step_table(lds_steps);  // (barrier)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1342,24 +1429,45 @@ __global__ __launch_bounds__(64 * (1 + kProducers)) void k_sweep_backward(BatchV
   const int T = v.T;
   if (wave == 0) {
     __builtin_amdgcn_s_setprio(3);
-    int have = 0;  // knots j < have are known to be produced
-    auto gate = [&](int t) __attribute__((always_inline)) {  // wave-uniform
+#ifdef ILQR_PHASE_TIMING
+    long long gate_spins = 0;
+#endif
+    int have = 0, have_hbm = 0;  // knots j < have are in the ring / < have_hbm are readable from HBM
+    auto gate = [&](int t, bool from_ring) __attribute__((always_inline)) {  // wave-uniform
       const int j = T - t;
-      if (j < have) return;
       const int round = j / kKnotsPerRound, w = (j % kKnotsPerRound) / 4;
-      __hip_atomic_store(&consumer_at, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      while (__hip_atomic_load(&rounds_done[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= round)
-        __builtin_amdgcn_s_sleep(2);
-      have = round * kKnotsPerRound + (w + 1) * 4;
+      if (from_ring) {
+        if (j < have) return;
+        __hip_atomic_store(&consumer_at, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(&rounds_done[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= round) {
+          __builtin_amdgcn_s_sleep(2);
+#ifdef ILQR_PHASE_TIMING
+          gate_spins++;
+#endif
+        }
+        have = round * kKnotsPerRound + (w + 1) * 4;
+      } else {  // a repeated pass (lambda retry) reads what the producers stored to HBM
+        if (j < have_hbm) return;
+        if (j >= have) __hip_atomic_store(&consumer_at, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(&rounds_stored[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= round)
+          __builtin_amdgcn_s_sleep(2);
+        have_hbm = round * kKnotsPerRound + (w + 1) * 4;
+        if (have_hbm > have) have = have_hbm;
+      }
     };
-    backward_quad(v, model, sp, mode, tile, lane, lds_steps, gate);
+    backward_quad(v, model, sp, mode, tile, lane, lds_steps, gate, ring);
+#ifdef ILQR_PHASE_TIMING
+    if (v.dbg && lane == 0 && tile < 64) v.dbg[tile * 8 + 7] = gate_spins;
+#endif
     // (a pass abandoned at lambdaMax never asks for the remaining knots: release the producers)
     __hip_atomic_store(&consumer_at, 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   } else {
     // Producers pace themselves to the consumer: running flat out they would saturate the CU's
     // store path for the first third of the kernel (the sweep alone is HBM-write-bound) and the
-    // backward wavefront's own loads and stores would queue behind theirs; a bounded lead spreads
-    // the writes over the whole pass and leaves the records in L2 for the consumer.
+    // backward wavefront's own stores would queue behind theirs; a bounded lead also is what keeps
+    // a ring slot from being overwritten before it is read.  A round is published for the ring as
+    // soon as its LDS writes are done; its HBM stores drain while the wavefront waits for its next
+    // turn and are published (rounds_stored) just before the next round starts.
     const int w = wave - 1;
     const int l = lane & (TW - 1), sub = lane >> 4;
     if (tile == 0 && threadIdx.x == 64) *v.n_running = 0;  // k_accept of this iteration recounts
@@ -1368,12 +1476,19 @@ __global__ __launch_bounds__(64 * (1 + kProducers)) void k_sweep_backward(BatchV
       const int j0 = r * kKnotsPerRound + w * 4;
       while (j0 > __hip_atomic_load(&consumer_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + kLeadKnots)
         __builtin_amdgcn_s_sleep(8);
+      if (r > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // round r-1 has reached the L2
+        if (lane == 0) __hip_atomic_store(&rounds_stored[w], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
       const int t = T - (j0 + sub);
-      if (t >= 0) derivatives_of_knot(v, model, force, commit_idx, tile, t, l);
-      // all stores of this wavefront have reached the L2 before the round is published
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (t >= 0)
+        derivatives_of_knot<M, true>(v, model, force, commit_idx, tile, t, l, ring + ((j0 + sub) % RS::SLOTS) * RS::DOUBLES + l * 2);
+      // LDS operations of a wavefront complete in order: once its writes are done the round is visible
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
       if (lane == 0) __hip_atomic_store(&rounds_done[w], r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(&rounds_stored[w], nrounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 }
 
