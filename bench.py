@@ -39,6 +39,10 @@ def algorithmic_bytes_per_timestep(n, m):
         # per alpha: reads us,k (2m), K (mn), xs (n); writes u_t (m) and one checkpoint state per 8 knots
         "rollout": 11 * (2 * m + m * n + n + m + n / 8.0) * s,                            # acrobot 11*92
         "accept": 2 * (n + m) * s,                                                       # commit copy
+        # k_sweep_backward (ilqr_iterate): the sweep's records reach the backward wavefront through LDS,
+        # so HBM sees: candidate u + 1/8 checkpoint x read, committed x,u written, the record written
+        # (retry passes / getters read it there), K and k written, the nominal u read.      acrobot 460
+        "sweep_backward": (m + n / 8.0 + (n + m) + (2 * n * n + 2 * n * m + m * m + n + m) + (m * n + m) + m) * s,
     }
 
 
@@ -161,9 +165,8 @@ def main():
                                 "algorithmic_GBps": bytes_ts[name] * B * T / (ms / launches * 1e-3) / 1e9}
         name_of = {i: g.lib.ilqr_stage_kernel_name(g.h, i).decode() for i in range(capi.NUM_STAGES)}
         if name_of[capi.STAGE_NAMES.index("backward")] == "k_sweep_backward":
-            # one kernel does the derivative sweep AND the backward pass of the tile: it writes the
-            # records (derivative bytes) and reads them back (backward bytes)
-            bytes_ts["backward"] += bytes_ts["derivatives"]
+            # one kernel does the derivative sweep AND the backward pass of the tile
+            bytes_ts["backward"] = bytes_ts["sweep_backward"]
             stages["backward"]["algorithmic_GBps"] = bytes_ts["backward"] * B * T / (stages["backward"]["ms_per_launch"] * 1e-3) / 1e9
             stages["backward"]["includes"] = "derivative sweep (fused kernel)"
         dom = max(stages, key=lambda k: stages[k]["ms_per_launch"])

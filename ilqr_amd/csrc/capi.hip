@@ -71,6 +71,7 @@ struct ilqr_batch {
   double* d_umin = nullptr;     // [nu] device copies of the limits (generic kernel)
   double* d_umax = nullptr;
   bool profile = false;
+  int num_cus = 256;
   StageTimer timers[ILQR_NUM_STAGES];
 };
 
@@ -318,8 +319,13 @@ static int launch_backward(ilqr_batch* h, int mode) {
 
 // STEP 1 + STEP 2 in one launch (k_sweep_backward): the tile's derivative sweep runs on the three
 // SIMDs the quad backward pass leaves idle.  Timed as ILQR_STAGE_BACKWARD.
+// One block of the fused kernel owns a whole CU (four wavefronts of ~290 registers, ~150 KB of LDS),
+// so it pays while the tiles fit on the device in one wave of blocks; beyond that (B > 16 x #CUs)
+// the two-kernel path keeps four tiles' backward wavefronts per CU busy and wins (measured at
+// B = 16384: 2.2 ms vs 3.2 ms per iteration).
 static bool use_fused_sweep(const ilqr_batch* h) {
-  return use_quad_backward(h) && !h->aos && !(h->flags & ILQR_FLAG_UNFUSED) && !getenv("ILQR_AMD_UNFUSED");
+  if (!use_quad_backward(h) || h->aos || (h->flags & ILQR_FLAG_UNFUSED) || getenv("ILQR_AMD_UNFUSED")) return false;
+  return getenv("ILQR_AMD_FUSED") || h->ntiles <= h->num_cus;
 }
 static int launch_sweep_backward(ilqr_batch* h, int mode, int force) {
   std::pair<hipEvent_t, hipEvent_t> ev;
@@ -424,6 +430,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     return fail(ILQR_ERR_NO_DEVICE, "no HIP device visible: libilqr_amd has no CPU path");
   if (d->device < 0 || d->device >= ndev) return fail(ILQR_ERR_NO_DEVICE, "device %d out of range (%d visible)", d->device, ndev);
   HIPCHK(hipSetDevice(d->device));
+  HIPCHK(hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, d->device));
   h->device = d->device;
   if (d->stream) {
     h->stream = (hipStream_t)d->stream;

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for profiles/ on the GPU box (run through gpurun from the repo root).
+# usage: scripts/collect_profiles.sh rNN
+set -u
+R=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o $R -- $BENCH --steps 20 --warmup 3 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o $R -- $BENCH --steps 5 --warmup 3 > /dev/null 2> $OUT/pmc_$C.err
+done
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace -d $OUT/pmc_sq1 -o $R -- $BENCH --steps 5 --warmup 3 > /dev/null 2> $OUT/pmc_sq1.err
+rocprofv3 --pmc SQ_INSTS_VMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $OUT/pmc_sq2 -o $R -- $BENCH --steps 5 --warmup 3 > /dev/null 2> $OUT/pmc_sq2.err
+cd $ROOT
+python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+for d in stats pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq1 pmc_sq2; do
+  f=$(find $OUT/$d -name "*.db" | head -1)
+  [ -n "$f" ] && python scripts/prof_summary.py $f > $OUT/$d.txt 2>&1
+done
+ls -la $OUT
