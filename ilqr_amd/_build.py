@@ -6,7 +6,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib", "libilqr_amd.so")
 SOURCES = [os.path.join(CSRC, "capi.hip")]
-HEADERS = [os.path.join(CSRC, f) for f in ("common.hpp", "models.hpp", "boxqp.hpp", "kernels.hpp", "backward_wave.hpp")] + \
+HEADERS = [os.path.join(CSRC, f) for f in ("common.hpp", "models.hpp", "boxqp.hpp", "kernels.hpp", "backward_wave.hpp", "generic.hpp")] + \
           [os.path.join(os.path.dirname(PKG), "include", "ilqr_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]

@@ -18,7 +18,9 @@ STATUS_NAMES = {0: "running", 1: "converged_grad", 2: "converged_cost", 3: "lamb
 _MODELS = {"acrobot": (capi.MODEL_ACROBOT, 4, 1), "double_integrator": (capi.MODEL_DOUBLE_INTEGRATOR, 4, 2),
            "integrator": (capi.MODEL_DOUBLE_INTEGRATOR, 4, 2),
            # host-evaluated model: only the backward pass runs on the device (nx, nu given by the caller)
-           "host": (capi.MODEL_HOST, None, None)}
+           "host": (capi.MODEL_HOST, None, None),
+           # synthetic LQ model (BASELINE.json configs[4]): lq=(A, B, Q, R, Qf), row-major; nx, nu from their shapes
+           "lq": (capi.MODEL_LQ, None, None)}
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 
@@ -33,9 +35,12 @@ def _p(a):
 
 class BatchILQR:
     def __init__(self, model, B, T, dt, u_min=None, u_max=None, goal=None, device=0, flags=0,
-                 stream=None, params=None, nx=None, nu=None):
+                 stream=None, params=None, nx=None, nu=None, lq=None):
         self.lib = capi.load()
         mid, mnx, mnu = _MODELS[model]
+        if lq is not None:
+            lq = [_c(a) for a in lq]
+            nx, nu = lq[1].shape
         nx, nu = (mnx or nx), (mnu or nu)
         self.model, self.nx, self.nu, self.B, self.T, self.dt = model, nx, nu, int(B), int(T), float(dt)
         self._keep = []
@@ -48,6 +53,10 @@ class BatchILQR:
                 arr = _c(np.broadcast_to(np.asarray(val, dtype=np.float64), (n,)))
                 self._keep.append(arr)
                 setattr(d, name, _p(arr))
+        if lq is not None:
+            assert lq[0].shape == (nx, nx) and lq[2].shape == (nx, nx) and lq[3].shape == (nu, nu) and lq[4].shape == (nx, nx)
+            self._keep.extend(lq)
+            d.lq_A, d.lq_B, d.lq_Q, d.lq_R, d.lq_Qf = (_p(a) for a in lq)
         d.stream = stream
         if params is not None:
             p = capi.Params()

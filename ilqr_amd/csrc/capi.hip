@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "backward_wave.hpp"
+#include "generic.hpp"
 #include "kernels.hpp"
 
 using namespace ilqr;
@@ -57,6 +58,7 @@ struct ilqr_batch {
   ilqr_params params;
   AcrobotModel acrobot;
   DoubleIntegratorModel dint;
+  LqModel lq;                   // ILQR_MODEL_LQ: padded matrices on the device
   BatchView v;
   SolverParams sp;
   hipStream_t stream = nullptr;
@@ -76,6 +78,13 @@ struct ilqr_batch {
 };
 
 static int rec_of(const ilqr_batch* h) { return rec_size(h->nx, h->nu); }
+// ILQR_MODEL_HOST: the model exists only as host code; nothing but the backward pass runs here
+static bool host_model(const ilqr_batch* h) { return h->model == ILQR_MODEL_HOST; }
+static int no_device_model();
+// elements of a per-knot array with S time slots of E doubles, in this handle's device layout
+static size_t dev_elems(const ilqr_batch* h, size_t S, size_t E) {
+  return h->aos ? (size_t)h->B * S * E : (size_t)h->ntiles * S * E * TW;
+}
 
 template <class T>
 static int dev_alloc(ilqr_batch* h, T** p, size_t n) {
@@ -88,6 +97,10 @@ static int dev_alloc(ilqr_batch* h, T** p, size_t n) {
 }
 
 static int grid_for(size_t n, int block) { return (int)std::min<size_t>((n + block - 1) / block, 65535u * 16u); }
+
+static int no_device_model() {
+  return fail(ILQR_ERR_UNSUPPORTED, "host-evaluated model: rollouts and finite differences stay on the host; only the backward pass (ilqr_set_derivatives + ilqr_backward_pass/_step) runs on the device");
+}
 
 // stage timing -------------------------------------------------------------------------------
 static int timer_begin(ilqr_batch* h, int stage, std::pair<hipEvent_t, hipEvent_t>* ev) {
@@ -235,10 +248,35 @@ static int launch_rollout_t(ilqr_batch* h, const M& m, bool gains, bool cand, co
   HIPCHK(hipGetLastError());
   return 0;
 }
+// generic path (generic.hpp): what = RG_INIT / RG_SEARCH / RG_COMMIT
+template <class M>
+static int launch_rollout_g(ilqr_batch* h, const M& m, int what, const AlphaSet& al, double* cost_out, int mode, int write_cost) {
+  if (what == RG_SEARCH)
+    hipLaunchKernelGGL((k_rollout_g<M, RG_SEARCH>), dim3((h->B + kSearchTraj - 1) / kSearchTraj), dim3(64), 0, h->stream, h->v, m, al,
+                       cost_out, nullptr, mode, 0);
+  else if (what == RG_INIT)
+    hipLaunchKernelGGL((k_rollout_g<M, RG_INIT>), dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->v, m, al, cost_out, nullptr, 0, 1);
+  else
+    hipLaunchKernelGGL((k_rollout_g<M, RG_COMMIT>), dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->v, m, al, cost_out,
+                       h->commit_idx, 0, write_cost);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 static int launch_rollout(ilqr_batch* h, bool gains, bool cand, const AlphaSet& al, int n_alpha, double* cost_out, int mode) {
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_ROLLOUT, &ev)) return rc;
   int rc;
+  if (h->model == ILQR_MODEL_LQ) {
+    if (!gains)
+      rc = launch_rollout_g(h, h->lq, RG_INIT, al, cost_out, 0, 1);
+    else if (n_alpha == NALPHA)
+      rc = launch_rollout_g(h, h->lq, RG_SEARCH, al, cost_out, mode, 0);
+    else  // a single closed-loop rollout written in place (warm start): slot commit_idx of `al`
+      rc = launch_rollout_g(h, h->lq, RG_COMMIT, al, cost_out, 0, 1);
+    if (rc) return rc;
+    return timer_end(h, ILQR_STAGE_ROLLOUT, ev);
+  }
   switch (h->model) {
     case ILQR_MODEL_ACROBOT: rc = launch_rollout_t(h, h->acrobot, gains, cand, al, n_alpha, cost_out, mode); break;
     case ILQR_MODEL_DOUBLE_INTEGRATOR: rc = launch_rollout_t(h, h->dint, gains, cand, al, n_alpha, cost_out, mode); break;
@@ -248,7 +286,10 @@ static int launch_rollout(ilqr_batch* h, bool gains, bool cand, const AlphaSet& 
   return timer_end(h, ILQR_STAGE_ROLLOUT, ev);
 }
 
+static AlphaSet line_search_alphas();
 static int launch_commit(ilqr_batch* h) {
+  if (h->model == ILQR_MODEL_LQ)  // no stored candidates on the generic path: re-run the accepted rollout in place
+    return launch_rollout_g(h, h->lq, RG_COMMIT, line_search_alphas(), h->v.cost, 0, 0);
   dim3 grid((h->T + 1 + 15) / 16, h->ntiles), block(256);
   switch (h->model) {
     case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_commit<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, h->commit_idx); break;
@@ -271,10 +312,17 @@ static int flush_commit(ilqr_batch* h) {
 }
 
 static int launch_derivatives(ilqr_batch* h, int force) {
+  if (h->model == ILQR_MODEL_LQ)  // the generic sweep has no fused commit: rebuild the accepted rollout first
+    if (int rc = flush_commit(h)) return rc;
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_DERIVATIVES, &ev)) return rc;
   dim3 grid((h->T + 1 + 15) / 16, h->ntiles), block(256);
   const int* ci = h->commit_pending ? h->commit_idx : nullptr;
+  if (h->model == ILQR_MODEL_LQ) {
+    hipLaunchKernelGGL((k_derivatives_g<LqModel>), dim3(h->B * (h->T + 1)), dim3(64), 0, h->stream, h->v, h->lq, force);
+    HIPCHK(hipGetLastError());
+    return timer_end(h, ILQR_STAGE_DERIVATIVES, ev);
+  }
   switch (h->model) {
     case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_derivatives<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, force, ci); break;
     case ILQR_MODEL_DOUBLE_INTEGRATOR: hipLaunchKernelGGL((k_derivatives<DoubleIntegratorModel>), grid, block, 0, h->stream, h->v, h->dint, force, ci); break;
@@ -470,10 +518,13 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
       m.u_max[j] = d->u_max ? d->u_max[j] : 0.5;
     }
   } else if (d->model == ILQR_MODEL_HOST || d->model == ILQR_MODEL_LQ) {
-    // Host-evaluated models (and, for now, the synthetic LQ model): derivatives arrive through
-    // ilqr_set_derivatives, the device runs the backward pass (one wavefront per trajectory).
-    REQUIRE(d->nx <= WN && d->nu <= WM, "generic backward kernel: nx <= %d, nu <= %d", WN, WM);
-    REQUIRE(d->u_min && d->u_max, "host-model handles need u_min/u_max (Model::u_min/u_max, include/model.h:17)");
+    // Generic dimensions: trajectory-contiguous layout, one wavefront per trajectory in the backward
+    // pass.  Host-evaluated models receive their derivatives through ilqr_set_derivatives; the LQ
+    // model has a device twin (generic.hpp) and runs end to end.
+    REQUIRE(d->nx <= WN && d->nu <= WM, "generic kernels: nx <= %d, nu <= %d", WN, WM);
+    REQUIRE(d->u_min && d->u_max, "generic handles need u_min/u_max (Model::u_min/u_max, include/model.h:17)");
+    if (d->model == ILQR_MODEL_LQ)
+      REQUIRE(d->lq_A && d->lq_B && d->lq_Q && d->lq_R && d->lq_Qf, "ILQR_MODEL_LQ needs lq_A, lq_B, lq_Q, lq_R, lq_Qf");
     h->aos = true;
   } else {
     return fail(ILQR_ERR_UNSUPPORTED, "model id %d is not available in this build", d->model);
@@ -501,6 +552,35 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     v.cand_u = nullptr;
     v.cand_x = nullptr;
     v.cost_c = nullptr;
+    if (d->model == ILQR_MODEL_LQ) {
+      rc |= dev_alloc(h, &v.cost_c, (size_t)NALPHA * Bp);
+      // zero-padded copies of the model matrices at the kernels' maximum dimensions
+      double* pad = nullptr;
+      const size_t nA = GN * GN, nB = GN * GM, nR = GM * GM, tot = 3 * nA + nB + nR;
+      rc |= dev_alloc(h, &pad, tot);
+      if (!rc) {
+        std::vector<double> hp(tot, 0.0);
+        double *pA = hp.data(), *pB = pA + nA, *pQ = pB + nB, *pR = pQ + nA, *pQf = pR + nR;
+        for (size_t i = 0; i < nx; i++) {
+          for (size_t j = 0; j < nx; j++) {
+            pA[i * GN + j] = d->lq_A[i * nx + j];
+            pQ[i * GN + j] = d->lq_Q[i * nx + j];
+            pQf[i * GN + j] = d->lq_Qf[i * nx + j];
+          }
+          for (size_t j = 0; j < nu; j++) pB[i * GM + j] = d->lq_B[i * nu + j];
+        }
+        for (size_t i = 0; i < nu; i++)
+          for (size_t j = 0; j < nu; j++) pR[i * GM + j] = d->lq_R[i * nu + j];
+        if (hipMemcpy(pad, hp.data(), tot * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = 1;
+        h->lq.nx = (int)nx;
+        h->lq.nu = (int)nu;
+        h->lq.A = pad;
+        h->lq.Bm = pad + nA;
+        h->lq.Q = pad + nA + nB;
+        h->lq.R = pad + 2 * nA + nB;
+        h->lq.Qf = pad + 2 * nA + nB + nR;
+      }
+    }
     if (!rc) {
       if (hipMemcpyAsync(h->d_umin, d->u_min, nu * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = 1;
       if (hipMemcpyAsync(h->d_umax, d->u_max, nu * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = 1;
@@ -595,15 +675,15 @@ int ilqr_synchronize(ilqr_batch* h) {
 // ---- whole-solve entry points --------------------------------------------------------------
 int ilqr_init_traj(ilqr_batch* h, const double* x0, const double* u0, double* cost_out) {
   if (!h || !x0 || !u0) return fail(ILQR_ERR_INVALID, "null argument");
-  if (h->aos) return fail(ILQR_ERR_UNSUPPORTED, "host-evaluated model: rollouts and finite differences stay on the host; only the backward pass (ilqr_set_derivatives + ilqr_backward_pass/_step) runs on the device");
+  if (host_model(h)) return no_device_model();
   HIPCHK(hipSetDevice(h->device));
   if (int rc = upload(h, x0, h->v.x0, 1, h->nx)) return rc;
   if (int rc = upload(h, u0, h->v.us, h->T, h->nu)) return rc;  // us = u_0, ilqr_core.cpp:17
   // ilqr_core.cpp:23-48: zero derivative/gain arrays; statics lambda/dlambda as for a fresh process
-  const size_t nt = h->ntiles, T = h->T, T1 = h->T + 1;
-  HIPCHK(hipMemsetAsync(h->v.D, 0, nt * T1 * rec_of(h) * TW * sizeof(double), h->stream));
-  HIPCHK(hipMemsetAsync(h->v.kff, 0, nt * T * h->nu * TW * sizeof(double), h->stream));
-  HIPCHK(hipMemsetAsync(h->v.Kfb, 0, nt * T * h->nu * h->nx * TW * sizeof(double), h->stream));
+  const size_t T = h->T, T1 = h->T + 1;
+  HIPCHK(hipMemsetAsync(h->v.D, 0, dev_elems(h, T1, rec_of(h)) * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(h->v.kff, 0, dev_elems(h, T, h->nu) * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(h->v.Kfb, 0, dev_elems(h, T, h->nu * h->nx) * sizeof(double), h->stream));
   hipLaunchKernelGGL(k_reset_state, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
                      h->params.dlambda_init);
   HIPCHK(hipGetLastError());
@@ -617,7 +697,7 @@ int ilqr_init_traj(ilqr_batch* h, const double* x0, const double* u0, double* co
 
 int ilqr_iterate(ilqr_batch* h, int n_iters) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
-  if (h->aos) return fail(ILQR_ERR_UNSUPPORTED, "host-evaluated model: rollouts and finite differences stay on the host; only the backward pass (ilqr_set_derivatives + ilqr_backward_pass/_step) runs on the device");
+  if (host_model(h)) return no_device_model();
   if (!h->initialised) return fail(ILQR_ERR_STATE, "ilqr_iterate before ilqr_init_traj/ilqr_set_trajectory");
   HIPCHK(hipSetDevice(h->device));
   for (int it = 0; it < n_iters; it++) {
@@ -667,16 +747,21 @@ int ilqr_solve(ilqr_batch* h, const double* x0, const double* u0) {
 
 int ilqr_warm_start(ilqr_batch* h, const double* x0) {
   if (!h || !x0) return fail(ILQR_ERR_INVALID, "null argument");
-  if (h->aos) return fail(ILQR_ERR_UNSUPPORTED, "host-evaluated model: rollouts and finite differences stay on the host; only the backward pass (ilqr_set_derivatives + ilqr_backward_pass/_step) runs on the device");
+  if (host_model(h)) return no_device_model();
   if (!h->initialised) return fail(ILQR_ERR_STATE, "warm start needs a previous solve (assert us.size()>0, ilqr_core.cpp:66)");
   HIPCHK(hipSetDevice(h->device));
   if (int rc = upload(h, x0, h->v.x0, 1, h->nx)) return rc;
   // forward_pass(x_0, us) with the stored gains: u = us[t] + K[t](x - xs[t])  (alpha*k term = 0)
   AlphaSet al;
   for (int i = 0; i < NALPHA; i++) al.a[i] = 0.0;
-  if (int rc = launch_rollout(h, true, true, al, 1, h->v.cost, 0)) return rc;
-  HIPCHK(hipMemsetAsync(h->commit_idx, 0, (size_t)h->Bp * sizeof(int), h->stream));  // slot 0 for everyone
-  if (int rc = launch_commit(h)) return rc;
+  if (h->model == ILQR_MODEL_LQ) {  // generic path: the rollout itself overwrites xs/us (slot 0 of `al` for everyone)
+    HIPCHK(hipMemsetAsync(h->commit_idx, 0, (size_t)h->Bp * sizeof(int), h->stream));
+    if (int rc = launch_rollout(h, true, true, al, 1, h->v.cost, 0)) return rc;
+  } else {
+    if (int rc = launch_rollout(h, true, true, al, 1, h->v.cost, 0)) return rc;
+    HIPCHK(hipMemsetAsync(h->commit_idx, 0, (size_t)h->Bp * sizeof(int), h->stream));  // slot 0 for everyone
+    if (int rc = launch_commit(h)) return rc;
+  }
   HIPCHK(hipMemsetAsync(h->commit_idx, 0xFF, (size_t)h->Bp * sizeof(int), h->stream));
   // a new outer loop starts: status/iters/flgChange reset, lambda & dlambda persist (file statics)
   std::vector<double> lam(h->B), dlam(h->B);
@@ -692,7 +777,7 @@ int ilqr_warm_start(ilqr_batch* h, const double* x0) {
 // ---- stages --------------------------------------------------------------------------------
 int ilqr_compute_derivatives(ilqr_batch* h) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
-  if (h->aos) return fail(ILQR_ERR_UNSUPPORTED, "host-evaluated model: rollouts and finite differences stay on the host; only the backward pass (ilqr_set_derivatives + ilqr_backward_pass/_step) runs on the device");
+  if (host_model(h)) return no_device_model();
   HIPCHK(hipSetDevice(h->device));
   return launch_derivatives(h, 1);
 }
@@ -713,7 +798,7 @@ int ilqr_backward_step(ilqr_batch* h) {
 
 int ilqr_rollout_candidates(ilqr_batch* h, double* cost_out) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
-  if (h->aos) return fail(ILQR_ERR_UNSUPPORTED, "host-evaluated model: rollouts and finite differences stay on the host; only the backward pass (ilqr_set_derivatives + ilqr_backward_pass/_step) runs on the device");
+  if (host_model(h)) return no_device_model();
   HIPCHK(hipSetDevice(h->device));
   if (int rc = do_rollout_candidates(h, 0)) return rc;
   if (cost_out) {
@@ -728,7 +813,7 @@ int ilqr_rollout_candidates(ilqr_batch* h, double* cost_out) {
 
 int ilqr_line_search(ilqr_batch* h) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
-  if (h->aos) return fail(ILQR_ERR_UNSUPPORTED, "host-evaluated model: rollouts and finite differences stay on the host; only the backward pass (ilqr_set_derivatives + ilqr_backward_pass/_step) runs on the device");
+  if (host_model(h)) return no_device_model();
   HIPCHK(hipSetDevice(h->device));
   if (int rc = flush_commit(h)) return rc;
   if (int rc = do_rollout_candidates(h, 1)) return rc;
@@ -832,7 +917,7 @@ int ilqr_get_status(ilqr_batch* h, int* status, int* iters, int* alpha_idx) {
 }
 int ilqr_get_candidate(ilqr_batch* h, int a, double* xs, double* us) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
-  if (h->aos) return fail(ILQR_ERR_UNSUPPORTED, "host-evaluated model: rollouts and finite differences stay on the host; only the backward pass (ilqr_set_derivatives + ilqr_backward_pass/_step) runs on the device");
+  if (host_model(h)) return no_device_model();
   REQUIRE(a >= 0 && a < NALPHA, "alpha index %d out of range", a);
   HIPCHK(hipSetDevice(h->device));
   const size_t nx_el = (size_t)h->B * (h->T + 1) * h->nx, nu_el = (size_t)h->B * h->T * h->nu;
@@ -883,12 +968,12 @@ int ilqr_profile_read(ilqr_batch* h, double ms_out[ILQR_NUM_STAGES], int launche
 }
 const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
   switch (stage) {
-    case ILQR_STAGE_DERIVATIVES: return "k_derivatives";
+    case ILQR_STAGE_DERIVATIVES: return (h && h->aos) ? "k_derivatives_g" : "k_derivatives";
     case ILQR_STAGE_BACKWARD:
       if (h && h->aos) return "k_backward_w";
       if (h && use_fused_sweep(h)) return "k_sweep_backward";  // what ilqr_iterate launches
       return (h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t";
-    case ILQR_STAGE_ROLLOUT: return "k_rollout";
+    case ILQR_STAGE_ROLLOUT: return (h && h->aos) ? "k_rollout_g" : "k_rollout";
     case ILQR_STAGE_ACCEPT: return "k_accept";
     default: return "";
   }

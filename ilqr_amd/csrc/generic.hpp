@@ -1,0 +1,331 @@
+// generic.hpp -- the device-model path for state / control dimensions up to 32 / 16.
+//
+//   LqModel           device twin of the synthetic LQ model (BASELINE.json configs[4])
+//   k_rollout_g<M>    forward_pass (src/ilqr_core.cpp:305-337): one THREAD per rollout, the state
+//                     and control vectors lane-private in registers
+//   k_derivatives_g<M> the finite-difference sweep (src/derivatives.cpp, include/finite_diff.h):
+//                     one WAVEFRONT per knot, one LANE per evaluation point
+//
+// Everything here works on the trajectory-contiguous ("AoS") layout of the generic handles
+//     xs [b][T+1][nx]   us,kff [b][T][nu]   Kfb [b][T][nu*nx] (column-major nu x nx)
+//     D  [b][T+1][REC]  record order FX,FU,CX,CXX,CXU,CU,CUU (common.hpp)
+// that k_backward_w (backward_wave.hpp) consumes.  A device model has compile-time MAXIMUM
+// dimensions NX, NU (vectors are register arrays, every loop is unrolled, padding entries are
+// zero and stay zero) and runtime dimensions nx <= NX, nu <= NU which bound what is loaded,
+// perturbed and stored.
+#pragma once
+#include "kernels.hpp"  // AlphaSet, quad_bcast, integrate_dynamics
+
+namespace ilqr {
+
+constexpr int GN = 32, GM = 16;
+
+// Reads through the constant address space: the matrices of a model are the same for every lane
+// and are not written while a kernel runs, so their loads become scalar loads (s_load) and the
+// products take them as SGPR operands.
+typedef const __attribute__((address_space(4))) double cmem_d;
+
+// Synthetic LQ model: xdot = A x + B u, cost 0.5 (x'Qx + u'Ru), final cost 0.5 x'Qf x.  The
+// matrices are row-major and zero-padded to the maximum dimensions.  Sums run left to right
+// over the column index (the padding adds exact zeros at the end of every sum).
+struct LqModel {
+  static constexpr int NX = GN, NU = GM;
+  int nx, nu;
+  const double *A, *Bm, *Q, *R, *Qf;  // device: [GN][GN], [GN][GM], [GN][GN], [GM][GM], [GN][GN]
+
+  __device__ __forceinline__ void dynamics(const double* x, const double* u, double* dx) const {
+    cmem_d* a = (cmem_d*)A;
+    cmem_d* bm = (cmem_d*)Bm;
+#pragma unroll
+    for (int i = 0; i < GN; i++) {
+      double acc = 0;
+#pragma unroll
+      for (int j = 0; j < GN; j++) acc += a[i * GN + j] * x[j];
+#pragma unroll
+      for (int j = 0; j < GM; j++) acc += bm[i * GM + j] * u[j];
+      dx[i] = acc;
+    }
+  }
+  template <int N>
+  static __device__ __forceinline__ double quad(cmem_d* Mx, const double* vv) {
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      double r = 0;
+#pragma unroll
+      for (int j = 0; j < N; j++) r += Mx[i * N + j] * vv[j];
+      s += vv[i] * r;
+    }
+    return s;
+  }
+  __device__ __forceinline__ double cost(const double* x, const double* u) const {
+    return 0.5 * (quad<GN>((cmem_d*)Q, x) + quad<GM>((cmem_d*)R, u));
+  }
+  __device__ __forceinline__ double final_cost(const double* x) const { return 0.5 * quad<GN>((cmem_d*)Qf, x); }
+};
+
+// ------------------------------------------------------------------------------------------
+// forward rollout
+// ------------------------------------------------------------------------------------------
+//   RG_INIT    u_t = us[t]                                (init_traj: K empty, ilqr_core.cpp:316)
+//              one lane per trajectory; writes xs, us and the cost in place
+//   RG_SEARCH  u_t = us[t] + alpha k[t] + K[t](x_t - xs[t])  for the 11 alphas (:185-220)
+//              a wavefront = 5 trajectories x 11 alphas, so the rollouts of one trajectory
+//              fetch its nominal knots and gains together; only the cost leaves the kernel
+//   RG_COMMIT  the same rollout for the ONE alpha k_accept chose (commit_idx), written over the
+//              nominal xs/us in place (knot t is read before it is overwritten); one lane per
+//              trajectory.  write_cost: warm start (:65-76), where this rollout also defines cost.
+// No candidate trajectories are stored on this path: with nx + nu = 48 doubles per knot they
+// would be 11 x 77 KB per trajectory and iteration; re-running the accepted rollout costs 1/11 of
+// the search.
+enum { RG_INIT = 0, RG_SEARCH = 1, RG_COMMIT = 2 };
+constexpr int kSearchTraj = 64 / NALPHA;  // trajectories per wavefront in RG_SEARCH (5)
+
+template <class M, int MODE>
+__global__ __launch_bounds__(64) void k_rollout_g(BatchView v, M model, AlphaSet alphas, double* __restrict__ cost_out,
+                                                  const int* __restrict__ commit_idx, int mode, int write_cost) {
+  constexpr int NX = M::NX, NU = M::NU;
+  const int nx = model.nx, nu = model.nu, T = v.T;
+  const int lane = threadIdx.x;
+  int b, a = 0;
+  if (MODE == RG_SEARCH) {
+    const int tl = lane / NALPHA;
+    a = lane - tl * NALPHA;
+    b = blockIdx.x * kSearchTraj + tl;
+    if (tl >= kSearchTraj) return;
+  } else {
+    b = blockIdx.x * 64 + lane;
+  }
+  if (b >= v.B) return;
+  if (MODE == RG_SEARCH && mode == 1 && !(v.status[b] == 0 && v.backpass_done[b])) return;
+  if (MODE == RG_COMMIT) {
+    a = commit_idx[b];
+    if (a < 0) return;
+  }
+  double alpha = 0;
+#pragma unroll
+  for (int q = 0; q < NALPHA; q++)
+    if (a == q) alpha = alphas.a[q];
+  const double dt = v.dt;
+
+  double x[NX];
+#pragma unroll
+  for (int i = 0; i < NX; i++) x[i] = (i < nx) ? v.x0[(size_t)b * nx + i] : 0.0;
+  double total = 0;
+  double* xsb = v.xs + (size_t)b * (T + 1) * nx;
+  double* usb = v.us + (size_t)b * T * nu;
+  const double* kb = v.kff + (size_t)b * T * nu;
+  const double* Kb = v.Kfb + (size_t)b * T * nu * nx;
+  for (int t = 0; t < T; t++) {
+    double u[NU];
+#pragma unroll
+    for (int j = 0; j < NU; j++) u[j] = (j < nu) ? usb[(size_t)t * nu + j] : 0.0;
+    if (MODE != RG_INIT) {
+      double d[NX];
+#pragma unroll
+      for (int i = 0; i < NX; i++) d[i] = (i < nx) ? x[i] - xsb[(size_t)t * nx + i] : 0.0;
+      const double* Kt = Kb + (size_t)t * nu * nx;
+#pragma unroll
+      for (int j = 0; j < NU; j++) {
+        if (j < nu) {
+          u[j] += kb[(size_t)t * nu + j] * alpha;  // :190
+          double acc = 0;
+#pragma unroll
+          for (int i = 0; i < NX; i++)
+            if (i < nx) acc += Kt[j + nu * i] * d[i];
+          u[j] += acc;  // :316
+        }
+      }
+    }
+    if (MODE != RG_SEARCH) {  // :323 (no clamping)
+#pragma unroll
+      for (int i = 0; i < NX; i++)
+        if (i < nx) xsb[(size_t)t * nx + i] = x[i];
+#pragma unroll
+      for (int j = 0; j < NU; j++)
+        if (j < nu) usb[(size_t)t * nu + j] = u[j];
+    }
+    total += model.cost(x, u);  // :324
+    double x1[NX];
+    integrate_dynamics(model, x, u, dt, x1);  // :325
+#pragma unroll
+    for (int i = 0; i < NX; i++) x[i] = x1[i];
+  }
+  if (MODE != RG_SEARCH) {
+#pragma unroll
+    for (int i = 0; i < NX; i++)
+      if (i < nx) xsb[(size_t)T * nx + i] = x[i];
+  }
+  total += model.final_cost(x);  // :335
+  if (MODE == RG_SEARCH)
+    cost_out[(size_t)a * v.Bp + b] = total;
+  else if (MODE == RG_INIT || write_cost)
+    cost_out[b] = total;
+}
+
+// ------------------------------------------------------------------------------------------
+// finite-difference derivatives
+// ------------------------------------------------------------------------------------------
+// One wavefront per knot (b, t); every lane evaluates the model at ONE perturbed point, then
+// neighbouring lanes combine their values (DPP inside a quad) exactly as the reference's
+// expressions do:
+//   fx, fu   column i = (F(+eps e_i) - F(-eps e_i)) / 2eps,  F = Euler map       finite_diff.h:35-47
+//   cx, cu   (f(+) - f(-)) / 2eps                                                  finite_diff.h:22-33
+//   cxx, cuu (f(pp) - f(mp) - f(pm) + f(mm)) / 4eps^2, j >= i, mirrored; the perturbations are
+//            applied one after the other (the diagonal is x + eps + eps, x + eps - eps, ...)   :67-86
+//   cxu      (c(px,pu) - c(mx,pu) - c(px,mu) + c(mx,mu)) / 4eps^2               derivatives.cpp:114-144
+// including the t = T special cases (fx[T] = fu[T] = 0, cx/cxx from final_cost, cu[T] = 0, cuu[T]
+// from cost(x_T, 0), the cxu[T] formula the reference itself marks wrong).
+template <class M>
+__global__ __launch_bounds__(64) void k_derivatives_g(BatchView v, M model, int force) {
+  constexpr int NX = M::NX, NU = M::NU;
+  const int nx = model.nx, nu = model.nu, T = v.T;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x / (T + 1), t = blockIdx.x - b * (T + 1);
+  if (blockIdx.x == 0 && lane == 0) *v.n_running = 0;  // k_accept of this iteration recounts
+  if (!(force || (v.status[b] == 0 && v.flg_change[b]))) return;
+  const int oFX = 0, oFU = oFX + nx * nx, oCX = oFU + nx * nu, oCXX = oCX + nx, oCXU = oCXX + nx * nx, oCU = oCXU + nx * nu,
+            oCUU = oCU + nu, REC = oCUU + nu * nu;
+  double* D = v.D + ((size_t)b * (T + 1) + t) * REC;
+  const bool last = (t == T);
+
+  double x[NX], u[NU];  // the knot (same in every lane)
+#pragma unroll
+  for (int i = 0; i < NX; i++) x[i] = (i < nx) ? v.xs[((size_t)b * (T + 1) + t) * nx + i] : 0.0;
+#pragma unroll
+  for (int j = 0; j < NU; j++) u[j] = (j < nu && !last) ? v.us[((size_t)b * T + t) * nu + j] : 0.0;  // derivatives.cpp:35-38
+
+  // point = knot, then (target 1, index i1) += d1, then (target 2, index i2) += d2; index -1 = none
+  auto perturbed = [&](bool x1, int i1, double d1, bool x2, int i2, double d2, double* px, double* pu)
+                       __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < NX; c++) {
+      double val = x[c];
+      val = (x1 && c == i1) ? val + d1 : val;
+      val = (x2 && c == i2) ? val + d2 : val;
+      px[c] = val;
+    }
+#pragma unroll
+    for (int c = 0; c < NU; c++) {
+      double val = u[c];
+      val = (!x1 && c == i1) ? val + d1 : val;
+      val = (!x2 && c == i2) ? val + d2 : val;
+      pu[c] = val;
+    }
+  };
+
+  // ---- fx, fu ----
+  if (!last) {
+    const int E = 2 * (nx + nu);
+    for (int base = 0; base < E; base += 64) {
+      const int e = base + lane;
+      const bool valid = e < E;
+      const int var = e >> 1;
+      const double d = (e & 1) ? -kEps : kEps;
+      double px[NX], pu[NU], F[NX];
+      perturbed(var < nx, valid ? (var < nx ? var : var - nx) : -1, d, true, -1, 0.0, px, pu);
+      integrate_dynamics(model, px, pu, v.dt, F);
+      double* col = (var < nx) ? D + oFX + nx * var : D + oFU + nx * (var - nx);
+#pragma unroll
+      for (int r = 0; r < NX; r++) {
+        const double fp = quad_bcast<0>(F[r]), fm = quad_bcast<1>(F[r]);      // lanes 4q, 4q+1
+        const double fp2 = quad_bcast<2>(F[r]), fm2 = quad_bcast<3>(F[r]);    // lanes 4q+2, 4q+3
+        const double val = ((lane & 2) ? (fp2 - fm2) : (fp - fm)) / (2 * kEps);
+        if (valid && !(e & 1) && r < nx) col[r] = val;
+      }
+    }
+  } else {
+    for (int e = lane; e < nx * nx + nx * nu; e += 64) D[oFX + e] = 0.0;  // fx[T], fu[T] stay zero
+    for (int e = lane; e < nu; e += 64) D[oCU + e] = 0.0;                 // :50-51
+  }
+
+  // ---- scalar-valued evaluations: one list, groups aligned to quads ----
+  const int n_cx = 2 * nx, n_cu = last ? 0 : 2 * nu;
+  const int n_cxx = 2 * nx * (nx + 1), n_cuu = 2 * nu * (nu + 1), n_cxu = 4 * nx * nu;
+  const int g_cu = (n_cx + 3) & ~3, g_cxx = g_cu + ((n_cu + 3) & ~3), g_cuu = g_cxx + n_cxx, g_cxu = g_cuu + n_cuu,
+            total = g_cxu + n_cxu;
+  for (int base = 0; base < total; base += 64) {
+    const int e = base + lane;
+    // decode: category, indices, perturbations
+    int cat = -1, i1 = -1, i2 = -1;
+    bool t1x = true, t2x = true;
+    double d1 = 0, d2 = 0;
+    if (e < n_cx) {
+      cat = 0;
+      i1 = e >> 1;
+      d1 = (e & 1) ? -kEps : kEps;
+    } else if (e >= g_cu && e < g_cu + n_cu) {
+      cat = 1;
+      t1x = false;
+      i1 = (e - g_cu) >> 1;
+      d1 = (e & 1) ? -kEps : kEps;
+    } else if (e >= g_cxx && e < total) {
+      int n, p;
+      if (e < g_cuu) {
+        cat = 2;
+        n = nx;
+        p = (e - g_cxx) >> 2;
+      } else if (e < g_cxu) {
+        cat = 3;
+        n = nu;
+        p = (e - g_cuu) >> 2;
+        t1x = t2x = false;
+      } else {
+        cat = 4;
+        n = 0;
+        p = (e - g_cxu) >> 2;
+        t2x = false;
+      }
+      if (cat == 4) {  // (i, j) row-major over nx x nu, as the loops of derivatives.cpp:117-118
+        i1 = p / nu;
+        i2 = p - i1 * nu;
+      } else {  // upper triangle, row by row (finite_diff.h:70-71)
+        int i = 0;
+        while (p >= n - i) {
+          p -= n - i;
+          i++;
+        }
+        i1 = i;
+        i2 = i + p;
+      }
+      const int combo = e & 3;  // 0: pp  1: mp  2: pm  3: mm   (first perturbation's sign changes fastest)
+      d1 = (combo & 1) ? -kEps : kEps;
+      d2 = (combo & 2) ? -kEps : kEps;
+    }
+    double px[NX], pu[NU];
+    perturbed(t1x, i1, d1, t2x, i2, d2, px, pu);
+    // which function: final_cost for the x-derivatives at t = T (:49, :92, :140); cuu[T] is cost(x_T, .)
+    double f = 0;
+    if (cat >= 0) {
+      if (last && cat != 3) {
+        double pz[NX];
+#pragma unroll
+        for (int c = 0; c < NX; c++) pz[c] = px[c];
+        f = model.final_cost(pz);
+      } else {
+        f = model.cost(px, pu);
+      }
+    }
+    const double f0 = quad_bcast<0>(f), f1 = quad_bcast<1>(f), f2 = quad_bcast<2>(f), f3 = quad_bcast<3>(f);
+    if (cat == 0 || cat == 1) {
+      if (!(e & 1)) {
+        const double g = (((lane & 2) ? f2 : f0) - ((lane & 2) ? f3 : f1)) / (2 * kEps);
+        D[(cat == 0 ? oCX : oCU) + i1] = g;
+      }
+    } else if (cat >= 2 && (e & 3) == 0) {
+      // (at t = T the cxu lanes hold final_cost(px), (mx), (px), (mx): the expression of :140)
+      const double val = (f0 - f1 - f2 + f3) / (4 * kEps * kEps);
+      if (cat == 2) {
+        D[oCXX + i1 + nx * i2] = val;
+        D[oCXX + i2 + nx * i1] = val;
+      } else if (cat == 3) {
+        D[oCUU + i1 + nu * i2] = val;
+        D[oCUU + i2 + nu * i1] = val;
+      } else {
+        D[oCXU + i1 + nx * i2] = val;
+      }
+    }
+  }
+}
+
+}  // namespace ilqr

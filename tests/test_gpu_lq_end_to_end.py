@@ -1,0 +1,150 @@
+"""The synthetic LQ model (BASELINE.json configs[4]: x+ = x + (Ax + Bu) dt, quadratic costs,
+n = 32, m = 16 at full size) end to end on the device: its device twin runs the rollout, the
+finite-difference sweep, the generic backward pass and the 11-alpha line search (generic.hpp,
+backward_wave.hpp), each stage compared with the oracle on the same inputs through the C ABI.
+Sizes are the ones the oracle finishes in seconds (the FD Hessian of a 32-dimensional quadratic is
+6 Mflop per knot); full dimensions n = 32 / m = 16 are covered at a small batch."""
+import numpy as np
+import pytest
+
+from tests.util import TOL, mat, relerr, relerr_abs
+from tests.test_gpu_parity import _is_clamp_knife_edge, _per_traj_err
+
+pytestmark = pytest.mark.gpu
+DT = 0.02
+
+
+def lq_mats(n, m, seed=7):
+    # SURVEY.md 8(d) cfg 5: A = -I + 0.1 N(0,1)/sqrt(n), B = N(0,1)/sqrt(n), Q = I, R = 0.1 I
+    rng = np.random.default_rng(seed)
+    A = -np.eye(n) + 0.1 * rng.normal(size=(n, n)) / np.sqrt(n)
+    Bm = rng.normal(size=(n, m)) / np.sqrt(n)
+    return A, Bm, np.eye(n), 0.1 * np.eye(m), np.eye(n)
+
+
+def dense_mats(n, m, seed=11):
+    """Non-diagonal symmetric weights: exercises every entry of the cost Hessians."""
+    rng = np.random.default_rng(seed)
+    A = -np.eye(n) + 0.3 * rng.normal(size=(n, n)) / np.sqrt(n)
+    Bm = rng.normal(size=(n, m)) / np.sqrt(n)
+
+    def spd(k, s):
+        W = rng.normal(size=(k, k)) / np.sqrt(k)
+        return s * (np.eye(k) + 0.5 * (W + W.T) * 0.5)
+    return A, Bm, spd(n, 1.0), spd(m, 0.2), spd(n, 3.0)
+
+
+def make(oracle, mats, B, T, lim=1.0, flags=0):
+    from ilqr_amd import BatchILQR
+    n, m = mats[1].shape
+    om = oracle.Model("lq", lq=mats, u_lim=lim)
+    g = BatchILQR("lq", B, T, DT, u_min=-lim, u_max=lim, lq=mats, flags=flags)
+    assert (g.nx, g.nu) == (n, m)
+    return om, g
+
+
+@pytest.mark.parametrize("n,m,B,T,dense", [(32, 16, 6, 12, False), (32, 16, 4, 8, True), (6, 3, 40, 25, True), (5, 2, 70, 9, True)])
+def test_lq_stages_match_oracle(oracle, n, m, B, T, dense):
+    mats = dense_mats(n, m) if dense else lq_mats(n, m)
+    om, g = make(oracle, mats, B, T)
+    rng = np.random.default_rng(5)
+    x0 = rng.uniform(-1, 1, (B, n))
+    u0 = rng.normal(size=(B, T, m)) * 0.3
+    # init_traj: open-loop rollout
+    c0 = g.init_traj(x0, u0)
+    xs_o, us_o, c_o = oracle.batch_rollout(om, x0, u0, DT)
+    xs, us = g.trajectory()
+    assert relerr(xs, xs_o) < 1e-12 and np.array_equal(us, us_o)
+    assert np.max(np.abs(c0 - c_o) / np.abs(c_o)) < 1e-12
+    # finite-difference sweep on the oracle's trajectory (teacher forcing)
+    g.set_trajectory(x0=x0, xs=xs_o, us=us_o, cost=c_o)
+    g.compute_derivatives()
+    d = g.derivatives()
+    do = oracle.batch_derivatives(om, xs_o, us_o, DT)
+    for name in ("fx", "fu", "cx", "cu"):
+        ref = do[name] if name in ("cx", "cu") else mat(do[name])
+        assert relerr(d[name], ref) < TOL, name
+    # second differences of a quadratic: exact value + rounding noise ~ 1e-16 f / eps^2
+    for name in ("cxx", "cuu", "cxu"):
+        ref = mat(do[name])
+        assert relerr_abs(d[name][:, :T], ref[:, :T], 1e-2) < TOL, name
+    assert relerr_abs(d["cxx"][:, T], mat(do["cxx"])[:, T], 1e-2) < TOL
+    assert np.all(d["fx"][:, T] == 0) and np.all(d["fu"][:, T] == 0) and np.all(d["cu"][:, T] == 0)
+    # backward pass from the oracle's derivatives
+    g.set_derivatives(**{k: (do[k] if k in ("cx", "cu") else mat(do[k])) for k in do})
+    k_prev = rng.normal(size=(B, T, m)) * 0.1
+    g.set_gains(k=k_prev, K=np.zeros((B, T, m, n)))
+    g.set_lambda(1.0, 1.0)
+    div = g.backward_pass()
+    ro = oracle.batch_backward(om, us_o, do, k_prev=k_prev, lam=1.0)
+    k, K = g.gains()
+    Ko = mat(ro["K"])
+    err = np.maximum(_per_traj_err(k, ro["k"]), _per_traj_err(K, Ko))
+    lo, hi = om.u_min[None, None, :] - us_o, om.u_max[None, None, :] - us_o
+    bad = np.flatnonzero((err >= TOL) | (div != ro["diverge"]))
+    for b in bad:
+        assert _is_clamp_knife_edge(k[b], K[b], ro["k"][b], Ko[b], lo[b], hi[b]), (b, err[b])
+    assert len(bad) <= max(1, B // 8)
+    # the 11 closed-loop rollouts of the line search, with the oracle's gains
+    g.set_gains(k=ro["k"], K=Ko)
+    costs = g.rollout_candidates()
+    from oracle.oracle import ALPHAS
+    for a in (0, 4, 10):
+        xa, ua, ca = oracle_closed_loop(oracle, om, x0, xs_o, us_o, ro["k"], Ko, ALPHAS[a])
+        fin = np.isfinite(ca)
+        assert np.max(np.abs(costs[fin, a] - ca[fin]) / np.abs(ca[fin])) < 1e-9, a
+    g.close()
+
+
+def oracle_closed_loop(oracle, om, x0, xs_nom, us_nom, k, K, alpha):
+    """forward_pass(x0, us + alpha k) with feedback K around xs_nom (ilqr_core.cpp:188-190, 305-337)."""
+    return oracle.batch_rollout(om, x0, us_nom + alpha * k, DT, xs_nom=xs_nom, K=K)
+
+
+@pytest.mark.parametrize("n,m,B,T", [(6, 3, 24, 30), (32, 16, 3, 10)])
+def test_lq_iterations_match_oracle(oracle, n, m, B, T):
+    """A few whole iterations (derivatives -> backward -> search -> accept -> commit), fixed work
+    on both sides.  The model is linear, so per-trajectory agreement holds across iterations."""
+    from ilqr_amd import capi
+    mats = dense_mats(n, m)
+    om, g = make(oracle, mats, B, T, flags=capi.FLAG_FIXED_WORK)
+    rng = np.random.default_rng(9)
+    x0 = rng.uniform(-1, 1, (B, n))
+    u0 = np.zeros((B, T, m))
+    iters = 3
+    g.init_traj(x0, u0)
+    g.iterate(iters)
+    ro = oracle.batch_solve(om, x0, u0, DT, max_iters=iters, fixed_work=True)
+    cost = g.cost()
+    xs, us = g.trajectory()
+    rel = np.abs(cost - ro["cost"]) / np.abs(ro["cost"])
+    assert (rel < TOL).mean() >= 0.9 and rel.max() < 1e-3, rel
+    ok = rel < TOL
+    assert relerr(xs[ok], ro["xs"][ok]) < 1e-5 and relerr_abs(us[ok], ro["us"][ok], 1e-3) < 1e-5
+    st, it, al = g.status()
+    assert np.all(it == iters)
+    g.close()
+
+
+def test_lq_full_solve_and_warm_start(oracle):
+    n, m, B, T = 6, 3, 16, 30
+    mats = dense_mats(n, m)
+    om, g = make(oracle, mats, B, T)
+    rng = np.random.default_rng(2)
+    x0 = rng.uniform(-1, 1, (B, n))
+    u0 = np.zeros((B, T, m))
+    c0 = g.init_traj(x0, u0)
+    g.generate_trajectory()
+    st, it, al = g.status()
+    assert g.count_running() == 0 and np.all(st > 0)
+    ro = oracle.batch_solve(om, x0, u0, DT)
+    cost = g.cost()
+    assert np.all(cost <= c0 * (1 + 1e-12))
+    rel = np.abs(cost - ro["cost"]) / np.abs(ro["cost"])
+    assert (rel < 1e-6).mean() >= 0.75 and rel.max() < 1e-2, rel  # absolute stopping tests: ties stop an iteration apart
+    # warm start from perturbed initial states keeps working (ilqr_core.cpp:65-76)
+    import ctypes as C
+    x1 = np.ascontiguousarray(x0 * 1.01)
+    assert g.lib.ilqr_warm_start(g.h, x1.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    assert g.count_running() == 0 and np.all(np.isfinite(g.cost()))
+    g.close()
