@@ -49,6 +49,8 @@ SYMBOLS = {
     "ilqr_backward_step": (C.c_int, [_H]),
     "ilqr_rollout_candidates": (C.c_int, [_H, _dp]),
     "ilqr_line_search": (C.c_int, [_H]),
+    "ilqr_accept_candidates": (C.c_int, [_H, _dp, _ip]),
+    "ilqr_reset_state": (C.c_int, [_H, C.c_int]),
     "ilqr_set_trajectory": (C.c_int, [_H, _dp, _dp, _dp, _dp]),
     "ilqr_set_gains": (C.c_int, [_H, _dp, _dp]),
     "ilqr_set_derivatives": (C.c_int, [_H] + [_dp] * 7),

@@ -551,9 +551,8 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     rc |= dev_alloc(h, &h->d_umax, nu);
     v.cand_u = nullptr;
     v.cand_x = nullptr;
-    v.cost_c = nullptr;
+    rc |= dev_alloc(h, &v.cost_c, (size_t)NALPHA * Bp);  // the 11 candidate costs (device or caller-evaluated)
     if (d->model == ILQR_MODEL_LQ) {
-      rc |= dev_alloc(h, &v.cost_c, (size_t)NALPHA * Bp);
       // zero-padded copies of the model matrices at the kernels' maximum dimensions
       double* pad = nullptr;
       const size_t nA = GN * GN, nB = GN * GM, nR = GM * GM, tot = 3 * nA + nB + nR;
@@ -819,6 +818,52 @@ int ilqr_line_search(ilqr_batch* h) {
   if (int rc = do_rollout_candidates(h, 1)) return rc;
   if (int rc = launch_accept(h)) return rc;
   return flush_commit(h);
+}
+
+int ilqr_accept_candidates(ilqr_batch* h, const double* cost_c, int* accepted) {
+  if (!h || !cost_c || !accepted) return fail(ILQR_ERR_INVALID, "null argument");
+  if (!h->v.cost_c) return fail(ILQR_ERR_UNSUPPORTED, "this handle has no candidate-cost buffer");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = flush_commit(h)) return rc;
+  std::vector<double> tmp((size_t)NALPHA * h->Bp, 0.0);
+  for (int b = 0; b < h->B; b++)
+    for (int a = 0; a < NALPHA; a++) tmp[(size_t)a * h->Bp + b] = cost_c[(size_t)b * NALPHA + a];
+  HIPCHK(hipMemcpyAsync(h->v.cost_c, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemsetAsync(h->v.n_running, 0, sizeof(int), h->stream));  // (the device sweeps do this for k_accept)
+  if (int rc = launch_accept(h)) return rc;
+  std::vector<int> ci(h->Bp);
+  HIPCHK(hipMemcpyAsync(ci.data(), h->commit_idx, (size_t)h->Bp * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemsetAsync(h->commit_idx, 0xFF, (size_t)h->Bp * sizeof(int), h->stream));  // the caller commits
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->commit_pending = false;
+  for (int b = 0; b < h->B; b++) accepted[b] = ci[b];
+  return 0;
+}
+
+int ilqr_reset_state(ilqr_batch* h, int warm) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = flush_commit(h)) return rc;
+  std::vector<double> lam, dlam;
+  if (warm) {
+    lam.resize(h->B);
+    dlam.resize(h->B);
+    if (int rc = scalars_to_host(h, h->v.lambda, lam.data())) return rc;
+    if (int rc = scalars_to_host(h, h->v.dlambda, dlam.data())) return rc;
+  } else {
+    const size_t T = h->T, T1 = h->T + 1;
+    HIPCHK(hipMemsetAsync(h->v.D, 0, dev_elems(h, T1, rec_of(h)) * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->v.kff, 0, dev_elems(h, T, h->nu) * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->v.Kfb, 0, dev_elems(h, T, h->nu * h->nx) * sizeof(double), h->stream));
+  }
+  hipLaunchKernelGGL(k_reset_state, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
+                     h->params.dlambda_init);
+  HIPCHK(hipGetLastError());
+  if (warm) {
+    if (int rc = scalars_to_dev(h, lam.data(), h->v.lambda)) return rc;
+    if (int rc = scalars_to_dev(h, dlam.data(), h->v.dlambda)) return rc;
+  }
+  return 0;
 }
 
 // ---- state exchange --------------------------------------------------------------------------

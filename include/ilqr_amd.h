@@ -52,15 +52,16 @@ enum ilqr_status_code {
 
 /* Device models: compile-time twins of the reference's Model subclasses (include/model.h:6-21).
  * A Model whose dynamics/cost exist only as host virtuals uses ILQR_MODEL_HOST: its rollouts and
- * finite differences stay on the host (C++ facade) and only the backward pass runs here. */
+ * finite differences stay with the caller (the C++ facade does it), the rest runs here. */
 enum ilqr_model_id {
   ILQR_MODEL_ACROBOT = 0,           /* include/acrobot.h            nx=4 nu=1 */
   ILQR_MODEL_DOUBLE_INTEGRATOR = 1, /* include/double_integrator.h  nx=4 nu=2 */
-  ILQR_MODEL_LQ = 2,                /* synthetic LQ (BASELINE.json configs[4]), nx<=32 nu<=16; this build: backward pass only, like HOST */
-  ILQR_MODEL_HOST = 3               /* host-evaluated model, nx<=32 nu<=16: derivatives supplied through
-                                       ilqr_set_derivatives, ilqr_backward_pass/_step run on the device
-                                       (one wavefront per trajectory); rollout / FD entry points return
-                                       ILQR_ERR_UNSUPPORTED */
+  ILQR_MODEL_LQ = 2,                /* synthetic LQ (BASELINE.json configs[4]): xdot = A x + B u, cost .5(x'Qx + u'Ru),
+                                       final .5 x'Qf x, nx<=32 nu<=16; device twin, runs end to end (lq_* of the desc) */
+  ILQR_MODEL_HOST = 3               /* a Model that exists only as host code, nx<=32 nu<=16: the caller evaluates its
+                                       rollouts and finite differences (ilqr_set_trajectory, ilqr_set_derivatives,
+                                       ilqr_accept_candidates), the backward pass / box-QPs / accept logic run on the
+                                       device; rollout and finite-difference entry points return ILQR_ERR_UNSUPPORTED */
 };
 
 /* where a trajectory's outer loop stands (src/ilqr_core.cpp:103-288) */
@@ -156,6 +157,22 @@ int ilqr_rollout_candidates(ilqr_batch* h, double* cost_out);
 /* STEP 3 + STEP 4, src/ilqr_core.cpp:175-282: candidates, first-accept selection in the
  * reference's serial order, lambda update, termination tests, commit of the accepted one. */
 int ilqr_line_search(ilqr_batch* h);
+/* Host-evaluated models (ILQR_MODEL_HOST): the caller rolled the 11 candidates out itself
+ * (forward_pass needs Model::dynamics/cost, host virtuals) and hands over their costs
+ * cost_c [B][11]; the device applies STEP 3/4 of src/ilqr_core.cpp:184-282 to them -- first
+ * accepted alpha in the reference's serial order, cost_s, lambda schedule, termination tests,
+ * iteration count -- and reports the accepted alpha index per trajectory (accepted [B], -1 =
+ * none).  The caller then stores the accepted rollout with ilqr_set_trajectory. */
+int ilqr_accept_candidates(ilqr_batch* h, const double* cost_c, int* accepted);
+/* For callers that produce the first rollout themselves (host-evaluated models) and pass it in
+ * with ilqr_set_trajectory.
+ *   warm = 0: the non-rollout part of iLQR::init_traj (src/ilqr_core.cpp:23-48 and the statics of
+ *             include/ilqr.h:17-18): zero the derivative and gain arrays, lambda = dlambda =
+ *             initial values, every trajectory running with zero iterations.
+ *   warm = 1: a new outer loop on the stored solution (warm start, src/ilqr_core.cpp:65-76):
+ *             status, iteration count and flgChange restart; lambda, dlambda, gains and
+ *             derivatives persist. */
+int ilqr_reset_state(ilqr_batch* h, int warm);
 
 /* ---- state exchange (canonical host layouts, see top) -------------------------------------- */
 int ilqr_set_trajectory(ilqr_batch* h, const double* x0, const double* xs, const double* us, const double* cost);

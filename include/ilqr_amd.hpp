@@ -9,9 +9,13 @@
 // Header-only; link with -lilqr_amd.  Vector/matrix types are Eigen's when <Eigen/Core> is on the
 // include path (the reference's users have it), otherwise the minimal dense types below.
 //
-// A Model subclass runs on the GPU only through a device twin: the subclass says which
-// one by overriding device_model_id().  The shipped Acrobot / DoubleIntegrator do; a host-only
-// Model makes the iLQR constructor throw (no silent CPU path).
+// A Model subclass runs inside the HIP rollout / finite-difference kernels only through a device
+// twin: the subclass says which one by overriding device_model_id(), as the shipped
+// Acrobot / DoubleIntegrator / LinearQuadratic do.  A Model that exists only as host virtuals
+// (device_model_id() == ILQR_MODEL_HOST, the default: a user's subclass compiled unchanged) is
+// evaluated where it lives -- its rollouts and finite differences call those virtuals on the host --
+// while the backward pass, its box-QPs and the accept / lambda / termination logic run on the
+// device (nx <= 32, nu <= 16).  Nothing here works without a GPU: ilqr_create fails loudly.
 #ifndef ILQR_AMD_HPP_
 #define ILQR_AMD_HPP_
 
@@ -107,6 +111,8 @@ class Model {
   virtual int device_model_id() const { return ILQR_MODEL_HOST; }
   // Model-specific parameter block handed to the device twin (the goal for DoubleIntegrator).
   virtual const double* device_goal() const { return nullptr; }
+  // Everything else a device twin needs in the handle descriptor (the LQ matrices).
+  virtual void fill_device_desc(ilqr_desc& d) const { d.goal = device_goal(); }
 };
 
 // include/acrobot.h (host evaluation; the kernels use ilqr::AcrobotModel)
@@ -188,6 +194,59 @@ class DoubleIntegrator : public Model {
   double goal_[4];
 };
 
+// The synthetic LQ model of BASELINE.json configs[4] (no counterpart in the reference):
+// xdot = A x + B u, cost 0.5 (x'Qx + u'Ru), final cost 0.5 x'Qf x; matrices row-major.
+class LinearQuadratic : public Model {
+ public:
+  LinearQuadratic(int n, int m, const std::vector<double>& A, const std::vector<double>& B, const std::vector<double>& Q,
+                  const std::vector<double>& R, const std::vector<double>& Qf, double u_lo, double u_hi)
+      : A_(A), B_(B), Q_(Q), R_(R), Qf_(Qf) {
+    if (A.size() != (size_t)n * n || B.size() != (size_t)n * m || Q.size() != (size_t)n * n || R.size() != (size_t)m * m ||
+        Qf.size() != (size_t)n * n)
+      throw std::invalid_argument("LinearQuadratic: A [n][n], B [n][m], Q [n][n], R [m][m], Qf [n][n]");
+    x_dims = n;
+    u_dims = m;
+    u_min = VectorXd(m);
+    u_max = VectorXd(m);
+    for (int j = 0; j < m; j++) {
+      u_min(j) = u_lo;
+      u_max(j) = u_hi;
+    }
+  }
+  VectorXd dynamics(const VectorXd& x, const VectorXd& u) override {
+    VectorXd dx(x_dims);
+    for (int i = 0; i < x_dims; i++) {
+      double a = 0;
+      for (int j = 0; j < x_dims; j++) a += A_[(size_t)i * x_dims + j] * x(j);
+      for (int j = 0; j < u_dims; j++) a += B_[(size_t)i * u_dims + j] * u(j);
+      dx(i) = a;
+    }
+    return dx;
+  }
+  double cost(const VectorXd& x, const VectorXd& u) override { return 0.5 * (quad(x_dims, Q_, x) + quad(u_dims, R_, u)); }
+  double final_cost(const VectorXd& x) override { return 0.5 * quad(x_dims, Qf_, x); }
+  int device_model_id() const override { return ILQR_MODEL_LQ; }
+  void fill_device_desc(ilqr_desc& d) const override {
+    d.lq_A = A_.data();
+    d.lq_B = B_.data();
+    d.lq_Q = Q_.data();
+    d.lq_R = R_.data();
+    d.lq_Qf = Qf_.data();
+  }
+
+ private:
+  static double quad(int n, const std::vector<double>& M, const VectorXd& v) {
+    double s = 0;
+    for (int i = 0; i < n; i++) {
+      double r = 0;
+      for (int j = 0; j < n; j++) r += M[(size_t)i * n + j] * v(j);
+      s += v(i) * r;
+    }
+    return s;
+  }
+  std::vector<double> A_, B_, Q_, R_, Qf_;
+};
+
 inline void check(int rc, const char* what) {
   if (rc != ILQR_OK) throw std::runtime_error(std::string(what) + ": " + ilqr_last_error());
 }
@@ -198,11 +257,14 @@ inline void check(int rc, const char* what) {
 class BatchILQR {
  public:
   BatchILQR(std::shared_ptr<Model> model, int B, int T, double dt, int device = 0, int flags = 0)
-      : model_(model), B_(B), T_(T), n_(model->x_dims), m_(model->u_dims), h_(nullptr) {
-    if (model->device_model_id() == ILQR_MODEL_HOST)
-      throw std::runtime_error(
-          "ilqr_amd: this Model has no device twin (device_model_id() == ILQR_MODEL_HOST); the HIP rollout and "
-          "finite-difference kernels cannot call host virtuals and there is no CPU fallback");
+      : model_(model), B_(B), T_(T), n_(model->x_dims), m_(model->u_dims), dt_(dt), h_(nullptr) {
+    // A Model without a device twin exists only as host virtuals, which no kernel can call: its
+    // rollouts and finite differences are evaluated HERE by calling those virtuals (that is the
+    // plugin, not a substitute for a kernel), and everything that does not need the model --
+    // the backward pass with its box-QPs, the lambda retries, the accept / lambda schedule /
+    // termination logic -- still runs on the device (ILQR_MODEL_HOST handle; nx <= 32, nu <= 16).
+    // There is still no path without a GPU.
+    host_ = (model->device_model_id() == ILQR_MODEL_HOST);
     std::vector<double> lo(m_), hi(m_);
     for (int j = 0; j < m_; j++) {
       lo[j] = model->u_min(j);
@@ -220,7 +282,7 @@ class BatchILQR {
     d.flags = flags;
     d.u_min = lo.data();
     d.u_max = hi.data();
-    d.goal = model->device_goal();
+    model->fill_device_desc(d);
     check(ilqr_create(&d, &h_), "ilqr_create");
   }
   ~BatchILQR() { ilqr_destroy(h_); }
@@ -234,17 +296,42 @@ class BatchILQR {
   std::vector<double> init_traj(const std::vector<double>& x0, const std::vector<double>& u0) {
     require(x0.size() == (size_t)B_ * n_ && u0.size() == (size_t)B_ * T_ * m_, "init_traj: x0 [B][nx], u0 [B][T][nu]");
     std::vector<double> cost(B_);
+    if (host_) return host_init_traj(x0, u0);
     check(ilqr_init_traj(h_, x0.data(), u0.data(), cost.data()), "ilqr_init_traj");
     return cost;
   }
-  void generate_trajectory() { check(ilqr_generate_trajectory(h_), "ilqr_generate_trajectory"); }
-  void generate_trajectory(const std::vector<double>& x0) { check(ilqr_warm_start(h_, x0.data()), "ilqr_warm_start"); }
+  void generate_trajectory() {
+    if (host_) {
+      int running = 0;
+      for (;;) {
+        check(ilqr_count_running(h_, &running), "ilqr_count_running");
+        if (!running) break;
+        host_iteration();
+      }
+      return;
+    }
+    check(ilqr_generate_trajectory(h_), "ilqr_generate_trajectory");
+  }
+  void generate_trajectory(const std::vector<double>& x0) {
+    if (host_) {
+      host_warm_start(x0);
+      generate_trajectory();
+      return;
+    }
+    check(ilqr_warm_start(h_, x0.data()), "ilqr_warm_start");
+  }
   void generate_trajectory(const std::vector<double>& x0, const std::vector<double>& u0) {
     init_traj(x0, u0);
     generate_trajectory();
   }
   void solve(const std::vector<double>& x0, const std::vector<double>& u0) { generate_trajectory(x0, u0); }
-  void iterate(int n) { check(ilqr_iterate(h_, n), "ilqr_iterate"); }
+  void iterate(int n) {
+    if (host_) {
+      for (int i = 0; i < n; i++) host_iteration();
+      return;
+    }
+    check(ilqr_iterate(h_, n), "ilqr_iterate");
+  }
 
   std::vector<double> states() {
     std::vector<double> xs((size_t)B_ * (T_ + 1) * n_);
@@ -286,9 +373,206 @@ class BatchILQR {
   static void require(bool ok, const char* msg) {
     if (!ok) throw std::invalid_argument(msg);  // the reference asserts (ilqr_core.cpp:66,80-82)
   }
+  // ---- host-evaluated models -----------------------------------------------------------------
+  static constexpr double kEps = 1e-3;  // include/finite_diff.h:9
+  VectorXd vec(const double* p, int n) const {
+    VectorXd v(n);
+    for (int i = 0; i < n; i++) v(i) = p[i];
+    return v;
+  }
+  // iLQR::forward_pass (src/ilqr_core.cpp:305-337) for trajectory b: controls u_in [T][m], optional
+  // feedback K [T][m*n] (column-major m x n) around xnom [T+1][n]; returns the cost
+  double host_forward(int b, const double* u_in, const double* K, const double* xnom, double* xs_out, double* us_out) {
+    VectorXd x = vec(&hx0_[(size_t)b * n_], n_);
+    double total = 0;
+    for (int t = 0; t < T_; t++) {
+      VectorXd u = vec(u_in + (size_t)t * m_, m_);
+      if (K) {  // :315-316
+        for (int a = 0; a < m_; a++) {
+          double acc = 0;
+          for (int j = 0; j < n_; j++) acc += K[(size_t)t * m_ * n_ + a + (size_t)m_ * j] * (x(j) - xnom[(size_t)t * n_ + j]);
+          u(a) += acc;
+        }
+      }
+      for (int i = 0; i < n_; i++) xs_out[(size_t)t * n_ + i] = x(i);
+      for (int a = 0; a < m_; a++) us_out[(size_t)t * m_ + a] = u(a);  // :323 (no clamping)
+      total += model_->cost(x, u);
+      x = model_->integrate_dynamics(x, u, dt_);
+    }
+    for (int i = 0; i < n_; i++) xs_out[(size_t)T_ * n_ + i] = x(i);
+    return total + model_->final_cost(x);
+  }
+  // central differences in the reference's own sequence of perturbed points
+  template <class F>
+  void fd_gradient(const VectorXd& x, F f, double* out) {  // finite_diff.h:22-33
+    for (int i = 0; i < (int)x.size(); i++) {
+      VectorXd p = x, m = x;
+      p(i) += kEps;
+      m(i) -= kEps;
+      out[i] = (f(p) - f(m)) / (2 * kEps);
+    }
+  }
+  template <class F>
+  void fd_hessian(const VectorXd& x, F f, double* out) {  // finite_diff.h:67-86, column-major N x N
+    const int N = (int)x.size();
+    for (int i = 0; i < N; i++)
+      for (int j = i; j < N; j++) {
+        VectorXd pp = x, pm = x, mp = x, mm = x;
+        pp(i) += kEps;
+        pp(j) += kEps;
+        pm(i) += kEps;
+        pm(j) -= kEps;
+        mp(i) -= kEps;
+        mp(j) += kEps;
+        mm(i) -= kEps;
+        mm(j) -= kEps;
+        const double v = (f(pp) - f(mp) - f(pm) + f(mm)) / (4 * kEps * kEps);
+        out[i + (size_t)N * j] = v;
+        out[j + (size_t)N * i] = v;
+      }
+  }
+  // src/derivatives.cpp for trajectory b, all knots, into the canonical arrays of ilqr_set_derivatives
+  void host_derivatives(int b) {
+    const int n = n_, m = m_, T1 = T_ + 1;
+    for (int t = 0; t <= T_; t++) {
+      const VectorXd x = vec(&hxs_[((size_t)b * T1 + t) * n], n);
+      VectorXd u(m);
+      for (int a = 0; a < m; a++) u(a) = (t < T_) ? hus_[((size_t)b * T_ + t) * m + a] : 0.0;
+      double* fx = &d_fx_[((size_t)b * T1 + t) * n * n];
+      double* fu = &d_fu_[((size_t)b * T1 + t) * n * m];
+      double* cx = &d_cx_[((size_t)b * T1 + t) * n];
+      double* cu = &d_cu_[((size_t)b * T1 + t) * m];
+      double* cxx = &d_cxx_[((size_t)b * T1 + t) * n * n];
+      double* cxu = &d_cxu_[((size_t)b * T1 + t) * n * m];
+      double* cuu = &d_cuu_[((size_t)b * T1 + t) * m * m];
+      if (t < T_) {
+        for (int i = 0; i < n; i++) {  // derivatives.cpp:19-25
+          VectorXd p = x, q = x;
+          p(i) += kEps;
+          q(i) -= kEps;
+          const VectorXd fp = model_->integrate_dynamics(p, u, dt_), fm = model_->integrate_dynamics(q, u, dt_);
+          for (int r = 0; r < n; r++) fx[r + (size_t)n * i] = (fp(r) - fm(r)) / (2 * kEps);
+        }
+        for (int i = 0; i < m; i++) {
+          VectorXd p = u, q = u;
+          p(i) += kEps;
+          q(i) -= kEps;
+          const VectorXd fp = model_->integrate_dynamics(x, p, dt_), fm = model_->integrate_dynamics(x, q, dt_);
+          for (int r = 0; r < n; r++) fu[r + (size_t)n * i] = (fp(r) - fm(r)) / (2 * kEps);
+        }
+        fd_gradient(x, [&](const VectorXd& xx) { return model_->cost(xx, u); }, cx);  // :44-47
+        fd_gradient(u, [&](const VectorXd& uu) { return model_->cost(x, uu); }, cu);
+        fd_hessian(x, [&](const VectorXd& xx) { return model_->cost(xx, u); }, cxx);  // :76-96
+      } else {  // fx[T], fu[T] stay zero; :49-51, :92
+        for (int e = 0; e < n * n; e++) fx[e] = 0;
+        for (int e = 0; e < n * m; e++) fu[e] = 0;
+        fd_gradient(x, [&](const VectorXd& xx) { return model_->final_cost(xx); }, cx);
+        for (int a = 0; a < m; a++) cu[a] = 0;
+        fd_hessian(x, [&](const VectorXd& xx) { return model_->final_cost(xx); }, cxx);
+      }
+      fd_hessian(u, [&](const VectorXd& uu) { return model_->cost(x, uu); }, cuu);  // :98-112 (u = 0 at T)
+      for (int i = 0; i < n; i++)  // :114-144
+        for (int j = 0; j < m; j++) {
+          VectorXd px = x, mx = x, pu = u, mu = u;
+          px(i) += kEps;
+          mx(i) -= kEps;
+          pu(j) += kEps;
+          mu(j) -= kEps;
+          double v;
+          if (t < T_)
+            v = (model_->cost(px, pu) - model_->cost(mx, pu) - model_->cost(px, mu) + model_->cost(mx, mu)) / (4 * (kEps * kEps));
+          else  // the reference's own "this is wrong" formula; the value is never consumed
+            v = (model_->final_cost(px) - model_->final_cost(mx) - model_->final_cost(px) + model_->final_cost(mx)) / (4 * (kEps * kEps));
+          cxu[i + (size_t)n * j] = v;
+        }
+    }
+  }
+  void host_alloc() {
+    const size_t B = B_, T1 = T_ + 1, n = n_, m = m_;
+    hxs_.assign(B * T1 * n, 0.0);
+    hus_.assign(B * T_ * m, 0.0);
+    d_fx_.assign(B * T1 * n * n, 0.0);
+    d_fu_.assign(B * T1 * n * m, 0.0);
+    d_cx_.assign(B * T1 * n, 0.0);
+    d_cu_.assign(B * T1 * m, 0.0);
+    d_cxx_.assign(B * T1 * n * n, 0.0);
+    d_cxu_.assign(B * T1 * n * m, 0.0);
+    d_cuu_.assign(B * T1 * m * m, 0.0);
+    need_derivs_.assign(B, 1);
+  }
+  std::vector<double> host_init_traj(const std::vector<double>& x0, const std::vector<double>& u0) {  // ilqr_core.cpp:11-56
+    hx0_ = x0;
+    host_alloc();
+    std::vector<double> cost(B_);
+    for (int b = 0; b < B_; b++)
+      cost[b] = host_forward(b, &u0[(size_t)b * T_ * m_], nullptr, nullptr, &hxs_[(size_t)b * (T_ + 1) * n_], &hus_[(size_t)b * T_ * m_]);
+    check(ilqr_reset_state(h_, 0), "ilqr_reset_state");
+    check(ilqr_set_trajectory(h_, hx0_.data(), hxs_.data(), hus_.data(), cost.data()), "ilqr_set_trajectory");
+    return cost;
+  }
+  void host_warm_start(const std::vector<double>& x0) {  // ilqr_core.cpp:65-76
+    require(!hus_.empty(), "warm start needs a previous solve (assert us.size()>0, ilqr_core.cpp:66)");
+    require(x0.size() == (size_t)B_ * n_, "warm start: x0 [B][nx]");
+    hx0_ = x0;
+    const std::vector<double> K = gains_K();
+    std::vector<double> nxs(hxs_.size()), nus(hus_.size()), cost(B_);
+    for (int b = 0; b < B_; b++)
+      cost[b] = host_forward(b, &hus_[(size_t)b * T_ * m_], &K[(size_t)b * T_ * m_ * n_], &hxs_[(size_t)b * (T_ + 1) * n_],
+                             &nxs[(size_t)b * (T_ + 1) * n_], &nus[(size_t)b * T_ * m_]);
+    hxs_.swap(nxs);
+    hus_.swap(nus);
+    need_derivs_.assign(B_, 1);
+    check(ilqr_reset_state(h_, 1), "ilqr_reset_state");
+    check(ilqr_set_trajectory(h_, hx0_.data(), hxs_.data(), hus_.data(), cost.data()), "ilqr_set_trajectory");
+  }
+  // one body of the outer loop (src/ilqr_core.cpp:103-288) for every running trajectory
+  void host_iteration() {
+    require(!hus_.empty(), "iterate before init_traj");
+    std::vector<int> st(B_);
+    check(ilqr_get_status(h_, st.data(), nullptr, nullptr), "ilqr_get_status");
+    bool any = false;
+    for (int b = 0; b < B_; b++)
+      if (st[b] == ILQR_RUNNING && need_derivs_[b]) {  // STEP 1, :115-120 (flgChange)
+        host_derivatives(b);
+        need_derivs_[b] = 0;
+        any = true;
+      }
+    if (any)
+      check(ilqr_set_derivatives(h_, d_fx_.data(), d_fu_.data(), d_cx_.data(), d_cu_.data(), d_cxx_.data(), d_cxu_.data(), d_cuu_.data()),
+            "ilqr_set_derivatives");
+    check(ilqr_backward_step(h_), "ilqr_backward_step");  // STEP 2 on the device
+    check(ilqr_get_status(h_, st.data(), nullptr, nullptr), "ilqr_get_status");
+    const std::vector<double> k = gains_k(), K = gains_K();
+    static const double alphas[11] = {1.0000, 0.5012, 0.2512, 0.1259, 0.0631, 0.0316, 0.0158, 0.0079, 0.0040, 0.0020, 0.0010};
+    std::vector<double> cost_c((size_t)B_ * 11, 0.0), u_try((size_t)T_ * m_), xs_try((size_t)(T_ + 1) * n_), us_try((size_t)T_ * m_);
+    auto roll = [&](int b, double alpha) {  // :188-190
+      for (size_t e = 0; e < u_try.size(); e++) u_try[e] = hus_[(size_t)b * T_ * m_ + e] + k[(size_t)b * T_ * m_ + e] * alpha;
+      return host_forward(b, u_try.data(), &K[(size_t)b * T_ * m_ * n_], &hxs_[(size_t)b * (T_ + 1) * n_], xs_try.data(), us_try.data());
+    };
+    for (int b = 0; b < B_; b++)
+      if (st[b] == ILQR_RUNNING)
+        for (int a = 0; a < 11; a++) cost_c[(size_t)b * 11 + a] = roll(b, alphas[a]);  // STEP 3 rollouts
+    std::vector<int> acc(B_);
+    check(ilqr_accept_candidates(h_, cost_c.data(), acc.data()), "ilqr_accept_candidates");  // STEP 3/4 decisions on the device
+    bool moved = false;
+    for (int b = 0; b < B_; b++)
+      if (acc[b] >= 0) {  // :210-213: xs, us keep the accepted rollout
+        roll(b, alphas[acc[b]]);
+        std::copy(xs_try.begin(), xs_try.end(), hxs_.begin() + (size_t)b * (T_ + 1) * n_);
+        std::copy(us_try.begin(), us_try.end(), hus_.begin() + (size_t)b * T_ * m_);
+        need_derivs_[b] = 1;
+        moved = true;
+      }
+    if (moved) check(ilqr_set_trajectory(h_, nullptr, hxs_.data(), hus_.data(), nullptr), "ilqr_set_trajectory");
+  }
+
   std::shared_ptr<Model> model_;
   int B_, T_, n_, m_;
+  double dt_;
   ilqr_batch* h_;
+  bool host_ = false;
+  std::vector<double> hx0_, hxs_, hus_, d_fx_, d_fu_, d_cx_, d_cu_, d_cxx_, d_cxu_, d_cuu_;
+  std::vector<char> need_derivs_;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -327,6 +611,11 @@ class iLQR {
     generate_trajectory();
   }
   void solve(const VectorXd& x_0, const VecOfVecXd& u0) { generate_trajectory(x_0, u0); }  // BASELINE.json's name
+  // one body of the outer loop (src/ilqr_core.cpp:103-288); generate_trajectory() loops over it
+  void step() {
+    if (!engine_) throw std::logic_error("step(): no trajectory initialised");
+    engine_->iterate(1);
+  }
 
   double init_traj(const VectorXd& x_0, const VecOfVecXd& u_0) {  // ilqr_core.cpp:11-56
     T = (int)u_0.size();
