@@ -37,29 +37,76 @@ struct LqModel {
     cmem_d* a = (cmem_d*)A;
     cmem_d* bm = (cmem_d*)Bm;
 #pragma unroll
-    for (int i = 0; i < GN; i++) {
-      double acc = 0;
+    for (int i = 0; i < GN; i += 4) {  // four independent row sums in flight (see quad)
+      double acc[4] = {0, 0, 0, 0};
 #pragma unroll
-      for (int j = 0; j < GN; j++) acc += a[i * GN + j] * x[j];
+      for (int j = 0; j < GN; j++)
 #pragma unroll
-      for (int j = 0; j < GM; j++) acc += bm[i * GM + j] * u[j];
-      dx[i] = acc;
+        for (int q = 0; q < 4; q++) acc[q] += a[(i + q) * GN + j] * x[j];
+#pragma unroll
+      for (int j = 0; j < GM; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] += bm[(i + q) * GM + j] * u[j];
+#pragma unroll
+      for (int q = 0; q < 4; q++) dx[i + q] = acc[q];
     }
   }
   template <int N>
   static __device__ __forceinline__ double quad(cmem_d* Mx, const double* vv) {
+    // four rows at a time: the same sums in the same order, but four independent accumulator
+    // chains in flight (one wavefront per SIMD has nothing else to hide the FMA latency)
+    static_assert(N % 4 == 0, "row blocking");
     double s = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-      double r = 0;
+    for (int i = 0; i < N; i += 4) {
+      double r0 = 0, r1 = 0, r2 = 0, r3 = 0;
 #pragma unroll
-      for (int j = 0; j < N; j++) r += Mx[i * N + j] * vv[j];
-      s += vv[i] * r;
+      for (int j = 0; j < N; j++) {
+        r0 += Mx[(i + 0) * N + j] * vv[j];
+        r1 += Mx[(i + 1) * N + j] * vv[j];
+        r2 += Mx[(i + 2) * N + j] * vv[j];
+        r3 += Mx[(i + 3) * N + j] * vv[j];
+      }
+      s += vv[i] * r0;
+      s += vv[i + 1] * r1;
+      s += vv[i + 2] * r2;
+      s += vv[i + 3] * r3;
     }
     return s;
   }
+  // the same quadratic form at TWO points: every matrix element is fetched once and used twice
+  // (the finite-difference sweep is bound by how fast the scalar loads deliver the matrices)
+  template <int N>
+  static __device__ __forceinline__ void quad2(cmem_d* Mx, const double* va, const double* vb, double& sa, double& sb) {
+    static_assert(N % 2 == 0, "row blocking");
+    sa = sb = 0;
+#pragma unroll
+    for (int i = 0; i < N; i += 2) {
+      double ra0 = 0, ra1 = 0, rb0 = 0, rb1 = 0;
+#pragma unroll
+      for (int j = 0; j < N; j++) {
+        const double m0 = Mx[i * N + j], m1 = Mx[(i + 1) * N + j];
+        ra0 += m0 * va[j];
+        rb0 += m0 * vb[j];
+        ra1 += m1 * va[j];
+        rb1 += m1 * vb[j];
+      }
+      sa += va[i] * ra0;
+      sa += va[i + 1] * ra1;
+      sb += vb[i] * rb0;
+      sb += vb[i + 1] * rb1;
+    }
+  }
   __device__ __forceinline__ double cost(const double* x, const double* u) const {
     return 0.5 * (quad<GN>((cmem_d*)Q, x) + quad<GM>((cmem_d*)R, u));
+  }
+  __device__ __forceinline__ void cost2(const double* xa, const double* ua, const double* xb, const double* ub, double& fa,
+                                        double& fb) const {
+    double qa, qb, ra, rb;
+    quad2<GN>((cmem_d*)Q, xa, xb, qa, qb);
+    quad2<GM>((cmem_d*)R, ua, ub, ra, rb);
+    fa = 0.5 * (qa + ra);
+    fb = 0.5 * (qb + rb);
   }
   __device__ __forceinline__ double final_cost(const double* x) const { return 0.5 * quad<GN>((cmem_d*)Qf, x); }
 };
@@ -244,87 +291,100 @@ __global__ __launch_bounds__(64) void k_derivatives_g(BatchView v, M model, int 
   const int n_cxx = 2 * nx * (nx + 1), n_cuu = 2 * nu * (nu + 1), n_cxu = 4 * nx * nu;
   const int g_cu = (n_cx + 3) & ~3, g_cxx = g_cu + ((n_cu + 3) & ~3), g_cuu = g_cxx + n_cxx, g_cxu = g_cuu + n_cuu,
             total = g_cxu + n_cxu;
-  for (int base = 0; base < total; base += 64) {
-    const int e = base + lane;
-    // decode: category, indices, perturbations
-    int cat = -1, i1 = -1, i2 = -1;
-    bool t1x = true, t2x = true;
-    double d1 = 0, d2 = 0;
+  struct Point {
+    int cat, i1, i2;
+    bool t1x, t2x;
+    double d1, d2;
+  };
+  auto decode = [&](int e) __attribute__((always_inline)) {
+    Point q;
+    q.cat = -1;
+    q.i1 = q.i2 = -1;
+    q.t1x = q.t2x = true;
+    q.d1 = q.d2 = 0;
     if (e < n_cx) {
-      cat = 0;
-      i1 = e >> 1;
-      d1 = (e & 1) ? -kEps : kEps;
+      q.cat = 0;
+      q.i1 = e >> 1;
+      q.d1 = (e & 1) ? -kEps : kEps;
     } else if (e >= g_cu && e < g_cu + n_cu) {
-      cat = 1;
-      t1x = false;
-      i1 = (e - g_cu) >> 1;
-      d1 = (e & 1) ? -kEps : kEps;
+      q.cat = 1;
+      q.t1x = false;
+      q.i1 = (e - g_cu) >> 1;
+      q.d1 = (e & 1) ? -kEps : kEps;
     } else if (e >= g_cxx && e < total) {
       int n, p;
       if (e < g_cuu) {
-        cat = 2;
+        q.cat = 2;
         n = nx;
         p = (e - g_cxx) >> 2;
       } else if (e < g_cxu) {
-        cat = 3;
+        q.cat = 3;
         n = nu;
         p = (e - g_cuu) >> 2;
-        t1x = t2x = false;
+        q.t1x = q.t2x = false;
       } else {
-        cat = 4;
+        q.cat = 4;
         n = 0;
         p = (e - g_cxu) >> 2;
-        t2x = false;
+        q.t2x = false;
       }
-      if (cat == 4) {  // (i, j) row-major over nx x nu, as the loops of derivatives.cpp:117-118
-        i1 = p / nu;
-        i2 = p - i1 * nu;
+      if (q.cat == 4) {  // (i, j) row-major over nx x nu, as the loops of derivatives.cpp:117-118
+        q.i1 = p / nu;
+        q.i2 = p - q.i1 * nu;
       } else {  // upper triangle, row by row (finite_diff.h:70-71)
         int i = 0;
         while (p >= n - i) {
           p -= n - i;
           i++;
         }
-        i1 = i;
-        i2 = i + p;
+        q.i1 = i;
+        q.i2 = i + p;
       }
       const int combo = e & 3;  // 0: pp  1: mp  2: pm  3: mm   (first perturbation's sign changes fastest)
-      d1 = (combo & 1) ? -kEps : kEps;
-      d2 = (combo & 2) ? -kEps : kEps;
+      q.d1 = (combo & 1) ? -kEps : kEps;
+      q.d2 = (combo & 2) ? -kEps : kEps;
     }
-    double px[NX], pu[NU];
-    perturbed(t1x, i1, d1, t2x, i2, d2, px, pu);
-    // which function: final_cost for the x-derivatives at t = T (:49, :92, :140); cuu[T] is cost(x_T, .)
-    double f = 0;
-    if (cat >= 0) {
-      if (last && cat != 3) {
-        double pz[NX];
-#pragma unroll
-        for (int c = 0; c < NX; c++) pz[c] = px[c];
-        f = model.final_cost(pz);
-      } else {
-        f = model.cost(px, pu);
-      }
-    }
+    return q;
+  };
+  // lanes of a quad combine their values and the lane of the first point stores the entry
+  auto combine = [&](int e, const Point& q, double f) __attribute__((always_inline)) {
     const double f0 = quad_bcast<0>(f), f1 = quad_bcast<1>(f), f2 = quad_bcast<2>(f), f3 = quad_bcast<3>(f);
-    if (cat == 0 || cat == 1) {
+    if (q.cat == 0 || q.cat == 1) {
       if (!(e & 1)) {
         const double g = (((lane & 2) ? f2 : f0) - ((lane & 2) ? f3 : f1)) / (2 * kEps);
-        D[(cat == 0 ? oCX : oCU) + i1] = g;
+        D[(q.cat == 0 ? oCX : oCU) + q.i1] = g;
       }
-    } else if (cat >= 2 && (e & 3) == 0) {
+    } else if (q.cat >= 2 && (e & 3) == 0) {
       // (at t = T the cxu lanes hold final_cost(px), (mx), (px), (mx): the expression of :140)
       const double val = (f0 - f1 - f2 + f3) / (4 * kEps * kEps);
-      if (cat == 2) {
-        D[oCXX + i1 + nx * i2] = val;
-        D[oCXX + i2 + nx * i1] = val;
-      } else if (cat == 3) {
-        D[oCUU + i1 + nu * i2] = val;
-        D[oCUU + i2 + nu * i1] = val;
+      if (q.cat == 2) {
+        D[oCXX + q.i1 + nx * q.i2] = val;
+        D[oCXX + q.i2 + nx * q.i1] = val;
+      } else if (q.cat == 3) {
+        D[oCUU + q.i1 + nu * q.i2] = val;
+        D[oCUU + q.i2 + nu * q.i1] = val;
       } else {
-        D[oCXU + i1 + nx * i2] = val;
+        D[oCXU + q.i1 + nx * q.i2] = val;
       }
     }
+  };
+  // two points per lane and trip (model.cost2: every model constant fetched once serves both)
+  for (int base = 0; base < total; base += 128) {
+    const int ea = base + lane, eb = base + 64 + lane;
+    const Point qa = decode(ea), qb = decode(eb);
+    double pxa[NX], pua[NU], pxb[NX], pub[NU];
+    perturbed(qa.t1x, qa.i1, qa.d1, qa.t2x, qa.i2, qa.d2, pxa, pua);
+    perturbed(qb.t1x, qb.i1, qb.d1, qb.t2x, qb.i2, qb.d2, pxb, pub);
+    double fa = 0, fb = 0;
+    if (!last) {
+      model.cost2(pxa, pua, pxb, pub, fa, fb);
+    } else {
+      // final_cost for the x-derivatives at t = T (:49, :92, :140); cuu[T] is cost(x_T, .)
+      if (qa.cat >= 0) fa = (qa.cat != 3) ? model.final_cost(pxa) : model.cost(pxa, pua);
+      if (qb.cat >= 0) fb = (qb.cat != 3) ? model.final_cost(pxb) : model.cost(pxb, pub);
+    }
+    combine(ea, qa, fa);
+    combine(eb, qb, fb);
   }
 }
 
