@@ -70,3 +70,22 @@ def test_stage_kernel_name_reports_the_fused_kernel():
     g = BatchILQR("acrobot", 16, 10, DT, flags=capi.FLAG_UNFUSED)
     assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("backward")) == b"k_backward_q"
     g.close()
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 5, 11, 12, 13, 25])
+def test_short_horizons_fused_equals_unfused(T):
+    """Horizons around the producers' round size (12 knots), the ring size (24) and the candidate
+    checkpoint spacing (8): partial rounds, a single knot, B = 1."""
+    from ilqr_amd import BatchILQR, capi
+    for B in (1, 19):
+        x0 = acrobot_x0(B, scale=0.2, seed=T)
+        u0 = np.full((B, T, 1), 0.3)
+        out = []
+        for fl in (0, capi.FLAG_UNFUSED):
+            g = BatchILQR("acrobot", B, T, DT, u_min=-1.0, u_max=1.0, flags=fl)
+            g.init_traj(x0, u0)
+            g.iterate(4)
+            out.append(_state(g))
+            g.close()
+        _same(out[0], out[1])
+        assert np.all(np.isfinite(out[0]["cost"]))
