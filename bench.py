@@ -72,7 +72,18 @@ def cpu_baseline(B_total, T, dt, lim, target_wall_s=4.0):
     if nb2 == B_total:                  # the whole batch is still too quick: run more iterations
         iters = int(min(40, max(iters, target_wall_s * rate / (T * nb2))))
     t2 = run(nb2, iters)
+    # backward pass alone on fixed derivatives (the north star's backward-only figure), same threads
+    nb3 = min(B_total, 8 * cores)
+    u3 = np.zeros((nb3, T, 1))
+    xs3, us3, _ = O.batch_rollout(om, x0_all[:nb3], u3, dt, nthreads=cores)
+    dv3 = O.batch_derivatives(om, xs3, us3, dt, nthreads=cores)
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        O.batch_backward(om, us3, dv3, lam=1.0, nthreads=cores)
+    t3 = (time.perf_counter() - t0) / reps
     return {"value": nb2 * T * iters / t2, "unit": "trajectory-timesteps/s", "cores": cores, "kind": "port",
+            "backward_only_value": nb3 * T / t3,
             "sample": "%d trajectories x %d fixed-work iterations of the same acrobot workload, %.1f s wall "
                       "(%.0f core-seconds), oracle/liboracle_ilqr.so with OpenMP over trajectories on all host "
                       "threads" % (nb2, iters, t2, t2 * cores)}
@@ -152,12 +163,26 @@ def main():
     prof = g.profile_read()
     g.profile(False)
 
+    # backward-pass-only figure of the north star (outside the timed region): the stand-alone quad
+    # kernel, one pass at the current lambda, on the derivative records of the final nominal trajectory
+    capi.check(g.lib.ilqr_compute_derivatives(g.h))
+    R = 20
+    for _ in range(10):  # code load of this kernel + clocks back up after the host-side gather
+        capi.check(g.lib.ilqr_backward_pass(g.h, None))
+    g.profile(True)
+    g.profile_reset()
+    for _ in range(R):
+        capi.check(g.lib.ilqr_backward_pass(g.h, None))
+    bw_ms = g.profile_read()["backward"][0] / R
+    g.profile(False)
+
     if rank == 0:
         costs = gathered.cpu().numpy()
         assert np.all(np.isfinite(costs)), "non-finite cost in the gathered result"
         steps = args.steps
         value = world * B * T * steps / elapsed
         bytes_ts = algorithmic_bytes_per_timestep(n, m)
+        bytes_ts_backward_only = bytes_ts["backward"]
         stages = {}
         for name, (ms, launches) in prof.items():
             if launches:
@@ -189,8 +214,11 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_ts[dom] * B * T,
                          "avg_launch_ms": stages[dom]["ms_per_launch"]},
             "stages": stages,
-            "backward_only_timesteps_per_s": (B * T / (stages["backward"]["ms_per_launch"] * 1e-3)) * world
-            if "backward" in stages else None,  # (with the fused kernel: sweep + backward)
+            # north star "backward-pass throughput": k_backward_q alone on fixed derivative records
+            "backward_only": {"kernel": "k_backward_q", "ms_per_launch": bw_ms,
+                              "timesteps_per_s": B * T / (bw_ms * 1e-3) * world,
+                              "algorithmic_GBps": bytes_ts_backward_only * B * T / (bw_ms * 1e-3) / 1e9,
+                              "frac_of_hbm_peak": bytes_ts_backward_only * B * T / (bw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "final_cost_mean": float(np.mean(costs)),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -427,8 +427,9 @@ ILQR_HD int box_qp_scalar(double Q, double c, double x0, double lo, double hi, d
 //   qp1_begin  iteration 0 up to the unit-step trial point
 //   qp1_backtrack_seq  the loop of boxqp.cpp:161-173 as written
 //   qp1_finish iteration 1's exit tests and the result ladder
-// box_qp_scalar_fast composes them sequentially (host tests, fallback).  A result of -1 means a
-// third iteration would be needed: the caller then runs box_qp_scalar (same answer).
+//   qp1_continue  iterations 1, 2, ... for the QPs that leave through none of the six exits
+// box_qp_scalar_fast composes them sequentially (host tests).  qp1_finish returns -1 when the
+// QP has to go on: the caller then runs qp1_continue.
 struct QP1State {
   double Q, c, lo, hi;
   double x, val0, g0, minv, search, slope, old_v;
@@ -478,7 +479,10 @@ ILQR_HD void qp1_backtrack_seq(QP1State& q) {  // boxqp.cpp:161-173
     q.step *= kStepDec;
     q.x1 = qp1_trial(q, q.step);
     q.v1 = qp1_value(q, q.x1);
-    if (q.step < kMinStep) {
+    // A trial that lands on x itself (the step is below half an ulp of x: the search direction is
+    // rounding noise) has v1 == old_v, and so has every shorter step: the reference's loop keeps
+    // failing the test until step < minStep (:167-171).  Same outcome, ~90 trips earlier.
+    if (q.step < kMinStep || q.x1 == q.x) {
       q.ls_failed = true;
       break;
     }
@@ -500,12 +504,77 @@ ILQR_HD int qp1_finish(const QP1State& q, double& x_out, int& free_out, double& 
   return stay ? outer : inner;
 }
 
+// Iterations >= 1 of the loop of box_qp_scalar, continued from the state the two-iteration fast
+// path leaves when none of its exits applies (qp1_finish returned -1): x = q.x1, val = q.v1,
+// oldvalue = q.val0.  (Iteration 1's exit tests are evaluated again -- same expressions, same
+// answers -- so the loop body is the reference's as written.)  `line_search(q)` performs
+// boxqp.cpp:143-178 for the state's x / search / slope / old_v and leaves x1, v1, ls_failed: the
+// kernel passes the quad-parallel Armijo search, the host tests the sequential loop.  QPs that
+// need this are the ones whose trial point comes inside the box before the Armijo test passes on
+// the bound: the Newton target stays outside, so they creep towards the bound over several
+// iterations.  Restarting the literal loop from iteration 0 for them (as the first version did)
+// made their wavefront the slowest of the launch once a solve had run ~20 iterations.
+template <class LineSearch>
+ILQR_HD int qp1_continue(QP1State& q, LineSearch line_search, double& x_out, int& free_out) {
+  double x = q.x1, val = q.v1, oldvalue = q.val0;
+  int result = 0, free_ = 1;
+  for (int iter = 1; iter <= kQpMaxIter; iter++) {
+    if ((oldvalue - val) < kMinRelImprove * fabs(oldvalue)) {  // boxqp.cpp:54-57 (iter > 0 here)
+      result = 4;
+      break;
+    }
+    const double grad = q.Q * x + q.c;
+    oldvalue = val;
+    const bool cl = ((fabs(x - q.lo) < kClampTol) & (grad > 0)) | ((fabs(x - q.hi) < kClampTol) & (grad < 0));
+    if (cl) {  // :74-77
+      free_ = 0;
+      result = 6;
+      break;
+    }
+    free_ = 1;
+    if (fabs(grad) < kMinGrad) {  // :93-97
+      result = 5;
+      break;
+    }
+    q.x = x;
+    q.g0 = grad;
+    q.search = -q.minv * q.c - x;
+    q.slope = q.search * grad;
+    if (q.slope >= 0) {  // :150-153
+      result = 2;
+      break;
+    }
+    q.old_v = qp1_value(q, x);
+    q.early = false;
+    q.ls_failed = false;
+    q.step = 1;
+    line_search(q);
+    if (q.ls_failed) {  // :121-125
+      result = 2;
+      break;
+    }
+    x = q.x1;
+    val = q.v1;
+  }
+  x_out = x;
+  free_out = free_;
+  return result;
+}
+ILQR_HD void qp1_line_search_seq(QP1State& q) {
+  q.step = 1;
+  q.x1 = qp1_trial(q, 1.0);
+  q.v1 = qp1_value(q, q.x1);
+  qp1_backtrack_seq(q);
+}
+
 ILQR_HD int box_qp_scalar_fast(double Q, double c, double x0, double lo, double hi, double& x_out, int& free_out,
                                double& minv_out) {
   QP1State q;
   qp1_begin(Q, c, x0, lo, hi, q);
   qp1_backtrack_seq(q);
-  return qp1_finish(q, x_out, free_out, minv_out);
+  int result = qp1_finish(q, x_out, free_out, minv_out);
+  if (result < 0) result = qp1_continue(q, [](QP1State& s) { qp1_line_search_seq(s); }, x_out, free_out);
+  return result;
 }
 
 // step sizes of the backtracking loop, exactly as it produces them: s[0] = 1, s[k+1] = s[k]*0.6

@@ -437,9 +437,32 @@ void ilqr_destroy(ilqr_batch* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
 #ifdef ILQR_PHASE_TIMING
   if (h->v.dbg) {
-    long long d[64 * 8];
+    long long d[1024];
     if (hipMemcpy(d, h->v.dbg, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess) {
       static const char* nm[8] = {"load-issue", "Q-products", "slowQP+K", "V-update+dpp", "vmcnt-wait", "stores", "fastQP", "slow-path steps/T"};
+      {  // spread over the first 64 tiles: the kernel lasts as long as its slowest tile
+        double tot[64];
+        int worst = 0;
+        for (int t = 0; t < 64; t++) {
+          tot[t] = 0;
+          for (int q = 0; q < 7; q++) tot[t] += (double)d[t * 8 + q];
+          if (tot[t] > tot[worst]) worst = t;
+        }
+        double mn = tot[0], sum = 0;
+        for (int t = 0; t < 64; t++) {
+          mn = tot[t] < mn ? tot[t] : mn;
+          sum += tot[t];
+        }
+        fprintf(stderr, "[phase timing, tiles 0..63] cycles/step min %.0f mean %.0f max %.0f (tile %d, slow-path %.3f/step)\n", mn / h->T,
+                sum / 64 / h->T, tot[worst] / h->T, worst, (double)d[worst * 8 + 7] / h->T);
+        {
+          const double* dd = reinterpret_cast<const double*>(d + 768);
+          fprintf(stderr, "[a sequential-fallback sample] search %.6g bound-x %.6g v_b-old_v %.6g slope %.6g Q %.6g x %.17g bound %.17g\n", dd[0], dd[1], dd[2], dd[3], dd[4], dd[5], dd[6]);
+        }
+        fprintf(stderr, "[worst tile] per step: QP-continues %.3f, continue iterations %.3f, sequential-search fallbacks %.3f, sequential trips %.2f\n",
+                (double)d[512 + worst * 4 + 0] / h->T, (double)d[512 + worst * 4 + 1] / h->T, (double)d[512 + worst * 4 + 2] / h->T,
+                (double)d[512 + worst * 4 + 3] / h->T);
+      }
       for (int t = 0; t < 3; t++) {
         fprintf(stderr, "[phase timing, tile %d, last backward pass] ", t * 20);
         for (int q = 0; q < 8; q++) fprintf(stderr, "%s %.2f  ", nm[q], (double)d[t * 20 * 8 + q] / h->T);
@@ -570,7 +593,11 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
         }
         for (size_t i = 0; i < nu; i++)
           for (size_t j = 0; j < nu; j++) pR[i * GM + j] = d->lq_R[i * nu + j];
-        if (hipMemcpy(pad, hp.data(), tot * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = 1;
+        // on the handle's stream, behind dev_alloc's zero fill of the same buffer (a copy on the null
+        // stream could be overtaken by it: the stream is non-blocking); hp must outlive the copy
+        if (hipMemcpyAsync(pad, hp.data(), tot * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess)
+          rc = 1;
         h->lq.nx = (int)nx;
         h->lq.nu = (int)nu;
         h->lq.A = pad;
@@ -610,7 +637,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   rc |= dev_alloc(h, &v.n_running, 1);
   rc |= dev_alloc(h, &h->commit_idx, Bp);
   if (!rc && hipMemsetAsync(h->commit_idx, 0xFF, Bp * sizeof(int), h->stream) != hipSuccess) rc = 1;
-  rc |= dev_alloc(h, &v.dbg, 64 * 8);
+  rc |= dev_alloc(h, &v.dbg, 1024);
   if (rc) return ILQR_ERR_HIP;
 
   h->sp.max_iter = h->params.max_iter;

@@ -864,7 +864,20 @@ __device__ __forceinline__ bool qp1_search_quad(QP1State& q, int s, int lane, co
   q.x1 = __shfl(my_x1, src, 64);
   q.v1 = __shfl(my_v1, src, 64);
   q.step = __shfl(my_step, src, 64);
-  return ok | q.early;
+  // A unit-step trial that lands on x itself (x sits on the bound the search points across, or the
+  // step is below half an ulp of x) stays there for every shorter step: value == old value, the
+  // Armijo ratio is 0 at every k, and the reference's loop runs its ~100 trips down to minStep and
+  // reports failure (boxqp.cpp:167-171).  Same outcome, without the trips -- late in a solve this
+  // was a quarter of the steps of the slowest tiles.
+  const bool stuck = (qp1_trial(q, 1.0) == q.x) & !q.early;
+  // The same once the search direction is rounding noise (late in a solve Quu reaches 1e12+ and x
+  // sits on the optimum to an ulp: search ~ 1e-19): steps 1 and 0.6 still move x by an ulp, from
+  // 0.36 on the trial IS x.  With the window at k = 1, 2, 3 every k <= 3 has been tested exactly;
+  // if none passes and the k = 3 trial equals x, no later k can pass either.
+  const unsigned int s4 = (unsigned int)(__ballot(my_x1 == q.x) >> (lane & ~3)) & 0xFu;
+  const bool dead = (k1 == 1) & (m4 == 0u) & ((s4 & 8u) != 0u) & !q.early;
+  q.ls_failed = q.ls_failed | stuck | dead;
+  return ok | q.early | stuck | dead;
 }
 
 template <int NU>
@@ -1006,6 +1019,7 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
 
 #ifdef ILQR_PHASE_TIMING
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long xc[4] = {0, 0, 0, 0};  // (per lane: counts of lane 0's own quad)
     long long tmark = clock64();
 #define ILQR_MARK(k) { __builtin_amdgcn_sched_barrier(0); const long long tn_ = clock64(); ph[k] += tn_ - tmark; tmark = tn_; __builtin_amdgcn_sched_barrier(0); }
 #else
@@ -1096,6 +1110,9 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
         QP1State q1;
         qp1_begin<false>(QuuF[0], Qu[0], kprev[0], lo[0], hi[0], q1);
         if (!qp1_search_quad(q1, s, lane, lds_steps)) {  // fallback: rare
+#ifdef ILQR_PHASE_TIMING
+          xc[2] += 1;
+#endif
           q1.step = 1;
           q1.x1 = qp1_trial(q1, 1.0);
           q1.v1 = qp1_value(q1, q1.x1);
@@ -1106,8 +1123,32 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
 #ifdef ILQR_PHASE_TIMING
         if (__any(result < 0)) ph[7] += 1;
 #endif
-        if (result < 0)  // rare: a third Newton iteration
-          result = box_qp_scalar(QuuF[0], Qu[0], kprev[0], lo[0], hi[0], qp.x[0], free0, minv);
+#ifdef ILQR_PHASE_TIMING
+        if (__any(result < 0)) xc[0] += 1;
+#endif
+        if (result < 0)  // the QP goes on (rare early in a solve, a quarter of the steps of some tiles later)
+          result = qp1_continue(
+              q1,
+              [&](QP1State& qs) __attribute__((always_inline)) {
+#ifdef ILQR_PHASE_TIMING
+                xc[1] += 1;
+#endif
+                if (!qp1_search_quad(qs, s, lane, lds_steps)) {
+#ifdef ILQR_PHASE_TIMING
+                  xc[2] += 1;
+                  if (v.dbg && s == 0) {
+                    const double bnd = (qs.search > 0) ? qs.hi : qs.lo;
+                    double* dd = reinterpret_cast<double*>(v.dbg + 768);
+                    dd[0] = qs.search; dd[1] = bnd - qs.x; dd[2] = qp1_value(qs, bnd) - qs.old_v; dd[3] = qs.slope; dd[4] = qs.Q; dd[5] = qs.x; dd[6] = bnd;
+                  }
+#endif
+                  qp1_line_search_seq(qs);
+#ifdef ILQR_PHASE_TIMING
+                  xc[3] += (long long)(log(qs.step) / log(0.6) + 0.5);
+#endif
+                }
+              },
+              qp.x[0], free0);
         ok = result >= 1;
         Kc[0] = free0 ? -minv * Quxc[0] : 0.0;  // :373-385
       } else {
@@ -1305,6 +1346,21 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
 #ifdef ILQR_PHASE_TIMING
     if (v.dbg && lane == 0 && tile < 64)
       for (int q = 0; q < 8; q++) v.dbg[tile * 8 + q] = ph[q];
+    {  // worst quad of the tile
+      long long m0 = xc[0], m1 = xc[1], m2 = xc[2], m3 = xc[3];
+      for (int off = 4; off < 64; off <<= 1) {
+        const long long o1 = __shfl_xor(m1, off, 64), o2 = __shfl_xor(m2, off, 64), o3 = __shfl_xor(m3, off, 64);
+        m1 = o1 > m1 ? o1 : m1;
+        m2 = o2 > m2 ? o2 : m2;
+        m3 = o3 > m3 ? o3 : m3;
+      }
+      if (v.dbg && lane == 0 && tile < 64) {
+        v.dbg[512 + tile * 4 + 0] = m0;
+        v.dbg[512 + tile * 4 + 1] = m1;
+        v.dbg[512 + tile * 4 + 2] = m2;
+        v.dbg[512 + tile * 4 + 3] = m3;
+      }
+    }
 #endif
   };
 

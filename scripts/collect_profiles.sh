@@ -14,9 +14,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace -d $OUT/pmc_sq1 -o $R -- $BENCH --steps 5 --warmup 3 > /dev/null 2> $OUT/pmc_sq1.err
 rocprofv3 --pmc SQ_INSTS_VMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $OUT/pmc_sq2 -o $R -- $BENCH --steps 5 --warmup 3 > /dev/null 2> $OUT/pmc_sq2.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/pmc_sq3 -o $R -- $BENCH --steps 5 --warmup 3 > /dev/null 2> $OUT/pmc_sq3.err
 cd $ROOT
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-for d in stats pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq1 pmc_sq2; do
+for d in stats pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq1 pmc_sq2 pmc_sq3; do
   f=$(find $OUT/$d -name "*.db" | head -1)
   [ -n "$f" ] && python scripts/prof_summary.py $f > $OUT/$d.txt 2>&1
 done

@@ -75,13 +75,10 @@ def test_scalar_solver_and_fast_path(oracle, dev):
         for fn in (dev.devfn_box_qp_scalar, dev.devfn_box_qp_scalar_fast):
             x, fr, mv = C.c_double(), C.c_int(), C.c_double()
             r = fn(Q, c, x0, lo, hi, C.byref(x), C.byref(fr), C.byref(mv))
-            if r < 0:  # the fast path asks for the general loop (third Newton iteration)
-                assert fn is dev.devfn_box_qp_scalar_fast
-                n_slow += 1
-                continue
+            assert r >= 0  # (the fast path continues by itself when a QP needs a third iteration)
             ok = fr.value == ro["v_free"][0] and abs(x.value - ro["x_opt"][0]) <= 1e-12 * max(1, abs(x.value))
             code_ok = r == ro["result"] or (Q <= 0 and {r, ro["result"]} == {2, 4})
             if not (ok and code_ok):
                 n_tie += 1  # clamp membership decided by a rounding-noise gradient (boxqp.h:61-64)
             assert (Q > 0) == (abs(mv.value - 1.0 / Q) <= 1e-15 * abs(1.0 / Q)) or Q <= 0
-    assert n_tie <= 4 and n_slow < N // 20
+    assert n_tie <= 4
