@@ -157,6 +157,7 @@ def main():
     g.iterate(args.steps)
     # the one exchange step of the path: gather of per-trajectory costs (RCCL over xGMI)
     capi.check(g.lib.ilqr_copy_cost_to_device(g.h, cost_dev.data_ptr()))
+    g.synchronize()  # the copy runs on the handle's stream, the collective on torch's: order them
     gathered = D.gather_costs(cost_dev)
     barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device="cuda")

@@ -193,7 +193,8 @@ int ilqr_get_status(ilqr_batch* h, int* status, int* iters, int* alpha_idx); /* 
 int ilqr_get_candidate(ilqr_batch* h, int alpha_idx, double* xs, double* us); /* one alpha's rollout */
 int ilqr_count_running(ilqr_batch* h, int* n_running);
 /* device-to-device copy of the per-trajectory costs [B] into caller-owned device memory
- * (the payload of the multi-GPU gather) */
+ * (the payload of the multi-GPU gather).  Enqueued on the handle's stream:
+ * ilqr_synchronize before handing the buffer to work on another stream (a collective). */
 int ilqr_copy_cost_to_device(ilqr_batch* h, void* dst_device);
 
 /* ---- measurement --------------------------------------------------------------------------- */
