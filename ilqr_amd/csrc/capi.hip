@@ -239,8 +239,10 @@ static int launch_rollout_t(ilqr_batch* h, const M& m, bool gains, bool cand, co
                             double* cost_out, int mode) {
   const int aw = (n_alpha + 3) / 4;  // wavefronts per tile: 4 alphas each
   dim3 grid(h->ntiles), block(64 * aw);
-  if (gains && cand)
-    hipLaunchKernelGGL((k_rollout<M, true, true>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode);
+  if (gains && cand && h->ntiles <= h->num_cus)  // one block per CU: deep prefetch (see k_rollout)
+    hipLaunchKernelGGL((k_rollout<M, true, true, 8>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode);
+  else if (gains && cand)
+    hipLaunchKernelGGL((k_rollout<M, true, true, 4>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode);
   else if (!gains && !cand)
     hipLaunchKernelGGL((k_rollout<M, false, false>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode);
   else

@@ -112,7 +112,7 @@ struct AlphaSet {
 //   CAND=true   : candidate `a` keeps every u_t and the state at every CT-th knot (common.hpp)
 // The cost goes to cost_out[a][b].  mode: 0 = all trajectories, 1 = only running ones whose
 // backward pass succeeded.
-template <class M, bool GAINS, bool CAND>
+template <class M, bool GAINS, bool CAND, int PD = 4>
 __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet alphas, int n_alpha,
                                                  double* __restrict__ cost_out, int mode) {
   constexpr int NX = M::NX, NU = M::NU;
@@ -139,7 +139,10 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
   // and one step of arithmetic (~600 cycles) is far shorter than an HBM round trip under load
   // (~2000+ cycles), so they are prefetched PD steps ahead into a ring of register sets; the
   // main loop is unrolled by PD so that every set is statically indexed.
-  constexpr int PD = 4;
+  // Measured on the bench workload (10 loads per step, one block per CU): PD 2 -> 0.298 ms,
+  // 4 -> 0.259, 8 -> 0.237, 12 -> 0.236 (more than vmcnt's 63 outstanding), 16 -> 0.76 (register
+  // spills).  Depth 8 costs 266 registers, i.e. one block per CU; when the tiles outnumber the CUs
+  // the launcher picks depth 4 (136 registers, several blocks per CU hide the latency instead).
   struct StepIn {
     double u[NU], k[GAINS ? NU : 1], K[GAINS ? NU * NX : 1], xnom[GAINS ? NX : 1];
   };
