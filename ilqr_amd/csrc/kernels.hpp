@@ -1276,10 +1276,18 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
 #pragma unroll
         for (int c = 0; c < 4; c++) Vf[r + 4 * c] = col[c];
       }
+      // 0.5 (V + V'): the diagonal is 0.5 (a + a) = a exactly, each off-diagonal pair is one sum
+      // (fp addition commutes), so 6 add/mul pairs instead of 16
 #pragma unroll
-      for (int r = 0; r < 4; r++)
+      for (int r = 0; r < 4; r++) {
+        Vxx[r + 4 * r] = Vf[r + 4 * r];
 #pragma unroll
-        for (int c = 0; c < 4; c++) Vxx[r + 4 * c] = 0.5 * (Vf[r + 4 * c] + Vf[c + 4 * r]);
+        for (int c = r + 1; c < 4; c++) {
+          const double sym = 0.5 * (Vf[r + 4 * c] + Vf[c + 4 * r]);
+          Vxx[r + 4 * c] = sym;
+          Vxx[c + 4 * r] = sym;
+        }
+      }
       quad_gather(Vxs, Vx);
       // :405-412 term of the gradient norm for this step (summed here in descending t)
       {

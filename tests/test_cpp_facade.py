@@ -54,6 +54,11 @@ int main() {
   Pendulum p; Eigen::VectorXd x(2); x << 0.1, 0.0; Eigen::VectorXd u(1); u << 0.5;
   Eigen::VectorXd x1 = p.integrate_dynamics(x, u, 0.02);
   if (std::abs(x1(0) - 0.1) > 1e-12) return 1;
+  // the shipped LQ model: host evaluation of xdot = Ax + Bu, 0.5(x'Qx + u'Ru)
+  ilqr_amd::LinearQuadratic lq(2, 1, {0, 1, -1, 0}, {0, 1}, {2, 0, 0, 2}, {4}, {2, 0, 0, 2}, -1, 1);
+  Eigen::VectorXd dx = lq.dynamics(x, u);
+  if (std::abs(dx(0) - 0.0) > 1e-15 || std::abs(dx(1) - (-0.1 + 0.5)) > 1e-15) return 4;
+  if (std::abs(lq.cost(x, u) - 0.5 * (2 * 0.01 + 4 * 0.25)) > 1e-15 || lq.device_model_id() != ILQR_MODEL_LQ) return 5;
   try { ilqr_amd::iLQR s(new Pendulum(), 0.02); ilqr_amd::VecOfVecXd u0(5, u); s.verbose = false; s.init_traj(x, u0); }
   catch (const std::runtime_error& e) { return std::string(e.what()).find("no HIP device") != std::string::npos ? 0 : 2; }
   return 3;
