@@ -97,16 +97,33 @@ struct LqModel {
       sb += vb[i + 1] * rb1;
     }
   }
+  // The running cost is a function of x plus a function of u.  A model that says so (kSeparableCost)
+  // lets the finite-difference sweep evaluate each part once per DISTINCT perturbed argument and
+  // assemble cost(x, u) = cost_from_parts(cost_x(x), cost_u(u)) -- the same arithmetic on the same
+  // values, so the same bits, from 2.6x fewer multiply-adds at n = 32, m = 16.
+#ifndef ILQR_LQ_SEPARABLE
+#define ILQR_LQ_SEPARABLE 1  // (0: experiment build that evaluates every point through cost(x, u))
+#endif
+  static constexpr bool kSeparableCost = ILQR_LQ_SEPARABLE != 0;
+  __device__ __forceinline__ double cost_x(const double* x) const { return quad<GN>((cmem_d*)Q, x); }
+  __device__ __forceinline__ double cost_u(const double* u) const { return quad<GM>((cmem_d*)R, u); }
+  __device__ __forceinline__ void cost_x2(const double* xa, const double* xb, double& qa, double& qb) const {
+    quad2<GN>((cmem_d*)Q, xa, xb, qa, qb);
+  }
+  __device__ __forceinline__ void cost_u2(const double* ua, const double* ub, double& qa, double& qb) const {
+    quad2<GM>((cmem_d*)R, ua, ub, qa, qb);
+  }
+  static __device__ __forceinline__ double cost_from_parts(double qx, double qu) { return 0.5 * (qx + qu); }
   __device__ __forceinline__ double cost(const double* x, const double* u) const {
-    return 0.5 * (quad<GN>((cmem_d*)Q, x) + quad<GM>((cmem_d*)R, u));
+    return cost_from_parts(cost_x(x), cost_u(u));
   }
   __device__ __forceinline__ void cost2(const double* xa, const double* ua, const double* xb, const double* ub, double& fa,
                                         double& fb) const {
     double qa, qb, ra, rb;
-    quad2<GN>((cmem_d*)Q, xa, xb, qa, qb);
-    quad2<GM>((cmem_d*)R, ua, ub, ra, rb);
-    fa = 0.5 * (qa + ra);
-    fb = 0.5 * (qb + rb);
+    cost_x2(xa, xb, qa, qb);
+    cost_u2(ua, ub, ra, rb);
+    fa = cost_from_parts(qa, ra);
+    fb = cost_from_parts(qb, rb);
   }
   __device__ __forceinline__ double final_cost(const double* x) const { return 0.5 * quad<GN>((cmem_d*)Qf, x); }
 };
@@ -284,6 +301,98 @@ __global__ __launch_bounds__(64) void k_derivatives_g(BatchView v, M model, int 
   } else {
     for (int e = lane; e < nx * nx + nx * nu; e += 64) D[oFX + e] = 0.0;  // fx[T], fu[T] stay zero
     for (int e = lane; e < nu; e += 64) D[oCU + e] = 0.0;                 // :50-51
+  }
+
+  // ---- cost derivatives of a separable running cost (t < T): every distinct argument once ----
+  if constexpr (M::kSeparableCost) {
+    if (!last) {
+      __shared__ double sx[2 * NX], su[2 * NU], s0[2];  // cost_x(x +- eps e_i), cost_u(u +- eps e_j), (cost_x(x), cost_u(u))
+      {
+        // x singles: lane e -> x + (-1)^e eps e_{e/2}
+        double px[NX], pu[NU];
+        perturbed(true, lane < 2 * nx ? (lane >> 1) : -1, (lane & 1) ? -kEps : kEps, true, -1, 0.0, px, pu);
+        const double qx = model.cost_x(px);
+        if (lane < 2 * nx) sx[lane] = qx;
+        // u singles on lanes 0..2nu-1, the two base values on the next two lanes
+        perturbed(false, lane < 2 * nu ? (lane >> 1) : -1, (lane & 1) ? -kEps : kEps, true, -1, 0.0, px, pu);
+        const double qu = model.cost_u(pu);
+        if (lane < 2 * nu) su[lane] = qu;
+        if (lane == 2 * nu) s0[1] = qu;  // (no perturbation applied on this lane: cost_u(u))
+        if (2 * nx < 64) {               // wave-uniform
+          if (lane == 2 * nx) s0[0] = qx;  // likewise cost_x(x)
+        } else {                         // nx = 32: no spare lane, one more (uniform) evaluation
+          double bx[NX];
+#pragma unroll
+          for (int c = 0; c < NX; c++) bx[c] = x[c];
+          const double q0 = model.cost_x(bx);
+          if (lane == 0) s0[0] = q0;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): one wavefront, LDS operations complete in order
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const double qx0 = s0[0], qu0 = s0[1];
+      // cx, cu (derivatives.cpp:44-47)
+      for (int i = lane; i < nx; i += 64)
+        D[oCX + i] = (M::cost_from_parts(sx[2 * i], qu0) - M::cost_from_parts(sx[2 * i + 1], qu0)) / (2 * kEps);
+      for (int j = lane; j < nu; j += 64)
+        D[oCU + j] = (M::cost_from_parts(qx0, su[2 * j]) - M::cost_from_parts(qx0, su[2 * j + 1])) / (2 * kEps);
+      // cxu (derivatives.cpp:114-144): c(px,pu) - c(mx,pu) - c(px,mu) + c(mx,mu)
+      for (int p = lane; p < nx * nu; p += 64) {
+        const int i = p / nu, j = p - i * nu;
+        const double v4 = M::cost_from_parts(sx[2 * i], su[2 * j]) - M::cost_from_parts(sx[2 * i + 1], su[2 * j]) -
+                          M::cost_from_parts(sx[2 * i], su[2 * j + 1]) + M::cost_from_parts(sx[2 * i + 1], su[2 * j + 1]);
+        D[oCXU + i + nx * j] = v4 / (4 * kEps * kEps);
+      }
+      // cxx, cuu: every point of the two Hessians is a distinct argument (finite_diff.h:67-86)
+      auto hessian = [&](auto on_x, int n, int oH, double other) __attribute__((always_inline)) {
+        constexpr bool X = decltype(on_x)::value;
+        const int npts = 2 * n * (n + 1);
+        for (int base = 0; base < npts; base += 128) {
+          double f[2];
+          int ii[2], jj[2], ee[2];
+          double pa[2][X ? NX : NU];
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int e = base + 64 * h + lane;
+            ee[h] = e;
+            int p = e >> 2, i = 0;
+            if (e < npts) {
+              while (p >= n - i) {
+                p -= n - i;
+                i++;
+              }
+            } else {
+              p = 0;
+            }
+            ii[h] = (e < npts) ? i : -1;
+            jj[h] = (e < npts) ? i + p : -1;
+            const double d1 = (e & 1) ? -kEps : kEps, d2 = (e & 2) ? -kEps : kEps;
+            double px[NX], pu[NU];
+            perturbed(X, ii[h], d1, X, jj[h], d2, px, pu);
+#pragma unroll
+            for (int c = 0; c < (X ? NX : NU); c++) pa[h][c] = X ? px[c] : pu[c];
+          }
+          if constexpr (X)
+            model.cost_x2(pa[0], pa[1], f[0], f[1]);
+          else
+            model.cost_u2(pa[0], pa[1], f[0], f[1]);
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const double fv = X ? M::cost_from_parts(f[h], other) : M::cost_from_parts(other, f[h]);
+            const double f0 = quad_bcast<0>(fv), f1 = quad_bcast<1>(fv), f2 = quad_bcast<2>(fv), f3 = quad_bcast<3>(fv);
+            if (ee[h] < npts && (ee[h] & 3) == 0) {
+              const double val = (f0 - f1 - f2 + f3) / (4 * kEps * kEps);
+              D[oH + ii[h] + n * jj[h]] = val;
+              D[oH + jj[h] + n * ii[h]] = val;
+            }
+          }
+        }
+      };
+      hessian(std::true_type{}, nx, oCXX, qu0);
+      hessian(std::false_type{}, nu, oCUU, qx0);
+      return;
+    }
   }
 
   // ---- scalar-valued evaluations: one list, groups aligned to quads ----
