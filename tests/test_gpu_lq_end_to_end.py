@@ -43,7 +43,8 @@ def make(oracle, mats, B, T, lim=1.0, flags=0):
     return om, g
 
 
-@pytest.mark.parametrize("n,m,B,T,dense", [(32, 16, 6, 12, False), (32, 16, 4, 8, True), (6, 3, 40, 25, True), (5, 2, 70, 9, True)])
+@pytest.mark.parametrize("n,m,B,T,dense", [(32, 16, 6, 12, False), (32, 16, 4, 8, True), (6, 3, 40, 25, True), (5, 2, 70, 9, True),
+                                            (1, 1, 3, 1, True), (2, 16, 5, 2, True), (31, 1, 2, 3, True)])
 def test_lq_stages_match_oracle(oracle, n, m, B, T, dense):
     mats = dense_mats(n, m) if dense else lq_mats(n, m)
     om, g = make(oracle, mats, B, T)
