@@ -236,15 +236,20 @@ static int scalars_to_dev(ilqr_batch* h, const T* host, T* dev) {
 // cand = true: controls + checkpoint states go to the candidate buffers; false: straight into xs/us (init)
 template <class M>
 static int launch_rollout_t(ilqr_batch* h, const M& m, bool gains, bool cand, const AlphaSet& al, int n_alpha,
-                            double* cost_out, int mode) {
+                            double* cost_out, int mode, bool with_accept) {
   const int aw = (n_alpha + 3) / 4;  // wavefronts per tile: 4 alphas each
   dim3 grid(h->ntiles), block(64 * aw);
-  if (gains && cand && h->ntiles <= h->num_cus)  // one block per CU: deep prefetch (see k_rollout)
-    hipLaunchKernelGGL((k_rollout<M, true, true, 8>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode);
+  const bool deep = h->ntiles <= h->num_cus;  // one block per CU: deep prefetch (see k_rollout)
+  if (gains && cand && with_accept && deep)
+    hipLaunchKernelGGL((k_rollout<M, true, true, 8, true>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode, h->sp, h->commit_idx);
+  else if (gains && cand && with_accept)
+    hipLaunchKernelGGL((k_rollout<M, true, true, 4, true>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode, h->sp, h->commit_idx);
+  else if (gains && cand && deep)
+    hipLaunchKernelGGL((k_rollout<M, true, true, 8>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode, h->sp, nullptr);
   else if (gains && cand)
-    hipLaunchKernelGGL((k_rollout<M, true, true, 4>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode);
+    hipLaunchKernelGGL((k_rollout<M, true, true, 4>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode, h->sp, nullptr);
   else if (!gains && !cand)
-    hipLaunchKernelGGL((k_rollout<M, false, false>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode);
+    hipLaunchKernelGGL((k_rollout<M, false, false>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode, h->sp, nullptr);
   else
     return fail(ILQR_ERR_INVALID, "unsupported rollout variant");
   HIPCHK(hipGetLastError());
@@ -265,7 +270,9 @@ static int launch_rollout_g(ilqr_batch* h, const M& m, int what, const AlphaSet&
   return 0;
 }
 
-static int launch_rollout(ilqr_batch* h, bool gains, bool cand, const AlphaSet& al, int n_alpha, double* cost_out, int mode) {
+// with_accept (tiled models, 11-alpha search): the rollout kernel also does STEP 3/4 for its tile
+static int launch_rollout(ilqr_batch* h, bool gains, bool cand, const AlphaSet& al, int n_alpha, double* cost_out, int mode,
+                          bool with_accept = false) {
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_ROLLOUT, &ev)) return rc;
   int rc;
@@ -280,8 +287,8 @@ static int launch_rollout(ilqr_batch* h, bool gains, bool cand, const AlphaSet& 
     return timer_end(h, ILQR_STAGE_ROLLOUT, ev);
   }
   switch (h->model) {
-    case ILQR_MODEL_ACROBOT: rc = launch_rollout_t(h, h->acrobot, gains, cand, al, n_alpha, cost_out, mode); break;
-    case ILQR_MODEL_DOUBLE_INTEGRATOR: rc = launch_rollout_t(h, h->dint, gains, cand, al, n_alpha, cost_out, mode); break;
+    case ILQR_MODEL_ACROBOT: rc = launch_rollout_t(h, h->acrobot, gains, cand, al, n_alpha, cost_out, mode, with_accept); break;
+    case ILQR_MODEL_DOUBLE_INTEGRATOR: rc = launch_rollout_t(h, h->dint, gains, cand, al, n_alpha, cost_out, mode, with_accept); break;
     default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device rollout", h->model);
   }
   if (rc) return rc;
@@ -735,8 +742,13 @@ int ilqr_iterate(ilqr_batch* h, int n_iters) {
       if (int rc = launch_derivatives(h, h->sp.fixed_work)) return rc;  // STEP 1
       if (int rc = launch_backward(h, 1)) return rc;                    // STEP 2
     }
-    if (int rc = do_rollout_candidates(h, 1)) return rc;              // STEP 3
-    if (int rc = launch_accept(h)) return rc;                         // STEP 3/4
+    if (!h->aos) {  // STEP 3 + STEP 3/4 in one launch: the rollout block of a tile also accepts for it
+      if (int rc = launch_rollout(h, true, true, line_search_alphas(), NALPHA, h->v.cost_c, 1, true)) return rc;
+      h->commit_pending = true;
+    } else {
+      if (int rc = do_rollout_candidates(h, 1)) return rc;              // STEP 3
+      if (int rc = launch_accept(h)) return rc;                         // STEP 3/4
+    }
   }
   return flush_commit(h);  // the last iteration's accepted trajectories
 }

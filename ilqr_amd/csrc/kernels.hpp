@@ -97,6 +97,70 @@ __global__ void k_reset_state(BatchView v, double lambda0, double dlambda0) {
 // ------------------------------------------------------------------------------------------
 // forward rollout
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// line-search selection + lambda schedule + termination (ilqr_core.cpp:185-282)
+// ------------------------------------------------------------------------------------------
+// STEP 3/4 for trajectory b; cost_of(a) = cost of its candidate a
+template <class CostOf>
+__device__ __forceinline__ void accept_one(const BatchView& v, const SolverParams& sp, int b, CostOf cost_of,
+                                           int* __restrict__ commit_idx) {
+  if (b >= v.Bp) return;
+  int commit = -1;
+  if (b < v.B && v.status[b] == 0) {
+    double lambda = v.lambda[b], dlambda = v.dlambda[b];
+    const double cost_s = v.cost[b];
+    bool fwd = false;
+    double new_cost = 0, dcost = 0;
+    int acc = -1;
+    if (v.backpass_done[b]) {  // :184
+      const double dV0 = v.dV[b], dV1 = v.dV[v.Bp + b];
+      for (int a = 0; a < NALPHA; a++) {  // the serial order of :185-220, first z > zMin wins
+        const double alpha = kAlpha[a];
+        new_cost = cost_of(a);
+        dcost = cost_s - new_cost;                          // :199
+        const double expected = -alpha * (dV0 + alpha * dV1);  // :200
+        double z;
+        if (expected > 0)
+          z = dcost / expected;
+        else
+          z = (double)((0.0 < dcost) - (dcost < 0.0));  // sgn, common.h:52
+        if (z > sp.z_min) {
+          fwd = true;
+          acc = a;
+          break;
+        }
+      }
+    }
+    int status = 0;
+    if (fwd) {  // :242-263
+      dlambda = fmin(dlambda / sp.lambda_factor, 1 / sp.lambda_factor);
+      lambda = lambda * dlambda * (lambda > sp.lambda_min ? 1.0 : 0.0);
+      v.cost[b] = new_cost;
+      v.flg_change[b] = 1;
+      commit = acc;
+      if (!sp.fixed_work && dcost < sp.tol_fun) status = 2;
+    } else {  // :264-282
+      dlambda = fmax(dlambda * sp.lambda_factor, sp.lambda_factor);
+      lambda = fmax(lambda * dlambda, sp.lambda_min);
+      v.flg_change[b] = 0;
+      if (!sp.fixed_work && lambda > sp.lambda_max) status = 3;
+    }
+    v.lambda[b] = lambda;
+    v.dlambda[b] = dlambda;
+    v.alpha_idx[b] = acc;
+    const int it = v.iters[b] + 1;
+    v.iters[b] = it;
+    if (status == 0 && it >= sp.max_iter) status = 4;  // :103
+    v.status[b] = status;
+    if (status == 0) atomicAdd(v.n_running, 1);
+  }
+  commit_idx[b] = commit;
+}
+__global__ void k_accept(BatchView v, SolverParams sp, int* __restrict__ commit_idx) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  accept_one(v, sp, b, [&](int a) { return v.cost_c[(size_t)a * v.Bp + b]; }, commit_idx);
+}
+
 struct AlphaSet {
   double a[NALPHA];
 };
@@ -112,9 +176,13 @@ struct AlphaSet {
 //   CAND=true   : candidate `a` keeps every u_t and the state at every CT-th knot (common.hpp)
 // The cost goes to cost_out[a][b].  mode: 0 = all trajectories, 1 = only running ones whose
 // backward pass succeeded.
-template <class M, bool GAINS, bool CAND, int PD = 4>
+// ACCEPT: the block also performs STEP 3/4 for its 16 trajectories once its three wavefronts have
+// their costs (k_accept's work without a launch of its own; sp, commit_idx are only used then).
+template <class M, bool GAINS, bool CAND, int PD = 4, bool ACCEPT = false>
 __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet alphas, int n_alpha,
-                                                 double* __restrict__ cost_out, int mode) {
+                                                 double* __restrict__ cost_out, int mode, SolverParams sp,
+                                                 int* __restrict__ commit_idx) {
+  __shared__ double lds_cost[ACCEPT ? NALPHA * TW : 1];
   constexpr int NX = M::NX, NU = M::NU;
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
@@ -125,7 +193,8 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
   const int b = tile * TW + l;
   bool active = (b < v.B) && (a < n_alpha);
   if (active && mode == 1) active = (v.status[b] == 0 && v.backpass_done[b]);
-  if (!active) return;
+  if (!ACCEPT && !active) return;
+  if (active) {
   const int T = v.T;
   const double alpha = alphas.a[a < NALPHA ? a : NALPHA - 1];
   const double dt = v.dt;
@@ -240,6 +309,13 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
 #endif
   total += model.final_cost(x);  // :335
   cost_out[(size_t)a * v.Bp + b] = total;
+  if (ACCEPT) lds_cost[a * TW + l] = total;
+  }  // if (active)
+  if constexpr (ACCEPT) {
+    __syncthreads();
+    if (threadIdx.x < TW)
+      accept_one(v, sp, tile * TW + (int)threadIdx.x, [&](int aa) { return lds_cost[aa * TW + threadIdx.x]; }, commit_idx);
+  }
 }
 
 // Knot t of candidate `a` of trajectory (tile, l): the control as stored, the state re-integrated
@@ -1560,63 +1636,8 @@ __global__ __launch_bounds__(64 * (1 + kProducers)) void k_sweep_backward(BatchV
 }
 
 // ------------------------------------------------------------------------------------------
-// line-search selection + lambda schedule + termination (one thread per trajectory)
+// commit of an accepted candidate
 // ------------------------------------------------------------------------------------------
-__global__ void k_accept(BatchView v, SolverParams sp, int* __restrict__ commit_idx) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= v.Bp) return;
-  int commit = -1;
-  if (b < v.B && v.status[b] == 0) {
-    double lambda = v.lambda[b], dlambda = v.dlambda[b];
-    const double cost_s = v.cost[b];
-    bool fwd = false;
-    double new_cost = 0, dcost = 0;
-    int acc = -1;
-    if (v.backpass_done[b]) {  // :184
-      const double dV0 = v.dV[b], dV1 = v.dV[v.Bp + b];
-      for (int a = 0; a < NALPHA; a++) {  // the serial order of :185-220, first z > zMin wins
-        const double alpha = kAlpha[a];
-        new_cost = v.cost_c[(size_t)a * v.Bp + b];
-        dcost = cost_s - new_cost;                          // :199
-        const double expected = -alpha * (dV0 + alpha * dV1);  // :200
-        double z;
-        if (expected > 0)
-          z = dcost / expected;
-        else
-          z = (double)((0.0 < dcost) - (dcost < 0.0));  // sgn, common.h:52
-        if (z > sp.z_min) {
-          fwd = true;
-          acc = a;
-          break;
-        }
-      }
-    }
-    int status = 0;
-    if (fwd) {  // :242-263
-      dlambda = fmin(dlambda / sp.lambda_factor, 1 / sp.lambda_factor);
-      lambda = lambda * dlambda * (lambda > sp.lambda_min ? 1.0 : 0.0);
-      v.cost[b] = new_cost;
-      v.flg_change[b] = 1;
-      commit = acc;
-      if (!sp.fixed_work && dcost < sp.tol_fun) status = 2;
-    } else {  // :264-282
-      dlambda = fmax(dlambda * sp.lambda_factor, sp.lambda_factor);
-      lambda = fmax(lambda * dlambda, sp.lambda_min);
-      v.flg_change[b] = 0;
-      if (!sp.fixed_work && lambda > sp.lambda_max) status = 3;
-    }
-    v.lambda[b] = lambda;
-    v.dlambda[b] = dlambda;
-    v.alpha_idx[b] = acc;
-    const int it = v.iters[b] + 1;
-    v.iters[b] = it;
-    if (status == 0 && it >= sp.max_iter) status = 4;  // :103
-    v.status[b] = status;
-    if (status == 0) atomicAdd(v.n_running, 1);
-  }
-  commit_idx[b] = commit;
-}
-
 // copy candidate commit_idx[b] into the nominal trajectory.  block 256 = 16 traj x 16 steps.
 template <class M>
 __global__ __launch_bounds__(256) void k_commit(BatchView v, M model, const int* __restrict__ commit_idx) {
