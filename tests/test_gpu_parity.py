@@ -132,6 +132,41 @@ def test_backward_teacher_forced(oracle, name, B, T, lim, lam):
         assert np.all(K[ok][clamped[ok]] == 0)
 
 
+@pytest.mark.parametrize("iters", [25, 45])
+def test_backward_teacher_forced_late_in_a_solve(oracle, iters):
+    """The state a solve is in after 25 / 45 iterations (lambda = 0 for most trajectories, Quu up to
+    1e14, box-QPs whose search direction is rounding noise, controls on the bounds): the oracle's
+    trajectories, gains and lambdas go in, one backward pass comes out.  This is where the scalar
+    QP leaves its two-iteration fast path (qp1_continue) and where the exact shortcuts for line
+    searches that can only run out apply."""
+    name, B, T, lim = "acrobot", 48, 499, 1.5  # the bench workload's horizon and limits
+    om, g, x0 = make(oracle, name, B, T, lim)
+    ro0 = oracle.batch_solve(om, x0, np.zeros((B, T, 1)), DT, max_iters=iters, fixed_work=True)
+    xs_o, us_o, lam = ro0["xs"], ro0["us"], ro0["lam"]
+    k_prev = ro0["k"]
+    do = oracle.batch_derivatives(om, xs_o, us_o, DT)
+    ro = oracle.batch_backward(om, us_o, do, k_prev=k_prev, lam=lam)
+    g.set_trajectory(x0=x0, xs=xs_o, us=us_o, cost=ro0["cost"])
+    g.set_derivatives(**{k: (do[k] if k in ("cx", "cu") else mat(do[k])) for k in do})
+    g.set_gains(k=k_prev, K=np.zeros((B, T, 1, 4)))
+    g.set_lambda(lam, 1.0)
+    div = g.backward_pass()
+    k, K = g.gains()
+    dV = g.dV()
+    Ko = mat(ro["K"])
+    lo, hi = om.u_min[None, None, :] - us_o, om.u_max[None, None, :] - us_o
+    conv = ro["diverge"] == 0
+    assert conv.mean() > 0.5 and (lam == 0).mean() > 0.2, (conv.mean(), (lam == 0).mean())
+    err = np.maximum.reduce([_per_traj_err(k, ro["k"]), _per_traj_err(K, Ko), _per_traj_err(dV, ro["dV"])])
+    good = (err < TOL) & (div == ro["diverge"])
+    ties = 0
+    for b in np.flatnonzero(conv & ~good):
+        assert _is_clamp_knife_edge(k[b], K[b], ro["k"][b], Ko[b], lo[b], hi[b]), (b, err[b])
+        ties += 1
+    assert ties <= B // 8, ties
+    assert np.array_equal(div[good | ~conv], ro["diverge"][good | ~conv])
+
+
 @pytest.mark.parametrize("name,B,T,lim", CASES)
 def test_rollout_candidates_teacher_forced(oracle, name, B, T, lim):
     om, g, x0 = make(oracle, name, B, T, lim)
