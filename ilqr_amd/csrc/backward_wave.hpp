@@ -32,11 +32,24 @@ constexpr int WN = 32, WM = 16;   // maximum dimensions of this kernel
 constexpr int LDN = WN + 1;       // leading dimension of LDS matrices with up to 32 rows
 constexpr int LDM = WM + 1;       // ... with up to 16 rows
 
+// Four matrices share storage with ones that are dead by the time they are written, which brings a
+// wavefront's LDS from 68 KB to 49 KB, i.e. from two to three wavefronts per CU (160 KB):
+//   Qxx  in Vxx : Vxx' is last read for A1 = fx'Vxx' and A2 = fu'Vxx'; Qxx is written after both and
+//                 read once, when Vn is assembled into A1; the new Vxx then overwrites it
+//   T1   in fu  : fu is last read for Quu (before the box-QP); T1 = K'Quu is written after it; the
+//                 next step refills fu completely
+//   K    in A2  : A2 is last read for Qux / Quu; K is written after the box-QP (A2's padding
+//                 columns are exact zeros, as K's must be)
+//   Ri   in Qf  : Qf (the Cholesky work copy) is dead once R has been taken from it
 struct WaveLds {
-  double Vxx[LDN * WN], fx[LDN * WN], A1[LDN * WN], Qxx[LDN * WN];
-  double fu[LDN * WM], T1[LDN * WM];
-  double A2[LDM * WN], Qux[LDM * WN], K[LDM * WN];
-  double Quu[LDM * WM], QuuF[LDM * WM], Qf[LDM * WM], R[LDM * WM], Ri[LDM * WM], Minv[LDM * WM];
+  double Vxx[LDN * WN], fx[LDN * WN], A1[LDN * WN];
+  double fu[LDN * WM];
+  double A2[LDM * WN], Qux[LDM * WN];
+  double Quu[LDM * WM], QuuF[LDM * WM], Qf[LDM * WM], R[LDM * WM], Minv[LDM * WM];
+  __device__ __forceinline__ double* Qxx() { return Vxx; }
+  __device__ __forceinline__ double* T1() { return fu; }
+  __device__ __forceinline__ double* K() { return A2; }
+  __device__ __forceinline__ double* Ri() { return Qf; }
   double Vx[WN], Qx[WN], Vxn[WN];
   double Qu[WM], x[WM], grad[WM], gc[WM], search[WM], lo[WM], hi[WM], clamped[WM], oldcl[WM], xr[WM], xc[WM], tmp[WM],
       kprev[WM], gfree[WM], xfree[WM];
@@ -210,19 +223,19 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
     // Ri = R^-1 (upper triangular, column j on lane j), Minv = Ri Ri'
     if (lane < nfR) {
       const int j = lane;
-      for (int i = 0; i < nfR; i++) L.Ri[i + LDM * j] = 0;
-      L.Ri[j + LDM * j] = 1.0 / L.R[j + LDM * j];
+      for (int i = 0; i < nfR; i++) L.Ri()[i + LDM * j] = 0;
+      L.Ri()[j + LDM * j] = 1.0 / L.R[j + LDM * j];
       for (int i = j - 1; i >= 0; i--) {
         double s = 0;
-        for (int l2 = i + 1; l2 <= j; l2++) s += L.R[i + LDM * l2] * L.Ri[l2 + LDM * j];
-        L.Ri[i + LDM * j] = -s / L.R[i + LDM * i];
+        for (int l2 = i + 1; l2 <= j; l2++) s += L.R[i + LDM * l2] * L.Ri()[l2 + LDM * j];
+        L.Ri()[i + LDM * j] = -s / L.R[i + LDM * i];
       }
     }
     lds_sync();
     for (int e = lane; e < nfR * nfR; e += 64) {
       const int a = e % nfR, b2 = e / nfR;
       double s = 0;
-      for (int l2 = 0; l2 < nfR; l2++) s += L.Ri[a + LDM * l2] * L.Ri[b2 + LDM * l2];
+      for (int l2 = 0; l2 < nfR; l2++) s += L.Ri()[a + LDM * l2] * L.Ri()[b2 + LDM * l2];
       L.Minv[a + LDM * b2] = s;
     }
     if (lane < m) {
@@ -451,7 +464,7 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
 #pragma unroll
           for (int rr = 0; rr < 4; rr++) {
             const int a = ti * 16 + orow + 4 * rr, c = tj * 16 + ocol;
-            L.Qxx[a + LDN * c] = (a < n && c < n) ? rec.cxx[(ti * 2 + tj) * 4 + rr] + acc[rr] : 0.0;
+            L.Qxx()[a + LDN * c] = (a < n && c < n) ? rec.cxx[(ti * 2 + tj) * 4 + rr] + acc[rr] : 0.0;
           }
         }
 #pragma unroll
@@ -488,7 +501,7 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
         break;
       }
       // :373-385  K rows of free dims
-      for (int c = lane >> 4; c < n; c += 4) L.K[(lane & 15) + LDM * c] = 0;
+      for (int c = lane >> 4; c < n; c += 4) L.K()[(lane & 15) + LDM * c] = 0;
       const unsigned long long free_mask = __ballot(lane < m && L.vfree[lane]);
       const int nf = __popcll(free_mask);
       if (lane < m && L.vfree[lane]) L.idx[__popcll(free_mask & ((1ull << lane) - 1ull))] = lane;
@@ -496,19 +509,19 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
       if (nf > 0) {
         if (lane < nfR) {
           const int j = lane;
-          for (int i2 = 0; i2 < nfR; i2++) L.Ri[i2 + LDM * j] = 0;
-          L.Ri[j + LDM * j] = 1.0 / L.R[j + LDM * j];
+          for (int i2 = 0; i2 < nfR; i2++) L.Ri()[i2 + LDM * j] = 0;
+          L.Ri()[j + LDM * j] = 1.0 / L.R[j + LDM * j];
           for (int i2 = j - 1; i2 >= 0; i2--) {
             double s = 0;
-            for (int l2 = i2 + 1; l2 <= j; l2++) s += L.R[i2 + LDM * l2] * L.Ri[l2 + LDM * j];
-            L.Ri[i2 + LDM * j] = -s / L.R[i2 + LDM * i2];
+            for (int l2 = i2 + 1; l2 <= j; l2++) s += L.R[i2 + LDM * l2] * L.Ri()[l2 + LDM * j];
+            L.Ri()[i2 + LDM * j] = -s / L.R[i2 + LDM * i2];
           }
         }
         lds_sync();
         for (int e = lane; e < nfR * nfR; e += 64) {
           const int a = e % nfR, b2 = e / nfR;
           double s = 0;
-          for (int l2 = 0; l2 < nfR; l2++) s += L.Ri[a + LDM * l2] * L.Ri[b2 + LDM * l2];
+          for (int l2 = 0; l2 < nfR; l2++) s += L.Ri()[a + LDM * l2] * L.Ri()[b2 + LDM * l2];
           L.Minv[a + LDM * b2] = s;
         }
         lds_sync();
@@ -517,7 +530,7 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
           const int rr = e % nuse, c = e / nuse;
           double acc = 0;
           for (int l2 = 0; l2 < nuse; l2++) acc += -L.Minv[rr + LDM * l2] * L.Qux[L.idx[l2] + LDM * c];
-          L.K[L.idx[rr] + LDM * c] = acc;
+          L.K()[L.idx[rr] + LDM * c] = acc;
         }
       }
       lds_sync();
@@ -539,17 +552,17 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
       for (int ti = 0; ti < 2; ti++) {
         if (ti >= NT) continue;
         const double4_t acc = mfma_tile<WM / 4>(
-            [&](int i2, int k) { return L.K[k + LDM * (ti * 16 + i2)]; }, [&](int k, int j) { return L.Quu[k + LDM * j]; },
+            [&](int i2, int k) { return L.K()[k + LDM * (ti * 16 + i2)]; }, [&](int k, int j) { return L.Quu[k + LDM * j]; },
             lane);
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) L.T1[(ti * 16 + orow + 4 * rr) + LDN * ocol] = acc[rr];
+        for (int rr = 0; rr < 4; rr++) L.T1()[(ti * 16 + orow + 4 * rr) + LDN * ocol] = acc[rr];
       }
       lds_sync();
       // :391 Vx ; :392 Vn = ((Qxx + T1 K) + K'Qux) + Qux'K into A1 ; :393 symmetrise into Vxx
       for (int a = lane; a < n; a += 64) {
         double t1 = 0, t2 = 0, t3 = 0;
-        for (int c = 0; c < m; c++) t1 += L.T1[a + LDN * c] * L.x[c];
-        for (int c = 0; c < m; c++) t2 += L.K[c + LDM * a] * L.Qu[c];
+        for (int c = 0; c < m; c++) t1 += L.T1()[a + LDN * c] * L.x[c];
+        for (int c = 0; c < m; c++) t2 += L.K()[c + LDM * a] * L.Qu[c];
         for (int c = 0; c < m; c++) t3 += L.Qux[c + LDM * a] * L.x[c];
         L.Vxn[a] = ((L.Qx[a] + t1) + t2) + t3;
       }
@@ -559,18 +572,18 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
         for (int tj = 0; tj < 2; tj++) {
           if (ti >= NT || tj >= NT) continue;
           const double4_t t1 = mfma_tile<WM / 4>(
-              [&](int i2, int k) { return L.T1[(ti * 16 + i2) + LDN * k]; },
-              [&](int k, int j) { return L.K[k + LDM * (tj * 16 + j)]; }, lane);
+              [&](int i2, int k) { return L.T1()[(ti * 16 + i2) + LDN * k]; },
+              [&](int k, int j) { return L.K()[k + LDM * (tj * 16 + j)]; }, lane);
           const double4_t t2 = mfma_tile<WM / 4>(
-              [&](int i2, int k) { return L.K[k + LDM * (ti * 16 + i2)]; },
+              [&](int i2, int k) { return L.K()[k + LDM * (ti * 16 + i2)]; },
               [&](int k, int j) { return L.Qux[k + LDM * (tj * 16 + j)]; }, lane);
           const double4_t t3 = mfma_tile<WM / 4>(
               [&](int i2, int k) { return L.Qux[k + LDM * (ti * 16 + i2)]; },
-              [&](int k, int j) { return L.K[k + LDM * (tj * 16 + j)]; }, lane);
+              [&](int k, int j) { return L.K()[k + LDM * (tj * 16 + j)]; }, lane);
 #pragma unroll
           for (int rr = 0; rr < 4; rr++) {
             const int a = ti * 16 + orow + 4 * rr, c = tj * 16 + ocol;
-            L.A1[a + LDN * c] = ((L.Qxx[a + LDN * c] + t1[rr]) + t2[rr]) + t3[rr];
+            L.A1[a + LDN * c] = ((L.Qxx()[a + LDN * c] + t1[rr]) + t2[rr]) + t3[rr];
           }
         }
       lds_sync();
@@ -592,7 +605,7 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
         L.kprev[lane] = L.x[lane];
       }
       for (int c = lane >> 4; c < n; c += 4)
-        if ((lane & 15) < m) Kb[(size_t)i * m * n + (lane & 15) + m * c] = L.K[(lane & 15) + LDM * c];
+        if ((lane & 15) < m) Kb[(size_t)i * m * n + (lane & 15) + m * c] = L.K()[(lane & 15) + LDM * c];
       lds_sync();
     }
 #ifdef ILQR_PHASE_TIMING
