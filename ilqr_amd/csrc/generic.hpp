@@ -148,6 +148,13 @@ struct LqModel {
     quad2<GM>((cmem_d*)R, ua, ub, qa, qb);
   }
   static __device__ __forceinline__ double cost_from_parts(double qx, double qu) { return 0.5 * (qx + qu); }
+  // cost_x is a quadratic form x'Mx with this (zero-padded, row-major) matrix: the 2n(n+1) points of
+  // the cxx sweep can then go through the matrix cores as one [32 x 32] x [32 x points] product
+#ifndef ILQR_LQ_MFMA_CXX
+#define ILQR_LQ_MFMA_CXX 1
+#endif
+  static constexpr bool kQuadraticCostX = ILQR_LQ_MFMA_CXX != 0;
+  __device__ __forceinline__ cmem_d* cost_x_matrix() const { return (cmem_d*)Q; }
   __device__ __forceinline__ double cost(const double* x, const double* u) const {
     return cost_from_parts(cost_x(x), cost_u(u));
   }
@@ -429,7 +436,90 @@ __global__ __launch_bounds__(64) void k_derivatives_g(BatchView v, M model, int 
           }
         }
       };
-      hessian(std::true_type{}, std::integral_constant<int, ILQR_FD_POINTS_X>{}, nx, oCXX, qu0);
+      if constexpr (M::kQuadraticCostX && NX == 32) {
+        // cxx on the matrix cores.  Y = Q P for 16 points at a time (v_mfma_f64_16x16x4_f64: two
+        // 16-row blocks of Q x eight k-steps), then f_j = p_j . y_j.  Lane l = (kq = l >> 4, j = l & 15)
+        // supplies A = Q[16 ib + j][4 ks + kq] (resident in registers for the whole kernel) and
+        // B = component 4 ks + kq of point j, built from the knot and the point's two perturbations;
+        // it receives rows kq + 4 r (+16) of y_j, i.e. exactly the components it supplied.  Same
+        // points, same Q as the VALU route; the sums inside a form run in the MFMA's order.
+        typedef double double4_t __attribute__((ext_vector_type(4)));
+        cmem_d* Qm = model.cost_x_matrix();
+        const int j16 = lane & 15, kq = lane >> 4;
+        double qa[2][8], xb[8];
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) qa[ib][ks] = ((const double*)model.Q)[(16 * ib + j16) * GN + 4 * ks + kq];
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {  // x[4 ks + kq] without indexing the register array by kq
+          const double a0 = x[4 * ks], a1 = x[4 * ks + 1], a2 = x[4 * ks + 2], a3 = x[4 * ks + 3];
+          xb[ks] = (kq == 0) ? a0 : (kq == 1) ? a1 : (kq == 2) ? a2 : a3;
+        }
+        (void)Qm;
+        const int npts = 2 * nx * (nx + 1);
+        // this lane's pair (i, i + rem) of the upper triangle, advanced incrementally: a tile of 16
+        // points is 4 pairs x 4 sign combinations, two tiles are in flight per trip (four
+        // independent accumulator chains for the MFMA pipe)
+        int pi = 0, prem = j16 >> 2;
+        auto normalise = [&](int& i, int& rem) __attribute__((always_inline)) {
+          while (i < nx && rem >= nx - i) {
+            rem -= nx - i;
+            i++;
+          }
+        };
+        normalise(pi, prem);
+        for (int base = 0; base < npts; base += 32) {
+          int ti[2], tj[2], te[2];
+          double bv[2][8];
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int e = base + 16 * h + j16;
+            te[h] = e;
+            ti[h] = (e < npts) ? pi : -1;
+            tj[h] = (e < npts) ? pi + prem : -1;
+            const double d1 = (e & 1) ? -kEps : kEps, d2 = (e & 2) ? -kEps : kEps;
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) {
+              const int comp = 4 * ks + kq;
+              double val = xb[ks];
+              val = (comp == ti[h]) ? val + d1 : val;
+              val = (comp == tj[h]) ? val + d2 : val;
+              bv[h][ks] = val;
+            }
+            prem += 4;  // the next tile's pair
+            normalise(pi, prem);
+          }
+          double4_t y[2][2] = {{{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}};
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              y[h][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[0][ks], bv[h][ks], y[h][0], 0, 0, 0);
+              y[h][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[1][ks], bv[h][ks], y[h][1], 0, 0, 0);
+            }
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            // y[h][0][r] = (Q p)[kq + 4 r], y[h][1][r] = (Q p)[16 + kq + 4 r]; matching components bv[r], bv[4 + r]
+            double part = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) part += bv[h][r] * y[h][0][r];
+#pragma unroll
+            for (int r = 0; r < 4; r++) part += bv[h][4 + r] * y[h][1][r];
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);  // p' Q p in the four lanes of the point's column
+            const double fv = M::cost_from_parts(part, qu0);
+            const double f0 = quad_bcast<0>(fv), f1 = quad_bcast<1>(fv), f2 = quad_bcast<2>(fv), f3 = quad_bcast<3>(fv);
+            if (te[h] < npts && (te[h] & 3) == 0 && kq == 0) {
+              const double val = (f0 - f1 - f2 + f3) / (4 * kEps * kEps);
+              D[oCXX + ti[h] + nx * tj[h]] = val;
+              D[oCXX + tj[h] + nx * ti[h]] = val;
+            }
+          }
+        }
+      } else {
+        hessian(std::true_type{}, std::integral_constant<int, ILQR_FD_POINTS_X>{}, nx, oCXX, qu0);
+      }
       hessian(std::false_type{}, std::integral_constant<int, 2>{}, nu, oCUU, qx0);
       return;
     }
