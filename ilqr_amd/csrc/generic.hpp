@@ -348,26 +348,103 @@ __global__ __launch_bounds__(64) void k_derivatives_g(BatchView v, M model, int 
   if constexpr (M::kSeparableCost) {
     if (!last) {
       __shared__ double sx[2 * NX], su[2 * NU], s0[2];  // cost_x(x +- eps e_i), cost_u(u +- eps e_j), (cost_x(x), cost_u(u))
+      // Matrix-core evaluation of x'Qx for models that expose Q (kQuadraticCostX): Y = Q P for 16
+      // points at a time (v_mfma_f64_16x16x4_f64: two 16-row blocks of Q x eight k-steps), then
+      // f_j = p_j . y_j.  Lane l = (kq = l >> 4, j = l & 15) supplies A = Q[16 ib + j][4 ks + kq]
+      // (resident in registers for the whole kernel) and B = component 4 ks + kq of point j, built
+      // from the knot and the point's perturbations; it receives rows kq + 4 r (+16) of y_j, i.e.
+      // exactly the components it supplied.  Two tiles = four accumulator chains are in flight.
+      typedef double double4_t __attribute__((ext_vector_type(4)));
+      const int j16 = lane & 15, kq = lane >> 4;
+      double qa[2][8], xb[8];
+      if constexpr (M::kQuadraticCostX) {
+        cmem_d* Qm = model.cost_x_matrix();
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) qa[ib][ks] = ((const double*)Qm)[(16 * ib + j16) * NX + 4 * ks + kq];
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {  // x[4 ks + kq] without indexing the register array by kq
+          const double a0 = x[4 * ks], a1 = x[4 * ks + 1], a2 = x[4 * ks + 2], a3 = x[4 * ks + 3];
+          xb[ks] = (kq == 0) ? a0 : (kq == 1) ? a1 : (kq == 2) ? a2 : a3;
+        }
+      }
+      // points (h = 0, 1): knot with component i1 += d1, then component i2 += d2 (index -1: none);
+      // returns p'Qp of each in all four lanes of the point's column
+      auto forms2 = [&](const int* i1, const double* d1, const int* i2, const double* d2, double* out) __attribute__((always_inline)) {
+        double bv[2][8];
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) {
+            const int comp = 4 * ks + kq;
+            double val = xb[ks];
+            val = (comp == i1[h]) ? val + d1[h] : val;
+            val = (comp == i2[h]) ? val + d2[h] : val;
+            bv[h][ks] = val;
+          }
+        double4_t y[2][2] = {{{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}};
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            y[h][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[0][ks], bv[h][ks], y[h][0], 0, 0, 0);
+            y[h][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[1][ks], bv[h][ks], y[h][1], 0, 0, 0);
+          }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          // y[h][0][r] = (Q p)[kq + 4 r], y[h][1][r] = (Q p)[16 + kq + 4 r]; matching components bv[r], bv[4 + r]
+          double part = 0;
+#pragma unroll
+          for (int r = 0; r < 4; r++) part += bv[h][r] * y[h][0][r];
+#pragma unroll
+          for (int r = 0; r < 4; r++) part += bv[h][4 + r] * y[h][1][r];
+          part += __shfl_xor(part, 16, 64);
+          part += __shfl_xor(part, 32, 64);
+          out[h] = part;
+        }
+      };
       {
-        // x singles: lane e -> x + (-1)^e eps e_{e/2}
         double px[NX], pu[NU];
-        perturbed(true, lane < 2 * nx ? (lane >> 1) : -1, (lane & 1) ? -kEps : kEps, true, -1, 0.0, px, pu);
-        const double qx = model.cost_x(px);
-        if (lane < 2 * nx) sx[lane] = qx;
-        // u singles on lanes 0..2nu-1, the two base values on the next two lanes
+        if constexpr (M::kQuadraticCostX && NX == 32) {
+          // x singles and the knot itself: points e = 0 .. 2 nx (e = 2 nx: no perturbation)
+          for (int base = 0; base <= 2 * nx; base += 32) {
+            int i1[2], i2[2] = {-1, -1};
+            double d1[2], d2[2] = {0.0, 0.0}, f[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const int e = base + 16 * h + j16;
+              i1[h] = (e < 2 * nx) ? (e >> 1) : -1;
+              d1[h] = (e & 1) ? -kEps : kEps;
+            }
+            forms2(i1, d1, i2, d2, f);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const int e = base + 16 * h + j16;
+              if (kq == 0 && e < 2 * nx) sx[e] = f[h];
+              if (kq == 0 && e == 2 * nx) s0[0] = f[h];
+            }
+          }
+        } else {
+          // x singles: lane e -> x + (-1)^e eps e_{e/2}
+          perturbed(true, lane < 2 * nx ? (lane >> 1) : -1, (lane & 1) ? -kEps : kEps, true, -1, 0.0, px, pu);
+          const double qx = model.cost_x(px);
+          if (lane < 2 * nx) sx[lane] = qx;
+          if (2 * nx < 64) {               // wave-uniform
+            if (lane == 2 * nx) s0[0] = qx;  // (no perturbation applied on this lane: cost_x(x))
+          } else {                         // nx = 32: no spare lane, one more (uniform) evaluation
+            double bx[NX];
+#pragma unroll
+            for (int c = 0; c < NX; c++) bx[c] = x[c];
+            const double q0 = model.cost_x(bx);
+            if (lane == 0) s0[0] = q0;
+          }
+        }
+        // u singles on lanes 0..2nu-1, cost_u(u) on the next lane
         perturbed(false, lane < 2 * nu ? (lane >> 1) : -1, (lane & 1) ? -kEps : kEps, true, -1, 0.0, px, pu);
         const double qu = model.cost_u(pu);
         if (lane < 2 * nu) su[lane] = qu;
-        if (lane == 2 * nu) s0[1] = qu;  // (no perturbation applied on this lane: cost_u(u))
-        if (2 * nx < 64) {               // wave-uniform
-          if (lane == 2 * nx) s0[0] = qx;  // likewise cost_x(x)
-        } else {                         // nx = 32: no spare lane, one more (uniform) evaluation
-          double bx[NX];
-#pragma unroll
-          for (int c = 0; c < NX; c++) bx[c] = x[c];
-          const double q0 = model.cost_x(bx);
-          if (lane == 0) s0[0] = q0;
-        }
+        if (lane == 2 * nu) s0[1] = qu;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): one wavefront, LDS operations complete in order
@@ -437,30 +514,11 @@ __global__ __launch_bounds__(64) void k_derivatives_g(BatchView v, M model, int 
         }
       };
       if constexpr (M::kQuadraticCostX && NX == 32) {
-        // cxx on the matrix cores.  Y = Q P for 16 points at a time (v_mfma_f64_16x16x4_f64: two
-        // 16-row blocks of Q x eight k-steps), then f_j = p_j . y_j.  Lane l = (kq = l >> 4, j = l & 15)
-        // supplies A = Q[16 ib + j][4 ks + kq] (resident in registers for the whole kernel) and
-        // B = component 4 ks + kq of point j, built from the knot and the point's two perturbations;
-        // it receives rows kq + 4 r (+16) of y_j, i.e. exactly the components it supplied.  Same
-        // points, same Q as the VALU route; the sums inside a form run in the MFMA's order.
-        typedef double double4_t __attribute__((ext_vector_type(4)));
-        cmem_d* Qm = model.cost_x_matrix();
-        const int j16 = lane & 15, kq = lane >> 4;
-        double qa[2][8], xb[8];
-#pragma unroll
-        for (int ib = 0; ib < 2; ib++)
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) qa[ib][ks] = ((const double*)model.Q)[(16 * ib + j16) * GN + 4 * ks + kq];
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) {  // x[4 ks + kq] without indexing the register array by kq
-          const double a0 = x[4 * ks], a1 = x[4 * ks + 1], a2 = x[4 * ks + 2], a3 = x[4 * ks + 3];
-          xb[ks] = (kq == 0) ? a0 : (kq == 1) ? a1 : (kq == 2) ? a2 : a3;
-        }
-        (void)Qm;
+        // cxx on the matrix cores: the 2 nx (nx + 1) points of the upper triangle, 4 sign
+        // combinations per pair.  This lane's pair (i, i + rem) is advanced incrementally (a tile of
+        // 16 points is 4 pairs).  Same points, same Q as the VALU route; the sums inside a form run
+        // in the MFMA's order.
         const int npts = 2 * nx * (nx + 1);
-        // this lane's pair (i, i + rem) of the upper triangle, advanced incrementally: a tile of 16
-        // points is 4 pairs x 4 sign combinations, two tiles are in flight per trip (four
-        // independent accumulator chains for the MFMA pipe)
         int pi = 0, prem = j16 >> 2;
         auto normalise = [&](int& i, int& rem) __attribute__((always_inline)) {
           while (i < nx && rem >= nx - i) {
@@ -471,44 +529,22 @@ __global__ __launch_bounds__(64) void k_derivatives_g(BatchView v, M model, int 
         normalise(pi, prem);
         for (int base = 0; base < npts; base += 32) {
           int ti[2], tj[2], te[2];
-          double bv[2][8];
+          double d1[2], d2[2], f[2];
 #pragma unroll
           for (int h = 0; h < 2; h++) {
             const int e = base + 16 * h + j16;
             te[h] = e;
             ti[h] = (e < npts) ? pi : -1;
             tj[h] = (e < npts) ? pi + prem : -1;
-            const double d1 = (e & 1) ? -kEps : kEps, d2 = (e & 2) ? -kEps : kEps;
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) {
-              const int comp = 4 * ks + kq;
-              double val = xb[ks];
-              val = (comp == ti[h]) ? val + d1 : val;
-              val = (comp == tj[h]) ? val + d2 : val;
-              bv[h][ks] = val;
-            }
+            d1[h] = (e & 1) ? -kEps : kEps;
+            d2[h] = (e & 2) ? -kEps : kEps;
             prem += 4;  // the next tile's pair
             normalise(pi, prem);
           }
-          double4_t y[2][2] = {{{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}};
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++)
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-              y[h][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[0][ks], bv[h][ks], y[h][0], 0, 0, 0);
-              y[h][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[1][ks], bv[h][ks], y[h][1], 0, 0, 0);
-            }
+          forms2(ti, d1, tj, d2, f);
 #pragma unroll
           for (int h = 0; h < 2; h++) {
-            // y[h][0][r] = (Q p)[kq + 4 r], y[h][1][r] = (Q p)[16 + kq + 4 r]; matching components bv[r], bv[4 + r]
-            double part = 0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) part += bv[h][r] * y[h][0][r];
-#pragma unroll
-            for (int r = 0; r < 4; r++) part += bv[h][4 + r] * y[h][1][r];
-            part += __shfl_xor(part, 16, 64);
-            part += __shfl_xor(part, 32, 64);  // p' Q p in the four lanes of the point's column
-            const double fv = M::cost_from_parts(part, qu0);
+            const double fv = M::cost_from_parts(f[h], qu0);
             const double f0 = quad_bcast<0>(fv), f1 = quad_bcast<1>(fv), f2 = quad_bcast<2>(fv), f3 = quad_bcast<3>(fv);
             if (te[h] < npts && (te[h] & 3) == 0 && kq == 0) {
               const double val = (f0 - f1 - f2 + f3) / (4 * kEps * kEps);
