@@ -6,7 +6,7 @@ from . import _build
 
 ABI_VERSION = 1
 MODEL_ACROBOT, MODEL_DOUBLE_INTEGRATOR, MODEL_LQ, MODEL_HOST = 0, 1, 2, 3
-FLAG_FIXED_WORK, FLAG_BACKWARD_THREAD_PER_TRAJ, FLAG_BACKWARD_LANE_GROUP, FLAG_UNFUSED = 1, 2, 4, 8
+FLAG_FIXED_WORK, FLAG_BACKWARD_THREAD_PER_TRAJ, FLAG_BACKWARD_LANE_GROUP, FLAG_UNFUSED, FLAG_ANALYTIC_DERIVATIVES = 1, 2, 4, 8, 16
 NUM_STAGES = 4
 STAGE_NAMES = ("derivatives", "backward", "rollout", "accept")
 

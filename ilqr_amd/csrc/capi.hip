@@ -569,6 +569,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   v.ntiles = h->ntiles;
   v.T = h->T;
   v.dt = h->dt;
+  v.analytic = (h->flags & ILQR_FLAG_ANALYTIC_DERIVATIVES) ? 1 : 0;
   int rc = 0;
   if (h->aos) {
     const size_t Bn = h->B;

@@ -119,6 +119,7 @@ struct BatchView {
   int* backpass_done; // ilqr_core.cpp:136
   int* n_running;     // [1] device counter
   long long* dbg;     // phase-timing scratch (only used by -DILQR_PHASE_TIMING experiment builds)
+  int analytic;       // ILQR_FLAG_ANALYTIC_DERIVATIVES: the models' exact derivatives instead of finite differences
 };
 
 }  // namespace ilqr

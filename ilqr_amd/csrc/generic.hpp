@@ -167,6 +167,40 @@ struct LqModel {
     fb = cost_from_parts(qb, rb);
   }
   __device__ __forceinline__ double final_cost(const double* x) const { return 0.5 * quad<GN>((cmem_d*)Qf, x); }
+  // exact derivatives (opt-in), written cooperatively by the 64 lanes of the knot's wavefront into
+  // the record D (runtime offsets for nx, nu; conventions of derivatives.cpp at t = T); x, u point
+  // to the knot in memory (u may be null at t = T)
+  __device__ __forceinline__ void analytic_record(const double* __restrict__ x, const double* __restrict__ u, double dt, bool last,
+                                                  double* __restrict__ D, int lane) const {
+    const int oFX = 0, oFU = oFX + nx * nx, oCX = oFU + nx * nu, oCXX = oCX + nx, oCXU = oCXX + nx * nx, oCU = oCXU + nx * nu,
+              oCUU = oCU + nu;
+    const double* Wx = last ? Qf : Q;
+    for (int e = lane; e < nx * nx; e += 64) {
+      const int r = e % nx, c = e / nx;
+      D[oFX + e] = last ? 0.0 : ((r == c) ? 1.0 : 0.0) + dt * A[r * GN + c];
+      D[oCXX + e] = 0.5 * (Wx[r * GN + c] + Wx[c * GN + r]);
+    }
+    for (int e = lane; e < nx * nu; e += 64) {
+      const int r = e % nx, c = e / nx;
+      D[oFU + e] = last ? 0.0 : dt * Bm[r * GM + c];
+      D[oCXU + e] = 0.0;
+    }
+    for (int e = lane; e < nu * nu; e += 64) {
+      const int r = e % nu, c = e / nu;
+      D[oCUU + e] = 0.5 * (R[r * GM + c] + R[c * GM + r]);
+    }
+    for (int i = lane; i < nx; i += 64) {  // d/dx 0.5 x'Wx = 0.5 (W + W') x
+      double acc = 0;
+      for (int j = 0; j < nx; j++) acc += 0.5 * (Wx[i * GN + j] + Wx[j * GN + i]) * x[j];
+      D[oCX + i] = acc;
+    }
+    for (int i = lane; i < nu; i += 64) {
+      double acc = 0;
+      if (!last)
+        for (int j = 0; j < nu; j++) acc += 0.5 * (R[i * GM + j] + R[j * GM + i]) * u[j];
+      D[oCU + i] = acc;
+    }
+  }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -299,6 +333,11 @@ __global__ __launch_bounds__(64) void k_derivatives_g(BatchView v, M model, int 
   for (int i = 0; i < NX; i++) x[i] = (i < nx) ? v.xs[((size_t)b * (T + 1) + t) * nx + i] : 0.0;
 #pragma unroll
   for (int j = 0; j < NU; j++) u[j] = (j < nu && !last) ? v.us[((size_t)b * T + t) * nu + j] : 0.0;  // derivatives.cpp:35-38
+
+  if (v.analytic) {  // opt-in: the model's exact derivatives (reads the knot from memory: runtime indices)
+    model.analytic_record(v.xs + ((size_t)b * (T + 1) + t) * nx, last ? nullptr : v.us + ((size_t)b * T + t) * nu, v.dt, last, D, lane);
+    return;
+  }
 
   // point = knot, then (target 1, index i1) += d1, then (target 2, index i2) += d2; index -1 = none
   auto perturbed = [&](bool x1, int i1, double d1, bool x2, int i2, double d2, double* px, double* pu)

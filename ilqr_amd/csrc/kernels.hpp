@@ -493,6 +493,13 @@ __device__ __forceinline__ void derivatives_of_knot(const BatchView& v, const M&
     for (int j = 0; j < NU; j++) rs[((RingSlot<NX, NU>::US + j) >> 1) * (2 * TW) + ((RingSlot<NX, NU>::US + j) & 1)] = u[j];
   }
 
+  if (v.analytic) {  // opt-in: the model's exact derivatives (wave-uniform branch)
+    double rec[R::SIZE];
+    model.analytic_record(x, u, dt, t == T, rec);
+#pragma unroll
+    for (int e = 0; e < R::SIZE; e += 2) put2(e, rec[e], rec[e + 1]);
+    return;
+  }
   if (t < T) {
     // fx, fu: central differences of the Euler map (derivatives.cpp:19-25, finite_diff.h:35-47)
 #pragma unroll

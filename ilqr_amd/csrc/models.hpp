@@ -84,6 +84,72 @@ struct AcrobotModel {
     dx[2] = (H11 * invdet) * r0 + (-H01 * invdet) * r1;
     dx[3] = (-H10 * invdet) * r0 + (H00 * invdet) * r1;
   }
+  // Exact derivatives (opt-in, ILQR_FLAG_ANALYTIC_DERIVATIVES; the reference only has finite
+  // differences): the record of knot (x, u) in Rec<4,1> order, column-major blocks.
+  // qdd = H^-1 r with r = (0,u) - C qd - G, so d qdd / dz = H^-1 (dr/dz - (dH/dz) qdd); the Euler map
+  // has fx = I + dt df/dx, fu = dt df/du.  t = T follows the conventions of derivatives.cpp
+  // (fx = fu = 0, cx / cxx from final_cost, cu = 0, cuu from cost(x_T, .), cxu = 0).
+  __device__ __forceinline__ void analytic_record(const double* x, const double* u, double dt, bool last, double* rec) const {
+    using R = Rec<4, 1>;
+#pragma unroll
+    for (int e = 0; e < R::SIZE; e++) rec[e] = 0.0;
+    rec[R::CUU] = 2 * 0.1 * 0.1;  // d2/du2 of Kr^2 u^2
+    if (last) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        rec[R::CX + i] = -2.0 * 400.0 * (goal[i] - x[i]);  // Ks^2 = Kd^2 = 400
+        rec[R::CXX + i + 4 * i] = 2.0 * 400.0;
+      }
+      return;
+    }
+    const double g = 9.81, b = 0.5;  // b = m2 l1 lc2
+    const double qd0 = x[2], qd1 = x[3];
+    double s1, c1, s2, c2;
+    sincos_shared(x[0], s1, c1);
+    sincos_shared(x[1], s2, c2);
+    const double s12 = s1 * c2 + c1 * s2, c12 = c1 * c2 - s1 * s2;
+    const double H00 = 3.0 + 2 * b * c2, H01 = 1.0 + b * c2, H11 = 1.0;
+    const double Cq0 = -2 * b * s2 * qd1 * qd0 - b * s2 * qd1 * qd1, Cq1 = b * s2 * qd0 * qd0;
+    const double G0 = g * (1.5 * s1 + 0.5 * s12), G1 = 0.5 * g * s12;
+    const double r0 = -Cq0 - G0, r1 = u[0] - Cq1 - G1;
+    const double invdet = 1.0 / (H00 * H11 - H01 * H01);
+    const double a0 = invdet * (H11 * r0 - H01 * r1), a1 = invdet * (-H01 * r0 + H00 * r1);  // qdd
+    double dr[5][2];  // columns q0, q1, qd0, qd1, u of dr/dz - (dH/dz) qdd
+    dr[0][0] = -g * (1.5 * c1 + 0.5 * c12);
+    dr[0][1] = -0.5 * g * c12;
+    {
+      const double dC0 = -2 * b * c2 * qd1 * qd0 - b * c2 * qd1 * qd1, dC1 = b * c2 * qd0 * qd0;
+      const double dG = 0.5 * g * c12;
+      const double dH00 = -2 * b * s2, dH01 = -b * s2;
+      dr[1][0] = -dC0 - dG - (dH00 * a0 + dH01 * a1);
+      dr[1][1] = -dC1 - dG - (dH01 * a0);
+    }
+    dr[2][0] = 2 * b * s2 * qd1;
+    dr[2][1] = -2 * b * s2 * qd0;
+    dr[3][0] = 2 * b * s2 * qd0 + 2 * b * s2 * qd1;
+    dr[3][1] = 0.0;
+    dr[4][0] = 0.0;
+    dr[4][1] = 1.0;
+    double dq[5][2];
+#pragma unroll
+    for (int z = 0; z < 5; z++) {
+      dq[z][0] = invdet * (H11 * dr[z][0] - H01 * dr[z][1]);
+      dq[z][1] = invdet * (-H01 * dr[z][0] + H00 * dr[z][1]);
+    }
+    // fx = I + dt * [[0,0,1,0],[0,0,0,1],[d qdd0/dx],[d qdd1/dx]]   (element (r, c) at r + 4 c)
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      rec[R::FX + c + 4 * c] = 1.0;
+      rec[R::FX + 2 + 4 * c] += dt * dq[c][0];
+      rec[R::FX + 3 + 4 * c] += dt * dq[c][1];
+    }
+    rec[R::FX + 0 + 4 * 2] += dt;
+    rec[R::FX + 1 + 4 * 3] += dt;
+    rec[R::FU + 2] = dt * dq[4][0];
+    rec[R::FU + 3] = dt * dq[4][1];
+    rec[R::CU] = 2 * 0.1 * 0.1 * u[0];
+  }
+
   // acrobot.h:83-92: Ks = Kd = 0, Kr = 0.1 -> the state terms are exact zeros for finite x
   __device__ __forceinline__ double cost(const double* x, const double* u) const {
     (void)x;
@@ -122,6 +188,30 @@ struct DoubleIntegratorModel {
       r[i] = scale * (hx[i] * d[i]);
     }
     return (r[0] * d[0] + r[2] * d[2]) + (r[1] * d[1] + r[3] * d[3]);
+  }
+  // exact derivatives (opt-in, see AcrobotModel::analytic_record): linear dynamics, quadratic costs
+  __device__ __forceinline__ void analytic_record(const double* x, const double* u, double dt, bool last, double* rec) const {
+    using R = Rec<4, 2>;
+    const double hx[4] = {1, 1, 0.2, 0.2};
+#pragma unroll
+    for (int e = 0; e < R::SIZE; e++) rec[e] = 0.0;
+    const double scale = last ? 10.0 : 1.0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      rec[R::CX + i] = -2.0 * scale * hx[i] * (goal[i] - x[i]);
+      rec[R::CXX + i + 4 * i] = 2.0 * scale * hx[i];
+    }
+    rec[R::CUU + 0] = 2.0;  // cuu at every t (at t = T from cost(x_T, .))
+    rec[R::CUU + 3] = 2.0;
+    if (last) return;
+#pragma unroll
+    for (int c = 0; c < 4; c++) rec[R::FX + c + 4 * c] = 1.0;
+    rec[R::FX + 0 + 4 * 2] = dt;
+    rec[R::FX + 1 + 4 * 3] = dt;
+    rec[R::FU + 2 + 4 * 0] = dt;  // mass = 1
+    rec[R::FU + 3 + 4 * 1] = dt;
+    rec[R::CU + 0] = 2.0 * u[0];
+    rec[R::CU + 1] = 2.0 * u[1];
   }
   // double_integrator.h:39-43
   __device__ __forceinline__ double cost(const double* x, const double* u) const {

@@ -84,7 +84,12 @@ enum ilqr_flags {
   /* ilqr_iterate / ilqr_solve normally run the derivative sweep and the backward pass of an
    * iteration in one kernel (nx = 4 models: the sweep uses the SIMDs the backward pass leaves
    * idle).  This flag launches them as two kernels, as the stage calls do.  Same results. */
-  ILQR_FLAG_UNFUSED = 8
+  ILQR_FLAG_UNFUSED = 8,
+  /* Opt-in (the reference has nothing like it): the derivative sweep takes the device
+   * model's exact derivatives of the Euler map and of the costs instead of eps = 1e-3 central
+   * differences.  Results then differ from the reference's by its finite differences' truncation and
+   * rounding error (~1e-6 relative on the records), so parity claims are made WITHOUT this flag. */
+  ILQR_FLAG_ANALYTIC_DERIVATIVES = 16
 };
 
 /* Solver tunables = the compile-time constants of include/ilqr.h:14-24 (defaults shown). */
