@@ -78,10 +78,26 @@ __device__ __forceinline__ double4_t mfma_tile(FA a_at, FB b_at, int lane) {
   return acc;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {  // sum over the 64 lanes (result in all lanes)
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+// sum over the 64 lanes (result in all lanes).  DPP inside each row of 16 lanes (xor 1, xor 2, half
+// mirror, mirror: every lane of a row ends with the row total), then the four row totals through
+// v_readlane.  The box-QP calls this a few times per Armijo trip; the ds_bpermute butterfly it
+// replaces (6 dependent LDS round trips) was most of the kernel's box-QP time.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  v += dpp_f64<0x140>(v);  // row_mirror
+  auto row = [&](int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+  };
+  return (row(0) + row(16)) + (row(32) + row(48));
 }
 __device__ __forceinline__ void lds_sync() {
   // One wavefront per block: the LDS pipeline executes a wavefront's DS instructions in issue
@@ -202,6 +218,27 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
       }
       nfR = nf;
       lds_sync();
+      // Ri = R^-1 (upper triangular, column j on lane j), Minv = Ri Ri'  (:105-112).  The reference
+      // inverts R in every iteration; R only changes here, so the product is computed here and kept
+      // (same values) -- for the iterations that reuse a stale factor and for the caller's K.
+      if (lane < nfR) {
+        const int j = lane;
+        for (int i = 0; i < nfR; i++) L.Ri()[i + LDM * j] = 0;
+        L.Ri()[j + LDM * j] = 1.0 / L.R[j + LDM * j];
+        for (int i = j - 1; i >= 0; i--) {
+          double s = 0;
+          for (int l2 = i + 1; l2 <= j; l2++) s += L.R[i + LDM * l2] * L.Ri()[l2 + LDM * j];
+          L.Ri()[i + LDM * j] = -s / L.R[i + LDM * i];
+        }
+      }
+      lds_sync();
+      for (int e = lane; e < nfR * nfR; e += 64) {
+        const int a = e % nfR, b2 = e / nfR;
+        double s = 0;
+        for (int l2 = 0; l2 < nfR; l2++) s += L.Ri()[a + LDM * l2] * L.Ri()[b2 + LDM * l2];
+        L.Minv[a + LDM * b2] = s;
+      }
+      lds_sync();
     }
     // :93-97
     {
@@ -220,24 +257,6 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
       L.gc[lane] = s + c[lane];
     }
     lds_sync();
-    // Ri = R^-1 (upper triangular, column j on lane j), Minv = Ri Ri'
-    if (lane < nfR) {
-      const int j = lane;
-      for (int i = 0; i < nfR; i++) L.Ri()[i + LDM * j] = 0;
-      L.Ri()[j + LDM * j] = 1.0 / L.R[j + LDM * j];
-      for (int i = j - 1; i >= 0; i--) {
-        double s = 0;
-        for (int l2 = i + 1; l2 <= j; l2++) s += L.R[i + LDM * l2] * L.Ri()[l2 + LDM * j];
-        L.Ri()[i + LDM * j] = -s / L.R[i + LDM * i];
-      }
-    }
-    lds_sync();
-    for (int e = lane; e < nfR * nfR; e += 64) {
-      const int a = e % nfR, b2 = e / nfR;
-      double s = 0;
-      for (int l2 = 0; l2 < nfR; l2++) s += L.Ri()[a + LDM * l2] * L.Ri()[b2 + LDM * l2];
-      L.Minv[a + LDM * b2] = s;
-    }
     if (lane < m) {
       L.search[lane] = 0;
       if (!cl) {
@@ -507,24 +526,7 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
       if (lane < m && L.vfree[lane]) L.idx[__popcll(free_mask & ((1ull << lane) - 1ull))] = lane;
       lds_sync();
       if (nf > 0) {
-        if (lane < nfR) {
-          const int j = lane;
-          for (int i2 = 0; i2 < nfR; i2++) L.Ri()[i2 + LDM * j] = 0;
-          L.Ri()[j + LDM * j] = 1.0 / L.R[j + LDM * j];
-          for (int i2 = j - 1; i2 >= 0; i2--) {
-            double s = 0;
-            for (int l2 = i2 + 1; l2 <= j; l2++) s += L.R[i2 + LDM * l2] * L.Ri()[l2 + LDM * j];
-            L.Ri()[i2 + LDM * j] = -s / L.R[i2 + LDM * i2];
-          }
-        }
-        lds_sync();
-        for (int e = lane; e < nfR * nfR; e += 64) {
-          const int a = e % nfR, b2 = e / nfR;
-          double s = 0;
-          for (int l2 = 0; l2 < nfR; l2++) s += L.Ri()[a + LDM * l2] * L.Ri()[b2 + LDM * l2];
-          L.Minv[a + LDM * b2] = s;
-        }
-        lds_sync();
+        // (L.Minv = R^-1 R^-T of the factor the box-QP returned, :379, left there by w_box_qp)
         const int nuse = (nf < nfR) ? nf : nfR;
         for (int e = lane; e < nuse * n; e += 64) {
           const int rr = e % nuse, c = e / nuse;
