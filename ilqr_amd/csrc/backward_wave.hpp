@@ -528,11 +528,34 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
       if (nf > 0) {
         // (L.Minv = R^-1 R^-T of the factor the box-QP returned, :379, left there by w_box_qp)
         const int nuse = (nf < nfR) ? nf : nfR;
-        for (int e = lane; e < nuse * n; e += 64) {
-          const int rr = e % nuse, c = e / nuse;
-          double acc = 0;
-          for (int l2 = 0; l2 < nuse; l2++) acc += -L.Minv[rr + LDM * l2] * L.Qux[L.idx[l2] + LDM * c];
-          L.K()[L.idx[rr] + LDM * c] = acc;
+        if (nf == nfR) {
+          // K = -(Minv scattered to the free rows / columns of an m x m matrix) Qux on the matrix
+          // cores: clamped rows of the scattered matrix are zero, so those rows of K come out zero,
+          // and the zero columns add exact zeros to the k-ordered sums over the free dims.
+          double* MF = L.Qf;  // (the Cholesky work copy / Ri: dead until the next factorisation)
+          for (int e = lane; e < LDM * WM; e += 64) MF[e] = 0.0;
+          lds_sync();
+          for (int e = lane; e < nf * nf; e += 64) {
+            const int a = e % nf, b2 = e / nf;
+            MF[L.idx[a] + LDM * L.idx[b2]] = L.Minv[a + LDM * b2];
+          }
+          lds_sync();
+#pragma unroll
+          for (int tj = 0; tj < 2; tj++) {
+            if (tj >= NT) continue;
+            const double4_t acc = mfma_tile<WM / 4>(
+                [&](int i2, int k) { return MF[i2 + LDM * k]; },
+                [&](int k, int j) { return L.Qux[k + LDM * (tj * 16 + j)]; }, lane);
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) L.K()[(orow + 4 * rr) + LDM * (tj * 16 + ocol)] = -acc[rr];
+          }
+        } else {  // a stale factor of another size (:80): the literal sums over its leading block
+          for (int e = lane; e < nuse * n; e += 64) {
+            const int rr = e % nuse, c = e / nuse;
+            double acc = 0;
+            for (int l2 = 0; l2 < nuse; l2++) acc += -L.Minv[rr + LDM * l2] * L.Qux[L.idx[l2] + LDM * c];
+            L.K()[L.idx[rr] + LDM * c] = acc;
+          }
         }
       }
       lds_sync();
