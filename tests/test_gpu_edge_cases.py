@@ -1,6 +1,7 @@
 """Edge cases through the C ABI: ragged batch sizes (B not a multiple of the 16-trajectory tile or
 the 64-lane wavefront, B = 1), horizons around the candidate-chunk size (T = 1, 7, 8, 9, 16, 17:
-the time-chunked candidate layout has a tail path for each), and both backward kernels agreeing."""
+the candidate checkpoints sit at every 8th knot), both backward kernels agreeing, and two handles
+driven from two host threads at once."""
 import numpy as np
 import pytest
 
@@ -85,3 +86,37 @@ def test_backward_kernel_variants_agree(oracle):
     assert same.mean() > 0.9
     assert relerr(k0[same] + 1, k1[same] + 1) < 1e-6 and relerr(K0[same] + 1, K1[same] + 1) < 1e-5
     assert np.allclose(gn0[same], gn1[same], rtol=1e-9)
+
+
+def test_handles_are_independent_across_host_threads():
+    """The reference is not re-entrant (file-static lambda/dlambda, fixed output file, SURVEY 8b);
+    here every handle owns its state and its stream: two solves driven from two host threads at the
+    same time give exactly what they give one after the other."""
+    import threading
+    from ilqr_amd import BatchILQR
+    jobs = [("acrobot", 48, 120, dict(u_min=-1.5, u_max=1.5), acrobot_x0(48, scale=0.3, seed=1)),
+            ("integrator", 33, 99, dict(goal=[1.0, 0.5, 0.0, 0.0]), integrator_x0(33))]
+
+    def run(job, out, i):
+        name, B, T, kw, x0 = job
+        g = BatchILQR(name, B, T, 0.02, **kw)
+        g.init_traj(x0, np.zeros((B, T, g.nu)))
+        for _ in range(6):
+            g.iterate(2)
+        xs, us = g.trajectory()
+        out[i] = (g.cost(), xs, us, g.status())
+        g.close()
+
+    seq = [None, None]
+    for i, job in enumerate(jobs):
+        run(job, seq, i)
+    par = [None, None]
+    th = [threading.Thread(target=run, args=(job, par, i)) for i, job in enumerate(jobs)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for a, b in zip(seq, par):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        for u, v in zip(a[3], b[3]):
+            assert np.array_equal(u, v)
