@@ -109,12 +109,32 @@ __device__ __forceinline__ void lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// sum_{j in [lo, hi)} a(j) b(j), j ascending, hi <= WM.  Written as WM unrolled, masked terms: a loop
+// with a runtime trip count reads LDS, waits, multiplies, one term at a time (~120 cycles each with
+// a single wavefront per SIMD); unrolled, the 2 x 16 reads go out back to back.  A masked-out term
+// contributes fma(0, 0, s) = s, so the value is that of the plain loop.
+template <class FA, class FB>
+__device__ __forceinline__ double dot_masked(int lo, int hi, FA a, FB b) {
+  double av[WM], bv[WM];
+#pragma unroll
+  for (int j = 0; j < WM; j++) {
+    av[j] = a(j);
+    bv[j] = b(j);
+  }
+  double s = 0;
+#pragma unroll
+  for (int j = 0; j < WM; j++) {
+    const bool in = (j >= lo) & (j < hi);
+    s = __builtin_fma(in ? av[j] : 0.0, in ? bv[j] : 0.0, s);
+  }
+  return s;
+}
+
 // 0.5 x'Qx + x.c with Q m x m (ld LDM), include/boxqp.h:53-55, evaluated ((0.5 x')Q) x + x.c
 __device__ __forceinline__ double w_quad_cost(int m, const double* Q, const double* c, const double* x, int lane) {
   double part = 0, lin = 0;
   if (lane < m) {
-    double r = 0;
-    for (int i = 0; i < m; i++) r += (0.5 * x[i]) * Q[i + LDM * lane];
+    const double r = dot_masked(0, m, [&](int i) { return 0.5 * x[i]; }, [&](int i) { return Q[i + LDM * lane]; });
     part = r * x[lane];
     lin = x[lane] * c[lane];
   }
@@ -123,7 +143,17 @@ __device__ __forceinline__ double w_quad_cost(int m, const double* Q, const doub
 
 // src/boxqp.cpp:26-139 for one trajectory per wavefront.  Inputs in LDS: QuuF (Q), Qu (c), kprev
 // (x0), lo, hi.  Outputs: L.x (solution), L.vfree, L.R (compact upper factor, ld LDM), nfR.
+#ifdef ILQR_PHASE_TIMING
+__device__ long long g_qp_count[8];  // [0] QPs, [1] iterations, [2] factorisations, [3] Armijo trips, [4..7] cycles: factor, inverse, search, rest
+#endif
 __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
+#ifdef ILQR_PHASE_TIMING
+  long long qc[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+  long long qmark = clock64();
+#define ILQR_QMARK(k) { const long long tn_ = clock64(); qc[k] += tn_ - qmark; qmark = tn_; }
+#else
+#define ILQR_QMARK(k)
+#endif
   const double* Q = L.QuuF;
   const double* c = L.Qu;
   // :35 clamp
@@ -140,8 +170,7 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
   {
     double part = 0, lin = 0;
     if (lane < m) {
-      double r = 0;
-      for (int i = 0; i < m; i++) r += L.x[i] * Q[i + LDM * lane];
+      const double r = dot_masked(0, m, [&](int i) { return L.x[i]; }, [&](int i) { return Q[i + LDM * lane]; });
       part = r * L.x[lane];
       lin = L.x[lane] * c[lane];
     }
@@ -150,6 +179,9 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
   double oldvalue = 0;
   int result = 0, nfR = 0;
   for (int iter = 0; iter <= kQpMaxIter; iter++) {
+#ifdef ILQR_PHASE_TIMING
+    qc[1]++;
+#endif
     if (iter > 0 && (oldvalue - val) < kMinRelImprove * fabs(oldvalue)) {  // :54-57
       result = 4;
       break;
@@ -158,8 +190,7 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
     int cl = 1;
     double dd = 0;
     if (lane < m) {
-      double s = 0;
-      for (int j = 0; j < m; j++) s += Q[lane + LDM * j] * L.x[j];
+      const double s = dot_masked(0, m, [&](int j) { return Q[lane + LDM * j]; }, [&](int j) { return L.x[j]; });
       const double g = s + c[lane];
       L.grad[lane] = g;
       L.oldcl[lane] = L.clamped[lane];
@@ -180,7 +211,11 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
     // ascending list of free dims (order-preserving compaction, eigen_helpers.h:15-61)
     if (lane < m && !cl) L.idx[__popcll(free_mask & ((1ull << lane) - 1ull))] = lane;
     lds_sync();
+    ILQR_QMARK(7)
     if (iter == 0 || dsum != 0) {  // :80
+#ifdef ILQR_PHASE_TIMING
+      qc[2]++;
+#endif
       // Qfree = Q[free, free]
       for (int e = lane; e < nf * nf; e += 64) {
         const int a = e % nf, b2 = e / nf;
@@ -191,8 +226,7 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
       for (int k = 0; k < nf; k++) {
         double xk = L.Qf[k + LDM * k];
         if (k > 0) {
-          double sq = 0;
-          for (int j = 0; j < k; j++) sq += L.Qf[k + LDM * j] * L.Qf[k + LDM * j];
+          const double sq = dot_masked(0, k, [&](int j) { return L.Qf[k + LDM * j]; }, [&](int j) { return L.Qf[k + LDM * j]; });
           xk -= sq;
         }
         if (xk <= 0.0) break;
@@ -203,8 +237,7 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
         if (i < nf) {
           double v = L.Qf[i + LDM * k];
           if (k > 0) {
-            double s = 0;
-            for (int j = 0; j < k; j++) s += L.Qf[i + LDM * j] * L.Qf[k + LDM * j];
+            const double s = dot_masked(0, k, [&](int j) { return L.Qf[i + LDM * j]; }, [&](int j) { return L.Qf[k + LDM * j]; });
             v -= s;
           }
           L.Qf[i + LDM * k] = v / xk;
@@ -218,6 +251,7 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
       }
       nfR = nf;
       lds_sync();
+      ILQR_QMARK(4)
       // Ri = R^-1 (upper triangular, column j on lane j), Minv = Ri Ri'  (:105-112).  The reference
       // inverts R in every iteration; R only changes here, so the product is computed here and kept
       // (same values) -- for the iterations that reuse a stale factor and for the caller's K.
@@ -226,19 +260,18 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
         for (int i = 0; i < nfR; i++) L.Ri()[i + LDM * j] = 0;
         L.Ri()[j + LDM * j] = 1.0 / L.R[j + LDM * j];
         for (int i = j - 1; i >= 0; i--) {
-          double s = 0;
-          for (int l2 = i + 1; l2 <= j; l2++) s += L.R[i + LDM * l2] * L.Ri()[l2 + LDM * j];
+          const double s = dot_masked(i + 1, j + 1, [&](int l2) { return L.R[i + LDM * l2]; }, [&](int l2) { return L.Ri()[l2 + LDM * j]; });
           L.Ri()[i + LDM * j] = -s / L.R[i + LDM * i];
         }
       }
       lds_sync();
       for (int e = lane; e < nfR * nfR; e += 64) {
         const int a = e % nfR, b2 = e / nfR;
-        double s = 0;
-        for (int l2 = 0; l2 < nfR; l2++) s += L.Ri()[a + LDM * l2] * L.Ri()[b2 + LDM * l2];
-        L.Minv[a + LDM * b2] = s;
+        L.Minv[a + LDM * b2] =
+            dot_masked(0, nfR, [&](int l2) { return L.Ri()[a + LDM * l2]; }, [&](int l2) { return L.Ri()[b2 + LDM * l2]; });
       }
       lds_sync();
+      ILQR_QMARK(5)
     }
     // :93-97
     {
@@ -252,8 +285,7 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
     if (lane < m) L.tmp[lane] = L.x[lane] * L.clamped[lane];
     lds_sync();
     if (lane < m) {
-      double s = 0;
-      for (int j = 0; j < m; j++) s += Q[lane + LDM * j] * L.tmp[j];
+      const double s = dot_masked(0, m, [&](int j) { return Q[lane + LDM * j]; }, [&](int j) { return L.tmp[j]; });
       L.gc[lane] = s + c[lane];
     }
     lds_sync();
@@ -268,19 +300,18 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
     lds_sync();
     // :103-119 search(free) = -(R^-1 R^-T) gc(free) - x(free)   (a stale factor of equal size is used as is)
     if (lane < nfR && lane < nf) {
-      double s = 0;
-      for (int l2 = 0; l2 < nfR && l2 < nf; l2++) s += -L.Minv[lane + LDM * l2] * L.gfree[l2];
+      const double s = dot_masked(0, (nfR < nf) ? nfR : nf, [&](int l2) { return -L.Minv[lane + LDM * l2]; }, [&](int l2) { return L.gfree[l2]; });
       L.search[L.idx[lane]] = s - L.xfree[lane];
     }
     lds_sync();
+    ILQR_QMARK(7)
     // :121 quadclamp_line_search (src/boxqp.cpp:143-178)
     bool failed = false;
     double v = 0;
     {
       double sl = 0;
       if (lane < m) {
-        double s = 0;
-        for (int j = 0; j < m; j++) s += Q[lane + LDM * j] * L.x[j];
+        const double s = dot_masked(0, m, [&](int j) { return Q[lane + LDM * j]; }, [&](int j) { return L.x[j]; });
         sl = L.search[lane] * (s + c[lane]);
       }
       const double slope = wave_sum(sl);
@@ -297,6 +328,9 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
         v = w_quad_cost(m, Q, c, L.xc, lane);
         const double old_v = w_quad_cost(m, Q, c, L.x, lane);
         while ((v - old_v) / (step * slope) < kArmijo) {
+#ifdef ILQR_PHASE_TIMING
+          qc[3]++;
+#endif
           step *= kStepDec;
           lds_sync();
           if (lane < m) {
@@ -313,6 +347,7 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
         }
       }
     }
+    ILQR_QMARK(6)
     if (failed) {  // :122-125, x not updated
       result = 2;
       break;
@@ -323,6 +358,11 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
     lds_sync();
   }
   lds_sync();
+#ifdef ILQR_PHASE_TIMING
+  ILQR_QMARK(7)
+  if (lane == 0 && blockIdx.x == 0)
+    for (int q = 0; q < 8; q++) g_qp_count[q] += qc[q];
+#endif
   nfR_out = nfR;
   return result;
 }
@@ -565,8 +605,7 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
         const double d0 = wave_sum(lane < m ? L.x[lane] * L.Qu[lane] : 0.0);
         double part = 0;
         if (lane < m) {
-          double rr = 0;
-          for (int a = 0; a < m; a++) rr += (0.5 * L.x[a]) * L.Quu[a + LDM * lane];
+          const double rr = dot_masked(0, m, [&](int a) { return 0.5 * L.x[a]; }, [&](int a) { return L.Quu[a + LDM * lane]; });
           part = rr * L.x[lane];
         }
         dV0 += d0;
@@ -585,10 +624,9 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
       lds_sync();
       // :391 Vx ; :392 Vn = ((Qxx + T1 K) + K'Qux) + Qux'K into A1 ; :393 symmetrise into Vxx
       for (int a = lane; a < n; a += 64) {
-        double t1 = 0, t2 = 0, t3 = 0;
-        for (int c = 0; c < m; c++) t1 += L.T1()[a + LDN * c] * L.x[c];
-        for (int c = 0; c < m; c++) t2 += L.K()[c + LDM * a] * L.Qu[c];
-        for (int c = 0; c < m; c++) t3 += L.Qux[c + LDM * a] * L.x[c];
+        const double t1 = dot_masked(0, m, [&](int c) { return L.T1()[a + LDN * c]; }, [&](int c) { return L.x[c]; });
+        const double t2 = dot_masked(0, m, [&](int c) { return L.K()[c + LDM * a]; }, [&](int c) { return L.Qu[c]; });
+        const double t3 = dot_masked(0, m, [&](int c) { return L.Qux[c + LDM * a]; }, [&](int c) { return L.x[c]; });
         L.Vxn[a] = ((L.Qx[a] + t1) + t2) + t3;
       }
 #pragma unroll

@@ -477,6 +477,13 @@ void ilqr_destroy(ilqr_batch* h) {
         for (int q = 0; q < 8; q++) fprintf(stderr, "%s %.2f  ", nm[q], (double)d[t * 20 * 8 + q] / h->T);
         fprintf(stderr, "\n");
       }
+      if (h->aos) {
+        long long qc[8];
+        if (hipMemcpyFromSymbol(qc, HIP_SYMBOL(g_qp_count), sizeof(qc)) == hipSuccess && qc[0] > 0)
+          fprintf(stderr, "[wave box-QP, trajectory 0, all passes] per QP: %.2f iterations, %.2f factorisations, %.2f Armijo trips; cycles: factor %.0f  inverse+Minv %.0f  line search %.0f  rest %.0f\n",
+                  (double)qc[1] / qc[0], (double)qc[2] / qc[0], (double)qc[3] / qc[0], (double)qc[4] / qc[0], (double)qc[5] / qc[0],
+                  (double)qc[6] / qc[0], (double)qc[7] / qc[0]);
+      }
       if (h->aos)
         fprintf(stderr, "[wave backward phase timing, cyc/step] lds-fill+prefetch %.0f  Qx,A1,A2 %.0f  Qxx,Qux,Quu %.0f  boxQP %.0f  K %.0f  dV,T1,Vx,Vn %.0f  sym+stores(+loop) %.0f\n",
                 (double)d[256 + 0] / h->T, (double)d[256 + 1] / h->T, (double)d[256 + 2] / h->T, (double)d[256 + 3] / h->T,
