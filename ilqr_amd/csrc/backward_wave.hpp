@@ -40,12 +40,13 @@ constexpr int LDM = WM + 1;       // ... with up to 16 rows
 //                 next step refills fu completely
 //   K    in A2  : A2 is last read for Qux / Quu; K is written after the box-QP (A2's padding
 //                 columns are exact zeros, as K's must be)
-//   Ri   in Qf  : Qf (the Cholesky work copy) is dead once R has been taken from it
+//   Ri   in Qf  : Ri is read once, for Minv, right after it is written; Qf is the caller's scatter
+//                 buffer for K afterwards (the Cholesky factor itself lives in registers)
 struct WaveLds {
   double Vxx[LDN * WN], fx[LDN * WN], A1[LDN * WN];
   double fu[LDN * WM];
   double A2[LDM * WN], Qux[LDM * WN];
-  double Quu[LDM * WM], QuuF[LDM * WM], Qf[LDM * WM], R[LDM * WM], Minv[LDM * WM];
+  double Quu[LDM * WM], QuuF[LDM * WM], Qf[LDM * WM], Minv[LDM * WM];
   __device__ __forceinline__ double* Qxx() { return Vxx; }
   __device__ __forceinline__ double* T1() { return fu; }
   __device__ __forceinline__ double* K() { return A2; }
@@ -142,7 +143,7 @@ __device__ __forceinline__ double w_quad_cost(int m, const double* Q, const doub
 }
 
 // src/boxqp.cpp:26-139 for one trajectory per wavefront.  Inputs in LDS: QuuF (Q), Qu (c), kprev
-// (x0), lo, hi.  Outputs: L.x (solution), L.vfree, L.R (compact upper factor, ld LDM), nfR.
+// (x0), lo, hi.  Outputs: L.x (solution), L.vfree, L.Minv (R^-1 R^-T of the last factor, ld LDM), nfR.
 #ifdef ILQR_PHASE_TIMING
 __device__ long long g_qp_count[8];  // [0] QPs, [1] iterations, [2] factorisations, [3] Armijo trips, [4..7] cycles: factor, inverse, search, rest
 #endif
@@ -216,59 +217,83 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
 #ifdef ILQR_PHASE_TIMING
       qc[2]++;
 #endif
-      // Qfree = Q[free, free]
-      for (int e = lane; e < nf * nf; e += 64) {
-        const int a = e % nf, b2 = e / nf;
-        L.Qf[a + LDM * b2] = Q[L.idx[a] + LDM * L.idx[b2]];
+      // Qfree = Q[free, free], row i on lane i, in registers: the factorisation and the inversion
+      // below are chains of short dot products with a square root / division between them; through
+      // LDS every link of the chain paid a write -> read round trip (~35 K cycles per QP at nf = 16),
+      // here a row-k broadcast is a v_readlane and the loops have compile-time bounds.
+      auto bcast = [&](double v, int l) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+      };
+      double row[WM];
+      {
+        const int gi = L.idx[(lane < nf) ? lane : 0];
+#pragma unroll
+        for (int j = 0; j < WM; j++) row[j] = (lane < nf && j < nf) ? Q[gi + LDM * L.idx[(j < nf) ? j : 0]] : 0.0;
       }
-      lds_sync();
       // Eigen llt_inplace<Lower>::unblocked (Cholesky/LLT.h:302-325); stops at a non-positive pivot
-      for (int k = 0; k < nf; k++) {
-        double xk = L.Qf[k + LDM * k];
-        if (k > 0) {
-          const double sq = dot_masked(0, k, [&](int j) { return L.Qf[k + LDM * j]; }, [&](int j) { return L.Qf[k + LDM * j]; });
-          xk -= sq;
-        }
-        if (xk <= 0.0) break;
-        xk = sqrt(xk);
-        lds_sync();
-        if (lane == 0) L.Qf[k + LDM * k] = xk;
-        const int i = k + 1 + lane;
-        if (i < nf) {
-          double v = L.Qf[i + LDM * k];
-          if (k > 0) {
-            const double s = dot_masked(0, k, [&](int j) { return L.Qf[i + LDM * j]; }, [&](int j) { return L.Qf[k + LDM * j]; });
-            v -= s;
+      // and leaves the rest of the lower triangle as it was
+      {
+        bool stopped = false;
+#pragma unroll
+        for (int k = 0; k < WM; k++) {
+          if (k < nf && !stopped) {
+            double rk[WM];
+            double sq = 0;
+#pragma unroll
+            for (int j = 0; j < k; j++) {
+              rk[j] = bcast(row[j], k);
+              sq = __builtin_fma(rk[j], rk[j], sq);
+            }
+            double xk = bcast(row[k], k);
+            if (k > 0) xk -= sq;
+            if (xk <= 0.0) {
+              stopped = true;
+            } else {
+              xk = sqrt(xk);
+              double s = 0;
+#pragma unroll
+              for (int j = 0; j < k; j++) s = __builtin_fma(row[j], rk[j], s);
+              double v = row[k];
+              if (k > 0) v -= s;
+              v = v / xk;
+              row[k] = (lane == k) ? xk : ((lane > k && lane < nf) ? v : row[k]);
+            }
           }
-          L.Qf[i + LDM * k] = v / xk;
         }
-        lds_sync();
-      }
-      // :86-88 R = L' (dense upper, zeros below)
-      for (int e = lane; e < nf * nf; e += 64) {
-        const int a = e % nf, b2 = e / nf;
-        L.R[a + LDM * b2] = (a <= b2) ? L.Qf[b2 + LDM * a] : 0.0;
       }
       nfR = nf;
-      lds_sync();
       ILQR_QMARK(4)
-      // Ri = R^-1 (upper triangular, column j on lane j), Minv = Ri Ri'  (:105-112).  The reference
-      // inverts R in every iteration; R only changes here, so the product is computed here and kept
-      // (same values) -- for the iterations that reuse a stale factor and for the caller's K.
-      if (lane < nfR) {
-        const int j = lane;
-        for (int i = 0; i < nfR; i++) L.Ri()[i + LDM * j] = 0;
-        L.Ri()[j + LDM * j] = 1.0 / L.R[j + LDM * j];
-        for (int i = j - 1; i >= 0; i--) {
-          const double s = dot_masked(i + 1, j + 1, [&](int l2) { return L.R[i + LDM * l2]; }, [&](int l2) { return L.Ri()[l2 + LDM * j]; });
-          L.Ri()[i + LDM * j] = -s / L.R[i + LDM * i];
+      // :86-88 R = L' (upper); Ri = R^-1 (upper triangular, column j on lane j), Minv = Ri Ri'
+      // (:105-112).  The reference inverts R in every iteration; R only changes here, so the product
+      // is computed here and kept (same values) -- for the iterations that reuse a stale factor and
+      // for the caller's K.  R(i, l2) = L(l2, i) = lane l2's row[i].
+      {
+        double ri[WM];
+#pragma unroll
+        for (int i = 0; i < WM; i++) ri[i] = 0.0;
+#pragma unroll
+        for (int i = WM - 1; i >= 0; i--) {
+          if (i < nfR) {
+            const double rii = bcast(row[i], i);
+            double s = 0;
+#pragma unroll
+            for (int l2 = i + 1; l2 < WM; l2++) s = __builtin_fma(bcast(row[i], l2), ri[l2], s);
+            const double off = -s / rii;
+            ri[i] = (lane >= nfR) ? 0.0 : ((lane == i) ? 1.0 / rii : ((lane > i) ? off : 0.0));
+          }
+        }
+        if (lane < WM) {
+#pragma unroll
+          for (int i = 0; i < WM; i++) L.Ri()[i + LDM * lane] = ri[i];
         }
       }
       lds_sync();
-      for (int e = lane; e < nfR * nfR; e += 64) {
-        const int a = e % nfR, b2 = e / nfR;
-        L.Minv[a + LDM * b2] =
-            dot_masked(0, nfR, [&](int l2) { return L.Ri()[a + LDM * l2]; }, [&](int l2) { return L.Ri()[b2 + LDM * l2]; });
+      {
+        const double4_t acc = mfma_tile<WM / 4>([&](int i, int k) { return L.Ri()[i + LDM * k]; },
+                                                [&](int k, int j) { return L.Ri()[j + LDM * k]; }, lane);
+        const int col = lane & 15, r0 = lane >> 4;
+#pragma unroll
+        for (int r = 0; r < 4; r++) L.Minv[(r0 + 4 * r) + LDM * col] = acc[r];
       }
       lds_sync();
       ILQR_QMARK(5)
