@@ -32,27 +32,34 @@ constexpr int WN = 32, WM = 16;   // maximum dimensions of this kernel
 constexpr int LDN = WN + 1;       // leading dimension of LDS matrices with up to 32 rows
 constexpr int LDM = WM + 1;       // ... with up to 16 rows
 
-// Four matrices share storage with ones that are dead by the time they are written, which brings a
-// wavefront's LDS from 68 KB to 49 KB, i.e. from two to three wavefronts per CU (160 KB):
+// Matrices share storage with ones that are dead by the time they are written, which brings a
+// wavefront's LDS from 68 KB to 39.6 KB, i.e. from two to FOUR wavefronts per CU (160 KB; one per
+// SIMD, which is also what the 512 registers of a wavefront allow):
 //   Qxx  in Vxx : Vxx' is last read for A1 = fx'Vxx' and A2 = fu'Vxx'; Qxx is written after both and
 //                 read once, when Vn is assembled into A1; the new Vxx then overwrites it
-//   T1   in fu  : fu is last read for Quu (before the box-QP); T1 = K'Quu is written after it; the
-//                 next step refills fu completely
+//   Quu, QuuF, Minv in fx : fx is last read for Qxx and Qux; the three m x m matrices are written
+//                 after that (Quu/QuuF in the same phase, Minv by the box-QP) and are dead at the
+//                 end of the step, when the next record's fx is copied in
+//   Ri / Qf in fu : fu is last read for Quu.  Ri is written and read (for Minv) inside a
+//                 factorisation; Qf is the scatter buffer of the K product after the box-QP
+//   T1   in fu  : T1 = K'Quu is written after K (i.e. after Qf's last read); the next step refills
+//                 fu completely
 //   K    in A2  : A2 is last read for Qux / Quu; K is written after the box-QP (A2's padding
 //                 columns are exact zeros, as K's must be)
-//   Ri   in Qf  : Ri is read once, for Minv, right after it is written; Qf is the caller's scatter
-//                 buffer for K afterwards (the Cholesky factor itself lives in registers)
 struct WaveLds {
   double Vxx[LDN * WN], fx[LDN * WN], A1[LDN * WN];
   double fu[LDN * WM];
   double A2[LDM * WN], Qux[LDM * WN];
-  double Quu[LDM * WM], QuuF[LDM * WM], Qf[LDM * WM], Minv[LDM * WM];
   __device__ __forceinline__ double* Qxx() { return Vxx; }
   __device__ __forceinline__ double* T1() { return fu; }
   __device__ __forceinline__ double* K() { return A2; }
-  __device__ __forceinline__ double* Ri() { return Qf; }
+  __device__ __forceinline__ double* Quu() { return fx; }
+  __device__ __forceinline__ double* QuuF() { return fx + LDM * WM; }
+  __device__ __forceinline__ double* Minv() { return fx + 2 * LDM * WM; }
+  __device__ __forceinline__ double* Qf() { return fu; }
+  __device__ __forceinline__ double* Ri() { return fu; }
   double Vx[WN], Qx[WN], Vxn[WN];
-  double Qu[WM], x[WM], grad[WM], gc[WM], search[WM], lo[WM], hi[WM], clamped[WM], oldcl[WM], xr[WM], xc[WM], tmp[WM],
+  double Qu[WM], x[WM], grad[WM], gc[WM], search[WM], lo[WM], hi[WM], clamped[WM], xc[WM], tmp[WM],
       kprev[WM], gfree[WM], xfree[WM];
   int vfree[WM], idx[WM];
 };
@@ -155,14 +162,13 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
 #else
 #define ILQR_QMARK(k)
 #endif
-  const double* Q = L.QuuF;
+  const double* Q = L.QuuF();
   const double* c = L.Qu;
   // :35 clamp
   if (lane < m) {
     const double a = (L.kprev[lane] < L.lo[lane]) ? L.lo[lane] : L.kprev[lane];
     L.x[lane] = (L.hi[lane] < a) ? L.hi[lane] : a;
     L.clamped[lane] = 0;
-    L.oldcl[lane] = 0;
     L.vfree[lane] = 0;
   }
   lds_sync();
@@ -194,12 +200,12 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
       const double s = dot_masked(0, m, [&](int j) { return Q[lane + LDM * j]; }, [&](int j) { return L.x[j]; });
       const double g = s + c[lane];
       L.grad[lane] = g;
-      L.oldcl[lane] = L.clamped[lane];
+      const double oldcl = L.clamped[lane];  // (lane-local: first pass reads the 0 written above)
       const bool isc = (fabs(L.x[lane] - L.lo[lane]) < kClampTol && g > 0) || (fabs(L.x[lane] - L.hi[lane]) < kClampTol && g < 0);
       L.clamped[lane] = isc ? 1.0 : 0.0;
       L.vfree[lane] = isc ? 0 : 1;
       cl = isc ? 1 : 0;
-      dd = L.oldcl[lane] - L.clamped[lane];
+      dd = oldcl - L.clamped[lane];
     }
     oldvalue = val;
     const unsigned long long free_mask = __ballot(lane < m && !cl);
@@ -293,7 +299,7 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
                                                 [&](int k, int j) { return L.Ri()[j + LDM * k]; }, lane);
         const int col = lane & 15, r0 = lane >> 4;
 #pragma unroll
-        for (int r = 0; r < 4; r++) L.Minv[(r0 + 4 * r) + LDM * col] = acc[r];
+        for (int r = 0; r < 4; r++) L.Minv()[(r0 + 4 * r) + LDM * col] = acc[r];
       }
       lds_sync();
       ILQR_QMARK(5)
@@ -325,7 +331,7 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
     lds_sync();
     // :103-119 search(free) = -(R^-1 R^-T) gc(free) - x(free)   (a stale factor of equal size is used as is)
     if (lane < nfR && lane < nf) {
-      const double s = dot_masked(0, (nfR < nf) ? nfR : nf, [&](int l2) { return -L.Minv[lane + LDM * l2]; }, [&](int l2) { return L.gfree[l2]; });
+      const double s = dot_masked(0, (nfR < nf) ? nfR : nf, [&](int l2) { return -L.Minv()[lane + LDM * l2]; }, [&](int l2) { return L.gfree[l2]; });
       L.search[L.idx[lane]] = s - L.xfree[lane];
     }
     lds_sync();
@@ -571,8 +577,8 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
           const int a = orow + 4 * rr, c = ocol;
           const bool in = (a < m && c < m);
           const double cuu = in ? rec.cuu[rr] : 0.0;
-          L.Quu[a + LDM * c] = in ? cuu + acc[rr] : 0.0;
-          L.QuuF[a + LDM * c] = in ? (cuu + ((a == c) ? lambda : 0.0)) + acc[rr] : 0.0;
+          L.Quu()[a + LDM * c] = in ? cuu + acc[rr] : 0.0;
+          L.QuuF()[a + LDM * c] = in ? (cuu + ((a == c) ? lambda : 0.0)) + acc[rr] : 0.0;
         }
       }
       lds_sync();
@@ -597,12 +603,12 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
           // K = -(Minv scattered to the free rows / columns of an m x m matrix) Qux on the matrix
           // cores: clamped rows of the scattered matrix are zero, so those rows of K come out zero,
           // and the zero columns add exact zeros to the k-ordered sums over the free dims.
-          double* MF = L.Qf;  // (the Cholesky work copy / Ri: dead until the next factorisation)
+          double* MF = L.Qf();  // (the Cholesky work copy / Ri: dead until the next factorisation)
           for (int e = lane; e < LDM * WM; e += 64) MF[e] = 0.0;
           lds_sync();
           for (int e = lane; e < nf * nf; e += 64) {
             const int a = e % nf, b2 = e / nf;
-            MF[L.idx[a] + LDM * L.idx[b2]] = L.Minv[a + LDM * b2];
+            MF[L.idx[a] + LDM * L.idx[b2]] = L.Minv()[a + LDM * b2];
           }
           lds_sync();
 #pragma unroll
@@ -618,7 +624,7 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
           for (int e = lane; e < nuse * n; e += 64) {
             const int rr = e % nuse, c = e / nuse;
             double acc = 0;
-            for (int l2 = 0; l2 < nuse; l2++) acc += -L.Minv[rr + LDM * l2] * L.Qux[L.idx[l2] + LDM * c];
+            for (int l2 = 0; l2 < nuse; l2++) acc += -L.Minv()[rr + LDM * l2] * L.Qux[L.idx[l2] + LDM * c];
             L.K()[L.idx[rr] + LDM * c] = acc;
           }
         }
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
         const double d0 = wave_sum(lane < m ? L.x[lane] * L.Qu[lane] : 0.0);
         double part = 0;
         if (lane < m) {
-          const double rr = dot_masked(0, m, [&](int a) { return 0.5 * L.x[a]; }, [&](int a) { return L.Quu[a + LDM * lane]; });
+          const double rr = dot_masked(0, m, [&](int a) { return 0.5 * L.x[a]; }, [&](int a) { return L.Quu()[a + LDM * lane]; });
           part = rr * L.x[lane];
         }
         dV0 += d0;
@@ -641,7 +647,7 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
       for (int ti = 0; ti < 2; ti++) {
         if (ti >= NT) continue;
         const double4_t acc = mfma_tile<WM / 4>(
-            [&](int i2, int k) { return L.K()[k + LDM * (ti * 16 + i2)]; }, [&](int k, int j) { return L.Quu[k + LDM * j]; },
+            [&](int i2, int k) { return L.K()[k + LDM * (ti * 16 + i2)]; }, [&](int k, int j) { return L.Quu()[k + LDM * j]; },
             lane);
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) L.T1()[(ti * 16 + orow + 4 * rr) + LDN * ocol] = acc[rr];
