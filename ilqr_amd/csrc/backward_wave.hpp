@@ -86,6 +86,14 @@ __device__ __forceinline__ double4_t mfma_tile(FA a_at, FB b_at, int lane) {
   return acc;
 }
 
+// this lane's share of one 16-wide operand block, f(i or j = l&15, k = 4 ks + (l>>4)), ks = 0..KSTEPS-1
+template <int KSTEPS, class F>
+__device__ __forceinline__ void ld_operand(F f, int lane, double (&o)[KSTEPS]) {
+  const int ij = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ks++) o[ks] = f(ij, ks * 4 + kq);
+}
+
 // sum over the 64 lanes (result in all lanes).  DPP inside each row of 16 lanes (xor 1, xor 2, half
 // mirror, mirror: every lane of a row ends with the row total), then the four row totals through
 // v_readlane.  The box-QP calls this a few times per Armijo trip; the ds_bpermute butterfly it
@@ -121,17 +129,17 @@ __device__ __forceinline__ void lds_sync() {
 // with a runtime trip count reads LDS, waits, multiplies, one term at a time (~120 cycles each with
 // a single wavefront per SIMD); unrolled, the 2 x 16 reads go out back to back.  A masked-out term
 // contributes fma(0, 0, s) = s, so the value is that of the plain loop.
-template <class FA, class FB>
+template <int N = WM, class FA, class FB>
 __device__ __forceinline__ double dot_masked(int lo, int hi, FA a, FB b) {
-  double av[WM], bv[WM];
+  double av[N], bv[N];
 #pragma unroll
-  for (int j = 0; j < WM; j++) {
+  for (int j = 0; j < N; j++) {
     av[j] = a(j);
     bv[j] = b(j);
   }
   double s = 0;
 #pragma unroll
-  for (int j = 0; j < WM; j++) {
+  for (int j = 0; j < N; j++) {
     const bool in = (j >= lo) & (j < hi);
     s = __builtin_fma(in ? av[j] : 0.0, in ? bv[j] : 0.0, s);
   }
@@ -427,14 +435,22 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
   }
   lds_sync();
 
-  // One step's record in registers, every load of it issued back to back (a single HBM round
-  // trip instead of one per loop iteration) and one step AHEAD of its use.  fx/fu are fetched
-  // row-contiguous for the copy into LDS; cxx/cxu/cuu are fetched directly in the MFMA output
-  // mapping (this lane's rows orow+4r, column ocol of each tile) where they are added.
-  struct RecRegs {
-    double fx[16], fu[8], cxx[16], cxu[8], cuu[4], cx, cu, us;
+  // One step's record goes through registers in two halves, every load of a half issued back to
+  // back (one HBM round trip, not one per loop iteration):
+  //   RecA  fx, fu (row-contiguous, for the copy into LDS), cx, cu, u: fetched one step AHEAD, right
+  //         after the products that need the most registers, and in flight during the box-QP;
+  //   RecB  cxx, cxu, cuu in the MFMA output mapping (this lane's rows orow+4r, column ocol of each
+  //         tile) where they are added: fetched at the top of their own step, consumed two product
+  //         phases later.
+  // (Holding a whole record a step ahead, as a first version did, spilled once the products kept all
+  // their operand sets in registers.)
+  struct RecA {
+    double fx[16], fu[8], cx, cu, us;
   };
-  auto load_rec = [&](int i, RecRegs& q) __attribute__((always_inline)) {
+  struct RecB {
+    double cxx[16], cxu[8], cuu[4];
+  };
+  auto load_rec_a = [&](int i, RecA& q) __attribute__((always_inline)) {
     const double* r = Db + (size_t)i * REC;
     const int a32 = lane & 31, chalf = lane >> 5;
 #pragma unroll
@@ -447,6 +463,12 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
       const int c = 2 * j + chalf;
       q.fu[j] = (a32 < n && c < m) ? r[oFU + a32 + n * c] : 0.0;
     }
+    q.cx = (lane < n) ? r[oCX + lane] : 0.0;
+    q.cu = (lane >= WN && lane - WN < m) ? r[oCU + lane - WN] : 0.0;  // (lanes 32.. : where Qu is computed)
+    q.us = (lane < m) ? usb[(size_t)i * m + lane] : 0.0;
+  };
+  auto load_rec_b = [&](int i, RecB& q) __attribute__((always_inline)) {
+    const double* r = Db + (size_t)i * REC;
 #pragma unroll
     for (int t2 = 0; t2 < 16; t2++) {
       const int a = (t2 >> 3) * 16 + orow + 4 * (t2 & 3), c = ((t2 >> 2) & 1) * 16 + ocol;
@@ -462,9 +484,6 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
       const int a = orow + 4 * rr;
       q.cuu[rr] = (a < m && ocol < m) ? r[oCUU + a + m * ocol] : 0.0;
     }
-    q.cx = (lane < n) ? r[oCX + lane] : 0.0;
-    q.cu = (lane < m) ? r[oCU + lane] : 0.0;
-    q.us = (lane < m) ? usb[(size_t)i * m + lane] : 0.0;
   };
 
   int diverge = 0;
@@ -489,8 +508,8 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
 #else
 #define ILQR_WMARK(k)
 #endif
-    RecRegs cur;
-    load_rec(T - 1, cur);
+    RecA cur;
+    load_rec_a(T - 1, cur);
     for (int i = T - 1; i >= 0; i--) {
       ILQR_WMARK(7)
       {  // fx, fu -> LDS (rows along lanes 0..31, two columns per pass)
@@ -504,22 +523,56 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
         L.lo[lane] = u_min[lane] - cur.us;  // :369
         L.hi[lane] = u_max[lane] - cur.us;
       }
-      const RecRegs rec = cur;           // this step's addends stay in registers
-      if (i > 0) load_rec(i - 1, cur);   // next step's record: in flight during this step
+      const double rec_cx = cur.cx, rec_cu = cur.cu;
+      RecB rec;
+      load_rec_b(i, rec);
       ILQR_WMARK(0)
       lds_sync();
       // :359-360
-      for (int a = lane; a < n; a += 64) {
-        double acc = 0;
-        for (int q = 0; q < n; q++) acc += L.fx[q + LDN * a] * L.Vx[q];
-        L.Qx[a] = rec.cx + acc;  // n <= 32: a == lane
-      }
-      if (lane < m) {
-        double acc = 0;
-        for (int q = 0; q < n; q++) acc += L.fu[q + LDN * lane] * L.Vx[q];
-        L.Qu[lane] = rec.cu + acc;
+      {  // (lanes 0..31: Qx, lanes 32..47: Qu -- one batch of LDS reads for both)
+        const bool isx = lane < WN;
+        const int col = isx ? lane : ((lane - WN) & (WM - 1));
+        const double* colp = isx ? &L.fx[LDN * col] : &L.fu[LDN * col];
+        const double acc = dot_masked<WN>(0, n, [&](int q) { return colp[q]; }, [&](int q) { return L.Vx[q]; });
+        if (isx && lane < n) L.Qx[lane] = rec_cx + acc;
+        if (!isx && lane - WN < m) L.Qu[lane - WN] = rec_cu + acc;
       }
       // A1 = fx' Vxx ; A2 = fu' Vxx      (matrix cores; LDS operands are zero-padded to whole tiles)
+      if (NT == 2) {
+        // all six output tiles at once: each operand set is read from LDS once (40 reads instead of
+        // 96) and the six independent accumulation chains interleave, so no MFMA waits for the one
+        // before it.  Per tile the k order is unchanged.
+        double aFx[2][WN / 4], aFu[WN / 4], bV[2][WN / 4];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; t2++) {
+          ld_operand<WN / 4>([&](int i2, int k) { return L.fx[k + LDN * (t2 * 16 + i2)]; }, lane, aFx[t2]);
+          ld_operand<WN / 4>([&](int j, int k) { return L.Vxx[k + LDN * (t2 * 16 + j)]; }, lane, bV[t2]);
+        }
+        ld_operand<WN / 4>([&](int i2, int k) { return L.fu[k + LDN * i2]; }, lane, aFu);
+        double4_t acc[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < WN / 4; ks++) {
+#pragma unroll
+          for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+            for (int tj = 0; tj < 2; tj++)
+              acc[ti * 2 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aFx[ti][ks], bV[tj][ks], acc[ti * 2 + tj], 0, 0, 0);
+#pragma unroll
+          for (int tj = 0; tj < 2; tj++) acc[4 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aFu[ks], bV[tj][ks], acc[4 + tj], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+          for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) L.A1[(ti * 16 + orow + 4 * rr) + LDN * (tj * 16 + ocol)] = acc[ti * 2 + tj][rr];
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) L.A2[(orow + 4 * rr) + LDM * (tj * 16 + ocol)] = acc[4 + tj][rr];
+      } else {
 #pragma unroll
       for (int ti = 0; ti < 2; ti++)
 #pragma unroll
@@ -540,9 +593,58 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) L.A2[(orow + 4 * rr) + LDM * (tj * 16 + ocol)] = acc[rr];
       }
+      }
       lds_sync();
       ILQR_WMARK(1)
       // :361 Qxx = cxx + A1 fx ; :362 Qux = cxu' + A2 fx ; :363/:367 Quu, QuuF = cuu (+ lambda I) + A2 fu
+      if (NT == 2) {  // seven tiles, six operand sets (as above)
+        double aA1[2][WN / 4], aA2[WN / 4], bFx[2][WN / 4], bFu[WN / 4];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; t2++) {
+          ld_operand<WN / 4>([&](int i2, int k) { return L.A1[(t2 * 16 + i2) + LDN * k]; }, lane, aA1[t2]);
+          ld_operand<WN / 4>([&](int j, int k) { return L.fx[k + LDN * (t2 * 16 + j)]; }, lane, bFx[t2]);
+        }
+        ld_operand<WN / 4>([&](int i2, int k) { return L.A2[i2 + LDM * k]; }, lane, aA2);
+        ld_operand<WN / 4>([&](int j, int k) { return L.fu[k + LDN * j]; }, lane, bFu);
+        double4_t acc[7];
+#pragma unroll
+        for (int q = 0; q < 7; q++) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < WN / 4; ks++) {
+#pragma unroll
+          for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+            for (int tj = 0; tj < 2; tj++)
+              acc[ti * 2 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA1[ti][ks], bFx[tj][ks], acc[ti * 2 + tj], 0, 0, 0);
+#pragma unroll
+          for (int tj = 0; tj < 2; tj++) acc[4 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA2[ks], bFx[tj][ks], acc[4 + tj], 0, 0, 0);
+          acc[6] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA2[ks], bFu[ks], acc[6], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+          for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+              const int a = ti * 16 + orow + 4 * rr, c = tj * 16 + ocol;
+              L.Qxx()[a + LDN * c] = (a < n && c < n) ? rec.cxx[(ti * 2 + tj) * 4 + rr] + acc[ti * 2 + tj][rr] : 0.0;
+            }
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            const int a = orow + 4 * rr, c = tj * 16 + ocol;
+            L.Qux[a + LDM * c] = (a < m && c < n) ? rec.cxu[tj * 4 + rr] + acc[4 + tj][rr] : 0.0;
+          }
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int a = orow + 4 * rr, c = ocol;
+          const bool in = (a < m && c < m);
+          const double cuu = in ? rec.cuu[rr] : 0.0;
+          L.Quu()[a + LDM * c] = in ? cuu + acc[6][rr] : 0.0;
+          L.QuuF()[a + LDM * c] = in ? (cuu + ((a == c) ? lambda : 0.0)) + acc[6][rr] : 0.0;
+        }
+      } else {
 #pragma unroll
       for (int ti = 0; ti < 2; ti++)
 #pragma unroll
@@ -581,6 +683,8 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
           L.QuuF()[a + LDM * c] = in ? (cuu + ((a == c) ? lambda : 0.0)) + acc[rr] : 0.0;
         }
       }
+      }
+      if (i > 0) load_rec_a(i - 1, cur);  // next step's fx, fu, ...: in flight during the box-QP
       lds_sync();
       ILQR_WMARK(2)
       int nfR = 0;
