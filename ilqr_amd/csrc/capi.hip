@@ -255,9 +255,24 @@ static int launch_rollout_t(ilqr_batch* h, const M& m, bool gains, bool cand, co
   HIPCHK(hipGetLastError());
   return 0;
 }
-// generic path (generic.hpp): what = RG_INIT / RG_SEARCH / RG_COMMIT
-template <class M>
-static int launch_rollout_g(ilqr_batch* h, const M& m, int what, const AlphaSet& al, double* cost_out, int mode, int write_cost) {
+// generic path (generic.hpp): what = RG_INIT / RG_SEARCH / RG_COMMIT.  The LQ model rolls out on the
+// matrix cores (k_rollout_lq, one wavefront per trajectory); ILQR_AMD_LQ_THREAD_ROLLOUT=1 selects the
+// generic thread-per-rollout kernel (same results bit for bit; kept as the cross-check and as the
+// template for device models without matrix structure).
+static bool lq_thread_rollout() { return getenv("ILQR_AMD_LQ_THREAD_ROLLOUT") != nullptr; }
+static int launch_rollout_g(ilqr_batch* h, const LqModel& m, int what, const AlphaSet& al, double* cost_out, int mode, int write_cost) {
+  if (!lq_thread_rollout()) {
+    const dim3 grid(h->B), block(64);
+    if (what == RG_SEARCH)
+      hipLaunchKernelGGL((k_rollout_lq<RG_SEARCH>), grid, block, 0, h->stream, h->v, m, al, cost_out, nullptr, mode, 0);
+    else if (what == RG_INIT)
+      hipLaunchKernelGGL((k_rollout_lq<RG_INIT>), grid, block, 0, h->stream, h->v, m, al, cost_out, nullptr, 0, 1);
+    else
+      hipLaunchKernelGGL((k_rollout_lq<RG_COMMIT>), grid, block, 0, h->stream, h->v, m, al, cost_out, h->commit_idx, 0, write_cost);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  typedef LqModel M;
   if (what == RG_SEARCH)
     hipLaunchKernelGGL((k_rollout_g<M, RG_SEARCH>), dim3((h->B + kSearchTraj - 1) / kSearchTraj), dim3(64), 0, h->stream, h->v, m, al,
                        cost_out, nullptr, mode, 0);
@@ -1067,7 +1082,7 @@ const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
       if (h && h->aos) return "k_backward_w";
       if (h && use_fused_sweep(h)) return "k_sweep_backward";  // what ilqr_iterate launches
       return (h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t";
-    case ILQR_STAGE_ROLLOUT: return (h && h->aos) ? "k_rollout_g" : "k_rollout";
+    case ILQR_STAGE_ROLLOUT: return (h && h->aos) ? (lq_thread_rollout() ? "k_rollout_g" : "k_rollout_lq") : "k_rollout";
     case ILQR_STAGE_ACCEPT: return "k_accept";
     default: return "";
   }

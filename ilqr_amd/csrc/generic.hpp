@@ -303,6 +303,193 @@ __global__ __launch_bounds__(64) void k_rollout_g(BatchView v, M model, AlphaSet
 }
 
 // ------------------------------------------------------------------------------------------
+// forward rollout of the LQ model on the matrix cores
+// ------------------------------------------------------------------------------------------
+// One WAVEFRONT per trajectory; the 11 candidate rollouts of the line search are the columns of
+// a [32 x 16] state block X (columns 11..15 run alpha = 0 and are dropped), and every product of
+// a rollout step is a chain of v_mfma_f64_16x16x4_f64 over that block:
+//     U  = us + alpha k + K (X - xs)          K D   : 1 tile  x 8 k-steps
+//     qx = diag(X' (Q X)),  qu = diag(U' (R U))   : 2 x 8 + 8,  4 + 4
+//     X1 = X + dt (A X + B U)                      : 2 tiles x (8 + 4)
+// 64 MFMAs per knot for 16 columns, against 3.3 K FMAs per knot and rollout of the thread-per-
+// rollout kernel above (k_rollout_g, whose fully unrolled scalar-operand products spill SGPRs: 38 ms
+// per search at B = 8192, T = 200).  What makes this layout work:
+//   * The C/D map of the instruction (lane l holds rows (l>>4) + 4r, column l&15) is also its B
+//     map with k-step r (k = 4r + (l>>4), j = l&15) and, transposed, its A map.  So a product's
+//     output registers ARE the next product's operand registers: the state block, the control
+//     block and Q X / R U never leave registers or change lanes for the whole rollout.
+//   * x'(Qx) for 16 columns is the diagonal of X'(QX): one more MFMA chain, whose k order is the
+//     order of the scalar sum (the 15/16 off-diagonal outputs are the price).
+//   * A, B, Q, R in operand layout are 44 doubles per lane, loaded once per kernel.
+// Each chain runs k ascending from a zero accumulator, as the sums of LqModel::dynamics / quad do,
+// so the results are those of k_rollout_g bit for bit (tests/test_gpu_lq_end_to_end.py compares them).
+// Modes as above.  RG_COMMIT / RG_INIT run the same block with every column on the same rollout and
+// store column 0.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_rollout_lq(BatchView v, LqModel model, AlphaSet alphas, double* __restrict__ cost_out,
+                                                   const int* __restrict__ commit_idx, int mode, int write_cost) {
+  typedef double double4_t __attribute__((ext_vector_type(4)));
+  const int nx = model.nx, nu = model.nu, T = v.T;
+  const int lane = threadIdx.x, g = lane >> 4, p = lane & 15;
+  const int b = blockIdx.x;
+  if (b >= v.B) return;
+  if (MODE == RG_SEARCH && mode == 1 && !(v.status[b] == 0 && v.backpass_done[b])) return;
+  int a = p;
+  if (MODE == RG_COMMIT) {
+    a = commit_idx[b];
+    if (a < 0) return;
+  }
+  double alpha = 0;
+#pragma unroll
+  for (int q = 0; q < NALPHA; q++)
+    if (a == q) alpha = alphas.a[q];
+  const double dt = v.dt;
+  auto mfma = [](double x, double y, double4_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, c, 0, 0, 0); };
+  const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+
+  // model matrices as A operands: row (16 ti + p), k = 4 ks + g
+  double opA[2][8], opQ[2][8], opB[2][4], opR[4];
+#pragma unroll
+  for (int ti = 0; ti < 2; ti++) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      opA[ti][ks] = model.A[(16 * ti + p) * GN + 4 * ks + g];
+      opQ[ti][ks] = model.Q[(16 * ti + p) * GN + 4 * ks + g];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) opB[ti][ks] = model.Bm[(16 * ti + p) * GM + 4 * ks + g];
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) opR[ks] = model.R[p * GM + 4 * ks + g];
+
+  double* xsb = v.xs + (size_t)b * (T + 1) * nx;
+  double* usb = v.us + (size_t)b * T * nu;
+  const double* kb = v.kff + (size_t)b * T * nu;
+  const double* Kb = v.Kfb + (size_t)b * T * nu * nx;
+
+  // this lane's share of knot t: xs rows 4ks+g, K(p, 4ks+g), us / k rows g+4r
+  struct Knot {
+    double xs[8], K[8], us[4], k[4];
+  };
+  auto load_knot = [&](int t, Knot& q) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      const int i = 4 * ks + g;
+      q.xs[ks] = (MODE != RG_INIT && i < nx) ? xsb[(size_t)t * nx + i] : 0.0;
+      q.K[ks] = (MODE != RG_INIT && i < nx && p < nu) ? Kb[(size_t)t * nu * nx + p + nu * i] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int j = g + 4 * r;
+      q.us[r] = (j < nu) ? usb[(size_t)t * nu + j] : 0.0;
+      q.k[r] = (MODE != RG_INIT && j < nu) ? kb[(size_t)t * nu + j] : 0.0;
+    }
+  };
+
+  double x[8];  // X rows 4ks+g, column p
+#pragma unroll
+  for (int ks = 0; ks < 8; ks++) x[ks] = (4 * ks + g < nx) ? v.x0[(size_t)b * nx + 4 * ks + g] : 0.0;
+  double4_t total = zero4;  // running cost of column p sits on the diagonal: lane g == (p & 3), element p >> 2
+  Knot cur;
+  if (T > 0) load_knot(0, cur);
+  for (int t = 0; t < T; t++) {
+    const Knot kn = cur;
+    if (t + 1 < T) load_knot(t + 1, cur);  // next knot in flight during this one
+    double u[4];
+    double4_t ax[2] = {zero4, zero4}, qx[2] = {zero4, zero4};
+    if (MODE != RG_INIT) {
+      double d[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) d[ks] = x[ks] - kn.xs[ks];
+      double4_t kd = zero4;
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {  // three independent chains share the issue slots
+        kd = mfma(kn.K[ks], d[ks], kd);
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++) {
+          qx[ti] = mfma(opQ[ti][ks], x[ks], qx[ti]);
+          ax[ti] = mfma(opA[ti][ks], x[ks], ax[ti]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        double uj = kn.us[r];
+        uj += kn.k[r] * alpha;  // :190
+        uj += kd[r];            // :316
+        u[r] = uj;
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++) {
+          qx[ti] = mfma(opQ[ti][ks], x[ks], qx[ti]);
+          ax[ti] = mfma(opA[ti][ks], x[ks], ax[ti]);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; r++) u[r] = kn.us[r];
+    }
+    if (MODE != RG_SEARCH && p == 0) {  // :323 (no clamping)
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++)
+        if (4 * ks + g < nx) xsb[(size_t)t * nx + 4 * ks + g] = x[ks];
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (g + 4 * r < nu) usb[(size_t)t * nu + g + 4 * r] = u[r];
+    }
+    // :324 cost = 0.5 (x'Qx + u'Ru)
+    double4_t ru = zero4, cx = zero4, cu = zero4;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      ru = mfma(opR[ks], u[ks], ru);
+#pragma unroll
+      for (int ti = 0; ti < 2; ti++) ax[ti] = mfma(opB[ti][ks], u[ks], ax[ti]);
+      cx = mfma(x[ks], qx[0][ks], cx);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      cx = mfma(x[4 + ks], qx[1][ks], cx);
+      cu = mfma(u[ks], ru[ks], cu);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) total[r] += LqModel::cost_from_parts(cx[r], cu[r]);
+    // :325 x1 = x + dx dt
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) x[4 * ti + r] = x[4 * ti + r] + ax[ti][r] * dt;
+  }
+  if (MODE != RG_SEARCH && p == 0) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++)
+      if (4 * ks + g < nx) xsb[(size_t)T * nx + 4 * ks + g] = x[ks];
+  }
+  {  // :335 final cost 0.5 x'Qf x
+    double4_t qf[2] = {zero4, zero4}, cf = zero4;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+      for (int ti = 0; ti < 2; ti++) qf[ti] = mfma(model.Qf[(16 * ti + p) * GN + 4 * ks + g], x[ks], qf[ti]);
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) cf = mfma(x[ks], qf[ks >> 2][ks & 3], cf);
+#pragma unroll
+    for (int r = 0; r < 4; r++) total[r] += 0.5 * cf[r];
+  }
+  // the diagonal element of column p: lane g == (p & 3), element p >> 2
+  double mine = total[0];
+#pragma unroll
+  for (int r = 1; r < 4; r++)
+    if ((p >> 2) == r) mine = total[r];
+  if (g == (p & 3)) {
+    if (MODE == RG_SEARCH) {
+      if (p < NALPHA) cost_out[(size_t)p * v.Bp + b] = mine;
+    } else if (p == 0 && (MODE == RG_INIT || write_cost)) {
+      cost_out[b] = mine;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // finite-difference derivatives
 // ------------------------------------------------------------------------------------------
 // One wavefront per knot (b, t); every lane evaluates the model at ONE perturbed point, then

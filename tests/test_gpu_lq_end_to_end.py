@@ -149,3 +149,35 @@ def test_lq_full_solve_and_warm_start(oracle):
     assert g.lib.ilqr_warm_start(g.h, x1.ctypes.data_as(C.POINTER(C.c_double))) == 0
     assert g.count_running() == 0 and np.all(np.isfinite(g.cost()))
     g.close()
+
+
+@pytest.mark.parametrize("n,m,B,T", [(32, 16, 9, 40), (6, 3, 33, 25), (31, 1, 2, 3), (2, 16, 5, 2), (1, 1, 3, 1)])
+def test_lq_matrix_core_rollout_equals_thread_per_rollout(n, m, B, T, monkeypatch):
+    """k_rollout_lq (one wavefront per trajectory, every product a v_mfma_f64_16x16x4_f64 chain over the
+    11 candidate columns) against the generic thread-per-rollout kernel k_rollout_g
+    (ILQR_AMD_LQ_THREAD_ROLLOUT=1): the chains run in the order of the scalar sums, so init rollout,
+    the 11 search costs, the committed trajectory and everything downstream are bit-identical."""
+    from ilqr_amd import BatchILQR, capi
+    mats = dense_mats(n, m)
+    rng = np.random.default_rng(8)
+    x0 = rng.uniform(-1, 1, (B, n))
+    u0 = rng.normal(size=(B, T, m)) * 0.3
+    out = []
+    for thread in (False, True):
+        if thread:
+            monkeypatch.setenv("ILQR_AMD_LQ_THREAD_ROLLOUT", "1")
+        else:
+            monkeypatch.delenv("ILQR_AMD_LQ_THREAD_ROLLOUT", raising=False)
+        g = BatchILQR("lq", B, T, DT, u_min=-0.4, u_max=0.4, lq=mats, flags=capi.FLAG_ANALYTIC_DERIVATIVES)
+        name = g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("rollout"))
+        assert name == (b"k_rollout_g" if thread else b"k_rollout_lq")
+        c0 = g.init_traj(x0, u0)
+        g.iterate(3)
+        xs, us = g.trajectory()
+        k, K = g.gains()
+        st, it, al = g.status()
+        out.append(dict(c0=c0, xs=xs, us=us, k=k, K=K, cost=g.cost(), al=al, it=it))
+        g.close()
+    for key in out[0]:
+        assert np.array_equal(out[0][key], out[1][key], equal_nan=True), key
+    assert np.all(out[0]["cost"] < out[0]["c0"])
