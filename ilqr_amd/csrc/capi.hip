@@ -343,7 +343,12 @@ static int launch_derivatives(ilqr_batch* h, int force) {
   dim3 grid((h->T + 1 + 15) / 16, h->ntiles), block(256);
   const int* ci = h->commit_pending ? h->commit_idx : nullptr;
   if (h->model == ILQR_MODEL_LQ) {
-    hipLaunchKernelGGL((k_derivatives_g<LqModel>), dim3(h->B * (h->T + 1)), dim3(64), 0, h->stream, h->v, h->lq, force);
+    if (h->v.analytic) {
+      const int nchunk = (h->T + 1 + kAnalyticChunk - 1) / kAnalyticChunk;
+      hipLaunchKernelGGL(k_analytic_lq, dim3(h->B * nchunk), dim3(64), 0, h->stream, h->v, h->lq, force);
+    } else {
+      hipLaunchKernelGGL((k_derivatives_g<LqModel>), dim3(h->B * (h->T + 1)), dim3(64), 0, h->stream, h->v, h->lq, force);
+    }
     HIPCHK(hipGetLastError());
     return timer_end(h, ILQR_STAGE_DERIVATIVES, ev);
   }
@@ -1077,7 +1082,7 @@ int ilqr_profile_read(ilqr_batch* h, double ms_out[ILQR_NUM_STAGES], int launche
 }
 const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
   switch (stage) {
-    case ILQR_STAGE_DERIVATIVES: return (h && h->aos) ? "k_derivatives_g" : "k_derivatives";
+    case ILQR_STAGE_DERIVATIVES: return (h && h->aos) ? ((h->v.analytic) ? "k_analytic_lq" : "k_derivatives_g") : "k_derivatives";
     case ILQR_STAGE_BACKWARD:
       if (h && h->aos) return "k_backward_w";
       if (h && use_fused_sweep(h)) return "k_sweep_backward";  // what ilqr_iterate launches

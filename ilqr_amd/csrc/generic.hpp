@@ -303,6 +303,87 @@ __global__ __launch_bounds__(64) void k_rollout_g(BatchView v, M model, AlphaSet
 }
 
 // ------------------------------------------------------------------------------------------
+// exact derivatives of the LQ model (ILQR_FLAG_ANALYTIC_DERIVATIVES)
+// ------------------------------------------------------------------------------------------
+// The record of a knot t < T is constant (fx = I + dt A, fu = dt B, cxx, cuu, cxu = 0) except for
+// cx = sym(Q) x_t and cu = sym(R) u_t; k_backward_w still wants one 27 KB record per knot, so this
+// kernel is a store stream: 44 GB per sweep at B = 8192, T = 200.  One wavefront per chunk of
+// kAnalyticChunk knots of one trajectory holds the constant part in registers in its store mapping
+// (rows along 32 lanes, two columns per instruction: 256-byte runs) and streams it out per knot;
+// values are the expressions of LqModel::analytic_record, which still writes knot T.
+constexpr int kAnalyticChunk = 8;
+__global__ __launch_bounds__(64) void k_analytic_lq(BatchView v, LqModel model, int force) {
+  const int nx = model.nx, nu = model.nu, T = v.T;
+  const int lane = threadIdx.x;
+  const int nchunk = (T + 1 + kAnalyticChunk - 1) / kAnalyticChunk;
+  const int b = blockIdx.x / nchunk, t0 = (blockIdx.x - b * nchunk) * kAnalyticChunk;
+  if (blockIdx.x == 0 && lane == 0) *v.n_running = 0;  // k_accept of this iteration recounts
+  if (!(force || (v.status[b] == 0 && v.flg_change[b]))) return;
+  const int oFX = 0, oFU = oFX + nx * nx, oCX = oFU + nx * nu, oCXX = oCX + nx, oCXU = oCXX + nx * nx, oCU = oCXU + nx * nu,
+            oCUU = oCU + nu, REC = oCUU + nu * nu;
+  const double dt = v.dt;
+  const int r32 = lane & 31, chalf = lane >> 5, r16 = lane & 15, cq = lane >> 4;
+  double fx[16], cxx[16], fu[8], cuu[4], wx[GN], wu[GM];
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const int c = 2 * j + chalf;
+    fx[j] = ((r32 == c) ? 1.0 : 0.0) + dt * model.A[r32 * GN + c];
+    cxx[j] = 0.5 * (model.Q[r32 * GN + c] + model.Q[c * GN + r32]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j++) fu[j] = dt * model.Bm[r32 * GM + 2 * j + chalf];
+#pragma unroll
+  for (int j = 0; j < 4; j++) cuu[j] = 0.5 * (model.R[r16 * GM + 4 * j + cq] + model.R[(4 * j + cq) * GM + r16]);
+  // rows of sym(Q) on lanes 0..31, rows of sym(R) on lanes 32..47
+#pragma unroll
+  for (int j = 0; j < GN; j++) wx[j] = 0.5 * (model.Q[r32 * GN + j] + model.Q[j * GN + r32]);
+#pragma unroll
+  for (int j = 0; j < GM; j++) wu[j] = 0.5 * (model.R[r16 * GM + j] + model.R[j * GM + r16]);
+
+  for (int t = t0; t < t0 + kAnalyticChunk && t <= T; t++) {
+    double* __restrict__ D = v.D + ((size_t)b * (T + 1) + t) * REC;
+    const double* __restrict__ x = v.xs + ((size_t)b * (T + 1) + t) * nx;
+    if (t == T) {
+      model.analytic_record(x, nullptr, dt, true, D, lane);
+      break;
+    }
+    const double* __restrict__ u = v.us + ((size_t)b * T + t) * nu;
+    double accx = 0, accu = 0;
+#pragma unroll
+    for (int j = 0; j < GN; j++)
+      if (j < nx) accx += wx[j] * x[j];
+#pragma unroll
+    for (int j = 0; j < GM; j++)
+      if (j < nu) accu += wu[j] * u[j];
+    if (r32 < nx) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int c = 2 * j + chalf;
+        if (c < nx) {
+          D[oFX + r32 + nx * c] = fx[j];
+          D[oCXX + r32 + nx * c] = cxx[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int c = 2 * j + chalf;
+        if (c < nu) {
+          D[oFU + r32 + nx * c] = fu[j];
+          D[oCXU + r32 + nx * c] = 0.0;
+        }
+      }
+    }
+    if (r16 < nu) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (4 * j + cq < nu) D[oCUU + r16 + nu * (4 * j + cq)] = cuu[j];
+    }
+    if (lane < nx) D[oCX + lane] = accx;
+    if (lane >= GN && lane - GN < nu) D[oCU + lane - GN] = accu;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // forward rollout of the LQ model on the matrix cores
 // ------------------------------------------------------------------------------------------
 // One WAVEFRONT per trajectory; the 11 candidate rollouts of the line search are the columns of
