@@ -508,6 +508,9 @@ void ilqr_destroy(ilqr_batch* h) {
         fprintf(stderr, "[wave backward phase timing, cyc/step] lds-fill+prefetch %.0f  Qx,A1,A2 %.0f  Qxx,Qux,Quu %.0f  boxQP %.0f  K %.0f  dV,T1,Vx,Vn %.0f  sym+stores(+loop) %.0f\n",
                 (double)d[256 + 0] / h->T, (double)d[256 + 1] / h->T, (double)d[256 + 2] / h->T, (double)d[256 + 3] / h->T,
                 (double)d[256 + 4] / h->T, (double)d[256 + 5] / h->T, (double)d[256 + 7] / h->T);
+      if (h->aos)
+        fprintf(stderr, "[generic FD sweep, knot (0,0), cycles] knot+fx,fu %lld  cost singles %lld  cx,cu,cxu %lld  cxx %lld  cuu %lld\n", d[272], d[273],
+                d[274], d[275], d[276]);
       for (int t = 0; t < 3; t++)
         fprintf(stderr, "[rollout phase timing, tile %d] loop+prefetch %.1f  wait+feedback+ustore %.1f  cost+dynamics %.1f  xstores %.1f cyc/step\n", t,
                 (double)d[512 - 16 + t * 4 + 0] / h->T, (double)d[512 - 16 + t * 4 + 1] / h->T, (double)d[512 - 16 + t * 4 + 2] / h->T,

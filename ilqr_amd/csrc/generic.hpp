@@ -155,6 +155,16 @@ struct LqModel {
 #endif
   static constexpr bool kQuadraticCostX = ILQR_LQ_MFMA_CXX != 0;
   __device__ __forceinline__ cmem_d* cost_x_matrix() const { return (cmem_d*)Q; }
+  // xdot = A x + B u with these (zero-padded, row-major) matrices, summed over x then over u: the
+  // 2 (nx + nu) points of the Jacobian sweep then go through the matrix cores as well
+#ifndef ILQR_LQ_MFMA_FX
+#define ILQR_LQ_MFMA_FX 1
+#endif
+  static constexpr bool kLinearDynamics = ILQR_LQ_MFMA_FX != 0;
+  __device__ __forceinline__ const double* dynamics_x_matrix() const { return A; }
+  __device__ __forceinline__ const double* dynamics_u_matrix() const { return Bm; }
+  // cost_u is the quadratic form u'Mu with this matrix (the cuu sweep on the matrix cores)
+  __device__ __forceinline__ const double* cost_u_matrix() const { return R; }
   __device__ __forceinline__ double cost(const double* x, const double* u) const {
     return cost_from_parts(cost_x(x), cost_u(u));
   }
@@ -584,7 +594,7 @@ __global__ __launch_bounds__(64) void k_rollout_lq(BatchView v, LqModel model, A
 // including the t = T special cases (fx[T] = fu[T] = 0, cx/cxx from final_cost, cu[T] = 0, cuu[T]
 // from cost(x_T, 0), the cxu[T] formula the reference itself marks wrong).
 template <class M>
-__global__ __launch_bounds__(64) void k_derivatives_g(BatchView v, M model, int force) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_derivatives_g(BatchView v, M model, int force) {
   constexpr int NX = M::NX, NU = M::NU;
   const int nx = model.nx, nu = model.nu, T = v.T;
   const int lane = threadIdx.x;
@@ -596,6 +606,12 @@ __global__ __launch_bounds__(64) void k_derivatives_g(BatchView v, M model, int 
   double* D = v.D + ((size_t)b * (T + 1) + t) * REC;
   const bool last = (t == T);
 
+#ifdef ILQR_PHASE_TIMING
+  long long dmark = clock64();
+#define ILQR_DMARK(k) { __builtin_amdgcn_sched_barrier(0); const long long tn_ = clock64(); if (v.dbg && blockIdx.x == 0 && lane == 0) v.dbg[272 + k] = tn_ - dmark; dmark = tn_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define ILQR_DMARK(k)
+#endif
   double x[NX], u[NU];  // the knot (same in every lane)
 #pragma unroll
   for (int i = 0; i < NX; i++) x[i] = (i < nx) ? v.xs[((size_t)b * (T + 1) + t) * nx + i] : 0.0;
@@ -629,6 +645,68 @@ __global__ __launch_bounds__(64) void k_derivatives_g(BatchView v, M model, int 
   // ---- fx, fu ----
   if (!last) {
     const int E = 2 * (nx + nu);
+    if constexpr (M::kLinearDynamics && NX == 32 && NU == 16) {
+      // F(P) = P + dt (A Px + B Pu) for 16 points at a time on the matrix cores: lane (g = l >> 4,
+      // p = l & 15) supplies component 4 ks + g of point base + p and receives rows g + 4 r (+16) of its
+      // image -- the components it supplied; each row's sum runs over x, then over u, k ascending, as
+      // LqModel::dynamics does.  The thread-per-point form of this product (below) needs A and B as
+      // scalar operands of 1.5 K unrolled FMAs per lane and spent most of its time spilling SGPRs:
+      // it was half of the whole sweep.
+      typedef double double4_t __attribute__((ext_vector_type(4)));
+      const int g = lane >> 4, p16 = lane & 15;
+      double opA[2][8], opB[2][4], xg[8], ug[4];
+      const double* Am = model.dynamics_x_matrix();
+      const double* Bmm = model.dynamics_u_matrix();
+#pragma unroll
+      for (int ti = 0; ti < 2; ti++) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) opA[ti][ks] = Am[(16 * ti + p16) * NX + 4 * ks + g];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) opB[ti][ks] = Bmm[(16 * ti + p16) * NU + 4 * ks + g];
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {  // x[4 ks + g] without indexing the register array by g
+        const double a0 = x[4 * ks], a1 = x[4 * ks + 1], a2 = x[4 * ks + 2], a3 = x[4 * ks + 3];
+        xg[ks] = (g == 0) ? a0 : (g == 1) ? a1 : (g == 2) ? a2 : a3;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        const double a0 = u[4 * ks], a1 = u[4 * ks + 1], a2 = u[4 * ks + 2], a3 = u[4 * ks + 3];
+        ug[ks] = (g == 0) ? a0 : (g == 1) ? a1 : (g == 2) ? a2 : a3;
+      }
+      for (int base = 0; base < E; base += 16) {
+        const int e = base + p16;
+        const bool valid = e < E;
+        const int var = e >> 1;
+        const double d = (e & 1) ? -kEps : kEps;
+        const int ix = (valid && var < nx) ? var : -1, iu = (valid && var >= nx) ? var - nx : -1;
+        double bx[8], bu[4];
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) bx[ks] = (4 * ks + g == ix) ? xg[ks] + d : xg[ks];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) bu[ks] = (4 * ks + g == iu) ? ug[ks] + d : ug[ks];
+        double4_t acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+          for (int ti = 0; ti < 2; ti++) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[ti][ks], bx[ks], acc[ti], 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+          for (int ti = 0; ti < 2; ti++) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(opB[ti][ks], bu[ks], acc[ti], 0, 0, 0);
+        double* col = (var < nx) ? D + oFX + nx * var : D + oFU + nx * (var - nx);
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const double F = bx[4 * ti + r] + acc[ti][r] * v.dt;  // include/model.h:12-15
+            const double other = dpp_swap1(F);                    // the point next door: e ^ 1
+            const double val = (F - other) / (2 * kEps);
+            const int row = 16 * ti + g + 4 * r;
+            if (valid && !(e & 1) && row < nx) col[row] = val;
+          }
+      }
+    } else
     for (int base = 0; base < E; base += 64) {
       const int e = base + lane;
       const bool valid = e < E;
@@ -651,6 +729,7 @@ __global__ __launch_bounds__(64) void k_derivatives_g(BatchView v, M model, int 
     for (int e = lane; e < nu; e += 64) D[oCU + e] = 0.0;                 // :50-51
   }
 
+  ILQR_DMARK(0)
   // ---- cost derivatives of a separable running cost (t < T): every distinct argument once ----
   if constexpr (M::kSeparableCost) {
     if (!last) {
@@ -756,6 +835,7 @@ __global__ __launch_bounds__(64) void k_derivatives_g(BatchView v, M model, int 
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): one wavefront, LDS operations complete in order
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      ILQR_DMARK(1)
       const double qx0 = s0[0], qu0 = s0[1];
       // cx, cu (derivatives.cpp:44-47)
       for (int i = lane; i < nx; i += 64)
@@ -769,6 +849,7 @@ __global__ __launch_bounds__(64) void k_derivatives_g(BatchView v, M model, int 
                           M::cost_from_parts(sx[2 * i], su[2 * j + 1]) + M::cost_from_parts(sx[2 * i + 1], su[2 * j + 1]);
         D[oCXU + i + nx * j] = v4 / (4 * kEps * kEps);
       }
+      ILQR_DMARK(2)
       // cxx, cuu: every point of the two Hessians is a distinct argument (finite_diff.h:67-86)
       auto hessian = [&](auto on_x, auto per_lane, int n, int oH, double other) __attribute__((always_inline)) {
         constexpr bool X = decltype(on_x)::value;
@@ -863,7 +944,9 @@ __global__ __launch_bounds__(64) void k_derivatives_g(BatchView v, M model, int 
       } else {
         hessian(std::true_type{}, std::integral_constant<int, ILQR_FD_POINTS_X>{}, nx, oCXX, qu0);
       }
+      ILQR_DMARK(3)
       hessian(std::false_type{}, std::integral_constant<int, 2>{}, nu, oCUU, qx0);
+      ILQR_DMARK(4)
       return;
     }
   }

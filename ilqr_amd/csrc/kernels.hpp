@@ -893,6 +893,13 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
 // (v_mov_b32 dpp, no LDS).  The derivative records of step i-1 are prefetched into a second
 // register set while step i computes: the recursion never waits on HBM.
 // ------------------------------------------------------------------------------------------
+// value of the neighbouring lane l ^ 1 (quad_perm:[1,0,3,2])
+__device__ __forceinline__ double dpp_swap1(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 template <int SRC>
 __device__ __forceinline__ double quad_bcast(double x) {
   constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);  // quad_perm:[SRC,SRC,SRC,SRC]

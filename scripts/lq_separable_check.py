@@ -1,7 +1,9 @@
 """The separable-cost route of k_derivatives_g against the every-point route (experiment build
 -DILQR_LQ_SEPARABLE=0): same records, bit for bit when the MFMA route is off (-DILQR_LQ_MFMA_CXX=0);
 with it (default) every x'Qx is summed in the matrix cores' order and the cost derivatives differ
-by the finite differences' own rounding noise (cxx ~1e-9, first derivatives ~1e-12).   python scripts/lq_separable_check.py <other.so>"""
+by the finite differences' own rounding noise (cxx ~1e-9, first derivatives ~1e-12).  The same script
+pins the matrix-core Jacobian sweep: a build with -DILQR_LQ_MFMA_FX=0 (thread-per-point dynamics) gives
+identical fx, fu (and everything else).   python scripts/lq_separable_check.py <other.so>"""
 import os, subprocess, sys, pickle
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
