@@ -323,6 +323,7 @@ __global__ __launch_bounds__(64) void k_rollout_g(BatchView v, M model, AlphaSet
 // values are the expressions of LqModel::analytic_record, which still writes knot T.
 constexpr int kAnalyticChunk = 8;
 __global__ __launch_bounds__(64) void k_analytic_lq(BatchView v, LqModel model, int force) {
+  static_assert(GN == 32 && GM == 16, "store mapping below is written for a 32 x 16 model");
   const int nx = model.nx, nu = model.nu, T = v.T;
   const int lane = threadIdx.x;
   const int nchunk = (T + 1 + kAnalyticChunk - 1) / kAnalyticChunk;
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(64) void k_analytic_lq(BatchView v, LqModel model, 
 template <int MODE>
 __global__ __launch_bounds__(64) void k_rollout_lq(BatchView v, LqModel model, AlphaSet alphas, double* __restrict__ cost_out,
                                                    const int* __restrict__ commit_idx, int mode, int write_cost) {
+  static_assert(GN == 32 && GM == 16, "operand blocks below are written for a 32 x 16 model");
   typedef double double4_t __attribute__((ext_vector_type(4)));
   const int nx = model.nx, nu = model.nu, T = v.T;
   const int lane = threadIdx.x, g = lane >> 4, p = lane & 15;
