@@ -155,9 +155,18 @@ class BatchILQR:
         capi.check(self.lib.ilqr_set_lambda(self.h, _p(lam), _p(dlam)))
 
     # ---- getters ----
-    def trajectory(self):
-        xs = np.zeros((self.B, self.T + 1, self.nx))
-        us = np.zeros((self.B, self.T, self.nu))
+    def trajectory(self, out=None):
+        """xs [B][T+1][nx], us [B][T][nu].  `out=(xs, us)`: C-contiguous float64 arrays to fill -- a
+        caller that keeps its result arrays across solves avoids the first-touch page faults of fresh
+        ones, which cost several times the PCIe transfer itself (PCIe-inclusive)."""
+        if out is None:
+            xs = np.zeros((self.B, self.T + 1, self.nx))
+            us = np.zeros((self.B, self.T, self.nu))
+        else:
+            xs, us = out
+            for a, shape in ((xs, (self.B, self.T + 1, self.nx)), (us, (self.B, self.T, self.nu))):
+                if a.shape != shape or a.dtype != np.float64 or not a.flags.c_contiguous:
+                    raise ValueError("out arrays must be C-contiguous float64 of shape %s" % (shape,))
         capi.check(self.lib.ilqr_get_trajectory(self.h, _p(xs), _p(us)))
         return xs, us
 

@@ -120,3 +120,19 @@ def test_handles_are_independent_across_host_threads():
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
         for u, v in zip(a[3], b[3]):
             assert np.array_equal(u, v)
+
+
+def test_trajectory_getter_fills_caller_arrays():
+    from ilqr_amd import BatchILQR
+    B, T = 7, 13
+    g = BatchILQR("acrobot", B, T, DT)
+    g.init_traj(acrobot_x0(B, seed=2), np.full((B, T, 1), 0.2))
+    xs, us = g.trajectory()
+    oxs, ous = np.full((B, T + 1, 4), np.nan), np.full((B, T, 1), np.nan)
+    rx, ru = g.trajectory(out=(oxs, ous))
+    assert rx is oxs and ru is ous and np.array_equal(oxs, xs) and np.array_equal(ous, us)
+    with pytest.raises(ValueError):
+        g.trajectory(out=(np.zeros((B, T, 4)), ous))
+    with pytest.raises(ValueError):
+        g.trajectory(out=(oxs.astype(np.float32), ous))
+    g.close()
