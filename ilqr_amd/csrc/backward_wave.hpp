@@ -695,10 +695,11 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
         break;
       }
       // :373-385  K rows of free dims
-      for (int c = lane >> 4; c < n; c += 4) L.K()[(lane & 15) + LDM * c] = 0;
       const unsigned long long free_mask = __ballot(lane < m && L.vfree[lane]);
       const int nf = __popcll(free_mask);
       if (lane < m && L.vfree[lane]) L.idx[__popcll(free_mask & ((1ull << lane) - 1ull))] = lane;
+      if (nf == 0 || nf != nfR)  // (the matrix-core route below writes every entry of K itself)
+        for (int c = lane >> 4; c < n; c += 4) L.K()[(lane & 15) + LDM * c] = 0;
       lds_sync();
       if (nf > 0) {
         // (L.Minv = R^-1 R^-T of the factor the box-QP returned, :379, left there by w_box_qp)
@@ -708,13 +709,17 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
           // cores: clamped rows of the scattered matrix are zero, so those rows of K come out zero,
           // and the zero columns add exact zeros to the k-ordered sums over the free dims.
           double* MF = L.Qf();  // (the Cholesky work copy / Ri: dead until the next factorisation)
-          for (int e = lane; e < LDM * WM; e += 64) MF[e] = 0.0;
-          lds_sync();
-          for (int e = lane; e < nf * nf; e += 64) {
-            const int a = e % nf, b2 = e / nf;
-            MF[L.idx[a] + LDM * L.idx[b2]] = L.Minv()[a + LDM * b2];
+          if (nf == m) {
+            MF = L.Minv();  // nothing clamped: the scatter is the identity
+          } else {
+            for (int e = lane; e < LDM * WM; e += 64) MF[e] = 0.0;
+            lds_sync();
+            for (int e = lane; e < nf * nf; e += 64) {
+              const int a = e % nf, b2 = e / nf;
+              MF[L.idx[a] + LDM * L.idx[b2]] = L.Minv()[a + LDM * b2];
+            }
+            lds_sync();
           }
-          lds_sync();
 #pragma unroll
           for (int tj = 0; tj < 2; tj++) {
             if (tj >= NT) continue;
