@@ -115,6 +115,16 @@ __device__ __forceinline__ double wave_sum(double v) {
   };
   return (row(0) + row(16)) + (row(32) + row(48));
 }
+// wave_sum of a value that is zero outside lanes 0..15 (everything indexed by a control dimension,
+// m <= WM = 16): rows 1..3 total +0.0, so only row 0 is fetched; same value as wave_sum, bit for bit
+__device__ __forceinline__ double wave_sum_row0(double v) {
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  v += dpp_f64<0x141>(v);
+  v += dpp_f64<0x140>(v);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0), __builtin_amdgcn_readlane(__double2loint(v), 0));
+  return (r0 + 0.0) + 0.0;
+}
 __device__ __forceinline__ void lds_sync() {
   // One wavefront per block: the LDS pipeline executes a wavefront's DS instructions in issue
   // order, so a ds_read after a ds_write sees it whichever lane wrote.  Only the COMPILER has to be
@@ -154,7 +164,7 @@ __device__ __forceinline__ double w_quad_cost(int m, const double* Q, const doub
     part = r * x[lane];
     lin = x[lane] * c[lane];
   }
-  return wave_sum(part) + wave_sum(lin);
+  return wave_sum_row0(part) + wave_sum_row0(lin);
 }
 
 // src/boxqp.cpp:26-139 for one trajectory per wavefront.  Inputs in LDS: QuuF (Q), Qu (c), kprev
@@ -189,7 +199,7 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
       part = r * L.x[lane];
       lin = L.x[lane] * c[lane];
     }
-    val = wave_sum(part) + wave_sum(lin);
+    val = wave_sum_row0(part) + wave_sum_row0(lin);
   }
   double oldvalue = 0;
   int result = 0, nfR = 0;
@@ -218,7 +228,7 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
     oldvalue = val;
     const unsigned long long free_mask = __ballot(lane < m && !cl);
     const int nf = __popcll(free_mask);
-    const double dsum = wave_sum(dd);
+    const double dsum = wave_sum_row0(dd);
     if (nf == 0) {  // :74-77
       result = 6;
       break;
@@ -314,7 +324,7 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
     }
     // :93-97
     {
-      const double gn2 = wave_sum((lane < m && !cl) ? L.grad[lane] * L.grad[lane] : 0.0);
+      const double gn2 = wave_sum_row0((lane < m && !cl) ? L.grad[lane] * L.grad[lane] : 0.0);
       if (sqrt(gn2) < kMinGrad) {
         result = 5;
         break;
@@ -353,7 +363,7 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
         const double s = dot_masked(0, m, [&](int j) { return Q[lane + LDM * j]; }, [&](int j) { return L.x[j]; });
         sl = L.search[lane] * (s + c[lane]);
       }
-      const double slope = wave_sum(sl);
+      const double slope = wave_sum_row0(sl);
       if (slope >= 0) {
         failed = true;
       } else {
@@ -742,14 +752,14 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
       ILQR_WMARK(4)
       // :388-389
       {
-        const double d0 = wave_sum(lane < m ? L.x[lane] * L.Qu[lane] : 0.0);
+        const double d0 = wave_sum_row0(lane < m ? L.x[lane] * L.Qu[lane] : 0.0);
         double part = 0;
         if (lane < m) {
           const double rr = dot_masked(0, m, [&](int a) { return 0.5 * L.x[a]; }, [&](int a) { return L.Quu()[a + LDM * lane]; });
           part = rr * L.x[lane];
         }
         dV0 += d0;
-        dV1 += wave_sum(part);
+        dV1 += wave_sum_row0(part);
       }
       // T1 = K' Quu (n x m)
 #pragma unroll
