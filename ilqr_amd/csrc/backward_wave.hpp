@@ -460,21 +460,26 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
   struct RecB {
     double cxx[16], cxu[8], cuu[4];
   };
+  // guarded load without a branch: padding lanes read element 0 of the record and drop it
+  auto ld0 = [](const double* r, bool in, int off) __attribute__((always_inline)) {
+    const double val = r[in ? off : 0];
+    return in ? val : 0.0;
+  };
   auto load_rec_a = [&](int i, RecA& q) __attribute__((always_inline)) {
     const double* r = Db + (size_t)i * REC;
     const int a32 = lane & 31, chalf = lane >> 5;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const int c = 2 * j + chalf;
-      q.fx[j] = (a32 < n && c < n) ? r[oFX + a32 + n * c] : 0.0;
+      q.fx[j] = ld0(r, a32 < n && c < n, oFX + a32 + n * c);
     }
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int c = 2 * j + chalf;
-      q.fu[j] = (a32 < n && c < m) ? r[oFU + a32 + n * c] : 0.0;
+      q.fu[j] = ld0(r, a32 < n && c < m, oFU + a32 + n * c);
     }
-    q.cx = (lane < n) ? r[oCX + lane] : 0.0;
-    q.cu = (lane >= WN && lane - WN < m) ? r[oCU + lane - WN] : 0.0;  // (lanes 32.. : where Qu is computed)
+    q.cx = ld0(r, lane < n, oCX + lane);
+    q.cu = ld0(r, lane >= WN && lane - WN < m, oCU + lane - WN);  // (lanes 32.. : where Qu is computed)
     q.us = (lane < m) ? usb[(size_t)i * m + lane] : 0.0;
   };
   auto load_rec_b = [&](int i, RecB& q) __attribute__((always_inline)) {
@@ -482,17 +487,17 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
 #pragma unroll
     for (int t2 = 0; t2 < 16; t2++) {
       const int a = (t2 >> 3) * 16 + orow + 4 * (t2 & 3), c = ((t2 >> 2) & 1) * 16 + ocol;
-      q.cxx[t2] = (a < n && c < n) ? r[oCXX + a + n * c] : 0.0;
+      q.cxx[t2] = ld0(r, a < n && c < n, oCXX + a + n * c);
     }
 #pragma unroll
     for (int t2 = 0; t2 < 8; t2++) {
       const int a = orow + 4 * (t2 & 3), c = (t2 >> 2) * 16 + ocol;
-      q.cxu[t2] = (a < m && c < n) ? r[oCXU + c + n * a] : 0.0;
+      q.cxu[t2] = ld0(r, a < m && c < n, oCXU + c + n * a);
     }
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
       const int a = orow + 4 * rr;
-      q.cuu[rr] = (a < m && ocol < m) ? r[oCUU + a + m * ocol] : 0.0;
+      q.cuu[rr] = ld0(r, a < m && ocol < m, oCUU + a + m * ocol);
     }
   };
 
