@@ -181,3 +181,33 @@ def test_lq_matrix_core_rollout_equals_thread_per_rollout(n, m, B, T, monkeypatc
     for key in out[0]:
         assert np.array_equal(out[0][key], out[1][key], equal_nan=True), key
     assert np.all(out[0]["cost"] < out[0]["c0"])
+
+
+def test_lq_full_size_properties():
+    """BASELINE.json configs[4] at full size (n = 32, m = 16, T = 200, B = 8192, limits active):
+    size-independent properties of two finite-difference iterations."""
+    from ilqr_amd import BatchILQR
+    n, m, B, T, lim = 32, 16, 8192, 200, 0.3
+    mats = lq_mats(n, m)
+    rng = np.random.default_rng(12)
+    x0 = rng.uniform(-1, 1, (B, n))
+    x0[1] = x0[0]
+    x0[B - 1] = x0[0]  # duplicates in other wavefronts / CUs
+    g = BatchILQR("lq", B, T, DT, u_min=-lim, u_max=lim, lq=mats)
+    c0 = g.init_traj(x0, np.zeros((B, T, m)))
+    g.iterate(2)
+    cost = g.cost()
+    st, it, al = g.status()
+    xs, us = g.trajectory()
+    k, K = g.gains()
+    g.close()
+    assert np.all(np.isfinite(cost)) and np.all(cost <= c0 * (1 + 1e-12))  # monotone (line search)
+    assert np.all(cost < c0) and np.mean(cost / c0) < 0.95 and (al >= 0).mean() > 0.99  # an LQ problem: every step helps
+    assert cost[0] == cost[1] == cost[B - 1]
+    assert np.array_equal(xs[0], xs[1]) and np.array_equal(K[0], K[B - 1]) and np.array_equal(us[0], us[B - 1])
+    assert np.array_equal(xs[:, 0], x0)
+    # (no bound on |us|: the reference's forward pass adds K (x - xs) without clamping, ilqr_core.cpp:316-323)
+    assert (np.abs(us) <= lim * (1 + 1e-9)).mean() > 0.9
+    # rows of K are zero where the control sits on a limit (boxqp.cpp: only free rows get a gain)
+    clamped_rows = (np.abs(K).max(axis=-1) == 0)
+    assert 0.001 < clamped_rows.mean() < 0.9
