@@ -46,8 +46,7 @@ static int fail(int code, const char* fmt, ...) {
 // the handle
 // ------------------------------------------------------------------------------------------
 struct StageTimer {
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // (begin, end); an event may end one stage and begin the next
   double ms = 0;
   int launches = 0;
 };
@@ -75,6 +74,12 @@ struct ilqr_batch {
   bool profile = false;
   int num_cus = 256;
   StageTimer timers[ILQR_NUM_STAGES];
+  std::vector<hipEvent_t> event_pool;
+  // inside ilqr_iterate nothing is enqueued between the end of one stage and the begin of the next: the
+  // end event serves as the next begin (one event record per kernel boundary instead of two; the
+  // records cost ~2.5 us each on the queue)
+  bool chain_timers = false;
+  hipEvent_t chain_event = nullptr;
 };
 
 static int rec_of(const ilqr_batch* h) { return rec_size(h->nx, h->nu); }
@@ -103,27 +108,37 @@ static int no_device_model() {
 }
 
 // stage timing -------------------------------------------------------------------------------
+static int timer_event(ilqr_batch* h, hipEvent_t* e) {
+  if (!h->event_pool.empty()) {
+    *e = h->event_pool.back();
+    h->event_pool.pop_back();
+    return 0;
+  }
+  HIPCHK(hipEventCreate(e));
+  return 0;
+}
 static int timer_begin(ilqr_batch* h, int stage, std::pair<hipEvent_t, hipEvent_t>* ev) {
   if (!h->profile) return 0;
-  StageTimer& t = h->timers[stage];
-  if (!t.pool.empty()) {
-    *ev = t.pool.back();
-    t.pool.pop_back();
+  (void)stage;
+  if (h->chain_timers && h->chain_event) {
+    ev->first = h->chain_event;
   } else {
-    HIPCHK(hipEventCreate(&ev->first));
-    HIPCHK(hipEventCreate(&ev->second));
+    if (int rc = timer_event(h, &ev->first)) return rc;
+    HIPCHK(hipEventRecord(ev->first, h->stream));
   }
-  HIPCHK(hipEventRecord(ev->first, h->stream));
-  return 0;
+  h->chain_event = nullptr;
+  return timer_event(h, &ev->second);
 }
 static int timer_end(ilqr_batch* h, int stage, const std::pair<hipEvent_t, hipEvent_t>& ev) {
   if (!h->profile) return 0;
   HIPCHK(hipEventRecord(ev.second, h->stream));
   h->timers[stage].pending.push_back(ev);
   h->timers[stage].launches++;
+  h->chain_event = h->chain_timers ? ev.second : nullptr;
   return 0;
 }
 static int timers_drain(ilqr_batch* h) {
+  std::vector<hipEvent_t> used;
   for (int s = 0; s < ILQR_NUM_STAGES; s++) {
     StageTimer& t = h->timers[s];
     for (auto& ev : t.pending) {
@@ -131,10 +146,15 @@ static int timers_drain(ilqr_batch* h) {
       HIPCHK(hipEventSynchronize(ev.second));
       HIPCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
       t.ms += ms;
-      t.pool.push_back(ev);
+      used.push_back(ev.first);
+      used.push_back(ev.second);
     }
     t.pending.clear();
   }
+  std::sort(used.begin(), used.end());
+  used.erase(std::unique(used.begin(), used.end()), used.end());
+  h->event_pool.insert(h->event_pool.end(), used.begin(), used.end());
+  h->chain_event = nullptr;
   return 0;
 }
 
@@ -520,16 +540,8 @@ void ilqr_destroy(ilqr_batch* h) {
 #endif
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->staging) (void)hipFree(h->staging);
-  for (auto& t : h->timers) {
-    for (auto& ev : t.pending) {
-      (void)hipEventDestroy(ev.first);
-      (void)hipEventDestroy(ev.second);
-    }
-    for (auto& ev : t.pool) {
-      (void)hipEventDestroy(ev.first);
-      (void)hipEventDestroy(ev.second);
-    }
-  }
+  (void)timers_drain(h);  // (every event back into the pool, each once)
+  for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -766,6 +778,11 @@ int ilqr_iterate(ilqr_batch* h, int n_iters) {
   if (host_model(h)) return no_device_model();
   if (!h->initialised) return fail(ILQR_ERR_STATE, "ilqr_iterate before ilqr_init_traj/ilqr_set_trajectory");
   HIPCHK(hipSetDevice(h->device));
+  struct Chain {  // stage timers share their boundary events for the duration of this call
+    ilqr_batch* h;
+    explicit Chain(ilqr_batch* hh) : h(hh) { h->chain_timers = true; h->chain_event = nullptr; }
+    ~Chain() { h->chain_timers = false; h->chain_event = nullptr; }
+  } chain(h);
   for (int it = 0; it < n_iters; it++) {
     if (use_fused_sweep(h)) {
       if (int rc = launch_sweep_backward(h, 1, h->sp.fixed_work)) return rc;  // STEP 1 + STEP 2
