@@ -142,7 +142,10 @@ def main():
                   flags=capi.FLAG_FIXED_WORK | args.flags, stream=stream)
     g.init_traj(x0, u0)
     g.iterate(args.warmup)
-    cost_dev = torch.empty(B, dtype=torch.float64, device="cuda")
+    cost_dev = torch.zeros(B, dtype=torch.float64, device="cuda")
+    if world > 1:  # warm-up of the one collective of the path: RCCL sets its rings up on the first call
+        D.gather_costs(cost_dev)
+        torch.cuda.synchronize()
 
     def barrier():
         torch.cuda.synchronize()
