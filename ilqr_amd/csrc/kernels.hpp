@@ -424,7 +424,10 @@ struct RingSlot {
   static constexpr int US = Rec<NX, NU>::SIZE;               // controls follow the record
   static constexpr int PAIRS = (Rec<NX, NU>::SIZE + NU + 1) / 2;
   static constexpr int DOUBLES = PAIRS * 2 * TW;             // per slot
-  static constexpr int SLOTS = ((150 * 1024 / 8) / DOUBLES) / 4 * 4;  // ring size: what fits in ~150 KB of LDS
+#ifndef ILQR_RING_KB
+#define ILQR_RING_KB 150  // (experiment builds: a smaller ring lets more than one block share a CU)
+#endif
+  static constexpr int SLOTS = ((ILQR_RING_KB * 1024 / 8) / DOUBLES) / 4 * 4;  // ring size: what fits in ~150 KB of LDS
 };
 
 template <class M, bool RING = false>
@@ -1572,7 +1575,7 @@ template <class M>
 __global__ __launch_bounds__(64 * (1 + kProducers)) void k_sweep_backward(BatchView v, M model, SolverParams sp, int mode, int force,
                                                         const int* __restrict__ commit_idx) {
   using RS = RingSlot<M::NX, M::NU>;
-  static_assert(RS::SLOTS >= kLeadKnots + 4 && RS::SLOTS >= 16, "the ring must hold the producers' lead");
+  static_assert(RS::SLOTS >= kLeadKnots + 4, "the ring must hold the producers' lead plus the four knots in production");
   __shared__ double lds_steps[104];
   __shared__ double ring[RS::SLOTS * RS::DOUBLES];  // knot j = T - t lives in slot j % SLOTS
   __shared__ int rounds_done[kProducers];    // rounds whose records are in the ring
