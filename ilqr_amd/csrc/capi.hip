@@ -417,21 +417,34 @@ static int launch_backward(ilqr_batch* h, int mode) {
 // STEP 1 + STEP 2 in one launch (k_sweep_backward): the tile's derivative sweep runs on the three
 // SIMDs the quad backward pass leaves idle.  Timed as ILQR_STAGE_BACKWARD.
 // One block of the fused kernel owns a whole CU (four wavefronts of ~290 registers, ~150 KB of LDS),
-// so it pays while the tiles fit on the device in one wave of blocks; beyond that (B > 16 x #CUs)
-// the two-kernel path keeps four tiles' backward wavefronts per CU busy and wins (measured at
-// B = 16384: 2.2 ms vs 3.2 ms per iteration).
-static bool use_fused_sweep(const ilqr_batch* h) {
-  if (!use_quad_backward(h) || h->aos || (h->flags & ILQR_FLAG_UNFUSED) || getenv("ILQR_AMD_UNFUSED")) return false;
-  return getenv("ILQR_AMD_FUSED") || h->ntiles <= h->num_cus;
+// so it pays while the tiles fit on the device in one wave of blocks; beyond two tiles per CU
+// (B > 32 x #CUs) the two-kernel path keeps four tiles' backward wavefronts per CU busy and wins
+// (measured at B = 16384: 2.2 ms vs 3.2 ms per iteration).
+// 16 x #CU < B <= 32 x #CU: the variant with one producer and a 60 KB ring, two blocks per CU (kernels.hpp;
+// B = 8192: 1.26 vs 1.42 ms per iteration).  ILQR_AMD_FUSED=1 / =2 force a variant for A/B runs and tests.
+static int fused_variant(const ilqr_batch* h) {  // 0: two kernels, 1: one block per CU, 2: two blocks per CU
+  if (!use_quad_backward(h) || h->aos || (h->flags & ILQR_FLAG_UNFUSED) || getenv("ILQR_AMD_UNFUSED")) return 0;
+  if (const char* f = getenv("ILQR_AMD_FUSED")) return (f[0] == '2') ? 2 : 1;
+  if (h->ntiles <= h->num_cus) return 1;
+  return (h->ntiles <= 2 * h->num_cus) ? 2 : 0;
+}
+static bool use_fused_sweep(const ilqr_batch* h) { return fused_variant(h) != 0; }
+constexpr int kRingKbTwoBlocks = 60;
+template <class M>
+static void launch_sweep_backward_t(ilqr_batch* h, const M& m, int variant, int mode, int force, const int* ci) {
+  if (variant == 2)
+    hipLaunchKernelGGL((k_sweep_backward<M, 1, kRingKbTwoBlocks>), dim3(h->ntiles), dim3(64 * 2), 0, h->stream, h->v, m, h->sp, mode, force, ci);
+  else
+    hipLaunchKernelGGL((k_sweep_backward<M>), dim3(h->ntiles), dim3(64 * (1 + kProducers)), 0, h->stream, h->v, m, h->sp, mode, force, ci);
 }
 static int launch_sweep_backward(ilqr_batch* h, int mode, int force) {
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_BACKWARD, &ev)) return rc;
-  dim3 grid(h->ntiles), block(64 * (1 + kProducers));
+  const int variant = fused_variant(h);
   const int* ci = h->commit_pending ? h->commit_idx : nullptr;
   switch (h->model) {
-    case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_sweep_backward<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, h->sp, mode, force, ci); break;
-    case ILQR_MODEL_DOUBLE_INTEGRATOR: hipLaunchKernelGGL((k_sweep_backward<DoubleIntegratorModel>), grid, block, 0, h->stream, h->v, h->dint, h->sp, mode, force, ci); break;
+    case ILQR_MODEL_ACROBOT: launch_sweep_backward_t(h, h->acrobot, variant, mode, force, ci); break;
+    case ILQR_MODEL_DOUBLE_INTEGRATOR: launch_sweep_backward_t(h, h->dint, variant, mode, force, ci); break;
     default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device backward pass yet", h->model);
   }
   HIPCHK(hipGetLastError());
@@ -553,6 +566,8 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   if (d->device < 0 || d->device >= ndev) return fail(ILQR_ERR_NO_DEVICE, "device %d out of range (%d visible)", d->device, ndev);
   HIPCHK(hipSetDevice(d->device));
   HIPCHK(hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, d->device));
+  if (const char* e = getenv("ILQR_AMD_NUM_CUS"))  // tests: exercise the batch-size thresholds of the route selection on small batches
+    if (atoi(e) > 0) h->num_cus = atoi(e);
   h->device = d->device;
   if (d->stream) {
     h->stream = (hipStream_t)d->stream;

@@ -419,15 +419,15 @@ __device__ __forceinline__ void fd_gradient(const double* x, F f, double* out) {
 // RING (k_sweep_backward): the record and the knot's nominal control are ALSO written to the LDS
 // slot `rs` (this lane's pair column of the slot: element e at rs[(e>>1)*2*TW + (e&1)], the
 // control behind the record), where the backward wavefront of the same block reads them.
-template <int NX, int NU>
+#ifndef ILQR_RING_KB
+#define ILQR_RING_KB 150  // one block per CU; the two-blocks-per-CU variant of k_sweep_backward uses 60
+#endif
+template <int NX, int NU, int RING_KB = ILQR_RING_KB>
 struct RingSlot {
   static constexpr int US = Rec<NX, NU>::SIZE;               // controls follow the record
   static constexpr int PAIRS = (Rec<NX, NU>::SIZE + NU + 1) / 2;
   static constexpr int DOUBLES = PAIRS * 2 * TW;             // per slot
-#ifndef ILQR_RING_KB
-#define ILQR_RING_KB 150  // (experiment builds: a smaller ring lets more than one block share a CU)
-#endif
-  static constexpr int SLOTS = ((ILQR_RING_KB * 1024 / 8) / DOUBLES) / 4 * 4;  // ring size: what fits in ~150 KB of LDS
+  static constexpr int SLOTS = ((RING_KB * 1024 / 8) / DOUBLES) / 4 * 4;  // ring size: what fits in RING_KB of LDS
 };
 
 template <class M, bool RING = false>
@@ -993,7 +993,7 @@ struct QuadStep {  // what lane (l, s) needs of one derivative record
 // co-resident producer wavefronts in k_sweep_backward.
 // ring != nullptr: the FIRST pass reads each knot from LDS slot (T - t) % SLOTS, where the producers
 // put it; lambda-retry passes (and ring == nullptr) read the records from HBM.
-template <class M, class Gate>
+template <class M, class Gate, int RING_KB = ILQR_RING_KB>
 __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model, const SolverParams& sp, int mode,
                                               int tile, int lane, const double* __restrict__ lds_steps, Gate gate,
                                               const double* ring = nullptr) {
@@ -1012,7 +1012,7 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
   double* __restrict__ kt = v.kff + tidx(tile, 0, 0, l, T, NU);
   double* __restrict__ Kt = v.Kfb + tidx(tile, 0, 0, l, T, NU * NX);
 
-  using RS = RingSlot<NX, NU>;
+  using RS = RingSlot<NX, NU, RING_KB>;
   bool from_ring = (ring != nullptr);  // cleared when a pass has to be repeated
   // what lane (l, s) needs of knot t, given accessors for element pairs (e even) / single elements
   auto fill = [&](auto pair, auto one, QuadStep<NU>& d) __attribute__((always_inline)) {
@@ -1562,19 +1562,25 @@ __global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverP
 // in the didx layout, where a lambda-retry pass and the getters find it as the stand-alone
 // kernels would have left it.  Workgroup-scope release/acquire is all the ordering needed.
 //   grid = ntiles, block = 64 * (1 + kProducers), LDS ~150 KB (one block per CU)
+// Two instantiations are shipped: <3 producers, 150 KB ring> = one block per CU, for batches of up to
+// 16 x #CU trajectories, and <1 producer, 60 KB ring> = two blocks (four wavefronts) per CU for up to
+// twice that -- one producer cannot quite feed a backward wavefront (0.66 instead of 0.55 ms per tile
+// at T = 499), but two tiles per CU side by side beat the two-kernel route (B = 8192: 1.26 against
+// 1.42 ms per iteration).
 #ifndef ILQR_PRODUCERS
 #define ILQR_PRODUCERS 3
 #endif
 constexpr int kProducers = ILQR_PRODUCERS;
-constexpr int kKnotsPerRound = 4 * kProducers;  // 4 knots per producer wavefront
 #ifndef ILQR_LEAD_ROUNDS
 #define ILQR_LEAD_ROUNDS 1
 #endif
-constexpr int kLeadKnots = ILQR_LEAD_ROUNDS * kKnotsPerRound;  // producers stay at most this far ahead of the consumer
-template <class M>
-__global__ __launch_bounds__(64 * (1 + kProducers)) void k_sweep_backward(BatchView v, M model, SolverParams sp, int mode, int force,
+template <class M, int kProd = kProducers, int RING_KB = ILQR_RING_KB>
+__global__ __launch_bounds__(64 * (1 + kProd)) void k_sweep_backward(BatchView v, M model, SolverParams sp, int mode, int force,
                                                         const int* __restrict__ commit_idx) {
-  using RS = RingSlot<M::NX, M::NU>;
+  constexpr int kProducers = kProd;               // (shadows the default: everything below is per instantiation)
+  constexpr int kKnotsPerRound = 4 * kProducers;  // 4 knots per producer wavefront
+  constexpr int kLeadKnots = ILQR_LEAD_ROUNDS * kKnotsPerRound;  // producers stay at most this far ahead of the consumer
+  using RS = RingSlot<M::NX, M::NU, RING_KB>;
   static_assert(RS::SLOTS >= kLeadKnots + 4, "the ring must hold the producers' lead plus the four knots in production");
   __shared__ double lds_steps[104];
   __shared__ double ring[RS::SLOTS * RS::DOUBLES];  // knot j = T - t lives in slot j % SLOTS
@@ -1615,7 +1621,7 @@ __global__ __launch_bounds__(64 * (1 + kProducers)) void k_sweep_backward(BatchV
         if (have_hbm > have) have = have_hbm;
       }
     };
-    backward_quad(v, model, sp, mode, tile, lane, lds_steps, gate, ring);
+    backward_quad<M, decltype(gate), RING_KB>(v, model, sp, mode, tile, lane, lds_steps, gate, ring);
 #ifdef ILQR_PHASE_TIMING
     if (v.dbg && lane == 0 && tile < 64) v.dbg[tile * 8 + 7] = gate_spins;
 #endif

@@ -89,3 +89,51 @@ def test_short_horizons_fused_equals_unfused(T):
             g.close()
         _same(out[0], out[1])
         assert np.all(np.isfinite(out[0]["cost"]))
+
+
+@pytest.mark.parametrize("name", ["acrobot", "integrator"])
+def test_two_blocks_per_cu_variant_equals_unfused(name, monkeypatch):
+    """The second instantiation of k_sweep_backward (one producer wavefront, 60 KB ring, two blocks per
+    CU: what ilqr_iterate picks for 16 x #CU < B <= 32 x #CU), forced here on small batches, normal mode
+    until every trajectory has left its loop (lambda retries re-read records from HBM)."""
+    from ilqr_amd import BatchILQR, capi
+    B, T = 37, 61
+    if name == "acrobot":
+        x0, nu, kw = acrobot_x0(B, scale=0.3, seed=9), 1, dict(u_min=-1.5, u_max=1.5, params=dict(max_iter=12))
+    else:
+        x0, nu, kw = integrator_x0(B), 2, dict(goal=[1.0, 0.5, 0.0, 0.0])
+    u0 = np.zeros((B, T, nu))
+    out = []
+    for fl, env in ((0, "2"), (capi.FLAG_UNFUSED, None)):
+        if env:
+            monkeypatch.setenv("ILQR_AMD_FUSED", env)
+        else:
+            monkeypatch.delenv("ILQR_AMD_FUSED", raising=False)
+        g = BatchILQR(name, B, T, DT, flags=fl, **kw)
+        g.generate_trajectory(x0, u0)
+        out.append(_state(g))
+        g.close()
+    _same(out[0], out[1])
+
+
+def test_batch_between_one_and_two_tiles_per_cu_takes_the_fused_route(monkeypatch):
+    """Route selection by batch size (ILQR_AMD_NUM_CUS scales the thresholds down to test sizes): up to one
+    tile per CU the three-producer kernel, up to two tiles per CU the one-producer kernel, then two kernels."""
+    from ilqr_amd import BatchILQR, capi
+    cus = 6
+    monkeypatch.setenv("ILQR_AMD_NUM_CUS", str(cus))
+    B, T = 16 * cus + 16, 20  # one tile more than one block per CU
+    x0 = acrobot_x0(B, scale=0.3, seed=4)
+    u0 = np.zeros((B, T, 1))
+    out = []
+    for fl in (0, capi.FLAG_UNFUSED):
+        g = BatchILQR("acrobot", B, T, DT, u_min=-1.5, u_max=1.5, flags=fl)
+        assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("backward")) == (b"k_backward_q" if fl else b"k_sweep_backward")
+        g.init_traj(x0, u0)
+        g.iterate(3)
+        out.append(_state(g))
+        g.close()
+    _same(out[0], out[1])
+    g = BatchILQR("acrobot", 32 * cus + 16, 4, DT)  # more than two tiles per CU: two kernels
+    assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("backward")) == b"k_backward_q"
+    g.close()
