@@ -345,6 +345,26 @@ __global__ __launch_bounds__(64) void k_analytic_lq(BatchView v, LqModel model, 
   for (int j = 0; j < 8; j++) fu[j] = dt * model.Bm[r32 * GM + 2 * j + chalf];
 #pragma unroll
   for (int j = 0; j < 4; j++) cuu[j] = 0.5 * (model.R[r16 * GM + 4 * j + cq] + model.R[(4 * j + cq) * GM + r16]);
+  // even nx: the same values as row PAIRS (rows 2 rp, 2 rp + 1 of column 4 j + cq), stored 16 bytes per
+  // lane -- 1 KB per store instruction instead of 512 B (every offset of the record is even then)
+  typedef double double2v __attribute__((ext_vector_type(2)));
+  const bool pairs = (nx & 1) == 0;
+  const int rp = lane & 15;
+  double2v fx2[8], cxx2[8], fu2[4];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int c = 4 * j + cq;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int r = 2 * rp + h;
+      fx2[j][h] = ((r == c) ? 1.0 : 0.0) + dt * model.A[r * GN + c];
+      cxx2[j][h] = 0.5 * (model.Q[r * GN + c] + model.Q[c * GN + r]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int h = 0; h < 2; h++) fu2[j][h] = dt * model.Bm[(2 * rp + h) * GM + 4 * j + cq];
   // rows of sym(Q) on lanes 0..31, rows of sym(R) on lanes 32..47
 #pragma unroll
   for (int j = 0; j < GN; j++) wx[j] = 0.5 * (model.Q[r32 * GN + j] + model.Q[j * GN + r32]);
@@ -366,7 +386,26 @@ __global__ __launch_bounds__(64) void k_analytic_lq(BatchView v, LqModel model, 
 #pragma unroll
     for (int j = 0; j < GM; j++)
       if (j < nu) accu += wu[j] * u[j];
-    if (r32 < nx) {
+    if (pairs) {
+      if (2 * rp < nx) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int c = 4 * j + cq;
+          if (c < nx) {
+            *reinterpret_cast<double2v*>(D + oFX + 2 * rp + nx * c) = fx2[j];
+            *reinterpret_cast<double2v*>(D + oCXX + 2 * rp + nx * c) = cxx2[j];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int c = 4 * j + cq;
+          if (c < nu) {
+            *reinterpret_cast<double2v*>(D + oFU + 2 * rp + nx * c) = fu2[j];
+            *reinterpret_cast<double2v*>(D + oCXU + 2 * rp + nx * c) = double2v{0.0, 0.0};
+          }
+        }
+      }
+    } else if (r32 < nx) {
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const int c = 2 * j + chalf;

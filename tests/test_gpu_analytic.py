@@ -61,7 +61,7 @@ def test_integrator_exact_derivatives_match_finite_differences():
     _cmp(fd, an, T, 1e-9, 1e-6)  # linear dynamics, quadratic costs: only rounding separates the two
 
 
-@pytest.mark.parametrize("n,m", [(32, 16), (6, 3)])
+@pytest.mark.parametrize("n,m", [(32, 16), (6, 3), (5, 2), (31, 16)])  # (odd nx: 8-byte stores in k_analytic_lq)
 def test_lq_exact_derivatives_match_finite_differences(n, m):
     from ilqr_amd import capi
     from tests.test_gpu_lq_end_to_end import dense_mats
