@@ -418,8 +418,12 @@ __device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
 
 // One wavefront per trajectory.  mode as in the quad kernel (0: one pass, all trajectories;
 // 1: STEP 2 with the lambda retry and the gradient-norm test for running trajectories).
+// const_rec != nullptr: the matrix blocks (fx, fu, cxx, cxu, cuu) of every knot t < T are those of this one
+// record (a model whose exact derivatives do not depend on the knot, k_analytic_lq); cx, cu and knot T come
+// from the per-knot records as always.
 __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, const double* __restrict__ u_min,
-                                                   const double* __restrict__ u_max, SolverParams sp, int mode) {
+                                                   const double* __restrict__ u_max, SolverParams sp, int mode,
+                                                   const double* __restrict__ const_rec) {
   __shared__ WaveLds L;
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
@@ -467,23 +471,24 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
   };
   auto load_rec_a = [&](int i, RecA& q) __attribute__((always_inline)) {
     const double* r = Db + (size_t)i * REC;
+    const double* rm = const_rec ? const_rec : r;
     const int a32 = lane & 31, chalf = lane >> 5;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const int c = 2 * j + chalf;
-      q.fx[j] = ld0(r, a32 < n && c < n, oFX + a32 + n * c);
+      q.fx[j] = ld0(rm, a32 < n && c < n, oFX + a32 + n * c);
     }
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int c = 2 * j + chalf;
-      q.fu[j] = ld0(r, a32 < n && c < m, oFU + a32 + n * c);
+      q.fu[j] = ld0(rm, a32 < n && c < m, oFU + a32 + n * c);
     }
     q.cx = ld0(r, lane < n, oCX + lane);
     q.cu = ld0(r, lane >= WN && lane - WN < m, oCU + lane - WN);  // (lanes 32.. : where Qu is computed)
     q.us = (lane < m) ? usb[(size_t)i * m + lane] : 0.0;
   };
   auto load_rec_b = [&](int i, RecB& q) __attribute__((always_inline)) {
-    const double* r = Db + (size_t)i * REC;
+    const double* r = const_rec ? const_rec : Db + (size_t)i * REC;
 #pragma unroll
     for (int t2 = 0; t2 < 16; t2++) {
       const int a = (t2 >> 3) * 16 + orow + 4 * (t2 & 3), c = ((t2 >> 2) & 1) * 16 + ocol;

@@ -64,6 +64,10 @@ struct ilqr_batch {
   bool own_stream = false;
   int* commit_idx = nullptr;
   double* staging = nullptr;  // device scratch for canonical <-> tiled conversion
+  // LQ model with exact derivatives: the sweep writes one copy of the constant matrices (const_rec) and
+  // per knot only cx, cu; records_partial says that D holds no matrices for t < T right now
+  double* const_rec = nullptr;
+  bool records_partial = false;
   size_t staging_elems = 0;
   std::vector<void*> allocs;
   bool initialised = false;  // init_traj / set_trajectory has run
@@ -201,7 +205,18 @@ static int download(ilqr_batch* h, const double* src_tiled, double* dst, int S, 
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
+// D as the getters and ilqr_set_derivatives expect it: fill in the constant matrices the partial sweep skipped
+static int materialise_records(ilqr_batch* h) {
+  if (!h->records_partial) return 0;
+  const int nchunk = (h->T + 1 + kAnalyticChunk - 1) / kAnalyticChunk;
+  hipLaunchKernelGGL(k_analytic_lq, dim3(h->B * nchunk), dim3(64), 0, h->stream, h->v, h->lq, 1, 2, h->const_rec, kAnalyticChunk);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 static int upload_rec(ilqr_batch* h, const double* src, int off, int E) {
+  if (int rc = materialise_records(h)) return rc;
+  h->records_partial = false;  // the caller's blocks replace the model's: every knot reads its own record again
+
   const int S = h->T + 1;
   const size_t n = (size_t)h->B * S * E;
   if (int rc = ensure_staging(h, n)) return rc;
@@ -364,8 +379,11 @@ static int launch_derivatives(ilqr_batch* h, int force) {
   const int* ci = h->commit_pending ? h->commit_idx : nullptr;
   if (h->model == ILQR_MODEL_LQ) {
     if (h->v.analytic) {
-      const int nchunk = (h->T + 1 + kAnalyticChunk - 1) / kAnalyticChunk;
-      hipLaunchKernelGGL(k_analytic_lq, dim3(h->B * nchunk), dim3(64), 0, h->stream, h->v, h->lq, force);
+      const int what = getenv("ILQR_AMD_FULL_RECORDS") ? 0 : 1;  // (the env switch: A/B runs and the bit-identity test)
+      const int chunk = (what == 1) ? 4 * kAnalyticChunk : kAnalyticChunk;
+      const int nchunk = (h->T + 1 + chunk - 1) / chunk;
+      hipLaunchKernelGGL(k_analytic_lq, dim3(h->B * nchunk), dim3(64), 0, h->stream, h->v, h->lq, force, what, h->const_rec, chunk);
+      h->records_partial = (what == 1);
     } else {
       hipLaunchKernelGGL((k_derivatives_g<LqModel>), dim3(h->B * (h->T + 1)), dim3(64), 0, h->stream, h->v, h->lq, force);
     }
@@ -394,7 +412,8 @@ static int launch_backward(ilqr_batch* h, int mode) {
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_BACKWARD, &ev)) return rc;
   if (h->aos) {
-    hipLaunchKernelGGL(k_backward_w, dim3(h->B), dim3(64), 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode);
+    hipLaunchKernelGGL(k_backward_w, dim3(h->B), dim3(64), 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode,
+                       h->records_partial ? h->const_rec : nullptr);
   } else if (use_quad_backward(h)) {
     dim3 grid(h->ntiles), block(64);  // one wavefront = one tile of 16 trajectories x 4 lanes
     switch (h->model) {
@@ -637,6 +656,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     rc |= dev_alloc(h, &v.kff, Bn * T * nu);
     rc |= dev_alloc(h, &v.Kfb, Bn * T * nu * nx);
     rc |= dev_alloc(h, &v.D, Bn * T1 * REC);
+    rc |= dev_alloc(h, &h->const_rec, REC);
     rc |= dev_alloc(h, &h->d_umin, nu);
     rc |= dev_alloc(h, &h->d_umax, nu);
     v.cand_u = nullptr;
@@ -1028,6 +1048,7 @@ int ilqr_get_derivatives(ilqr_batch* h, double* fx, double* fu, double* cx, doub
   int off[7], len[7];
   rec_offsets(h->nx, h->nu, off, len);
   double* dsts[7] = {fx, fu, cx, cu, cxx, cxu, cuu};
+  if (int rc = materialise_records(h)) return rc;
   for (int i = 0; i < 7; i++)
     if (dsts[i]) if (int rc = download_rec(h, dsts[i], off[i], len[i])) return rc;
   return 0;

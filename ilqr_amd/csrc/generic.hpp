@@ -322,19 +322,28 @@ __global__ __launch_bounds__(64) void k_rollout_g(BatchView v, M model, AlphaSet
 // (rows along 32 lanes, two columns per instruction: 256-byte runs) and streams it out per knot;
 // values are the expressions of LqModel::analytic_record, which still writes knot T.
 constexpr int kAnalyticChunk = 8;
-__global__ __launch_bounds__(64) void k_analytic_lq(BatchView v, LqModel model, int force) {
+// what: 0 = whole records; 1 = only what differs from knot to knot (cx, cu; the whole record of knot T)
+// plus ONE copy of the constant matrices in const_rec, which k_backward_w then reads for every knot
+// t < T -- 77 KB + one record per trajectory instead of 5.4 MB; 2 = the constant matrices of every
+// knot t < T, unconditionally (fills in what 1 skipped, for the derivative getter).
+__global__ __launch_bounds__(64) void k_analytic_lq(BatchView v, LqModel model, int force, int what, double* __restrict__ const_rec,
+                                                    int chunk) {
   static_assert(GN == 32 && GM == 16, "store mapping below is written for a 32 x 16 model");
   const int nx = model.nx, nu = model.nu, T = v.T;
   const int lane = threadIdx.x;
-  const int nchunk = (T + 1 + kAnalyticChunk - 1) / kAnalyticChunk;
-  const int b = blockIdx.x / nchunk, t0 = (blockIdx.x - b * nchunk) * kAnalyticChunk;
-  if (blockIdx.x == 0 && lane == 0) *v.n_running = 0;  // k_accept of this iteration recounts
-  if (!(force || (v.status[b] == 0 && v.flg_change[b]))) return;
+  const int nchunk = (T + 1 + chunk - 1) / chunk;  // knots per wavefront: kAnalyticChunk, or more when only cx, cu are written
+  const int b = blockIdx.x / nchunk, t0 = (blockIdx.x - b * nchunk) * chunk;
+  if (what != 2 && blockIdx.x == 0 && lane == 0) *v.n_running = 0;  // k_accept of this iteration recounts
+  const bool fill_const = (what == 1 && blockIdx.x == 0);
+  if (what != 2 && !fill_const && !(force || (v.status[b] == 0 && v.flg_change[b]))) return;
+  const bool skip_knots = (what == 1) && !(force || (v.status[b] == 0 && v.flg_change[b]));  // (block 0 came for const_rec only)
   const int oFX = 0, oFU = oFX + nx * nx, oCX = oFU + nx * nu, oCXX = oCX + nx, oCXU = oCXX + nx * nx, oCU = oCXU + nx * nu,
             oCUU = oCU + nu, REC = oCUU + nu * nu;
   const double dt = v.dt;
   const int r32 = lane & 31, chalf = lane >> 5, r16 = lane & 15, cq = lane >> 4;
   double fx[16], cxx[16], fu[8], cuu[4], wx[GN], wu[GM];
+  const bool need_matrices = (what != 1) || fill_const;  // (wave-uniform: a vectors-only wavefront skips these loads)
+  if (need_matrices) {
 #pragma unroll
   for (int j = 0; j < 16; j++) {
     const int c = 2 * j + chalf;
@@ -345,12 +354,14 @@ __global__ __launch_bounds__(64) void k_analytic_lq(BatchView v, LqModel model, 
   for (int j = 0; j < 8; j++) fu[j] = dt * model.Bm[r32 * GM + 2 * j + chalf];
 #pragma unroll
   for (int j = 0; j < 4; j++) cuu[j] = 0.5 * (model.R[r16 * GM + 4 * j + cq] + model.R[(4 * j + cq) * GM + r16]);
+  }
   // even nx: the same values as row PAIRS (rows 2 rp, 2 rp + 1 of column 4 j + cq), stored 16 bytes per
   // lane -- 1 KB per store instruction instead of 512 B (every offset of the record is even then)
   typedef double double2v __attribute__((ext_vector_type(2)));
   const bool pairs = (nx & 1) == 0;
   const int rp = lane & 15;
   double2v fx2[8], cxx2[8], fu2[4];
+  if (need_matrices) {
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const int c = 4 * j + cq;
@@ -365,27 +376,36 @@ __global__ __launch_bounds__(64) void k_analytic_lq(BatchView v, LqModel model, 
   for (int j = 0; j < 4; j++)
 #pragma unroll
     for (int h = 0; h < 2; h++) fu2[j][h] = dt * model.Bm[(2 * rp + h) * GM + 4 * j + cq];
+  }
   // rows of sym(Q) on lanes 0..31, rows of sym(R) on lanes 32..47
 #pragma unroll
   for (int j = 0; j < GN; j++) wx[j] = 0.5 * (model.Q[r32 * GN + j] + model.Q[j * GN + r32]);
 #pragma unroll
   for (int j = 0; j < GM; j++) wu[j] = 0.5 * (model.R[r16 * GM + j] + model.R[j * GM + r16]);
 
-  for (int t = t0; t < t0 + kAnalyticChunk && t <= T; t++) {
-    double* __restrict__ D = v.D + ((size_t)b * (T + 1) + t) * REC;
-    const double* __restrict__ x = v.xs + ((size_t)b * (T + 1) + t) * nx;
+  // knot -1 stands for const_rec (matrices only)
+  for (int t = fill_const ? -1 : t0; t < t0 + chunk && t <= T; t++) {
+    if (t >= 0 && skip_knots) break;
+    double* __restrict__ D = (t < 0) ? const_rec : v.D + ((size_t)b * (T + 1) + t) * REC;
+    const bool matrices = (t < 0) || what != 1, vectors = (t >= 0) && what != 2;
     if (t == T) {
-      model.analytic_record(x, nullptr, dt, true, D, lane);
+      if (what != 2) model.analytic_record(v.xs + ((size_t)b * (T + 1) + t) * nx, nullptr, dt, true, D, lane);
       break;
     }
-    const double* __restrict__ u = v.us + ((size_t)b * T + t) * nu;
     double accx = 0, accu = 0;
+    if (vectors) {
+      const double* __restrict__ x = v.xs + ((size_t)b * (T + 1) + t) * nx;
+      const double* __restrict__ u = v.us + ((size_t)b * T + t) * nu;
 #pragma unroll
-    for (int j = 0; j < GN; j++)
-      if (j < nx) accx += wx[j] * x[j];
+      for (int j = 0; j < GN; j++)
+        if (j < nx) accx += wx[j] * x[j];
 #pragma unroll
-    for (int j = 0; j < GM; j++)
-      if (j < nu) accu += wu[j] * u[j];
+      for (int j = 0; j < GM; j++)
+        if (j < nu) accu += wu[j] * u[j];
+      if (lane < nx) D[oCX + lane] = accx;
+      if (lane >= GN && lane - GN < nu) D[oCU + lane - GN] = accu;
+    }
+    if (!matrices) continue;
     if (pairs) {
       if (2 * rp < nx) {
 #pragma unroll
@@ -428,8 +448,6 @@ __global__ __launch_bounds__(64) void k_analytic_lq(BatchView v, LqModel model, 
       for (int j = 0; j < 4; j++)
         if (4 * j + cq < nu) D[oCUU + r16 + nu * (4 * j + cq)] = cuu[j];
     }
-    if (lane < nx) D[oCX + lane] = accx;
-    if (lane >= GN && lane - GN < nu) D[oCU + lane - GN] = accu;
   }
 }
 

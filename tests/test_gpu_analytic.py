@@ -97,3 +97,43 @@ def test_solves_with_exact_derivatives_reach_the_same_optimum():
     c = g.cost()
     assert np.all(c < 0.01 * c0) and abs(c[0] - c[1]) == 0  # FD solve: 5.40 from 3947.6
     g.close()
+
+
+@pytest.mark.parametrize("n,m", [(32, 16), (5, 2)])
+def test_lq_partial_records_equal_whole_records(n, m, monkeypatch):
+    """With exact derivatives the LQ sweep writes the knot-independent matrices once (const_rec) and per
+    knot only cx, cu; k_backward_w reads the shared copy.  ILQR_AMD_FULL_RECORDS=1 writes and reads whole
+    records: same solve bit for bit, same records from the getter (which fills the matrices in on demand),
+    also after ilqr_set_derivatives replaced them."""
+    from ilqr_amd import BatchILQR, capi
+    from tests.test_gpu_lq_end_to_end import dense_mats
+    B, T = 9, 17
+    mats = dense_mats(n, m)
+    rng = np.random.default_rng(16)
+    x0 = rng.uniform(-1, 1, (B, n))
+    u0 = rng.normal(size=(B, T, m)) * 0.3
+    out = []
+    for full in (False, True):
+        if full:
+            monkeypatch.setenv("ILQR_AMD_FULL_RECORDS", "1")
+        else:
+            monkeypatch.delenv("ILQR_AMD_FULL_RECORDS", raising=False)
+        g = BatchILQR("lq", B, T, DT, u_min=-0.4, u_max=0.4, lq=mats, flags=capi.FLAG_ANALYTIC_DERIVATIVES)
+        g.init_traj(x0, u0)
+        g.iterate(3)
+        d = g.derivatives()
+        xs, us = g.trajectory()
+        k, K = g.gains()
+        # caller-provided records replace the model's: the backward pass must read them knot by knot
+        d2 = {kk: np.array(vv) for kk, vv in d.items()}
+        d2["fx"] = d2["fx"] * (1 + 0.01 * rng.standard_normal((B, T + 1, 1, 1)))
+        g.set_derivatives(**d2)
+        g.set_lambda(1.0, 1.0)
+        g.backward_pass()
+        k2, K2 = g.gains()
+        out.append(dict(xs=xs, us=us, k=k, K=K, cost=g.cost(), k2=k2, K2=K2, **{"d_" + kk: vv for kk, vv in d.items()}))
+        g.close()
+        rng = np.random.default_rng(16); rng.uniform(-1, 1, (B, n)); rng.normal(size=(B, T, m))  # same perturbation next round
+    for key in out[0]:
+        assert np.array_equal(out[0][key], out[1][key], equal_nan=True), key
+    assert not np.array_equal(out[0]["K2"], out[0]["K"])
