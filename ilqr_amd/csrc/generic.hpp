@@ -394,14 +394,19 @@ __global__ __launch_bounds__(64) void k_analytic_lq(BatchView v, LqModel model, 
     }
     double accx = 0, accu = 0;
     if (vectors) {
+      // the knot arrives with ONE coalesced load per vector (lane j holds x_j / u_j) and is handed round with
+      // v_readlane; 48 separate broadcast loads per knot made this the whole cost of the sweep once the
+      // matrices were no longer stored per knot.  Padding terms are fma(0, 0, acc): the sums are unchanged.
       const double* __restrict__ x = v.xs + ((size_t)b * (T + 1) + t) * nx;
       const double* __restrict__ u = v.us + ((size_t)b * T + t) * nu;
+      const double xv = (lane < nx) ? x[lane] : 0.0, uv = (lane < nu) ? u[lane] : 0.0;
+      auto lane_value = [](double val, int l) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(val), l), __builtin_amdgcn_readlane(__double2loint(val), l));
+      };
 #pragma unroll
-      for (int j = 0; j < GN; j++)
-        if (j < nx) accx += wx[j] * x[j];
+      for (int j = 0; j < GN; j++) accx = __builtin_fma(wx[j], lane_value(xv, j), accx);
 #pragma unroll
-      for (int j = 0; j < GM; j++)
-        if (j < nu) accu += wu[j] * u[j];
+      for (int j = 0; j < GM; j++) accu = __builtin_fma(wu[j], lane_value(uv, j), accu);
       if (lane < nx) D[oCX + lane] = accx;
       if (lane >= GN && lane - GN < nu) D[oCU + lane - GN] = accu;
     }
