@@ -676,11 +676,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #else
 #define ILQR_DMARK(k)
 #endif
-  double x[NX], u[NU];  // the knot (same in every lane)
+  double x[NX], u[NU];  // the knot (same in every lane): one coalesced load per vector, handed round with
+                        // v_readlane (NX + NU same-address loads cost ~10 us per knot, see k_analytic_lq)
+  {
+    static_assert(NX <= 64 && NU <= 64, "one lane per component");
+    const double xv = (lane < nx) ? v.xs[((size_t)b * (T + 1) + t) * nx + lane] : 0.0;
+    const double uv = (lane < nu && !last) ? v.us[((size_t)b * T + (last ? 0 : t)) * nu + lane] : 0.0;  // derivatives.cpp:35-38
+    auto lane_value = [](double val, int l) {
+      return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(val), l), __builtin_amdgcn_readlane(__double2loint(val), l));
+    };
 #pragma unroll
-  for (int i = 0; i < NX; i++) x[i] = (i < nx) ? v.xs[((size_t)b * (T + 1) + t) * nx + i] : 0.0;
+    for (int i = 0; i < NX; i++) x[i] = lane_value(xv, i);
 #pragma unroll
-  for (int j = 0; j < NU; j++) u[j] = (j < nu && !last) ? v.us[((size_t)b * T + t) * nu + j] : 0.0;  // derivatives.cpp:35-38
+    for (int j = 0; j < NU; j++) u[j] = lane_value(uv, j);
+  }
 
   if (v.analytic) {  // opt-in: the model's exact derivatives (reads the knot from memory: runtime indices)
     model.analytic_record(v.xs + ((size_t)b * (T + 1) + t) * nx, last ? nullptr : v.us + ((size_t)b * T + t) * nu, v.dt, last, D, lane);
