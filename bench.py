@@ -117,6 +117,23 @@ def main():
 
     import torch
     import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as plain `python bench.py --gpus N`: become the N-rank job (one process per GPU) instead
+        # of quietly measuring one GPU
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (args.gpus, have))
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                  "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+
     from ilqr_amd import BatchILQR, capi
     from ilqr_amd import dist as D
     from tests.util import acrobot_x0
@@ -124,13 +141,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d: one rank per GPU" % (args.gpus, world))
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: no HIP device %d (%d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, "launch one rank per GPU (torch.distributed.run)"
 
     B, T, dt, lim, n, m = args.batch, args.T, 0.02, args.limit, 4, 1
     # this rank's shard of the global synthetic batch (trajectory b of rank r = global r*B + b)

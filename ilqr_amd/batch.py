@@ -125,6 +125,11 @@ class BatchILQR:
     def line_search(self):
         capi.check(self.lib.ilqr_line_search(self.h))
 
+    def reset_state(self, warm=False):
+        """warm=False: the non-rollout part of init_traj; warm=True: a new outer loop on the stored
+        solution (status / iteration count / flgChange restart, lambda and gains persist)."""
+        capi.check(self.lib.ilqr_reset_state(self.h, int(bool(warm))))
+
     # ---- setters (canonical layouts; matrices given as [..., rows, cols]) ----
     def set_trajectory(self, x0=None, xs=None, us=None, cost=None):
         a = [None if v is None else _c(v) for v in (x0, xs, us, cost)]

@@ -370,6 +370,16 @@ static int flush_commit(ilqr_batch* h) {
   return timer_end(h, ILQR_STAGE_ACCEPT, ev);
 }
 
+// A fresh solve starts: nothing of an earlier one may leak into it -- neither an accepted candidate whose
+// copy is still pending (an ilqr_iterate that returned early on an error leaves one), nor the "records hold
+// no matrices" state of an exact-derivative LQ sweep (init_traj promises zeroed records, ilqr_core.cpp:39-45).
+static int forget_pending(ilqr_batch* h) {
+  h->records_partial = false;
+  h->commit_pending = false;
+  HIPCHK(hipMemsetAsync(h->commit_idx, 0xFF, (size_t)h->Bp * sizeof(int), h->stream));  // all -1
+  return 0;
+}
+
 static int launch_derivatives(ilqr_batch* h, int force) {
   if (h->model == ILQR_MODEL_LQ)  // the generic sweep has no fused commit: rebuild the accepted rollout first
     if (int rc = flush_commit(h)) return rc;
@@ -765,6 +775,7 @@ int ilqr_create(const ilqr_desc* d, ilqr_batch** out) {
 
 int ilqr_set_stream(ilqr_batch* h, void* s) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->own_stream) {
     HIPCHK(hipStreamDestroy(h->stream));
@@ -781,6 +792,7 @@ int ilqr_set_stream(ilqr_batch* h, void* s) {
 
 int ilqr_synchronize(ilqr_batch* h) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -797,6 +809,7 @@ int ilqr_init_traj(ilqr_batch* h, const double* x0, const double* u0, double* co
   HIPCHK(hipMemsetAsync(h->v.D, 0, dev_elems(h, T1, rec_of(h)) * sizeof(double), h->stream));
   HIPCHK(hipMemsetAsync(h->v.kff, 0, dev_elems(h, T, h->nu) * sizeof(double), h->stream));
   HIPCHK(hipMemsetAsync(h->v.Kfb, 0, dev_elems(h, T, h->nu * h->nx) * sizeof(double), h->stream));
+  if (int rc = forget_pending(h)) return rc;
   hipLaunchKernelGGL(k_reset_state, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
                      h->params.dlambda_init);
   HIPCHK(hipGetLastError());
@@ -838,6 +851,7 @@ int ilqr_iterate(ilqr_batch* h, int n_iters) {
 
 int ilqr_count_running(ilqr_batch* h, int* n) {
   if (!h || !n) return fail(ILQR_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(h->device));
   std::vector<int> st(h->B);
   if (int rc = scalars_to_host(h, h->v.status, st.data())) return rc;
   int c = 0;
@@ -902,12 +916,14 @@ int ilqr_compute_derivatives(ilqr_batch* h) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
   if (host_model(h)) return no_device_model();
   HIPCHK(hipSetDevice(h->device));
+  if (!h->initialised) return fail(ILQR_ERR_STATE, "stage call before ilqr_init_traj/ilqr_set_trajectory (the reference asserts, ilqr_core.cpp:80-82)");
   return launch_derivatives(h, 1);
 }
 
 int ilqr_backward_pass(ilqr_batch* h, int* diverge_out) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
   HIPCHK(hipSetDevice(h->device));
+  if (!h->initialised) return fail(ILQR_ERR_STATE, "stage call before ilqr_init_traj/ilqr_set_trajectory (the reference asserts, ilqr_core.cpp:80-82)");
   if (int rc = launch_backward(h, 0)) return rc;
   if (diverge_out) return scalars_to_host(h, h->v.diverge, diverge_out);
   return 0;
@@ -916,6 +932,7 @@ int ilqr_backward_pass(ilqr_batch* h, int* diverge_out) {
 int ilqr_backward_step(ilqr_batch* h) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
   HIPCHK(hipSetDevice(h->device));
+  if (!h->initialised) return fail(ILQR_ERR_STATE, "stage call before ilqr_init_traj/ilqr_set_trajectory (the reference asserts, ilqr_core.cpp:80-82)");
   return launch_backward(h, 1);
 }
 
@@ -923,6 +940,7 @@ int ilqr_rollout_candidates(ilqr_batch* h, double* cost_out) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
   if (host_model(h)) return no_device_model();
   HIPCHK(hipSetDevice(h->device));
+  if (!h->initialised) return fail(ILQR_ERR_STATE, "stage call before ilqr_init_traj/ilqr_set_trajectory (the reference asserts, ilqr_core.cpp:80-82)");
   if (int rc = do_rollout_candidates(h, 0)) return rc;
   if (cost_out) {
     std::vector<double> tmp((size_t)NALPHA * h->Bp);
@@ -938,6 +956,7 @@ int ilqr_line_search(ilqr_batch* h) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
   if (host_model(h)) return no_device_model();
   HIPCHK(hipSetDevice(h->device));
+  if (!h->initialised) return fail(ILQR_ERR_STATE, "stage call before ilqr_init_traj/ilqr_set_trajectory (the reference asserts, ilqr_core.cpp:80-82)");
   if (int rc = flush_commit(h)) return rc;
   if (int rc = do_rollout_candidates(h, 1)) return rc;
   if (int rc = launch_accept(h)) return rc;
@@ -948,6 +967,7 @@ int ilqr_accept_candidates(ilqr_batch* h, const double* cost_c, int* accepted) {
   if (!h || !cost_c || !accepted) return fail(ILQR_ERR_INVALID, "null argument");
   if (!h->v.cost_c) return fail(ILQR_ERR_UNSUPPORTED, "this handle has no candidate-cost buffer");
   HIPCHK(hipSetDevice(h->device));
+  if (!h->initialised) return fail(ILQR_ERR_STATE, "stage call before ilqr_init_traj/ilqr_set_trajectory (the reference asserts, ilqr_core.cpp:80-82)");
   if (int rc = flush_commit(h)) return rc;
   std::vector<double> tmp((size_t)NALPHA * h->Bp, 0.0);
   for (int b = 0; b < h->B; b++)
@@ -979,6 +999,7 @@ int ilqr_reset_state(ilqr_batch* h, int warm) {
     HIPCHK(hipMemsetAsync(h->v.D, 0, dev_elems(h, T1, rec_of(h)) * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(h->v.kff, 0, dev_elems(h, T, h->nu) * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(h->v.Kfb, 0, dev_elems(h, T, h->nu * h->nx) * sizeof(double), h->stream));
+    if (int rc = forget_pending(h)) return rc;
   }
   hipLaunchKernelGGL(k_reset_state, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
                      h->params.dlambda_init);
@@ -1055,16 +1076,19 @@ int ilqr_get_derivatives(ilqr_batch* h, double* fx, double* fu, double* cx, doub
 }
 int ilqr_get_cost(ilqr_batch* h, double* cost) {
   if (!h || !cost) return fail(ILQR_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(h->device));
   return scalars_to_host(h, h->v.cost, cost);
 }
 int ilqr_get_lambda(ilqr_batch* h, double* lambda, double* dlambda) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
   if (lambda) if (int rc = scalars_to_host(h, h->v.lambda, lambda)) return rc;
   if (dlambda) if (int rc = scalars_to_host(h, h->v.dlambda, dlambda)) return rc;
   return 0;
 }
 int ilqr_get_dV(ilqr_batch* h, double* dV) {
   if (!h || !dV) return fail(ILQR_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(h->device));
   std::vector<double> tmp(2 * (size_t)h->Bp);
   HIPCHK(hipMemcpyAsync(tmp.data(), h->v.dV, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1076,10 +1100,12 @@ int ilqr_get_dV(ilqr_batch* h, double* dV) {
 }
 int ilqr_get_gnorm(ilqr_batch* h, double* g) {
   if (!h || !g) return fail(ILQR_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(h->device));
   return scalars_to_host(h, h->v.gnorm, g);
 }
 int ilqr_get_status(ilqr_batch* h, int* status, int* iters, int* alpha_idx) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
   if (status) if (int rc = scalars_to_host(h, h->v.status, status)) return rc;
   if (iters) if (int rc = scalars_to_host(h, h->v.iters, iters)) return rc;
   if (alpha_idx) if (int rc = scalars_to_host(h, h->v.alpha_idx, alpha_idx)) return rc;
@@ -1108,6 +1134,7 @@ int ilqr_get_candidate(ilqr_batch* h, int a, double* xs, double* us) {
 }
 int ilqr_copy_cost_to_device(ilqr_batch* h, void* dst) {
   if (!h || !dst) return fail(ILQR_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpyAsync(dst, h->v.cost, (size_t)h->B * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   return 0;
 }

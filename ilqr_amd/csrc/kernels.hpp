@@ -150,7 +150,9 @@ __device__ __forceinline__ void accept_one(const BatchView& v, const SolverParam
     v.alpha_idx[b] = acc;
     const int it = v.iters[b] + 1;
     v.iters[b] = it;
-    if (status == 0 && it >= sp.max_iter) status = 4;  // :103
+    // :103.  Not in bench mode: ILQR_FLAG_FIXED_WORK promises that B*T*iters is exactly the work done,
+    // whatever max_iter says.
+    if (status == 0 && !sp.fixed_work && it >= sp.max_iter) status = 4;
     v.status[b] = status;
     if (status == 0) atomicAdd(v.n_running, 1);
   }

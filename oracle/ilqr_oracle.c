@@ -20,12 +20,24 @@
 /* include/finite_diff.h:9 `static const double eps = 1e-3;`, src/derivatives.cpp:10 `#define eps2 1e-3` */
 static const double EPS = 1e-3;
 /* include/ilqr.h:14-24 */
-static const double tolFun = 1e-6;
-static const double tolGrad = 1e-6;
-static const double lambdaFactor = 1.6;
-static const double lambdaMax = 1e11;
-static const double lambdaMin = 1e-8;
-static const double zMin = 0;
+/* (compile-time constants in the reference; settable here -- orc_set_params -- because the C ABI of
+ * the product exposes them as ilqr_params and the tests exercise e.g. the gradient-norm exit with
+ * a looser tolGrad.  Defaults are the reference's.) */
+static double tolFun = 1e-6;
+static double tolGrad = 1e-6;
+static double lambdaFactor = 1.6;
+static double lambdaMax = 1e11;
+static double lambdaMin = 1e-8;
+static double zMin = 0;
+void orc_set_params(double tol_fun, double tol_grad, double lambda_factor, double lambda_max,
+                    double lambda_min, double z_min) {
+  tolFun = tol_fun;
+  tolGrad = tol_grad;
+  lambdaFactor = lambda_factor;
+  lambdaMax = lambda_max;
+  lambdaMin = lambda_min;
+  zMin = z_min;
+}
 static const double Alpha[ORC_NALPHA] = {1.0000, 0.5012, 0.2512, 0.1259, 0.0631, 0.0316,
                                          0.0158, 0.0079, 0.0040, 0.0020, 0.0010};
 /* include/boxqp.h:19-24 */
@@ -1008,6 +1020,60 @@ int orc_batch_solve(const orc_model* m, int B, int T, double dt, const double* x
     if (iters_out) iters_out[b] = s->iters;
     if (status_out) status_out[b] = s->status;
     if (lambda_out) lambda_out[b] = s->lambda;
+    orc_traj_free(s);
+  }
+  return 0;
+}
+
+/* n_iters bodies of the outer loop (orc_iterate_once) from a GIVEN state instead of from init_traj:
+ * the nominal trajectory (xs, us, cost), the gains (k is the box-QP warm start of t = T-1, K feeds
+ * the closed-loop rollouts) and lambda/dlambda.  flgChange starts at 1 (derivatives are recomputed),
+ * i.e. the state is what an accepted iteration leaves behind.  This is how the per-iteration
+ * teacher-forced parity tests step both sides from the same point. */
+int orc_batch_iterate_from(const orc_model* m, int B, int T, double dt, const double* x0,
+                           const double* xs, const double* us, const double* k, const double* K,
+                           const double* cost, const double* lambda, const double* dlambda,
+                           int n_iters, int fixed_work, int nthreads, double* xs_out,
+                           double* us_out, double* k_out, double* K_out, double* cost_out,
+                           int* iters_out, int* status_out, double* lambda_out, double* dlambda_out,
+                           int* alpha_out, double* gnorm_out, double* dV_out) {
+  const int n = m->nx, mu = m->nu;
+  const size_t T1 = (size_t)T + 1;
+  const int nt = pick_threads(nthreads);
+  (void)nt;
+#pragma omp parallel for num_threads(nt) schedule(dynamic, 1)
+  for (int b = 0; b < B; b++) {
+    orc_traj* s = orc_traj_alloc(n, mu, T, dt);
+    memcpy(s->x0, &x0[(size_t)b * n], sizeof(double) * n);
+    memcpy(s->xs, &xs[(size_t)b * T1 * n], sizeof(double) * T1 * n);
+    memcpy(s->us, &us[(size_t)b * T * mu], sizeof(double) * (size_t)T * mu);
+    if (k) memcpy(s->k, &k[(size_t)b * T * mu], sizeof(double) * (size_t)T * mu);
+    if (K) memcpy(s->K, &K[(size_t)b * T * mu * n], sizeof(double) * (size_t)T * mu * n);
+    s->has_gains = 1;
+    s->cost_s = cost[b];
+    s->lambda = lambda[b];
+    s->dlambda = dlambda[b];
+    s->status = ORC_STATUS_RUNNING;
+    int flgChange = 1;
+    for (int it = 0; it < n_iters; it++) {
+      s->iters = it + 1;
+      if (orc_iterate_once(m, s, &flgChange, fixed_work)) break;
+    }
+    if (xs_out) memcpy(&xs_out[(size_t)b * T1 * n], s->xs, sizeof(double) * T1 * n);
+    if (us_out) memcpy(&us_out[(size_t)b * T * mu], s->us, sizeof(double) * (size_t)T * mu);
+    if (k_out) memcpy(&k_out[(size_t)b * T * mu], s->k, sizeof(double) * (size_t)T * mu);
+    if (K_out) memcpy(&K_out[(size_t)b * T * mu * n], s->K, sizeof(double) * (size_t)T * mu * n);
+    if (cost_out) cost_out[b] = s->cost_s;
+    if (iters_out) iters_out[b] = s->iters;
+    if (status_out) status_out[b] = s->status;
+    if (lambda_out) lambda_out[b] = s->lambda;
+    if (dlambda_out) dlambda_out[b] = s->dlambda;
+    if (alpha_out) alpha_out[b] = s->last_alpha_idx;
+    if (gnorm_out) gnorm_out[b] = s->gnorm;
+    if (dV_out) {
+      dV_out[2 * b] = s->dV[0];
+      dV_out[2 * b + 1] = s->dV[1];
+    }
     orc_traj_free(s);
   }
   return 0;

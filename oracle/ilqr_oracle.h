@@ -36,6 +36,10 @@ extern "C" {
 #define ORC_MAX_ITER 100
 #define ORC_NALPHA 11
 
+/* solver tunables of include/ilqr.h:14-24 (process-wide; defaults 1e-6, 1e-6, 1.6, 1e11, 1e-8, 0) */
+void orc_set_params(double tol_fun, double tol_grad, double lambda_factor, double lambda_max,
+                    double lambda_min, double z_min);
+
 enum { ORC_MODEL_ACROBOT = 0, ORC_MODEL_DOUBLE_INTEGRATOR = 1, ORC_MODEL_LQ = 2 };
 
 /* status of a solve (where the outer loop of src/ilqr_core.cpp:103-288 left) */
@@ -147,6 +151,15 @@ int orc_batch_solve(const orc_model* m, int B, int T, double dt, const double* x
                     const double* u0, int max_iters, int fixed_work, int nthreads,
                     double* xs_out, double* us_out, double* k_out, double* K_out,
                     double* cost_out, int* iters_out, int* status_out, double* lambda_out);
+
+/* n_iters outer iterations from a given state (see the .c); every output pointer may be NULL */
+int orc_batch_iterate_from(const orc_model* m, int B, int T, double dt, const double* x0,
+                           const double* xs, const double* us, const double* k, const double* K,
+                           const double* cost, const double* lambda, const double* dlambda,
+                           int n_iters, int fixed_work, int nthreads, double* xs_out,
+                           double* us_out, double* k_out, double* K_out, double* cost_out,
+                           int* iters_out, int* status_out, double* lambda_out, double* dlambda_out,
+                           int* alpha_out, double* gnorm_out, double* dV_out);
 
 /* teacher-forced single stages over a batch */
 int orc_batch_rollout(const orc_model* m, int B, int T, double dt, const double* x0,

@@ -79,6 +79,11 @@ def _c(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+def set_params(tol_fun=1e-6, tol_grad=1e-6, lambda_factor=1.6, lambda_max=1e11, lambda_min=1e-8, z_min=0.0):
+    """Solver tunables of include/ilqr.h:14-24 (process-wide in the oracle); no arguments = the reference's."""
+    lib().orc_set_params(*[C.c_double(v) for v in (tol_fun, tol_grad, lambda_factor, lambda_max, lambda_min, z_min)])
+
+
 def _p(a):
     return a.ctypes.data_as(_dp) if a is not None else None
 
@@ -326,6 +331,27 @@ def batch_solve(model, x0, u0, dt, max_iters=0, fixed_work=False, nthreads=0):
                           _p(out["K"]), _p(out["cost"]), _pi(out["iters"]), _pi(out["status"]),
                           _p(out["lam"]))
     out["K"] = out["K"].transpose(0, 1, 3, 2)  # -> [B][T][nu][nx] view
+    return out
+
+
+def batch_iterate_from(model, x0, xs, us, k, K, cost, lam, dlam, dt, n_iters=1, fixed_work=False, nthreads=0):
+    """n_iters outer iterations from the given state (K as [B][T][nu][nx]); returns the state after."""
+    x0, xs, us, k, cost = _c(x0), _c(xs), _c(us), _c(k), _c(cost)
+    B, T = us.shape[0], us.shape[1]
+    n, m = model.nx, model.nu
+    Kc = _c(np.asarray(K).transpose(0, 1, 3, 2))
+    lam = _c(np.broadcast_to(lam, (B,)))
+    dlam = _c(np.broadcast_to(dlam, (B,)))
+    out = dict(xs=np.zeros((B, T + 1, n)), us=np.zeros((B, T, m)), k=np.zeros((B, T, m)),
+               K=np.zeros((B, T, n, m)), cost=np.zeros(B), iters=np.zeros(B, dtype=np.int32),
+               status=np.zeros(B, dtype=np.int32), lam=np.zeros(B), dlam=np.zeros(B),
+               alpha=np.zeros(B, dtype=np.int32), gnorm=np.zeros(B), dV=np.zeros((B, 2)))
+    lib().orc_batch_iterate_from(model.ref, B, T, C.c_double(dt), _p(x0), _p(xs), _p(us), _p(k), _p(Kc),
+                                 _p(cost), _p(lam), _p(dlam), int(n_iters), int(fixed_work), nthreads,
+                                 _p(out["xs"]), _p(out["us"]), _p(out["k"]), _p(out["K"]), _p(out["cost"]),
+                                 _pi(out["iters"]), _pi(out["status"]), _p(out["lam"]), _p(out["dlam"]),
+                                 _pi(out["alpha"]), _p(out["gnorm"]), _p(out["dV"]))
+    out["K"] = out["K"].transpose(0, 1, 3, 2)
     return out
 
 

@@ -12,7 +12,11 @@ import numpy as np
 from ilqr_amd import BatchILQR, capi
 from oracle import oracle as O
 from tests.test_gpu_lq_end_to_end import dense_mats, lq_mats
-from tests.test_gpu_parity import _is_clamp_knife_edge
+from tests.parity import first_gain_mismatch_is_knife_edge
+
+
+def _is_clamp_knife_edge(k, K, ko, Ko, lo, hi):
+    return first_gain_mismatch_is_knife_edge(k, K, ko, Ko, np.zeros_like(k), lo, hi)
 from tests.util import mat
 
 DT = 0.02

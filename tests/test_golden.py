@@ -88,7 +88,7 @@ def test_gpu_matches_reference_fd_vectors(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["acrobot", "integrator"])
-def test_gpu_matches_golden_stages(name):
+def test_gpu_matches_golden_stages(oracle, name):
     d = np.load(os.path.join(G, "stages_%s.npz" % name))
     B, T = d["u0"].shape[:2]
     g = _gpu(name, d, B, T)
@@ -111,5 +111,9 @@ def test_gpu_matches_golden_stages(name):
     g.iterate(3)
     st, it, al = g.status()
     ok = np.isclose(g.cost(), d["sol_cost"], rtol=TOL)
-    assert ok.mean() >= 0.8
     assert np.array_equal(it[ok], d["sol_iters"][ok])
+    # every trajectory that left the golden solution did so at a proven tie (tests/parity.py)
+    from tests.parity import walk_iterations
+    om = _model(oracle, name, d["goal"], float(d["lim"]))
+    r = walk_iterations(oracle, om, g, d["x0"], np.zeros_like(d["u0"]), DT, 3)
+    assert (~ok).sum() <= r["ties_backward"] + r["ties_search"] + r["ties_stop"], (r, (~ok).sum())

@@ -5,6 +5,7 @@ driven from two host threads at once."""
 import numpy as np
 import pytest
 
+from tests.parity import gains_knot_err, walk_iterations
 from tests.util import TOL, acrobot_x0, integrator_x0, mat, relerr
 
 pytestmark = pytest.mark.gpu
@@ -36,18 +37,20 @@ def test_horizons_around_chunk_size(oracle, name, B, T):
     for a in (0, 5, 10):
         xa, ua, ca = oracle.batch_rollout(om, x0, us_o + ALPHAS[a] * k, DT, xs_nom=xs_o, K=K)
         xg, ug = g.candidate(a)
-        assert relerr(xg, xa) < 1e-5 and relerr(ug + 1.0, ua + 1.0) < 1e-5, (a, T)
-        assert np.allclose(cc[:, a], ca, rtol=1e-5)
+        assert relerr(xg, xa) < TOL and np.abs(ug - ua).max() <= TOL * (1.0 + np.abs(ua).max()), (a, T)
+        assert np.allclose(cc[:, a], ca, rtol=TOL)
     # full iterations (exercise accept + fused commit + flush) stay in step with the oracle
     g.init_traj(x0, u0)
     g.iterate(2)
     ro = oracle.batch_solve(om, x0, u0, DT, max_iters=2)
     ok = np.isclose(g.cost(), ro["cost"], rtol=TOL)
-    assert ok.mean() >= 0.8
     xs2, us2 = g.trajectory()
-    assert relerr(xs2[ok], ro["xs"][ok]) < 1e-5
+    assert relerr(xs2[ok], ro["xs"][ok]) < TOL
     st, it, al = g.status()
     assert np.array_equal(it[ok], ro["iters"][ok])
+    # every trajectory that left the oracle's path did so at a proven tie (tests/parity.py)
+    r = walk_iterations(oracle, om, g, x0, u0, DT, 2)
+    assert (~ok).sum() <= r["ties_backward"] + r["ties_search"] + r["ties_stop"], (r, (~ok).sum())
 
 
 @pytest.mark.parametrize("B", [1, 15, 16, 17, 63, 64, 65, 130])
@@ -62,9 +65,12 @@ def test_ragged_batches(oracle, B):
     g.iterate(3)
     ro = oracle.batch_solve(om, x0, u0, DT, max_iters=3)
     ok = np.isclose(g.cost(), ro["cost"], rtol=TOL)
-    assert ok.mean() >= 0.85, (g.cost(), ro["cost"])
     k, K = g.gains()
-    assert relerr(k[ok] + 1.0, ro["k"][ok] + 1.0) < 1e-5
+    xs, us = g.trajectory()
+    if ok.any():  # gains of the third backward pass, per knot (two iterations of amplification behind them)
+        assert gains_knot_err(k[ok], K[ok], ro["k"][ok], ro["K"][ok], us[ok]).max() < 1e-4
+    r = walk_iterations(oracle, om, g, x0, u0, DT, 3)
+    assert (~ok).sum() <= r["ties_backward"] + r["ties_search"] + r["ties_stop"], (r, g.cost(), ro["cost"])
 
 
 def test_backward_kernel_variants_agree(oracle):

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 from tests.util import TOL, mat
-from tests.test_gpu_parity import _is_clamp_knife_edge, _per_traj_err
+from tests.parity import first_gain_mismatch_is_knife_edge, gains_knot_err
+from tests.test_gpu_parity import _per_traj_err
 
 pytestmark = pytest.mark.gpu
 DT = 0.02
@@ -19,7 +20,7 @@ def lq_model(oracle, n, m, seed=7, lim=1.0):
     return oracle.Model("lq", lq=(A, Bm, Q, R, Q), u_lim=lim)
 
 
-def run_case(oracle, om, B, T, lam, x_scale=1.0, u_scale=0.5):
+def run_case(oracle, om, B, T, lam, x_scale=1.0, u_scale=0.5, cuu_shift=None):
     from ilqr_amd import BatchILQR
     n, m = om.nx, om.nu
     rng = np.random.default_rng(3)
@@ -27,6 +28,8 @@ def run_case(oracle, om, B, T, lam, x_scale=1.0, u_scale=0.5):
     u0 = rng.normal(size=(B, T, m)) * u_scale
     xs, us, cost = oracle.batch_rollout(om, x0, u0, DT)
     dv = oracle.batch_derivatives(om, xs, us, DT)
+    if cuu_shift is not None:  # [m] added to the diagonal of every cuu[t]: makes Quu indefinite
+        dv["cuu"] = dv["cuu"] + np.diag(cuu_shift)[None, None]
     k_prev = rng.normal(size=(B, T, m)) * 0.1
     ro = oracle.batch_backward(om, us, dv, k_prev=k_prev, lam=lam)
     g = BatchILQR("host", B, T, DT, nx=n, nu=m, u_min=om.u_min, u_max=om.u_max)
@@ -45,15 +48,16 @@ def run_case(oracle, om, B, T, lam, x_scale=1.0, u_scale=0.5):
     lo, hi = om.u_min[None, None, :] - us, om.u_max[None, None, :] - us
     conv = ro["diverge"] == 0
     assert conv.sum() > 0
-    err = np.maximum.reduce([_per_traj_err(k, ro["k"]), _per_traj_err(K, Ko), _per_traj_err(dV, ro["dV"])])
+    err = np.maximum(gains_knot_err(k, K, ro["k"], Ko, us), _per_traj_err(dV, ro["dV"]))  # gains: per knot
     good = (err < TOL) & (div == ro["diverge"])
     ties = 0
     for b in np.flatnonzero(conv & ~good):
-        assert _is_clamp_knife_edge(k[b], K[b], ro["k"][b], Ko[b], lo[b], hi[b]), (b, err[b])
+        assert first_gain_mismatch_is_knife_edge(k[b], K[b], ro["k"][b], Ko[b], us[b], lo[b], hi[b]), (b, err[b])
         ties += 1
     assert ties <= max(1, B // 8), ties
     ok = conv & good
     clamped = (np.abs(k - lo) < 1e-9) | (np.abs(k - hi) < 1e-9)
+    g.last = dict(div=div, ro=ro, ok=ok, ties=ties)
     return clamped[ok].mean(), g
 
 
@@ -82,3 +86,21 @@ def test_host_path_equals_device_model_path(oracle):
     assert frac > 0.02
     with pytest.raises(Exception, match="host-evaluated model"):
         g.iterate(1)
+
+
+@pytest.mark.parametrize("n,m,where", [(6, 2, "last"), (6, 2, "first"), (32, 16, "middle"), (32, 16, "first"), (12, 16, "two")])
+def test_non_positive_definite_quu(oracle, n, m, where):
+    """Quu NOT positive definite, lambda = 0, through the wave-per-trajectory kernel's own Cholesky / box-QP
+    (backward_wave.hpp).  Eigen's unblocked LLT (Cholesky/LLT.h:302-325) stops at the first non-positive
+    pivot and leaves the rest of the lower triangle untouched, boxqp.cpp:85-88 never looks at info(), so the
+    PARTIAL factor is used -- the pass does not diverge, it returns whatever that factor gives.
+    The pivot fails first / in the middle / last / at two places; gains compared per knot with the oracle."""
+    om = lq_model(oracle, n, m, seed=3, lim=0.5)
+    shift = np.zeros(m)
+    idx = {"first": [0], "last": [m - 1], "middle": [m // 2], "two": [3, m - 2]}[where]
+    shift[idx] = -0.35  # cuu = R = 0.1 I: these diagonal entries become -0.25, fu' Vxx fu adds O(dt^2)
+    frac, g = run_case(oracle, om, B=8, T=10, lam=0.0, u_scale=0.2, cuu_shift=shift)
+    ro, div = g.last["ro"], g.last["div"]
+    assert np.array_equal(div, ro["diverge"])
+    assert g.last["ok"].sum() >= 6, g.last  # (ties allowed as everywhere, see run_case)
+    g.close()

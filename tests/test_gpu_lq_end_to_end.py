@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from tests.util import TOL, mat, relerr, relerr_abs
-from tests.test_gpu_parity import _is_clamp_knife_edge, _per_traj_err
+from tests.parity import first_gain_mismatch_is_knife_edge, gains_knot_err, walk_iterations
 
 pytestmark = pytest.mark.gpu
 DT = 0.02
@@ -80,11 +80,11 @@ def test_lq_stages_match_oracle(oracle, n, m, B, T, dense):
     ro = oracle.batch_backward(om, us_o, do, k_prev=k_prev, lam=1.0)
     k, K = g.gains()
     Ko = mat(ro["K"])
-    err = np.maximum(_per_traj_err(k, ro["k"]), _per_traj_err(K, Ko))
+    err = gains_knot_err(k, K, ro["k"], Ko, us_o)  # per knot
     lo, hi = om.u_min[None, None, :] - us_o, om.u_max[None, None, :] - us_o
     bad = np.flatnonzero((err >= TOL) | (div != ro["diverge"]))
     for b in bad:
-        assert _is_clamp_knife_edge(k[b], K[b], ro["k"][b], Ko[b], lo[b], hi[b]), (b, err[b])
+        assert first_gain_mismatch_is_knife_edge(k[b], K[b], ro["k"][b], Ko[b], us_o[b], lo[b], hi[b]), (b, err[b])
     assert len(bad) <= max(1, B // 8)
     # the 11 closed-loop rollouts of the line search, with the oracle's gains
     g.set_gains(k=ro["k"], K=Ko)
@@ -113,13 +113,16 @@ def test_lq_iterations_match_oracle(oracle, n, m, B, T):
     x0 = rng.uniform(-1, 1, (B, n))
     u0 = np.zeros((B, T, m))
     iters = 3
+    r = walk_iterations(oracle, om, g, x0, u0, DT, iters, fixed_work=True)  # every deviation a proven tie
+    n_ties = r["ties_backward"] + r["ties_search"]
+    assert r["checked"] == B * iters and n_ties <= max(1, B // 8), r
     g.init_traj(x0, u0)
     g.iterate(iters)
     ro = oracle.batch_solve(om, x0, u0, DT, max_iters=iters, fixed_work=True)
     cost = g.cost()
     xs, us = g.trajectory()
     rel = np.abs(cost - ro["cost"]) / np.abs(ro["cost"])
-    assert (rel < TOL).mean() >= 0.9 and rel.max() < 1e-3, rel
+    assert (rel >= TOL).sum() <= n_ties and rel.max() < 1e-3, (rel, r)
     ok = rel < TOL
     assert relerr(xs[ok], ro["xs"][ok]) < 1e-5 and relerr_abs(us[ok], ro["us"][ok], 1e-3) < 1e-5
     st, it, al = g.status()
@@ -183,11 +186,13 @@ def test_lq_matrix_core_rollout_equals_thread_per_rollout(n, m, B, T, monkeypatc
     assert np.all(out[0]["cost"] < out[0]["c0"])
 
 
-def test_lq_full_size_properties():
-    """BASELINE.json configs[4] at full size (n = 32, m = 16, T = 200, B = 8192, limits active):
-    size-independent properties of two finite-difference iterations."""
+@pytest.mark.parametrize("lim", [1.0, 0.3])
+def test_lq_full_size_properties(lim):
+    """BASELINE.json configs[4] at full size (n = 32, m = 16, T = 200, B = 8192; limits +-1 as SURVEY.md 8d
+    cfg 5 has them, and +-0.3 where far more box-QPs end clamped): size-independent properties of two
+    finite-difference iterations."""
     from ilqr_amd import BatchILQR
-    n, m, B, T, lim = 32, 16, 8192, 200, 0.3
+    n, m, B, T = 32, 16, 8192, 200
     mats = lq_mats(n, m)
     rng = np.random.default_rng(12)
     x0 = rng.uniform(-1, 1, (B, n))
@@ -210,4 +215,5 @@ def test_lq_full_size_properties():
     assert (np.abs(us) <= lim * (1 + 1e-9)).mean() > 0.9
     # rows of K are zero where the control sits on a limit (boxqp.cpp: only free rows get a gain)
     clamped_rows = (np.abs(K).max(axis=-1) == 0)
-    assert 0.001 < clamped_rows.mean() < 0.9
+    assert (0.001 if lim < 1 else 0.0) < clamped_rows.mean() < 0.9
+    print("lim", lim, "clamped gain rows", clamped_rows.mean())
