@@ -37,6 +37,8 @@ class BatchILQR:
     def __init__(self, model, B, T, dt, u_min=None, u_max=None, goal=None, device=0, flags=0,
                  stream=None, params=None, nx=None, nu=None, lq=None):
         self.lib = capi.load()
+        self._ctor = dict(model=model, B=B, T=T, dt=dt, u_min=u_min, u_max=u_max, goal=goal, device=device, flags=flags,
+                          stream=stream, params=params, nx=nx, nu=nu, lq=lq)
         mid, mnx, mnu = _MODELS[model]
         if lq is not None:
             lq = [_c(a) for a in lq]
@@ -67,6 +69,10 @@ class BatchILQR:
             d.params = C.pointer(p)
         self.h = C.c_void_p()
         capi.check(self.lib.ilqr_create(C.byref(d), C.byref(self.h)))
+
+    def clone(self):
+        """A second, independent handle for the same problem description (own device memory and state)."""
+        return BatchILQR(**self._ctor)
 
     def close(self):
         if getattr(self, "h", None):

@@ -11,26 +11,27 @@
 #include "ilqr_oracle.h"
 
 #include <math.h>
+#include <tgmath.h> /* sin/cos/sqrt/fabs/fmax/fmin pick the flavour of their argument type */
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
 
-/* include/finite_diff.h:9 `static const double eps = 1e-3;`, src/derivatives.cpp:10 `#define eps2 1e-3` */
-static const double EPS = 1e-3;
+/* include/finite_diff.h:9 `static const orc_real eps = 1e-3;`, src/derivatives.cpp:10 `#define eps2 1e-3` */
+static const orc_fd EPS = 1e-3;
 /* include/ilqr.h:14-24 */
 /* (compile-time constants in the reference; settable here -- orc_set_params -- because the C ABI of
  * the product exposes them as ilqr_params and the tests exercise e.g. the gradient-norm exit with
  * a looser tolGrad.  Defaults are the reference's.) */
-static double tolFun = 1e-6;
-static double tolGrad = 1e-6;
-static double lambdaFactor = 1.6;
-static double lambdaMax = 1e11;
-static double lambdaMin = 1e-8;
-static double zMin = 0;
-void orc_set_params(double tol_fun, double tol_grad, double lambda_factor, double lambda_max,
-                    double lambda_min, double z_min) {
+static orc_acc tolFun = 1e-6;
+static orc_acc tolGrad = 1e-6;
+static orc_acc lambdaFactor = 1.6;
+static orc_acc lambdaMax = 1e11;
+static orc_acc lambdaMin = 1e-8;
+static orc_acc zMin = 0;
+void orc_set_params(orc_f64 tol_fun, orc_f64 tol_grad, orc_f64 lambda_factor, orc_f64 lambda_max,
+                    orc_f64 lambda_min, orc_f64 z_min) {
   tolFun = tol_fun;
   tolGrad = tol_grad;
   lambdaFactor = lambda_factor;
@@ -38,76 +39,42 @@ void orc_set_params(double tol_fun, double tol_grad, double lambda_factor, doubl
   lambdaMin = lambda_min;
   zMin = z_min;
 }
-static const double Alpha[ORC_NALPHA] = {1.0000, 0.5012, 0.2512, 0.1259, 0.0631, 0.0316,
+static const orc_f64 Alpha[ORC_NALPHA] = {1.0000, 0.5012, 0.2512, 0.1259, 0.0631, 0.0316,
                                          0.0158, 0.0079, 0.0040, 0.0020, 0.0010};
 /* include/boxqp.h:19-24 */
 static const int qp_maxIter = 100;
-static const double minGrad = 1e-8;
-static const double minRelImprove = 1e-8;
-static const double stepDec = 0.6;
-static const double minStep = 1e-22;
-static const double Armijo = 0.1;
+static const orc_real minGrad = 1e-8;
+static const orc_real minRelImprove = 1e-8;
+static const orc_real stepDec = 0.6;
+static const orc_real minStep = 1e-22;
+static const orc_real Armijo = 0.1;
 
 /* ------------------------------------------------------------------------------------------ */
 /* Models                                                                                      */
 /* ------------------------------------------------------------------------------------------ */
 
-/* include/acrobot.h:43-81.  Parameters I1=I2=l1=l2=m1=m2=1, lc1=lc2=0.5, g=9.81 (:19-25). */
-static void acrobot_dynamics(const orc_model* m, const double* x, const double* u, double* dx) {
-  (void)m;
-  const double I1 = 1, I2 = 1, l1 = 1, l2 = 1, m1 = 1, m2 = 1, g = 9.81;
-  const double lc1 = 0.5 * l1, lc2 = 0.5 * l2;
-  const double q0 = x[0], q1 = x[1], qd0 = x[2], qd1 = x[3];
-  /* H(q), acrobot.h:43-51 */
-  const double c2 = cos(q1);
-  const double H00 = I1 + I2 + m2 * l1 * l1 + 2 * m2 * l1 * lc2 * c2;
-  const double H01 = I2 + m2 * l1 * lc2 * c2;
-  const double H10 = I2 + m2 * l1 * lc2 * c2;
-  const double H11 = I2;
-  /* C(q,qdot), acrobot.h:53-61 */
-  const double s2 = sin(q1);
-  const double C00 = -2 * m2 * l1 * lc2 * s2 * qd1;
-  const double C01 = -m2 * l2 * lc2 * s2 * qd1;
-  const double C10 = m2 * l1 * lc2 * s2 * qd0;
-  const double C11 = 0;
-  /* G(q), acrobot.h:63-70 */
-  const double s1 = sin(q0);
-  const double s1p2 = sin(q0 + q1);
-  const double G0 = m1 * g * lc1 * s1 + m2 * g * (l1 * s1 + lc2 * s1p2);
-  const double G1 = m2 * g * lc2 * s1p2;
-  /* rhs = (0,u) - C*qdot - G, acrobot.h:80 */
-  const double Cq0 = C00 * qd0 + C01 * qd1;
-  const double Cq1 = C10 * qd0 + C11 * qd1;
-  const double r0 = (0.0 - Cq0) - G0;
-  const double r1 = (u[0] - Cq1) - G1;
-  /* H.inverse() for a fixed 2x2: Eigen LU/InverseImpl.h:76-96 (invdet = 1/det; 4 products) */
-  const double det = H00 * H11 - H10 * H01;
-  const double invdet = 1.0 / det;
-  const double Hi00 = H11 * invdet;
-  const double Hi10 = -H10 * invdet;
-  const double Hi01 = -H01 * invdet;
-  const double Hi11 = H00 * invdet;
-  dx[0] = qd0; /* acrobot.h:79 */
-  dx[1] = qd1;
-  dx[2] = Hi00 * r0 + Hi01 * r1;
-  dx[3] = Hi10 * r0 + Hi11 * r1;
-}
-
-/* include/acrobot.h:83-92: Ks=Kd=0, Kr=0.1 */
-static double acrobot_cost(const orc_model* m, const double* x, const double* u) {
-  const double q0 = m->goal[0] - x[0], q1 = m->goal[1] - x[1];
-  const double qd0 = m->goal[2] - x[2], qd1 = m->goal[3] - x[3];
-  const double Ks = 0.0, Kd = 0.0, Kr = 0.1;
-  return Ks * Ks * (q0 * q0 + q1 * q1) + Kd * Kd * (qd0 * qd0 + qd1 * qd1) + Kr * Kr * (u[0] * u[0]);
-}
-
-/* include/acrobot.h:94-100: Ks=Kd=20 */
-static double acrobot_final_cost(const orc_model* m, const double* x) {
-  const double q0 = m->goal[0] - x[0], q1 = m->goal[1] - x[1];
-  const double qd0 = m->goal[2] - x[2], qd1 = m->goal[3] - x[3];
-  const double Ks = 20.0, Kd = 20.0;
-  return Ks * Ks * (q0 * q0 + q1 * q1) + Kd * Kd * (qd0 * qd0 + qd1 * qd1);
-}
+#define MT orc_real
+#define MN(name) name
+#include "orc_models.inc"
+#undef MT
+#undef MN
+#ifdef ORC_FD_IS_DOUBLE /* fp32 build: a second, double-precision flavour for the finite differences */
+#define MT orc_fd
+#define MN(name) name##_fd
+#include "orc_models.inc"
+#undef MT
+#undef MN
+#else
+#define acrobot_dynamics_fd acrobot_dynamics
+#define acrobot_cost_fd acrobot_cost
+#define acrobot_final_cost_fd acrobot_final_cost
+#define dint_dynamics_fd dint_dynamics
+#define dint_cost_fd dint_cost
+#define dint_final_cost_fd dint_final_cost
+#define lq_dynamics_fd lq_dynamics
+#define lq_cost_fd lq_cost
+#define lq_final_cost_fd lq_final_cost
+#endif
 
 void orc_model_init_acrobot(orc_model* m) {
   memset(m, 0, sizeof(*m));
@@ -120,41 +87,12 @@ void orc_model_init_acrobot(orc_model* m) {
   m->dynamics = acrobot_dynamics;
   m->cost = acrobot_cost;
   m->final_cost = acrobot_final_cost;
+  m->dynamics_fd = acrobot_dynamics_fd;
+  m->cost_fd = acrobot_cost_fd;
+  m->final_cost_fd = acrobot_final_cost_fd;
 }
 
-/* include/double_integrator.h:29-37, mass = 1 (:51) */
-static void dint_dynamics(const orc_model* m, const double* x, const double* u, double* dx) {
-  (void)m;
-  const double mass = 1.0;
-  dx[0] = x[2];
-  dx[1] = x[3];
-  dx[2] = u[0] / mass;
-  dx[3] = u[1] / mass;
-}
-static const double DINT_HX[4] = {1, 1, 0.2, 0.2}; /* double_integrator.h:19-22 (diagonal) */
-/* double_integrator.h:39-43: (goal-x)' Hx (goal-x) + u' Hu u, Hu = I.  Evaluated as
- * (d' Hx) d with the dense 4x4 Hx; the off-diagonal zeros contribute exact +0 terms. */
-static double dint_quad4(const double* goal, const double* x, double scale) {
-  /* (d' H) d for the dense 4x4 H: row_j = d_j*H_jj (+ exact zeros); the final dot of two
-   * dynamic 4-vectors is reduced by Eigen's SSE2 redux as (r0 d0 + r2 d2) + (r1 d1 + r3 d3)
-   * (Core/Redux.h linear vectorised traversal, two packet accumulators). */
-  double r[4], d[4];
-  for (int i = 0; i < 4; i++) {
-    d[i] = goal[i] - x[i];
-    r[i] = scale * (DINT_HX[i] * d[i]); /* gemv applies the extracted scalar factor last */
-  }
-  return (r[0] * d[0] + r[2] * d[2]) + (r[1] * d[1] + r[3] * d[3]);
-}
-static double dint_cost(const orc_model* m, const double* x, const double* u) {
-  const double cx = dint_quad4(m->goal, x, 1.0);
-  const double cu = (u[0] * 1.0) * u[0] + (u[1] * 1.0) * u[1];
-  return cx + cu;
-}
-/* double_integrator.h:45-48: (goal-x)' (10 Hx) (goal-x) */
-static double dint_final_cost(const orc_model* m, const double* x) {
-  return dint_quad4(m->goal, x, 10.0);
-}
-void orc_model_init_double_integrator(orc_model* m, const double* goal) {
+void orc_model_init_double_integrator(orc_model* m, const orc_real* goal) {
   memset(m, 0, sizeof(*m));
   m->id = ORC_MODEL_DOUBLE_INTEGRATOR;
   m->nx = 4; /* double_integrator.h:16-17 */
@@ -165,38 +103,14 @@ void orc_model_init_double_integrator(orc_model* m, const double* goal) {
   m->dynamics = dint_dynamics;
   m->cost = dint_cost;
   m->final_cost = dint_final_cost;
+  m->dynamics_fd = dint_dynamics_fd;
+  m->cost_fd = dint_cost_fd;
+  m->final_cost_fd = dint_final_cost_fd;
 }
 
-/* Synthetic LQ model (BASELINE.json configs[4]; no counterpart in the reference):
- * xdot = A x + B u (row-major A[nx][nx], B[nx][nu]); cost 0.5 (x'Qx + u'Ru); final 0.5 x'Qf x.
- * Sums run left to right over the column index. */
-static void lq_dynamics(const orc_model* m, const double* x, const double* u, double* dx) {
-  const int n = m->nx, mu = m->nu;
-  for (int i = 0; i < n; i++) {
-    double a = 0;
-    for (int j = 0; j < n; j++) a += m->A[i * n + j] * x[j];
-    for (int j = 0; j < mu; j++) a += m->Bm[i * mu + j] * u[j];
-    dx[i] = a;
-  }
-}
-static double lq_quad(int n, const double* M, const double* v) {
-  double s = 0;
-  for (int i = 0; i < n; i++) {
-    double r = 0;
-    for (int j = 0; j < n; j++) r += M[i * n + j] * v[j];
-    s += v[i] * r;
-  }
-  return s;
-}
-static double lq_cost(const orc_model* m, const double* x, const double* u) {
-  return 0.5 * (lq_quad(m->nx, m->Q, x) + lq_quad(m->nu, m->R, u));
-}
-static double lq_final_cost(const orc_model* m, const double* x) {
-  return 0.5 * lq_quad(m->nx, m->Qf, x);
-}
-void orc_model_init_lq(orc_model* m, int nx, int nu, const double* A, const double* Bm,
-                       const double* Q, const double* R, const double* Qf, double umin,
-                       double umax) {
+void orc_model_init_lq(orc_model* m, int nx, int nu, const orc_real* A, const orc_real* Bm,
+                       const orc_real* Q, const orc_real* R, const orc_real* Qf, orc_f64 umin,
+                       orc_f64 umax) {
   memset(m, 0, sizeof(*m));
   m->id = ORC_MODEL_LQ;
   m->nx = nx;
@@ -213,13 +127,23 @@ void orc_model_init_lq(orc_model* m, int nx, int nu, const double* A, const doub
   m->dynamics = lq_dynamics;
   m->cost = lq_cost;
   m->final_cost = lq_final_cost;
+  m->dynamics_fd = lq_dynamics_fd;
+  m->cost_fd = lq_cost_fd;
+  m->final_cost_fd = lq_final_cost_fd;
 }
 
 /* include/model.h:12-15: x1 = x + dynamics(x,u)*dt */
-void orc_integrate_dynamics(const orc_model* m, const double* x, const double* u, double dt,
-                            double* x1) {
-  double dx[ORC_MAXN];
+void orc_integrate_dynamics(const orc_model* m, const orc_real* x, const orc_real* u, orc_f64 dt_,
+                            orc_real* x1) {
+  const orc_real dt = (orc_real)dt_;
+  orc_real dx[ORC_MAXN];
   m->dynamics(m, x, u, dx);
+  for (int i = 0; i < m->nx; i++) x1[i] = x[i] + dx[i] * dt;
+}
+/* the same map in the finite differences' arithmetic (== the above except in the fp32 build) */
+static void integrate_dynamics_fd(const orc_model* m, const orc_fd* x, const orc_fd* u, orc_fd dt, orc_fd* x1) {
+  orc_fd dx[ORC_MAXN];
+  m->dynamics_fd(m, x, u, dx);
   for (int i = 0; i < m->nx; i++) x1[i] = x[i] + dx[i] * dt;
 }
 
@@ -228,44 +152,44 @@ void orc_integrate_dynamics(const orc_model* m, const double* x, const double* u
 /* ------------------------------------------------------------------------------------------ */
 
 /* include/boxqp.h:48-51: upper.cwiseMin(x.cwiseMax(lower)) */
-void orc_clamp_to_limits(int n, const double* x, const double* lo, const double* hi, double* out) {
+void orc_clamp_to_limits(int n, const orc_real* x, const orc_real* lo, const orc_real* hi, orc_real* out) {
   for (int i = 0; i < n; i++) {
-    const double a = (x[i] < lo[i]) ? lo[i] : x[i]; /* cwiseMax(lower) */
+    const orc_real a = (x[i] < lo[i]) ? lo[i] : x[i]; /* cwiseMax(lower) */
     out[i] = (hi[i] < a) ? hi[i] : a;               /* upper.cwiseMin(.) */
   }
 }
 
 /* include/boxqp.h:53-55: 0.5*x.transpose()*Q*x + x.dot(c), evaluated ((0.5 x')Q) x + x.c */
-double orc_quad_cost(int n, const double* Q, const double* c, const double* x) {
-  double quad = 0, lin = 0;
+orc_real orc_quad_cost(int n, const orc_real* Q, const orc_real* c, const orc_real* x) {
+  orc_real quad = 0, lin = 0;
   for (int j = 0; j < n; j++) {
-    double r = 0;
-    for (int i = 0; i < n; i++) r += (0.5 * x[i]) * Q[i + n * j];
+    orc_real r = 0;
+    for (int i = 0; i < n; i++) r += ((orc_real)0.5 * x[i]) * Q[i + n * j];
     quad += r * x[j];
   }
   for (int i = 0; i < n; i++) lin += x[i] * c[i];
   return quad + lin;
 }
 
-static void matvec(int n, const double* Q, const double* x, double* y) {
+static void matvec(int n, const orc_real* Q, const orc_real* x, orc_real* y) {
   for (int i = 0; i < n; i++) {
-    double s = 0;
+    orc_real s = 0;
     for (int j = 0; j < n; j++) s += Q[i + n * j] * x[j];
     y[i] = s;
   }
 }
 
 /* src/boxqp.cpp:143-178 */
-int orc_quadclamp_line_search(int n, const double* x0, const double* dir, const double* Q,
-                              const double* c, const double* lo, const double* hi, double* x_opt,
-                              double* v_opt, int* n_steps) {
-  double step = 1;
-  double grad[ORC_MAXM], x_reach[ORC_MAXM], x_clamped[ORC_MAXM];
+int orc_quadclamp_line_search(int n, const orc_real* x0, const orc_real* dir, const orc_real* Q,
+                              const orc_real* c, const orc_real* lo, const orc_real* hi, orc_real* x_opt,
+                              orc_real* v_opt, int* n_steps) {
+  orc_real step = 1;
+  orc_real grad[ORC_MAXM], x_reach[ORC_MAXM], x_clamped[ORC_MAXM];
   int nsteps = 0;
   int failed = 0;
   matvec(n, Q, x0, grad);
   for (int i = 0; i < n; i++) grad[i] += c[i]; /* :149 */
-  double local_slope = 0;
+  orc_real local_slope = 0;
   for (int i = 0; i < n; i++) local_slope += dir[i] * grad[i]; /* :150 */
   if (local_slope >= 0) { /* :151-154: result fields left untouched */
     if (n_steps) *n_steps = 0;
@@ -273,8 +197,8 @@ int orc_quadclamp_line_search(int n, const double* x0, const double* dir, const 
   }
   for (int i = 0; i < n; i++) x_reach[i] = x0[i] + step * dir[i]; /* :156 */
   orc_clamp_to_limits(n, x_reach, lo, hi, x_clamped);
-  double v = orc_quad_cost(n, Q, c, x_clamped);
-  const double old_v = orc_quad_cost(n, Q, c, x0);
+  orc_real v = orc_quad_cost(n, Q, c, x_clamped);
+  const orc_real old_v = orc_quad_cost(n, Q, c, x0);
   while ((v - old_v) / (step * local_slope) < Armijo) { /* :161 */
     step *= stepDec;
     nsteps++;
@@ -296,20 +220,20 @@ int orc_quadclamp_line_search(int n, const double* x0, const double* dir, const 
  * size < 32, LLT.h:332-333).  Only the lower triangle is read/written.  On a non-positive pivot
  * it returns k and leaves column k.. untouched -- and src/boxqp.cpp:85-88 never looks at info(),
  * so that partial factor IS used downstream. */
-int orc_llt_lower_unblocked(int n, double* A) {
+int orc_llt_lower_unblocked(int n, orc_real* A) {
   for (int k = 0; k < n; k++) {
     const int rs = n - k - 1;
-    double x = A[k + n * k];
+    orc_real x = A[k + n * k];
     if (k > 0) {
-      double sq = 0;
+      orc_real sq = 0;
       for (int j = 0; j < k; j++) sq += A[k + n * j] * A[k + n * j]; /* A10.squaredNorm() */
       x -= sq;
     }
-    if (x <= 0.0) return k;
+    if (x <= (orc_real)0.0) return k;
     A[k + n * k] = x = sqrt(x);
     if (k > 0 && rs > 0) { /* A21 -= A20 * A10' */
       for (int i = k + 1; i < n; i++) {
-        double s = 0;
+        orc_real s = 0;
         for (int j = 0; j < k; j++) s += A[i + n * j] * A[k + n * j];
         A[i + n * k] -= s;
       }
@@ -324,51 +248,51 @@ int orc_llt_lower_unblocked(int n, double* A) {
  * dynamic-size .inverse() calls = partialPivLu().inverse() (LU/InverseImpl.h:22-29) and one
  * product (boxqp.cpp:105-112, ilqr_core.cpp:379); a triangular inverse agrees with that to
  * rounding*cond(R). */
-static void rinv_rinvT(int nf, const double* R, double* M) {
-  double Ri[ORC_MAXM * ORC_MAXM];
+static void rinv_rinvT(int nf, const orc_real* R, orc_real* M) {
+  orc_real Ri[ORC_MAXM * ORC_MAXM];
   /* upper-triangular inverse by back substitution, column by column */
   for (int j = 0; j < nf; j++) {
     for (int i = 0; i < nf; i++) Ri[i + nf * j] = 0;
-    Ri[j + nf * j] = 1.0 / R[j + nf * j];
+    Ri[j + nf * j] = (orc_real)1.0 / R[j + nf * j];
     for (int i = j - 1; i >= 0; i--) {
-      double s = 0;
+      orc_real s = 0;
       for (int l = i + 1; l <= j; l++) s += R[i + nf * l] * Ri[l + nf * j];
       Ri[i + nf * j] = -s / R[i + nf * i];
     }
   }
   for (int i = 0; i < nf; i++)
     for (int j = 0; j < nf; j++) {
-      double s = 0;
+      orc_real s = 0;
       for (int l = 0; l < nf; l++) s += Ri[i + nf * l] * Ri[j + nf * l]; /* Ri * Ri' */
       M[i + nf * j] = s;
     }
 }
 
 /* src/boxqp.cpp:26-139.  R_free/v_free follow boxQPResult (include/boxqp.h:35-43). */
-int orc_boxqp(int n, const double* Q, const double* c, const double* x0, const double* lo,
-              const double* hi, double* x_opt, int* v_free, double* R_free, int* nfree_out,
+int orc_boxqp(int n, const orc_real* Q, const orc_real* c, const orc_real* x0, const orc_real* lo,
+              const orc_real* hi, orc_real* x_opt, int* v_free, orc_real* R_free, int* nfree_out,
               int* iters_out) {
-  double x[ORC_MAXM], grad[ORC_MAXM], grad_clamped[ORC_MAXM], search[ORC_MAXM];
-  double clamped[ORC_MAXM], old_clamped[ORC_MAXM], tmp[ORC_MAXM];
-  double Qfree[ORC_MAXM * ORC_MAXM], Minv[ORC_MAXM * ORC_MAXM];
+  orc_real x[ORC_MAXM], grad[ORC_MAXM], grad_clamped[ORC_MAXM], search[ORC_MAXM];
+  orc_real clamped[ORC_MAXM], old_clamped[ORC_MAXM], tmp[ORC_MAXM];
+  orc_real Qfree[ORC_MAXM * ORC_MAXM], Minv[ORC_MAXM * ORC_MAXM];
   int result = 0;
   int nfree_R = 0; /* size of the factor currently held in R_free */
   int iter;
 
   orc_clamp_to_limits(n, x0, lo, hi, x); /* :35 */
   /* :36  val = x'Qx + x.c  -- note: no 0.5 */
-  double val;
+  orc_real val;
   {
-    double quad = 0, lin = 0;
+    orc_real quad = 0, lin = 0;
     for (int j = 0; j < n; j++) {
-      double r = 0;
+      orc_real r = 0;
       for (int i = 0; i < n; i++) r += x[i] * Q[i + n * j];
       quad += r * x[j];
     }
     for (int i = 0; i < n; i++) lin += x[i] * c[i];
     val = quad + lin;
   }
-  double oldvalue = 0;
+  orc_real oldvalue = 0;
   for (int i = 0; i < n; i++) {
     clamped[i] = 0; /* uninitialised in the reference; only read when iter>0 */
     old_clamped[i] = 0;
@@ -390,7 +314,7 @@ int orc_boxqp(int n, const double* Q, const double* c, const double* x0, const d
       old_clamped[i] = clamped[i];
       clamped[i] = 0;
       v_free[i] = 1;
-      if ((fabs(x[i] - lo[i]) < 1e-4 && grad[i] > 0) || (fabs(x[i] - hi[i]) < 1e-4 && grad[i] < 0)) {
+      if ((fabs(x[i] - lo[i]) < (orc_real)1e-4 && grad[i] > 0) || (fabs(x[i] - hi[i]) < (orc_real)1e-4 && grad[i] < 0)) {
         clamped[i] = 1;
         v_free[i] = 0;
       }
@@ -401,7 +325,7 @@ int orc_boxqp(int n, const double* Q, const double* c, const double* x0, const d
       break;
     }
 
-    double dsum = 0;
+    orc_real dsum = 0;
     for (int i = 0; i < n; i++) dsum += old_clamped[i] - clamped[i];
     if (iter == 0 || dsum != 0) { /* :80: refactor only if the COUNT of clamped dims changed */
       int nf = 0;
@@ -413,12 +337,12 @@ int orc_boxqp(int n, const double* Q, const double* c, const double* x0, const d
       orc_llt_lower_unblocked(nf, Qfree); /* :85, info() ignored */
       /* :86-88  R_free = matrixL().transpose(): dense upper triangle, zeros below */
       for (int a = 0; a < nf; a++)
-        for (int b = 0; b < nf; b++) R_free[a + nf * b] = (a <= b) ? Qfree[b + nf * a] : 0.0;
+        for (int b = 0; b < nf; b++) R_free[a + nf * b] = (a <= b) ? Qfree[b + nf * a] : (orc_real)0.0;
       nfree_R = nf;
     }
 
     /* :93-97 */
-    double gn2 = 0;
+    orc_real gn2 = 0;
     int nf_now = 0;
     for (int i = 0; i < n; i++)
       if (v_free[i] > 0) {
@@ -440,7 +364,7 @@ int orc_boxqp(int n, const double* Q, const double* c, const double* x0, const d
     for (int i = 0; i < n; i++) search[i] = 0;
     {
       const int nf = nfree_R;
-      double gfree[ORC_MAXM], xfree[ORC_MAXM];
+      orc_real gfree[ORC_MAXM], xfree[ORC_MAXM];
       int idx[ORC_MAXM], a = 0;
       for (int i = 0; i < n; i++)
         if (v_free[i] > 0) {
@@ -454,13 +378,13 @@ int orc_boxqp(int n, const double* Q, const double* c, const double* x0, const d
       (void)nf_now;
       rinv_rinvT(nf, R_free, Minv);
       for (int r = 0; r < nf; r++) {
-        double s = 0;
+        orc_real s = 0;
         for (int l = 0; l < nf; l++) s += -Minv[r + nf * l] * gfree[l];
         search[idx[r]] = s - xfree[r];
       }
     }
 
-    double ls_x[ORC_MAXM], ls_v = 0;
+    orc_real ls_x[ORC_MAXM], ls_v = 0;
     const int failed = orc_quadclamp_line_search(n, x, search, Q, c, lo, hi, ls_x, &ls_v, 0); /* :121 */
     if (failed) { /* :122-125: x is NOT updated */
       result = 2;
@@ -479,17 +403,17 @@ int orc_boxqp(int n, const double* Q, const double* c, const double* x0, const d
 /* Trajectory state                                                                            */
 /* ------------------------------------------------------------------------------------------ */
 
-orc_traj* orc_traj_alloc(int nx, int nu, int T, double dt) {
+orc_traj* orc_traj_alloc(int nx, int nu, int T, orc_f64 dt) {
   orc_traj* s = (orc_traj*)calloc(1, sizeof(orc_traj));
   const size_t n = (size_t)nx, m = (size_t)nu, T1 = (size_t)T + 1;
   size_t tot = n + T1 * n + T * m + T1 * (n * n + n * m + n + m + n * n + n * m + m * m) +
                T1 * (n + n * n) + T * m + T * m * n;
-  double* p = (double*)calloc(tot, sizeof(double));
+  orc_real* p = (orc_real*)calloc(tot, sizeof(orc_real));
   s->owned = p;
   s->nx = nx;
   s->nu = nu;
   s->T = T;
-  s->dt = dt;
+  s->dt = (orc_real)dt;
   s->x0 = p; p += n;
   s->xs = p; p += T1 * n;
   s->us = p; p += T * m;
@@ -516,17 +440,17 @@ void orc_traj_free(orc_traj* s) {
 }
 
 /* src/ilqr_core.cpp:305-337.  `u` may alias s->us (init_traj passes `us` itself). */
-double orc_forward_pass(const orc_model* m, orc_traj* s, const double* x0, const double* u) {
+orc_acc orc_forward_pass(const orc_model* m, orc_traj* s, const orc_real* x0, const orc_real* u) {
   const int n = s->nx, mu = s->nu, T = s->T;
-  double total_cost = 0;
-  double x_curr[ORC_MAXN], u_curr[ORC_MAXM], xn[ORC_MAXN];
-  double* x_new = (double*)malloc(sizeof(double) * (size_t)(T + 1) * n);
+  orc_acc total_cost = 0; /* the sum over the horizon is a per-trajectory accumulator (orc_acc) */
+  orc_real x_curr[ORC_MAXN], u_curr[ORC_MAXM], xn[ORC_MAXN];
+  orc_real* x_new = (orc_real*)malloc(sizeof(orc_real) * (size_t)(T + 1) * n);
   for (int i = 0; i < n; i++) x_curr[i] = x_new[i] = x0[i];
   for (int t = 0; t < T; t++) {
     for (int a = 0; a < mu; a++) u_curr[a] = u[t * mu + a]; /* :315 */
     if (s->has_gains) { /* :316  u += K[t]*(x_new[t]-xs[t]) */
       for (int a = 0; a < mu; a++) {
-        double acc = 0;
+        orc_real acc = 0;
         for (int j = 0; j < n; j++) acc += s->K[(size_t)t * mu * n + a + mu * j] * (x_new[t * n + j] - s->xs[t * n + j]);
         u_curr[a] += acc;
       }
@@ -536,7 +460,7 @@ double orc_forward_pass(const orc_model* m, orc_traj* s, const double* x0, const
     orc_integrate_dynamics(m, x_curr, u_curr, s->dt, xn);      /* :325 */
     for (int i = 0; i < n; i++) x_curr[i] = x_new[(t + 1) * n + i] = xn[i];
   }
-  memcpy(s->xs, x_new, sizeof(double) * (size_t)(T + 1) * n); /* :334 */
+  memcpy(s->xs, x_new, sizeof(orc_real) * (size_t)(T + 1) * n); /* :334 */
   free(x_new);
   total_cost += m->final_cost(m, &s->xs[(size_t)T * n]); /* :335 */
   s->n_rollouts++;
@@ -544,24 +468,24 @@ double orc_forward_pass(const orc_model* m, orc_traj* s, const double* x0, const
 }
 
 /* src/ilqr_core.cpp:11-56 */
-double orc_init_traj(const orc_model* m, orc_traj* s, const double* x0, const double* u0) {
+orc_acc orc_init_traj(const orc_model* m, orc_traj* s, const orc_real* x0, const orc_real* u0) {
   const int n = s->nx, mu = s->nu, T = s->T;
   for (int i = 0; i < n; i++) s->x0[i] = s->xs[i] = x0[i];
-  memcpy(s->us, u0, sizeof(double) * (size_t)T * mu);
+  memcpy(s->us, u0, sizeof(orc_real) * (size_t)T * mu);
   s->has_gains = 0; /* K.size()==0 on a fresh object, :316 */
-  const double cost_i = orc_forward_pass(m, s, s->x0, s->us); /* :20 */
+  const orc_acc cost_i = orc_forward_pass(m, s, s->x0, s->us); /* :20 */
   /* :23-48 allocate + zero everything */
-  memset(s->fx, 0, sizeof(double) * (size_t)(T + 1) * n * n);
-  memset(s->fu, 0, sizeof(double) * (size_t)(T + 1) * n * mu);
-  memset(s->cx, 0, sizeof(double) * (size_t)(T + 1) * n);
-  memset(s->cu, 0, sizeof(double) * (size_t)(T + 1) * mu);
-  memset(s->cxx, 0, sizeof(double) * (size_t)(T + 1) * n * n);
-  memset(s->cxu, 0, sizeof(double) * (size_t)(T + 1) * n * mu);
-  memset(s->cuu, 0, sizeof(double) * (size_t)(T + 1) * mu * mu);
-  memset(s->Vx, 0, sizeof(double) * (size_t)(T + 1) * n);
-  memset(s->Vxx, 0, sizeof(double) * (size_t)(T + 1) * n * n);
-  memset(s->k, 0, sizeof(double) * (size_t)T * mu);
-  memset(s->K, 0, sizeof(double) * (size_t)T * mu * n);
+  memset(s->fx, 0, sizeof(orc_real) * (size_t)(T + 1) * n * n);
+  memset(s->fu, 0, sizeof(orc_real) * (size_t)(T + 1) * n * mu);
+  memset(s->cx, 0, sizeof(orc_real) * (size_t)(T + 1) * n);
+  memset(s->cu, 0, sizeof(orc_real) * (size_t)(T + 1) * mu);
+  memset(s->cxx, 0, sizeof(orc_real) * (size_t)(T + 1) * n * n);
+  memset(s->cxu, 0, sizeof(orc_real) * (size_t)(T + 1) * n * mu);
+  memset(s->cuu, 0, sizeof(orc_real) * (size_t)(T + 1) * mu * mu);
+  memset(s->Vx, 0, sizeof(orc_real) * (size_t)(T + 1) * n);
+  memset(s->Vxx, 0, sizeof(orc_real) * (size_t)(T + 1) * n * n);
+  memset(s->k, 0, sizeof(orc_real) * (size_t)T * mu);
+  memset(s->K, 0, sizeof(orc_real) * (size_t)T * mu * n);
   s->has_gains = 1; /* K.resize(T): K.size()>0 from now on */
   s->cost_s = cost_i;
   return cost_i;
@@ -571,30 +495,40 @@ double orc_init_traj(const orc_model* m, orc_traj* s, const double* x0, const do
 /* Finite differences                                                                          */
 /* ------------------------------------------------------------------------------------------ */
 
+/* All three sweeps run in orc_fd: the knot (x_t, u_t) is widened once, the model's _fd flavour is
+ * evaluated at the perturbed points, differences and quotients are taken in orc_fd and the results are
+ * rounded to orc_real when stored.  orc_fd == orc_real in the fp64 build (this is then the reference's
+ * arithmetic, operation for operation) and in the fp80 build. */
+static void knot_fd(const orc_traj* s, int t, orc_fd* x, orc_fd* u) {
+  const int n = s->nx, mu = s->nu;
+  for (int j = 0; j < n; j++) x[j] = s->xs[(size_t)t * n + j];
+  for (int a = 0; a < mu; a++) u[a] = (t < s->T) ? s->us[(size_t)t * mu + a] : (orc_real)0.0; /* derivatives.cpp:35-38 */
+}
+
 /* src/derivatives.cpp:15-26 + include/finite_diff.h:35-47.  F = Euler map of include/model.h:12-15.
  * fx[T], fu[T] are never written (stay zero). */
 void orc_get_dynamics_derivatives(const orc_model* m, orc_traj* s) {
   const int n = s->nx, mu = s->nu, T = s->T;
-  double plus[ORC_MAXN], minus[ORC_MAXN], fp[ORC_MAXN], fm[ORC_MAXN];
+  const orc_fd dt = s->dt;
+  orc_fd x[ORC_MAXN], u[ORC_MAXM], plus[ORC_MAXN], minus[ORC_MAXN], fp[ORC_MAXN], fm[ORC_MAXN];
   for (int t = 0; t < T; t++) {
-    const double* x = &s->xs[(size_t)t * n];
-    const double* u = &s->us[(size_t)t * mu];
-    double* fx = &s->fx[(size_t)t * n * n];
-    double* fu = &s->fu[(size_t)t * n * mu];
+    knot_fd(s, t, x, u);
+    orc_real* fx = &s->fx[(size_t)t * n * n];
+    orc_real* fu = &s->fu[(size_t)t * n * mu];
     for (int i = 0; i < n; i++) { /* finite_diff_jacobian(dyn_x, x[t]) */
       for (int j = 0; j < n; j++) plus[j] = minus[j] = x[j];
       plus[i] += EPS;
       minus[i] -= EPS;
-      orc_integrate_dynamics(m, plus, u, s->dt, fp);
-      orc_integrate_dynamics(m, minus, u, s->dt, fm);
+      integrate_dynamics_fd(m, plus, u, dt, fp);
+      integrate_dynamics_fd(m, minus, u, dt, fm);
       for (int r = 0; r < n; r++) fx[r + n * i] = (fp[r] - fm[r]) / (2 * EPS);
     }
     for (int i = 0; i < mu; i++) { /* finite_diff_jacobian(dyn_u, u[t]) */
       for (int j = 0; j < mu; j++) plus[j] = minus[j] = u[j];
       plus[i] += EPS;
       minus[i] -= EPS;
-      orc_integrate_dynamics(m, x, plus, s->dt, fp);
-      orc_integrate_dynamics(m, x, minus, s->dt, fm);
+      integrate_dynamics_fd(m, x, plus, dt, fp);
+      integrate_dynamics_fd(m, x, minus, dt, fm);
       for (int r = 0; r < n; r++) fu[r + n * i] = (fp[r] - fm[r]) / (2 * EPS);
     }
   }
@@ -603,50 +537,48 @@ void orc_get_dynamics_derivatives(const orc_model* m, orc_traj* s) {
 /* src/derivatives.cpp:29-54 + include/finite_diff.h:22-33 */
 void orc_get_cost_derivatives(const orc_model* m, orc_traj* s) {
   const int n = s->nx, mu = s->nu, T = s->T;
-  double plus[ORC_MAXN], minus[ORC_MAXN], ut[ORC_MAXM];
+  orc_fd x[ORC_MAXN], plus[ORC_MAXN], minus[ORC_MAXN], ut[ORC_MAXM];
   for (int t = 0; t < T + 1; t++) {
-    const double* x = &s->xs[(size_t)t * n];
-    for (int a = 0; a < mu; a++) ut[a] = (t < T) ? s->us[(size_t)t * mu + a] : 0.0;
-    double* cx = &s->cx[(size_t)t * n];
-    double* cu = &s->cu[(size_t)t * mu];
+    knot_fd(s, t, x, ut);
+    orc_real* cx = &s->cx[(size_t)t * n];
+    orc_real* cu = &s->cu[(size_t)t * mu];
     if (t < T) {
       for (int i = 0; i < n; i++) {
         for (int j = 0; j < n; j++) plus[j] = minus[j] = x[j];
         plus[i] += EPS;
         minus[i] -= EPS;
-        cx[i] = (m->cost(m, plus, ut) - m->cost(m, minus, ut)) / (2 * EPS);
+        cx[i] = (m->cost_fd(m, plus, ut) - m->cost_fd(m, minus, ut)) / (2 * EPS);
       }
       for (int i = 0; i < mu; i++) {
         for (int j = 0; j < mu; j++) plus[j] = minus[j] = ut[j];
         plus[i] += EPS;
         minus[i] -= EPS;
-        cu[i] = (m->cost(m, x, plus) - m->cost(m, x, minus)) / (2 * EPS);
+        cu[i] = (m->cost_fd(m, x, plus) - m->cost_fd(m, x, minus)) / (2 * EPS);
       }
     } else { /* :48-52 */
       for (int i = 0; i < n; i++) {
         for (int j = 0; j < n; j++) plus[j] = minus[j] = x[j];
         plus[i] += EPS;
         minus[i] -= EPS;
-        cx[i] = (m->final_cost(m, plus) - m->final_cost(m, minus)) / (2 * EPS);
+        cx[i] = (m->final_cost_fd(m, plus) - m->final_cost_fd(m, minus)) / (2 * EPS);
       }
       for (int i = 0; i < mu; i++) cu[i] = 0;
     }
   }
 }
 
-typedef double (*scalar_fn)(const orc_model* m, const double* v, const double* other, int which);
 /* which: 0 = cost(v, other) [v is x], 1 = cost(other, v) [v is u], 2 = final_cost(v) */
-static double eval_fn(const orc_model* m, const double* v, const double* other, int which) {
-  if (which == 0) return m->cost(m, v, other);
-  if (which == 1) return m->cost(m, other, v);
-  return m->final_cost(m, v);
+static orc_fd eval_fn(const orc_model* m, const orc_fd* v, const orc_fd* other, int which) {
+  if (which == 0) return m->cost_fd(m, v, other);
+  if (which == 1) return m->cost_fd(m, other, v);
+  return m->final_cost_fd(m, v);
 }
 
 /* include/finite_diff.h:67-86.  Diagonal entries use +-2 eps (pp[i] += eps twice) and
  * pm/mp = x+eps-eps, which is not bit-identical to x. */
-static void fd_hessian(const orc_model* m, int nd, const double* x, const double* other,
-                       int which, double* out) {
-  double pp[ORC_MAXN], pm[ORC_MAXN], mp[ORC_MAXN], mm[ORC_MAXN];
+static void fd_hessian(const orc_model* m, int nd, const orc_fd* x, const orc_fd* other,
+                       int which, orc_real* out) {
+  orc_fd pp[ORC_MAXN], pm[ORC_MAXN], mp[ORC_MAXN], mm[ORC_MAXN];
   for (int i = 0; i < nd; i++)
     for (int j = i; j < nd; j++) {
       for (int l = 0; l < nd; l++) pp[l] = pm[l] = mp[l] = mm[l] = x[l];
@@ -658,27 +590,26 @@ static void fd_hessian(const orc_model* m, int nd, const double* x, const double
       mp[j] += EPS;
       mm[i] -= EPS;
       mm[j] -= EPS;
-      const double v = (eval_fn(m, pp, other, which) - eval_fn(m, mp, other, which) -
+      const orc_fd v = (eval_fn(m, pp, other, which) - eval_fn(m, mp, other, which) -
                         eval_fn(m, pm, other, which) + eval_fn(m, mm, other, which)) /
                        (4 * EPS * EPS);
-      out[i + nd * j] = out[j + nd * i] = v;
+      out[i + nd * j] = out[j + nd * i] = (orc_real)v;
     }
 }
 
 /* src/derivatives.cpp:57-144 */
 void orc_get_cost_2nd_derivatives(const orc_model* m, orc_traj* s) {
   const int n = s->nx, mu = s->nu, T = s->T;
-  double ut[ORC_MAXM];
+  orc_fd x[ORC_MAXN], ut[ORC_MAXM];
   for (int t = 0; t < T + 1; t++) {
-    const double* x = &s->xs[(size_t)t * n];
-    for (int a = 0; a < mu; a++) ut[a] = (t < T) ? s->us[(size_t)t * mu + a] : 0.0;
+    knot_fd(s, t, x, ut);
     /* calculate_cxx :76-96 */
     fd_hessian(m, n, x, ut, (t < T) ? 0 : 2, &s->cxx[(size_t)t * n * n]);
     /* calculate_cuu :98-112 (also at t = T, with ut = 0) */
     fd_hessian(m, mu, ut, x, 1, &s->cuu[(size_t)t * mu * mu]);
     /* calculate_cxu :114-144 */
-    double px[ORC_MAXN], mx[ORC_MAXN], pu[ORC_MAXM], mu_[ORC_MAXM];
-    double* cxu = &s->cxu[(size_t)t * n * mu];
+    orc_fd px[ORC_MAXN], mx[ORC_MAXN], pu[ORC_MAXM], mu_[ORC_MAXM];
+    orc_real* cxu = &s->cxu[(size_t)t * n * mu];
     for (int i = 0; i < n; i++)
       for (int j = 0; j < mu; j++) {
         for (int l = 0; l < n; l++) px[l] = mx[l] = x[l];
@@ -688,10 +619,10 @@ void orc_get_cost_2nd_derivatives(const orc_model* m, orc_traj* s) {
         pu[j] += EPS;
         mu_[j] -= EPS;
         if (t < T)
-          cxu[i + n * j] = (m->cost(m, px, pu) - m->cost(m, mx, pu) - m->cost(m, px, mu_) + m->cost(m, mx, mu_)) /
+          cxu[i + n * j] = (m->cost_fd(m, px, pu) - m->cost_fd(m, mx, pu) - m->cost_fd(m, px, mu_) + m->cost_fd(m, mx, mu_)) /
                            (4 * (EPS * EPS));
         else /* :140, "TODO this is wrong" in the reference; value unused downstream */
-          cxu[i + n * j] = (m->final_cost(m, px) - m->final_cost(m, mx) - m->final_cost(m, px) + m->final_cost(m, mx)) /
+          cxu[i + n * j] = (m->final_cost_fd(m, px) - m->final_cost_fd(m, mx) - m->final_cost_fd(m, px) + m->final_cost_fd(m, mx)) /
                            (4 * (EPS * EPS));
       }
   }
@@ -708,19 +639,19 @@ void orc_compute_derivatives(const orc_model* m, orc_traj* s) { /* ilqr_core.cpp
 /* ------------------------------------------------------------------------------------------ */
 
 /* C(nr x nc) = A' (A is k x nr) * B (k x nc) */
-static void mul_AtB(int k, int nr, int nc, const double* A, const double* B, double* C) {
+static void mul_AtB(int k, int nr, int nc, const orc_real* A, const orc_real* B, orc_real* C) {
   for (int i = 0; i < nr; i++)
     for (int j = 0; j < nc; j++) {
-      double s = 0;
+      orc_real s = 0;
       for (int l = 0; l < k; l++) s += A[l + k * i] * B[l + k * j];
       C[i + nr * j] = s;
     }
 }
 /* C(nr x nc) = A (nr x k) * B (k x nc) */
-static void mul_AB(int nr, int k, int nc, const double* A, const double* B, double* C) {
+static void mul_AB(int nr, int k, int nc, const orc_real* A, const orc_real* B, orc_real* C) {
   for (int i = 0; i < nr; i++)
     for (int j = 0; j < nc; j++) {
-      double s = 0;
+      orc_real s = 0;
       for (int l = 0; l < k; l++) s += A[i + nr * l] * B[l + k * j];
       C[i + nr * j] = s;
     }
@@ -730,36 +661,36 @@ static void mul_AB(int nr, int k, int nc, const double* A, const double* B, doub
  * success, :371 vs :142) or 0. */
 int orc_backward_pass(const orc_model* m, orc_traj* s) {
   const int n = s->nx, mu = s->nu, T = s->T;
-  double Qx[ORC_MAXN], Qu[ORC_MAXM], k_i[ORC_MAXM], lo[ORC_MAXM], hi[ORC_MAXM];
-  static _Thread_local double Qxx[ORC_MAXN * ORC_MAXN], Qux[ORC_MAXM * ORC_MAXN], Quu[ORC_MAXM * ORC_MAXM],
+  orc_real Qx[ORC_MAXN], Qu[ORC_MAXM], k_i[ORC_MAXM], lo[ORC_MAXM], hi[ORC_MAXM];
+  static _Thread_local orc_real Qxx[ORC_MAXN * ORC_MAXN], Qux[ORC_MAXM * ORC_MAXN], Quu[ORC_MAXM * ORC_MAXM],
       QuuF[ORC_MAXM * ORC_MAXM], K_i[ORC_MAXM * ORC_MAXN], A1[ORC_MAXN * ORC_MAXN], A2[ORC_MAXM * ORC_MAXN],
       R[ORC_MAXM * ORC_MAXM], Minv[ORC_MAXM * ORC_MAXM], T1[ORC_MAXM * ORC_MAXN], T2[ORC_MAXN * ORC_MAXN];
   int v_free[ORC_MAXM];
   s->n_backward++;
 
-  memcpy(&s->Vx[(size_t)T * n], &s->cx[(size_t)T * n], sizeof(double) * n);           /* :353 */
-  memcpy(&s->Vxx[(size_t)T * n * n], &s->cxx[(size_t)T * n * n], sizeof(double) * n * n); /* :354 */
+  memcpy(&s->Vx[(size_t)T * n], &s->cx[(size_t)T * n], sizeof(orc_real) * n);           /* :353 */
+  memcpy(&s->Vxx[(size_t)T * n * n], &s->cxx[(size_t)T * n * n], sizeof(orc_real) * n * n); /* :354 */
   s->dV[0] = s->dV[1] = 0; /* :356 */
 
   for (int i = T - 1; i >= 0; i--) {
-    const double* fx = &s->fx[(size_t)i * n * n];
-    const double* fu = &s->fu[(size_t)i * n * mu];
-    const double* cx = &s->cx[(size_t)i * n];
-    const double* cu = &s->cu[(size_t)i * mu];
-    const double* cxx = &s->cxx[(size_t)i * n * n];
-    const double* cxu = &s->cxu[(size_t)i * n * mu];
-    const double* cuu = &s->cuu[(size_t)i * mu * mu];
-    const double* Vx1 = &s->Vx[(size_t)(i + 1) * n];
-    const double* Vxx1 = &s->Vxx[(size_t)(i + 1) * n * n];
+    const orc_real* fx = &s->fx[(size_t)i * n * n];
+    const orc_real* fu = &s->fu[(size_t)i * n * mu];
+    const orc_real* cx = &s->cx[(size_t)i * n];
+    const orc_real* cu = &s->cu[(size_t)i * mu];
+    const orc_real* cxx = &s->cxx[(size_t)i * n * n];
+    const orc_real* cxu = &s->cxu[(size_t)i * n * mu];
+    const orc_real* cuu = &s->cuu[(size_t)i * mu * mu];
+    const orc_real* Vx1 = &s->Vx[(size_t)(i + 1) * n];
+    const orc_real* Vxx1 = &s->Vxx[(size_t)(i + 1) * n * n];
 
     /* :359-360 */
     for (int a = 0; a < n; a++) {
-      double acc = 0;
+      orc_real acc = 0;
       for (int l = 0; l < n; l++) acc += fx[l + n * a] * Vx1[l];
       Qx[a] = cx[a] + acc;
     }
     for (int a = 0; a < mu; a++) {
-      double acc = 0;
+      orc_real acc = 0;
       for (int l = 0; l < n; l++) acc += fu[l + n * a] * Vx1[l];
       Qu[a] = cu[a] + acc;
     }
@@ -776,9 +707,9 @@ int orc_backward_pass(const orc_model* m, orc_traj* s) {
     mul_AB(mu, n, mu, A2, fu, Quu);
     for (int a = 0; a < mu; a++)
       for (int b = 0; b < mu; b++) {
-        const double f = Quu[a + mu * b];
+        const orc_real f = Quu[a + mu * b];
         Quu[a + mu * b] = cuu[a + mu * b] + f;
-        QuuF[a + mu * b] = (cuu[a + mu * b] + ((a == b) ? s->lambda : 0.0)) + f;
+        QuuF[a + mu * b] = (cuu[a + mu * b] + ((a == b) ? (orc_real)s->lambda : (orc_real)0.0)) + f;
       }
 
     /* :369  boxQP(QuuF, Qu, k[min(i+1,T-1)], u_min-us[i], u_max-us[i]) */
@@ -805,7 +736,7 @@ int orc_backward_pass(const orc_model* m, orc_traj* s) {
        * stale factor is in play, in which case Eigen would assert on the size mismatch. */
       for (int r = 0; r < nf && r < nfree; r++)
         for (int j = 0; j < n; j++) {
-          double acc = 0;
+          orc_real acc = 0;
           for (int l = 0; l < nfree && l < nf; l++) acc += -Minv[r + nfree * l] * Qux[idx[l] + mu * j];
           K_i[idx[r] + mu * j] = acc;
         }
@@ -813,13 +744,13 @@ int orc_backward_pass(const orc_model* m, orc_traj* s) {
 
     /* :388-389 */
     {
-      double d0 = 0;
+      orc_real d0 = 0;
       for (int a = 0; a < mu; a++) d0 += k_i[a] * Qu[a];
       s->dV[0] += d0;
-      double d1 = 0;
+      orc_real d1 = 0;
       for (int b = 0; b < mu; b++) {
-        double r = 0;
-        for (int a = 0; a < mu; a++) r += (0.5 * k_i[a]) * Quu[a + mu * b];
+        orc_real r = 0;
+        for (int a = 0; a < mu; a++) r += ((orc_real)0.5 * k_i[a]) * Quu[a + mu * b];
         d1 += r * k_i[b];
       }
       s->dV[1] += d1;
@@ -827,10 +758,10 @@ int orc_backward_pass(const orc_model* m, orc_traj* s) {
 
     /* :391  Vx = Qx + K'Quu k + K'Qu + Qux'k */
     {
-      double Quuk[ORC_MAXM];
+      orc_real Quuk[ORC_MAXM];
       mul_AtB(mu, n, mu, K_i, Quu, T1); /* T1 = K' Quu  (n x mu) */
       for (int a = 0; a < n; a++) {
-        double t1 = 0, t2 = 0, t3 = 0;
+        orc_real t1 = 0, t2 = 0, t3 = 0;
         for (int b = 0; b < mu; b++) t1 += T1[a + n * b] * k_i[b];
         for (int b = 0; b < mu; b++) t2 += K_i[b + mu * a] * Qu[b];
         for (int b = 0; b < mu; b++) t3 += Qux[b + mu * a] * k_i[b];
@@ -838,34 +769,34 @@ int orc_backward_pass(const orc_model* m, orc_traj* s) {
       }
       (void)Quuk;
       /* :392  Vxx = Qxx + K'Quu K + K'Qux + Qux'K ; :393 symmetrise */
-      double* Vxx = &s->Vxx[(size_t)i * n * n];
+      orc_real* Vxx = &s->Vxx[(size_t)i * n * n];
       mul_AB(n, mu, n, T1, K_i, T2); /* K'Quu K */
       for (int a = 0; a < n; a++)
         for (int b = 0; b < n; b++) {
-          double t2 = 0, t3 = 0;
+          orc_real t2 = 0, t3 = 0;
           for (int l = 0; l < mu; l++) t2 += K_i[l + mu * a] * Qux[l + mu * b];
           for (int l = 0; l < mu; l++) t3 += Qux[l + mu * a] * K_i[l + mu * b];
           A1[a + n * b] = ((Qxx[a + n * b] + T2[a + n * b]) + t2) + t3;
         }
       for (int a = 0; a < n; a++)
-        for (int b = 0; b < n; b++) Vxx[a + n * b] = 0.5 * (A1[a + n * b] + A1[b + n * a]);
+        for (int b = 0; b < n; b++) Vxx[a + n * b] = (orc_real)0.5 * (A1[a + n * b] + A1[b + n * a]);
     }
 
     /* :396-397 */
     for (int a = 0; a < mu; a++) s->k[(size_t)i * mu + a] = k_i[a];
-    memcpy(&s->K[(size_t)i * mu * n], K_i, sizeof(double) * mu * n);
+    memcpy(&s->K[(size_t)i * mu * n], K_i, sizeof(orc_real) * mu * n);
   }
   return 0;
 }
 
 /* src/ilqr_core.cpp:405-412: mean_t max_i |k_i|/(|u_i|+1) */
-double orc_gradient_norm(const orc_traj* s) {
+orc_acc orc_gradient_norm(const orc_traj* s) {
   const int mu = s->nu, T = s->T;
-  double acc = 0;
+  orc_acc acc = 0;
   for (int t = 0; t < T; t++) {
-    double mx = -INFINITY;
+    orc_real mx = -INFINITY;
     for (int a = 0; a < mu; a++) {
-      const double v = fabs(s->k[(size_t)t * mu + a]) / (fabs(s->us[(size_t)t * mu + a]) + 1);
+      const orc_real v = fabs(s->k[(size_t)t * mu + a]) / (fabs(s->us[(size_t)t * mu + a]) + 1);
       if (a == 0 || v > mx) mx = v;
     }
     acc += mx;
@@ -878,32 +809,33 @@ double orc_gradient_norm(const orc_traj* s) {
 /* ------------------------------------------------------------------------------------------ */
 
 /* src/ilqr_core.cpp:184-226 */
-int orc_line_search(const orc_model* m, orc_traj* s, double* new_cost_out, double* dcost_out,
-                    double* expected_out) {
+int orc_line_search(const orc_model* m, orc_traj* s, orc_acc* new_cost_out, orc_acc* dcost_out,
+                    orc_acc* expected_out) {
   const int n = s->nx, mu = s->nu, T = s->T;
-  double* x_old = (double*)malloc(sizeof(double) * (size_t)(T + 1) * n);
-  double* u_old = (double*)malloc(sizeof(double) * (size_t)T * mu);
-  double* u_ff = (double*)malloc(sizeof(double) * (size_t)T * mu);
-  memcpy(x_old, s->xs, sizeof(double) * (size_t)(T + 1) * n); /* :104 */
-  memcpy(u_old, s->us, sizeof(double) * (size_t)T * mu);
+  orc_real* x_old = (orc_real*)malloc(sizeof(orc_real) * (size_t)(T + 1) * n);
+  orc_real* u_old = (orc_real*)malloc(sizeof(orc_real) * (size_t)T * mu);
+  orc_real* u_ff = (orc_real*)malloc(sizeof(orc_real) * (size_t)T * mu);
+  memcpy(x_old, s->xs, sizeof(orc_real) * (size_t)(T + 1) * n); /* :104 */
+  memcpy(u_old, s->us, sizeof(orc_real) * (size_t)T * mu);
   int accepted = -1;
-  double new_cost = 0, dcost = 0, expected = 0, z = 0;
+  orc_acc new_cost = 0, dcost = 0, expected = 0, z = 0;
   for (int ai = 0; ai < ORC_NALPHA; ai++) {
-    const double alpha = Alpha[ai];
+    const orc_real alpha = (orc_real)Alpha[ai]; /* what the rollout multiplies k with */
+    const orc_acc alpha_s = Alpha[ai];          /* the literal of include/ilqr.h:24 in the scalar test below */
     for (int e = 0; e < T * mu; e++) u_ff[e] = s->us[e] + s->k[e] * alpha; /* :188-190 */
     new_cost = orc_forward_pass(m, s, s->x0, u_ff);                        /* :197 */
     dcost = s->cost_s - new_cost;                                          /* :199 */
-    expected = -alpha * (s->dV[0] + alpha * s->dV[1]);                     /* :200 */
+    expected = -alpha_s * (s->dV[0] + alpha_s * s->dV[1]);                 /* :200 */
     if (expected > 0)
       z = dcost / expected;
     else
-      z = (double)((0.0 < dcost) - (dcost < 0.0)); /* sgn, include/common.h:52 */
+      z = (orc_acc)((0.0 < dcost) - (dcost < 0.0)); /* sgn, include/common.h:52 */
     if (z > zMin) {
       accepted = ai;
       break;
     }
-    memcpy(s->xs, x_old, sizeof(double) * (size_t)(T + 1) * n); /* :218-219 */
-    memcpy(s->us, u_old, sizeof(double) * (size_t)T * mu);
+    memcpy(s->xs, x_old, sizeof(orc_real) * (size_t)(T + 1) * n); /* :218-219 */
+    memcpy(s->us, u_old, sizeof(orc_real) * (size_t)T * mu);
   }
   free(x_old);
   free(u_old);
@@ -942,7 +874,7 @@ int orc_iterate_once(const orc_model* m, orc_traj* s, int* flg_change, int fixed
   }
   /* STEP 3 :175-226 */
   int fwdPassDone = 0;
-  double new_cost = 0, dcost = 0, expected = 0;
+  orc_acc new_cost = 0, dcost = 0, expected = 0;
   if (backPassDone) {
     fwdPassDone = orc_line_search(m, s, &new_cost, &dcost, &expected) >= 0;
   } else {
@@ -971,7 +903,7 @@ int orc_iterate_once(const orc_model* m, orc_traj* s, int* flg_change, int fixed
 
 /* src/ilqr_core.cpp:79-302 */
 int orc_generate_trajectory(const orc_model* m, orc_traj* s, int max_iters, int fixed_work,
-                            double* cost_log) {
+                            orc_acc* cost_log) {
   int flgChange = 1;
   if (max_iters <= 0 || max_iters > ORC_MAX_ITER) max_iters = ORC_MAX_ITER;
   s->status = ORC_STATUS_RUNNING;
@@ -1000,10 +932,10 @@ static int pick_threads(int nthreads) {
 #endif
 }
 
-int orc_batch_solve(const orc_model* m, int B, int T, double dt, const double* x0,
-                    const double* u0, int max_iters, int fixed_work, int nthreads,
-                    double* xs_out, double* us_out, double* k_out, double* K_out,
-                    double* cost_out, int* iters_out, int* status_out, double* lambda_out) {
+int orc_batch_solve(const orc_model* m, int B, int T, orc_f64 dt, const orc_real* x0,
+                    const orc_real* u0, int max_iters, int fixed_work, int nthreads,
+                    orc_real* xs_out, orc_real* us_out, orc_real* k_out, orc_real* K_out,
+                    orc_acc* cost_out, int* iters_out, int* status_out, orc_acc* lambda_out) {
   const int n = m->nx, mu = m->nu;
   const int nt = pick_threads(nthreads);
   (void)nt;
@@ -1012,10 +944,10 @@ int orc_batch_solve(const orc_model* m, int B, int T, double dt, const double* x
     orc_traj* s = orc_traj_alloc(n, mu, T, dt);
     orc_init_traj(m, s, &x0[(size_t)b * n], &u0[(size_t)b * T * mu]);
     orc_generate_trajectory(m, s, max_iters, fixed_work, 0);
-    if (xs_out) memcpy(&xs_out[(size_t)b * (T + 1) * n], s->xs, sizeof(double) * (size_t)(T + 1) * n);
-    if (us_out) memcpy(&us_out[(size_t)b * T * mu], s->us, sizeof(double) * (size_t)T * mu);
-    if (k_out) memcpy(&k_out[(size_t)b * T * mu], s->k, sizeof(double) * (size_t)T * mu);
-    if (K_out) memcpy(&K_out[(size_t)b * T * mu * n], s->K, sizeof(double) * (size_t)T * mu * n);
+    if (xs_out) memcpy(&xs_out[(size_t)b * (T + 1) * n], s->xs, sizeof(orc_real) * (size_t)(T + 1) * n);
+    if (us_out) memcpy(&us_out[(size_t)b * T * mu], s->us, sizeof(orc_real) * (size_t)T * mu);
+    if (k_out) memcpy(&k_out[(size_t)b * T * mu], s->k, sizeof(orc_real) * (size_t)T * mu);
+    if (K_out) memcpy(&K_out[(size_t)b * T * mu * n], s->K, sizeof(orc_real) * (size_t)T * mu * n);
     if (cost_out) cost_out[b] = s->cost_s;
     if (iters_out) iters_out[b] = s->iters;
     if (status_out) status_out[b] = s->status;
@@ -1030,13 +962,13 @@ int orc_batch_solve(const orc_model* m, int B, int T, double dt, const double* x
  * the closed-loop rollouts) and lambda/dlambda.  flgChange starts at 1 (derivatives are recomputed),
  * i.e. the state is what an accepted iteration leaves behind.  This is how the per-iteration
  * teacher-forced parity tests step both sides from the same point. */
-int orc_batch_iterate_from(const orc_model* m, int B, int T, double dt, const double* x0,
-                           const double* xs, const double* us, const double* k, const double* K,
-                           const double* cost, const double* lambda, const double* dlambda,
-                           int n_iters, int fixed_work, int nthreads, double* xs_out,
-                           double* us_out, double* k_out, double* K_out, double* cost_out,
-                           int* iters_out, int* status_out, double* lambda_out, double* dlambda_out,
-                           int* alpha_out, double* gnorm_out, double* dV_out) {
+int orc_batch_iterate_from(const orc_model* m, int B, int T, orc_f64 dt, const orc_real* x0,
+                           const orc_real* xs, const orc_real* us, const orc_real* k, const orc_real* K,
+                           const orc_acc* cost, const orc_acc* lambda, const orc_acc* dlambda,
+                           int n_iters, int fixed_work, int nthreads, orc_real* xs_out,
+                           orc_real* us_out, orc_real* k_out, orc_real* K_out, orc_acc* cost_out,
+                           int* iters_out, int* status_out, orc_acc* lambda_out, orc_acc* dlambda_out,
+                           int* alpha_out, orc_acc* gnorm_out, orc_acc* dV_out) {
   const int n = m->nx, mu = m->nu;
   const size_t T1 = (size_t)T + 1;
   const int nt = pick_threads(nthreads);
@@ -1044,11 +976,11 @@ int orc_batch_iterate_from(const orc_model* m, int B, int T, double dt, const do
 #pragma omp parallel for num_threads(nt) schedule(dynamic, 1)
   for (int b = 0; b < B; b++) {
     orc_traj* s = orc_traj_alloc(n, mu, T, dt);
-    memcpy(s->x0, &x0[(size_t)b * n], sizeof(double) * n);
-    memcpy(s->xs, &xs[(size_t)b * T1 * n], sizeof(double) * T1 * n);
-    memcpy(s->us, &us[(size_t)b * T * mu], sizeof(double) * (size_t)T * mu);
-    if (k) memcpy(s->k, &k[(size_t)b * T * mu], sizeof(double) * (size_t)T * mu);
-    if (K) memcpy(s->K, &K[(size_t)b * T * mu * n], sizeof(double) * (size_t)T * mu * n);
+    memcpy(s->x0, &x0[(size_t)b * n], sizeof(orc_real) * n);
+    memcpy(s->xs, &xs[(size_t)b * T1 * n], sizeof(orc_real) * T1 * n);
+    memcpy(s->us, &us[(size_t)b * T * mu], sizeof(orc_real) * (size_t)T * mu);
+    if (k) memcpy(s->k, &k[(size_t)b * T * mu], sizeof(orc_real) * (size_t)T * mu);
+    if (K) memcpy(s->K, &K[(size_t)b * T * mu * n], sizeof(orc_real) * (size_t)T * mu * n);
     s->has_gains = 1;
     s->cost_s = cost[b];
     s->lambda = lambda[b];
@@ -1059,10 +991,10 @@ int orc_batch_iterate_from(const orc_model* m, int B, int T, double dt, const do
       s->iters = it + 1;
       if (orc_iterate_once(m, s, &flgChange, fixed_work)) break;
     }
-    if (xs_out) memcpy(&xs_out[(size_t)b * T1 * n], s->xs, sizeof(double) * T1 * n);
-    if (us_out) memcpy(&us_out[(size_t)b * T * mu], s->us, sizeof(double) * (size_t)T * mu);
-    if (k_out) memcpy(&k_out[(size_t)b * T * mu], s->k, sizeof(double) * (size_t)T * mu);
-    if (K_out) memcpy(&K_out[(size_t)b * T * mu * n], s->K, sizeof(double) * (size_t)T * mu * n);
+    if (xs_out) memcpy(&xs_out[(size_t)b * T1 * n], s->xs, sizeof(orc_real) * T1 * n);
+    if (us_out) memcpy(&us_out[(size_t)b * T * mu], s->us, sizeof(orc_real) * (size_t)T * mu);
+    if (k_out) memcpy(&k_out[(size_t)b * T * mu], s->k, sizeof(orc_real) * (size_t)T * mu);
+    if (K_out) memcpy(&K_out[(size_t)b * T * mu * n], s->K, sizeof(orc_real) * (size_t)T * mu * n);
     if (cost_out) cost_out[b] = s->cost_s;
     if (iters_out) iters_out[b] = s->iters;
     if (status_out) status_out[b] = s->status;
@@ -1079,9 +1011,9 @@ int orc_batch_iterate_from(const orc_model* m, int B, int T, double dt, const do
   return 0;
 }
 
-int orc_batch_rollout(const orc_model* m, int B, int T, double dt, const double* x0,
-                      const double* u, const double* xs_nom, const double* K, int nthreads,
-                      double* xs_out, double* us_out, double* cost_out) {
+int orc_batch_rollout(const orc_model* m, int B, int T, orc_f64 dt, const orc_real* x0,
+                      const orc_real* u, const orc_real* xs_nom, const orc_real* K, int nthreads,
+                      orc_real* xs_out, orc_real* us_out, orc_acc* cost_out) {
   const int n = m->nx, mu = m->nu;
   const int nt = pick_threads(nthreads);
   (void)nt;
@@ -1089,22 +1021,22 @@ int orc_batch_rollout(const orc_model* m, int B, int T, double dt, const double*
   for (int b = 0; b < B; b++) {
     orc_traj* s = orc_traj_alloc(n, mu, T, dt);
     if (xs_nom && K) {
-      memcpy(s->xs, &xs_nom[(size_t)b * (T + 1) * n], sizeof(double) * (size_t)(T + 1) * n);
-      memcpy(s->K, &K[(size_t)b * T * mu * n], sizeof(double) * (size_t)T * mu * n);
+      memcpy(s->xs, &xs_nom[(size_t)b * (T + 1) * n], sizeof(orc_real) * (size_t)(T + 1) * n);
+      memcpy(s->K, &K[(size_t)b * T * mu * n], sizeof(orc_real) * (size_t)T * mu * n);
       s->has_gains = 1;
     }
-    const double c = orc_forward_pass(m, s, &x0[(size_t)b * n], &u[(size_t)b * T * mu]);
-    if (xs_out) memcpy(&xs_out[(size_t)b * (T + 1) * n], s->xs, sizeof(double) * (size_t)(T + 1) * n);
-    if (us_out) memcpy(&us_out[(size_t)b * T * mu], s->us, sizeof(double) * (size_t)T * mu);
+    const orc_acc c = orc_forward_pass(m, s, &x0[(size_t)b * n], &u[(size_t)b * T * mu]);
+    if (xs_out) memcpy(&xs_out[(size_t)b * (T + 1) * n], s->xs, sizeof(orc_real) * (size_t)(T + 1) * n);
+    if (us_out) memcpy(&us_out[(size_t)b * T * mu], s->us, sizeof(orc_real) * (size_t)T * mu);
     if (cost_out) cost_out[b] = c;
     orc_traj_free(s);
   }
   return 0;
 }
 
-int orc_batch_derivatives(const orc_model* m, int B, int T, double dt, const double* xs,
-                          const double* us, int nthreads, double* fx, double* fu, double* cx,
-                          double* cu, double* cxx, double* cxu, double* cuu) {
+int orc_batch_derivatives(const orc_model* m, int B, int T, orc_f64 dt, const orc_real* xs,
+                          const orc_real* us, int nthreads, orc_real* fx, orc_real* fu, orc_real* cx,
+                          orc_real* cu, orc_real* cxx, orc_real* cxu, orc_real* cuu) {
   const int n = m->nx, mu = m->nu;
   const size_t T1 = (size_t)T + 1;
   const int nt = pick_threads(nthreads);
@@ -1112,26 +1044,26 @@ int orc_batch_derivatives(const orc_model* m, int B, int T, double dt, const dou
 #pragma omp parallel for num_threads(nt) schedule(static)
   for (int b = 0; b < B; b++) {
     orc_traj* s = orc_traj_alloc(n, mu, T, dt);
-    memcpy(s->xs, &xs[(size_t)b * T1 * n], sizeof(double) * T1 * n);
-    memcpy(s->us, &us[(size_t)b * T * mu], sizeof(double) * (size_t)T * mu);
+    memcpy(s->xs, &xs[(size_t)b * T1 * n], sizeof(orc_real) * T1 * n);
+    memcpy(s->us, &us[(size_t)b * T * mu], sizeof(orc_real) * (size_t)T * mu);
     orc_compute_derivatives(m, s);
-    memcpy(&fx[(size_t)b * T1 * n * n], s->fx, sizeof(double) * T1 * n * n);
-    memcpy(&fu[(size_t)b * T1 * n * mu], s->fu, sizeof(double) * T1 * n * mu);
-    memcpy(&cx[(size_t)b * T1 * n], s->cx, sizeof(double) * T1 * n);
-    memcpy(&cu[(size_t)b * T1 * mu], s->cu, sizeof(double) * T1 * mu);
-    memcpy(&cxx[(size_t)b * T1 * n * n], s->cxx, sizeof(double) * T1 * n * n);
-    memcpy(&cxu[(size_t)b * T1 * n * mu], s->cxu, sizeof(double) * T1 * n * mu);
-    memcpy(&cuu[(size_t)b * T1 * mu * mu], s->cuu, sizeof(double) * T1 * mu * mu);
+    memcpy(&fx[(size_t)b * T1 * n * n], s->fx, sizeof(orc_real) * T1 * n * n);
+    memcpy(&fu[(size_t)b * T1 * n * mu], s->fu, sizeof(orc_real) * T1 * n * mu);
+    memcpy(&cx[(size_t)b * T1 * n], s->cx, sizeof(orc_real) * T1 * n);
+    memcpy(&cu[(size_t)b * T1 * mu], s->cu, sizeof(orc_real) * T1 * mu);
+    memcpy(&cxx[(size_t)b * T1 * n * n], s->cxx, sizeof(orc_real) * T1 * n * n);
+    memcpy(&cxu[(size_t)b * T1 * n * mu], s->cxu, sizeof(orc_real) * T1 * n * mu);
+    memcpy(&cuu[(size_t)b * T1 * mu * mu], s->cuu, sizeof(orc_real) * T1 * mu * mu);
     orc_traj_free(s);
   }
   return 0;
 }
 
-int orc_batch_backward(const orc_model* m, int B, int T, const double* us, const double* fx,
-                       const double* fu, const double* cx, const double* cu, const double* cxx,
-                       const double* cxu, const double* cuu, const double* k_prev,
-                       const double* lambda, int nthreads, double* k_out, double* K_out,
-                       double* dV_out, int* diverge_out, double* Vx0_out, double* Vxx0_out) {
+int orc_batch_backward(const orc_model* m, int B, int T, const orc_real* us, const orc_real* fx,
+                       const orc_real* fu, const orc_real* cx, const orc_real* cu, const orc_real* cxx,
+                       const orc_real* cxu, const orc_real* cuu, const orc_real* k_prev,
+                       const orc_acc* lambda, int nthreads, orc_real* k_out, orc_real* K_out,
+                       orc_acc* dV_out, int* diverge_out, orc_real* Vx0_out, orc_real* Vxx0_out) {
   const int n = m->nx, mu = m->nu;
   const size_t T1 = (size_t)T + 1;
   const int nt = pick_threads(nthreads);
@@ -1139,24 +1071,24 @@ int orc_batch_backward(const orc_model* m, int B, int T, const double* us, const
 #pragma omp parallel for num_threads(nt) schedule(static)
   for (int b = 0; b < B; b++) {
     orc_traj* s = orc_traj_alloc(n, mu, T, 0.0);
-    memcpy(s->us, &us[(size_t)b * T * mu], sizeof(double) * (size_t)T * mu);
-    memcpy(s->fx, &fx[(size_t)b * T1 * n * n], sizeof(double) * T1 * n * n);
-    memcpy(s->fu, &fu[(size_t)b * T1 * n * mu], sizeof(double) * T1 * n * mu);
-    memcpy(s->cx, &cx[(size_t)b * T1 * n], sizeof(double) * T1 * n);
-    memcpy(s->cu, &cu[(size_t)b * T1 * mu], sizeof(double) * T1 * mu);
-    memcpy(s->cxx, &cxx[(size_t)b * T1 * n * n], sizeof(double) * T1 * n * n);
-    memcpy(s->cxu, &cxu[(size_t)b * T1 * n * mu], sizeof(double) * T1 * n * mu);
-    memcpy(s->cuu, &cuu[(size_t)b * T1 * mu * mu], sizeof(double) * T1 * mu * mu);
-    if (k_prev) memcpy(s->k, &k_prev[(size_t)b * T * mu], sizeof(double) * (size_t)T * mu);
+    memcpy(s->us, &us[(size_t)b * T * mu], sizeof(orc_real) * (size_t)T * mu);
+    memcpy(s->fx, &fx[(size_t)b * T1 * n * n], sizeof(orc_real) * T1 * n * n);
+    memcpy(s->fu, &fu[(size_t)b * T1 * n * mu], sizeof(orc_real) * T1 * n * mu);
+    memcpy(s->cx, &cx[(size_t)b * T1 * n], sizeof(orc_real) * T1 * n);
+    memcpy(s->cu, &cu[(size_t)b * T1 * mu], sizeof(orc_real) * T1 * mu);
+    memcpy(s->cxx, &cxx[(size_t)b * T1 * n * n], sizeof(orc_real) * T1 * n * n);
+    memcpy(s->cxu, &cxu[(size_t)b * T1 * n * mu], sizeof(orc_real) * T1 * n * mu);
+    memcpy(s->cuu, &cuu[(size_t)b * T1 * mu * mu], sizeof(orc_real) * T1 * mu * mu);
+    if (k_prev) memcpy(s->k, &k_prev[(size_t)b * T * mu], sizeof(orc_real) * (size_t)T * mu);
     s->lambda = lambda ? lambda[b] : 1.0;
     const int div = orc_backward_pass(m, s);
-    memcpy(&k_out[(size_t)b * T * mu], s->k, sizeof(double) * (size_t)T * mu);
-    memcpy(&K_out[(size_t)b * T * mu * n], s->K, sizeof(double) * (size_t)T * mu * n);
+    memcpy(&k_out[(size_t)b * T * mu], s->k, sizeof(orc_real) * (size_t)T * mu);
+    memcpy(&K_out[(size_t)b * T * mu * n], s->K, sizeof(orc_real) * (size_t)T * mu * n);
     dV_out[2 * b] = s->dV[0];
     dV_out[2 * b + 1] = s->dV[1];
     diverge_out[b] = div;
-    if (Vx0_out) memcpy(&Vx0_out[(size_t)b * n], s->Vx, sizeof(double) * n);
-    if (Vxx0_out) memcpy(&Vxx0_out[(size_t)b * n * n], s->Vxx, sizeof(double) * n * n);
+    if (Vx0_out) memcpy(&Vx0_out[(size_t)b * n], s->Vx, sizeof(orc_real) * n);
+    if (Vxx0_out) memcpy(&Vxx0_out[(size_t)b * n * n], s->Vxx, sizeof(orc_real) * n * n);
     orc_traj_free(s);
   }
   return 0;

@@ -5,7 +5,7 @@ driven from two host threads at once."""
 import numpy as np
 import pytest
 
-from tests.parity import gains_knot_err, walk_iterations
+from tests.parity import assert_free_run, gains_knot_err, walk_both
 from tests.util import TOL, acrobot_x0, integrator_x0, mat, relerr
 
 pytestmark = pytest.mark.gpu
@@ -43,14 +43,14 @@ def test_horizons_around_chunk_size(oracle, name, B, T):
     g.init_traj(x0, u0)
     g.iterate(2)
     ro = oracle.batch_solve(om, x0, u0, DT, max_iters=2)
-    ok = np.isclose(g.cost(), ro["cost"], rtol=TOL)
+    cost2 = g.cost()
     xs2, us2 = g.trajectory()
-    assert relerr(xs2[ok], ro["xs"][ok]) < TOL
     st, it, al = g.status()
+    # every step checked against the oracle; a trajectory that left the oracle's path did so at a proven tie
+    tied, r_o, r_g = walk_both(oracle, om, g, x0, u0, DT, 2)
+    ok = assert_free_run(cost2, ro["cost"], tied, (name, T))
+    assert relerr(xs2[ok], ro["xs"][ok]) < 1e-5
     assert np.array_equal(it[ok], ro["iters"][ok])
-    # every trajectory that left the oracle's path did so at a proven tie (tests/parity.py)
-    r = walk_iterations(oracle, om, g, x0, u0, DT, 2)
-    assert (~ok).sum() <= r["ties_backward"] + r["ties_search"] + r["ties_stop"], (r, (~ok).sum())
 
 
 @pytest.mark.parametrize("B", [1, 15, 16, 17, 63, 64, 65, 130])
@@ -64,13 +64,13 @@ def test_ragged_batches(oracle, B):
     g.init_traj(x0, u0)
     g.iterate(3)
     ro = oracle.batch_solve(om, x0, u0, DT, max_iters=3)
-    ok = np.isclose(g.cost(), ro["cost"], rtol=TOL)
+    cost3 = g.cost()
     k, K = g.gains()
     xs, us = g.trajectory()
+    tied, r_o, r_g = walk_both(oracle, om, g, x0, u0, DT, 3)
+    ok = assert_free_run(cost3, ro["cost"], tied, B)
     if ok.any():  # gains of the third backward pass, per knot (two iterations of amplification behind them)
         assert gains_knot_err(k[ok], K[ok], ro["k"][ok], ro["K"][ok], us[ok]).max() < 1e-4
-    r = walk_iterations(oracle, om, g, x0, u0, DT, 3)
-    assert (~ok).sum() <= r["ties_backward"] + r["ties_search"] + r["ties_stop"], (r, g.cost(), ro["cost"])
 
 
 def test_backward_kernel_variants_agree(oracle):

@@ -137,3 +137,39 @@ def test_batch_between_one_and_two_tiles_per_cu_takes_the_fused_route(monkeypatc
     g = BatchILQR("acrobot", 32 * cus + 16, 4, DT)  # more than two tiles per CU: two kernels
     assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("backward")) == b"k_backward_q"
     g.close()
+
+
+@pytest.mark.parametrize("name", ["acrobot", "integrator"])
+def test_committed_trajectory_is_the_rollout_that_was_scored(name):
+    """Candidate states are not stored: the commit (k_commit, the sweep's fused commit) and the getter
+    (k_unpack_cand) re-integrate them from checkpoints with their own inlined copies of
+    integrate_dynamics.  The committed trajectory must be, bit for bit, the rollout whose cost was
+    accepted -- whatever FMA-contraction choices the compiler made in each kernel: (i) commit == getter,
+    (ii) an open-loop replay of the committed controls by yet another instantiation of the rollout kernel
+    (init_traj) reproduces the committed states and the accepted cost exactly."""
+    from ilqr_amd import BatchILQR
+    B, T = 53, 77
+    if name == "acrobot":
+        x0, nu, kw = acrobot_x0(B, scale=0.5, seed=21), 1, dict(u_min=-1.5, u_max=1.5)
+    else:
+        x0, nu, kw = integrator_x0(B), 2, dict(goal=[1.0, 0.5, 0.0, 0.0])
+    g = BatchILQR(name, B, T, DT, **kw)
+    g.init_traj(x0, np.zeros((B, T, nu)))
+    for n_it in (1, 2):  # 2: the first accept is committed by the second iteration's sweep
+        g.init_traj(x0, np.zeros((B, T, nu)))
+        g.iterate(n_it)
+        xs, us = g.trajectory()
+        cost = g.cost()
+        st, it, al = g.status()
+        assert (al >= 0).sum() > B // 2
+        for a in np.unique(al[al >= 0]):
+            xa, ua = g.candidate(int(a))
+            sel = al == a
+            assert np.array_equal(xa[sel], xs[sel]) and np.array_equal(ua[sel], us[sel]), (n_it, a)
+        g2 = BatchILQR(name, B, T, DT, **kw)
+        c2 = g2.init_traj(x0, us)
+        xs2, us2 = g2.trajectory()
+        g2.close()
+        assert np.array_equal(xs2, xs), n_it
+        assert np.array_equal(c2[al >= 0], cost[al >= 0]), n_it
+    g.close()

@@ -5,8 +5,7 @@ import numpy as np
 import pytest
 
 from tests.util import TOL, mat
-from tests.parity import first_gain_mismatch_is_knife_edge, gains_knot_err
-from tests.test_gpu_parity import _per_traj_err
+from tests.parity import check_backward
 
 pytestmark = pytest.mark.gpu
 DT = 0.02
@@ -46,16 +45,8 @@ def run_case(oracle, om, B, T, lam, x_scale=1.0, u_scale=0.5, cuu_shift=None):
     dV = g.dV()
     Ko = mat(ro["K"])
     lo, hi = om.u_min[None, None, :] - us, om.u_max[None, None, :] - us
-    conv = ro["diverge"] == 0
-    assert conv.sum() > 0
-    err = np.maximum(gains_knot_err(k, K, ro["k"], Ko, us), _per_traj_err(dV, ro["dV"]))  # gains: per knot
-    good = (err < TOL) & (div == ro["diverge"])
-    ties = 0
-    for b in np.flatnonzero(conv & ~good):
-        assert first_gain_mismatch_is_knife_edge(k[b], K[b], ro["k"][b], Ko[b], us[b], lo[b], hi[b]), (b, err[b])
-        ties += 1
-    assert ties <= max(1, B // 8), ties
-    ok = conv & good
+    r = check_backward(oracle, om, us, dv, k_prev, lam, k, K, dV, div, ro, max_ties=max(1, B // 8))  # gains: per knot
+    ok, ties = r["good"], r["ties"]
     clamped = (np.abs(k - lo) < 1e-9) | (np.abs(k - hi) < 1e-9)
     g.last = dict(div=div, ro=ro, ok=ok, ties=ties)
     return clamped[ok].mean(), g
@@ -102,5 +93,6 @@ def test_non_positive_definite_quu(oracle, n, m, where):
     frac, g = run_case(oracle, om, B=8, T=10, lam=0.0, u_scale=0.2, cuu_shift=shift)
     ro, div = g.last["ro"], g.last["div"]
     assert np.array_equal(div, ro["diverge"])
-    assert g.last["ok"].sum() >= 6, g.last  # (ties allowed as everywhere, see run_case)
+    assert g.last["ok"].sum() >= 6, g.last  # (ties allowed as everywhere; "ok" includes trajectories where fp64 itself
+    # cannot pin the answer: a first pivot < 0 leaves R = Q untouched and the "solve" amplifies rounding by 1e15)
     g.close()

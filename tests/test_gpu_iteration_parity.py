@@ -23,6 +23,15 @@ def build(oracle, name, B, T, lim, params=None):
     return om, g
 
 
+def assert_rare(r):
+    """Proven ties stay rare (a tie needs a control within 1e-4 of a bound with a noise-sized gradient, or a
+    cost change of rounding size), and so do steps whose per-knot gain agreement is limited by fp64
+    conditioning by more than 10x the fp64 oracle's own distance from extended precision."""
+    ties = r["ties_backward"] + r["ties_search"] + r["ties_stop"]
+    assert ties <= max(2, r["checked"] // 20), r
+    assert r["cond_over10"] <= max(1, r["checked"] // 50), r
+
+
 CASES = [
     # name, B, T, limit, x0 scale, iterations
     ("acrobot", 64, 120, 1.5, 1.0, 8),     # the bench workload's regime: clamps active, chaotic
@@ -40,12 +49,9 @@ def test_iterations_teacher_forced(oracle, name, B, T, lim, scale, iters):
     u0 = np.zeros((B, T, om.nu))
     r = walk_iterations(oracle, om, g, x0, u0, DT, iters)
     g.close()
-    ties = r["ties_backward"] + r["ties_search"] + r["ties_stop"]
     print(name, r)
     assert r["checked"] >= B * min(iters, 2)
-    # proven ties stay rare: a tie needs a control within 1e-4 of a bound with a noise-sized gradient, or a
-    # cost change of rounding size
-    assert ties <= max(2, r["checked"] // 20), r
+    assert_rare(r)
 
 
 def test_iterations_teacher_forced_fixed_work(oracle):
@@ -59,7 +65,8 @@ def test_iterations_teacher_forced_fixed_work(oracle):
         g = BatchILQR("acrobot", B, T, DT, u_min=-lim, u_max=lim, flags=capi.FLAG_FIXED_WORK | extra)
         r = walk_iterations(oracle, om, g, x0, np.zeros((B, T, 1)), DT, 6, fixed_work=True)
         g.close()
-        assert r["checked"] == 6 * B and r["ties_backward"] + r["ties_search"] <= 12, r
+        assert r["checked"] == 6 * B, r
+        assert_rare(r)
 
 
 def test_gradient_norm_exit(oracle):
@@ -68,15 +75,15 @@ def test_gradient_norm_exit(oracle):
     tolGrad (an ilqr_params field here, a compile-time constant there): the exit then needs lambda < 1e-5,
     i.e. seven accepted iterations, and the gradient norm below the threshold at the start of one."""
     from ilqr_amd import BatchILQR
-    B, T, lim = 32, 150, 5.0
-    tol_grad = 2e-2
-    params = dict(tol_grad=tol_grad, tol_fun=1e-9)
+    B, T, lim = 32, 100, 5.0
+    tol_grad = 5e-2
+    params = dict(tol_grad=tol_grad)
     om, g = build(oracle, "acrobot", B, T, lim, params=params)
-    x0 = acrobot_x0(B, scale=0.05, seed=5)
+    x0 = acrobot_x0(B, scale=0.3, seed=5)
     u0 = np.zeros((B, T, 1))
-    oracle.set_params(tol_grad=tol_grad, tol_fun=1e-9)
+    oracle.set_params(tol_grad=tol_grad)
     try:
-        r = walk_iterations(oracle, om, g, x0, u0, DT, 30, params=dict(tol_fun=1e-9))
+        r = walk_iterations(oracle, om, g, x0, u0, DT, 12, params=params)
         # free-running on both sides as well: same exits
         g.init_traj(x0, u0)
         g.generate_trajectory()
@@ -92,7 +99,7 @@ def test_gradient_norm_exit(oracle):
     assert both.sum() >= (ro["status"] == 1).sum() * 3 // 4
     assert np.array_equal(it[both], ro["iters"][both])
     assert np.all(gn[st == 1] < tol_grad) and np.all(lam[st == 1] < 1e-5)
-    assert r["ties_backward"] + r["ties_search"] + r["ties_stop"] <= max(2, r["checked"] // 20), r
+    assert_rare(r)
 
 
 def test_gnorm_matches_oracle(oracle):

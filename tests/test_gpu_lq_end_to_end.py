@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from tests.util import TOL, mat, relerr, relerr_abs
-from tests.parity import first_gain_mismatch_is_knife_edge, gains_knot_err, walk_iterations
+from tests.parity import check_backward, walk_iterations
 
 pytestmark = pytest.mark.gpu
 DT = 0.02
@@ -80,12 +80,7 @@ def test_lq_stages_match_oracle(oracle, n, m, B, T, dense):
     ro = oracle.batch_backward(om, us_o, do, k_prev=k_prev, lam=1.0)
     k, K = g.gains()
     Ko = mat(ro["K"])
-    err = gains_knot_err(k, K, ro["k"], Ko, us_o)  # per knot
-    lo, hi = om.u_min[None, None, :] - us_o, om.u_max[None, None, :] - us_o
-    bad = np.flatnonzero((err >= TOL) | (div != ro["diverge"]))
-    for b in bad:
-        assert first_gain_mismatch_is_knife_edge(k[b], K[b], ro["k"][b], Ko[b], us_o[b], lo[b], hi[b]), (b, err[b])
-    assert len(bad) <= max(1, B // 8)
+    check_backward(oracle, om, us_o, do, k_prev, 1.0, k, K, g.dV(), div, ro, max_ties=max(1, B // 8))  # gains: per knot
     # the 11 closed-loop rollouts of the line search, with the oracle's gains
     g.set_gains(k=ro["k"], K=Ko)
     costs = g.rollout_candidates()
@@ -114,7 +109,7 @@ def test_lq_iterations_match_oracle(oracle, n, m, B, T):
     u0 = np.zeros((B, T, m))
     iters = 3
     r = walk_iterations(oracle, om, g, x0, u0, DT, iters, fixed_work=True)  # every deviation a proven tie
-    n_ties = r["ties_backward"] + r["ties_search"]
+    n_ties = len(r["tied"])
     assert r["checked"] == B * iters and n_ties <= max(1, B // 8), r
     g.init_traj(x0, u0)
     g.iterate(iters)

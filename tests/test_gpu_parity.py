@@ -6,7 +6,7 @@ status, iteration counts) must match exactly."""
 import numpy as np
 import pytest
 
-from tests.parity import first_gain_mismatch_is_knife_edge, gains_knot_err, walk_iterations
+from tests.parity import assert_free_run, check_backward, gains_knot_err, walk_both, walk_iterations
 from tests.util import TOL, acrobot_x0, integrator_x0, mat, relerr, relerr_abs
 
 pytestmark = pytest.mark.gpu
@@ -94,16 +94,9 @@ def test_backward_teacher_forced(oracle, name, B, T, lim, lam):
     Ko = mat(ro["K"])
     lo, hi = om.u_min[None, None, :] - us_o, om.u_max[None, None, :] - us_o
     conv = ro["diverge"] == 0
-    assert conv.sum() > 0
-    # PER-KNOT relative error of the gains (every time step against its own magnitude), dV per trajectory
-    err = np.maximum(gains_knot_err(k, K, ro["k"], Ko, us_o), _per_traj_err(dV, ro["dV"]))
-    good = (err < TOL) & (div == ro["diverge"])
-    ties = 0
-    for b in np.flatnonzero(conv & ~good):
-        assert first_gain_mismatch_is_knife_edge(k[b], K[b], ro["k"][b], Ko[b], us_o[b], lo[b], hi[b]), (b, err[b])
-        ties += 1
-    assert ties <= max(1, B // 16), ties  # branch agreement: >= ~94 % of trajectories identical path
-    assert np.array_equal(div[good | ~conv], ro["diverge"][good | ~conv])
+    # per-knot gains, dV, diverge flags; deviations must be fp64 conditioning or proven clamp ties (tests/parity.py)
+    r = check_backward(oracle, om, us_o, do, k_prev, lam, k, K, dV, div, ro, max_ties=max(1, B // 16))
+    good = r["good"]
     # k stays inside the box it was solved for
     ok = conv & good
     assert np.all(k[ok] >= lo[ok] - 1e-12) and np.all(k[ok] <= hi[ok] + 1e-12)
@@ -135,19 +128,10 @@ def test_backward_teacher_forced_late_in_a_solve(oracle, iters):
     div = g.backward_pass()
     k, K = g.gains()
     dV = g.dV()
-    Ko = mat(ro["K"])
-    lo, hi = om.u_min[None, None, :] - us_o, om.u_max[None, None, :] - us_o
     conv = ro["diverge"] == 0
     assert conv.mean() > 0.5 and (lam == 0).mean() > 0.2, (conv.mean(), (lam == 0).mean())
-    # PER-KNOT relative error of the gains (every time step against its own magnitude), dV per trajectory
-    err = np.maximum(gains_knot_err(k, K, ro["k"], Ko, us_o), _per_traj_err(dV, ro["dV"]))
-    good = (err < TOL) & (div == ro["diverge"])
-    ties = 0
-    for b in np.flatnonzero(conv & ~good):
-        assert first_gain_mismatch_is_knife_edge(k[b], K[b], ro["k"][b], Ko[b], us_o[b], lo[b], hi[b]), (b, err[b])
-        ties += 1
-    assert ties <= B // 8, ties
-    assert np.array_equal(div[good | ~conv], ro["diverge"][good | ~conv])
+    r = check_backward(oracle, om, us_o, do, k_prev, lam, k, K, dV, div, ro, max_ties=B // 8)
+    print("late in a solve:", {kk: v for kk, v in r.items() if kk != "good"})
 
 
 @pytest.mark.parametrize("name,B,T,lim", CASES)
@@ -180,7 +164,7 @@ def test_one_iteration_from_same_state(oracle, name, B, T, lim):
     om, g, x0 = make(oracle, name, B, T, lim)
     u0 = np.zeros((B, T, om.nu))
     r = walk_iterations(oracle, om, g, x0, u0, DT, 1)
-    assert r["checked"] == B and r["ties_backward"] + r["ties_search"] + r["ties_stop"] <= max(1, B // 32), r
+    assert r["checked"] == B and len(r["tied"]) <= max(1, B // 32), r
     # and from the device's own init_traj (the rollouts differ in the last bit)
     g.init_traj(x0, u0)
     g.iterate(1)
@@ -188,7 +172,7 @@ def test_one_iteration_from_same_state(oracle, name, B, T, lim):
     st, it, al = g.status()
     assert np.array_equal(it, ro["iters"])
     same = np.isclose(g.cost(), ro["cost"], rtol=TOL)
-    assert same.sum() >= B - max(1, B // 32) - r["ties_backward"] - r["ties_search"]
+    assert same.sum() >= B - max(1, B // 32) - len(r["tied"])
     lam, dlam = g.lambdas()
     assert np.allclose(lam[same], ro["lam"][same], rtol=1e-12)
     xs, us = g.trajectory()
@@ -243,14 +227,12 @@ def test_small_scale_multi_iteration(oracle):
     x0 = acrobot_x0(B, scale=0.01)
     u0 = np.zeros((B, T, 1))
     g = BatchILQR("acrobot", B, T, DT)
-    r = walk_iterations(oracle, om, g, x0, u0, DT, 5)
-    n_ties = r["ties_backward"] + r["ties_search"] + r["ties_stop"]
+    tied, r, r_g = walk_both(oracle, om, g, x0, u0, DT, 5)
     g.init_traj(x0, u0)
     g.iterate(5)
     ro = oracle.batch_solve(om, x0, u0, DT, max_iters=5)
     cost = g.cost()
-    ok = np.isclose(cost, ro["cost"], rtol=TOL)
-    assert (~ok).sum() <= n_ties, (cost, ro["cost"], r)
+    ok = assert_free_run(cost, ro["cost"], tied)
     k, K = g.gains()
     xs, us = g.trajectory()
     assert gains_knot_err(k[ok], K[ok], ro["k"][ok], ro["K"][ok], us[ok]).max() < 1e-4  # five iterations of amplification
