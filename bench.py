@@ -28,20 +28,22 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (dense)
 
 
-def algorithmic_bytes_per_timestep(n, m):
-    """SURVEY.md 8(d) / BASELINE.md 4: fp64 bytes per trajectory-timestep of each kernel."""
-    s = 8
+def algorithmic_bytes_per_timestep(n, m, s=8):
+    """SURVEY.md 8(d) / BASELINE.md 4: bytes per trajectory-timestep of each kernel (s = sizeof scalar)."""
     return {
-        "backward": (2 * n * n + 2 * n * m + m * m + n + 2 * m + m * n + m) * s,          # acrobot 416
-        "derivatives": (n + m + 2 * n * n + 2 * n * m + m * m + n + m) * s,              # acrobot 408
-        # per alpha: reads us,k (2m), K (mn), xs (n); writes u_t (m) and one checkpoint state per 8 knots
-        "rollout": 11 * (2 * m + m * n + n + m + n / 8.0) * s,                            # acrobot 11*92
+        "backward": (2 * n * n + 2 * n * m + m * m + n + 2 * m + m * n + m) * s,          # acrobot fp64 416
+        "derivatives": (n + m + 2 * n * n + 2 * n * m + m * m + n + m) * s,              # acrobot fp64 408
+        # UNIQUE bytes of the 11-alpha search: the nominal us,k (2m), K (mn), xs (n) are read once per tile and
+        # shared by the 11 candidates; every candidate writes its u_t (m) and one checkpoint state per 8 knots.
+        # (SURVEY's nominal figure charges the reads to every alpha: 11 x 92 B; that is not what reaches HBM.)
+        "rollout": ((2 * m + m * n + n) + 11 * (m + n / 8.0)) * s,                        # acrobot fp64 204
         "accept": 2 * (n + m) * s,                                                       # commit copy
-        # k_sweep_backward (ilqr_iterate): the sweep's records reach the backward wavefront through LDS,
-        # so HBM sees: candidate u + 1/8 checkpoint x read, committed x,u written, the record written
-        # (retry passes / getters read it there), K and k written, the nominal u read.      acrobot 460
+        # k_sweep_backward (ilqr_iterate): the sweep's records reach the backward wavefront through LDS, so
+        # HBM sees: candidate u + 1/8 checkpoint x read, committed x,u written, the record written (retry
+        # passes / getters read it there), K and k written, the nominal u read.              acrobot fp64 468
         "sweep_backward": (m + n / 8.0 + (n + m) + (2 * n * n + 2 * n * m + m * m + n + m) + (m * n + m) + m) * s,
     }
 
@@ -103,6 +105,30 @@ def pmc_traffic(kernel):
         return None, None
 
 
+# VALU issue: one wave64 instruction occupies a SIMD's 16 lanes for 4 cycles, so a SIMD issues at most 0.25
+# VALU instructions per cycle (MI355X_MICROARCH.md).  The dominant kernel is one dependent chain per tile and is
+# bound by that, not by bytes: the figure quoted is from the committed SQ-counter pass (profiles/), which the
+# bench cannot collect on itself.
+def issue_roofline(kernel):
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        e = json.load(open(path))["kernels"][kernel]
+        ipc = e["valu_insts_per_launch"] / (e["busy_simds"] * e["avg_launch_us"] * 1e-6 * e["sclk_hz"])
+        return {"bound": "valu_issue", "kernel": kernel, "achieved": ipc, "peak": 0.25, "unit": "VALU instructions / cycle / SIMD",
+                "frac": ipc / 0.25, "valu_insts_per_timestep": e["valu_insts_per_launch"] / e["timesteps_per_launch"],
+                "source": e.get("source")}
+    except Exception:
+        return None
+
+
+def lq_mats(n, m, seed=7):
+    """SURVEY.md 8(d) cfg 5: A = -I + 0.1 N(0,1)/sqrt(n), B = N(0,1)/sqrt(n), Q = I, R = 0.1 I."""
+    rng = np.random.default_rng(seed)
+    A = -np.eye(n) + 0.1 * rng.normal(size=(n, n)) / np.sqrt(n)
+    Bm = rng.normal(size=(n, m)) / np.sqrt(n)
+    return A, Bm, np.eye(n), 0.1 * np.eye(m), np.eye(n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,7 +137,10 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU")
     ap.add_argument("--T", type=int, default=499)
     ap.add_argument("--limit", type=float, default=1.5)
+    ap.add_argument("--dtype", choices=("f64", "f32"), default="f64", help="arithmetic of the HEADLINE run (the other "
+                    "one is reported under configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="only the headline workload")
     ap.add_argument("--flags", type=int, default=0, help="extra ilqr_flags (kernel variant selection)")
     args = ap.parse_args()
 
@@ -150,17 +179,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    B, T, dt, lim, n, m = args.batch, args.T, 0.02, args.limit, 4, 1
-    # this rank's shard of the global synthetic batch (trajectory b of rank r = global r*B + b)
-    lo, hi = D.shard(B * world, rank, world)
-    x0 = acrobot_x0(B * world)[lo:hi]
-    u0 = np.zeros((B, T, m))
+    T, dt, n, m = args.T, 0.02, 4, 1
     stream = torch.cuda.current_stream().cuda_stream
-    g = BatchILQR("acrobot", B, T, dt, u_min=-lim, u_max=lim, device=local_rank,
-                  flags=capi.FLAG_FIXED_WORK | args.flags, stream=stream)
-    g.init_traj(x0, u0)
-    g.iterate(args.warmup)
-    cost_dev = torch.zeros(B, dtype=torch.float64, device="cuda")
+    cost_dev = torch.zeros(args.batch, dtype=torch.float64, device="cuda")
     if world > 1:  # warm-up of the one collective of the path: RCCL sets its rings up on the first call
         D.gather_costs(cost_dev)
         torch.cuda.synchronize()
@@ -171,19 +192,65 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    g.profile(True)
-    g.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    g.iterate(args.steps)
-    # the one exchange step of the path: gather of per-trajectory costs (RCCL over xGMI)
-    capi.check(g.lib.ilqr_copy_cost_to_device(g.h, cost_dev.data_ptr()))
-    g.synchronize()  # the copy runs on the handle's stream, the collective on torch's: order them
-    gathered = D.gather_costs(cost_dev)
-    barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t0, device="cuda")
-    prof = g.profile_read()
-    g.profile(False)
+    def acrobot_run(dtype, B, lim, steps, warmup, flags=0, gather=True):
+        """W untimed + K timed fixed-work iterations of this rank's shard; returns (handle, seconds = max over ranks,
+        stage profile, gathered costs or None)."""
+        lo, hi = D.shard(B * world, rank, world)   # trajectory b of rank r = global r*B + b
+        x0 = acrobot_x0(B * world)[lo:hi]
+        # max_iter beyond the run: ILQR_FLAG_FIXED_WORK keeps every trajectory running (checked below)
+        g = BatchILQR("acrobot", B, T, dt, u_min=-lim, u_max=lim, device=local_rank, dtype=dtype,
+                      flags=capi.FLAG_FIXED_WORK | flags, stream=stream, params=dict(max_iter=warmup + steps + 1))
+        g.init_traj(x0, np.zeros((B, T, m)))
+        g.iterate(warmup)
+        g.profile(True)
+        g.profile_reset()
+        barrier()
+        t0 = time.perf_counter()
+        g.iterate(steps)
+        gathered = None
+        if gather:  # the one exchange step of the path: gather of per-trajectory costs (RCCL over xGMI)
+            cd = cost_dev if B == args.batch else torch.zeros(B, dtype=torch.float64, device="cuda")
+            capi.check(g.lib.ilqr_copy_cost_to_device(g.h, cd.data_ptr()))
+            g.synchronize()  # the copy runs on the handle's stream, the collective on torch's: order them
+            gathered = D.gather_costs(cd)
+        barrier()
+        elapsed = D.max_over_ranks(time.perf_counter() - t0, device="cuda")
+        prof = g.profile_read()
+        g.profile(False)
+        assert g.count_running() == B, "fixed-work run lost trajectories: the throughput figure would be inflated"
+        return g, elapsed, prof, gathered
+
+    def stage_table(g, prof, B, s_bytes):
+        bytes_ts = algorithmic_bytes_per_timestep(n, m, s_bytes)
+        name_of = {i: g.lib.ilqr_stage_kernel_name(g.h, i).decode() for i in range(capi.NUM_STAGES)}
+        fused = name_of[capi.STAGE_NAMES.index("backward")] == "k_sweep_backward"
+        if fused:  # one kernel does the derivative sweep AND the backward pass of the tile
+            bytes_ts["backward"] = bytes_ts["sweep_backward"]
+        stages = {}
+        for name, (ms, launches) in prof.items():
+            if launches:
+                stages[name] = {"kernel": name_of[capi.STAGE_NAMES.index(name)], "ms_per_launch": ms / launches, "launches": launches,
+                                "algorithmic_bytes_per_timestep": bytes_ts[name],
+                                "algorithmic_GBps": bytes_ts[name] * B * T / (ms / launches * 1e-3) / 1e9}
+        if fused:
+            stages["backward"]["includes"] = "derivative sweep (fused kernel)"
+        return stages, bytes_ts
+
+    def roofline_of(stages, bytes_ts, B):
+        dom = max(stages, key=lambda k: stages[k]["ms_per_launch"])
+        kern = stages[dom]["kernel"]
+        achieved = stages[dom]["algorithmic_GBps"]
+        traffic, traffic_src = pmc_traffic(kern)
+        return {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": bytes_ts[dom] * B * T, "avg_launch_ms": stages[dom]["ms_per_launch"],
+                "limiter": "neither roofline: one dependent Riccati chain per tile, bound by VALU issue + latency "
+                           "(see roofline_issue); HBM is the contract's nominal bound for this byte-light path"}
+
+    # ---------------- headline: BASELINE.json metric, configs[2] ----------------
+    B, lim, steps = args.batch, args.limit, args.steps
+    s_bytes = 8 if args.dtype == "f64" else 4
+    g, elapsed, prof, gathered = acrobot_run(args.dtype, B, lim, steps, args.warmup, args.flags)
 
     # backward-pass-only figure of the north star (outside the timed region): the stand-alone quad
     # kernel, one pass at the current lambda, on the derivative records of the final nominal trajectory
@@ -197,51 +264,100 @@ def main():
         capi.check(g.lib.ilqr_backward_pass(g.h, None))
     bw_ms = g.profile_read()["backward"][0] / R
     g.profile(False)
+    stages, bytes_ts = stage_table(g, prof, B, s_bytes)
+    g.close()
+
+    # ---------------- the other configurations (each a fixed-work run of its own) ----------------
+    extra = {}
+    if not args.no_extra_configs:
+        # late in a solve: iterations 4..103 of the same workload -- box-QPs leave the fast path
+        # once lambda has reached 0, the launch lasts as long as its slowest tile
+        g2, el2, prof2, _ = acrobot_run(args.dtype, B, lim, 100, args.warmup, args.flags, gather=False)
+        st2, _ = stage_table(g2, prof2, B, s_bytes)
+        g2.close()
+        extra["late_solve"] = {"workload": "the headline workload, 100 timed iterations (4..103 of the solve)",
+                               "late_ms_per_step": el2 / 100 * 1e3, "value": world * B * T * 100 / el2,
+                               "stages_ms": {k: v["ms_per_launch"] for k, v in st2.items()}}
+        # BASELINE configs[3]: acrobot T=500, fp32, 4096 per GPU (32768 over 8), limits +-5 (SURVEY 8d cfg 4);
+        # under --dtype f32 this slot holds the fp64 run of the same shape instead
+        other = "f32" if args.dtype == "f64" else "f64"
+        so = 4 if other == "f32" else 8
+        for label, fl in ((other, 0), (other + "_analytic", capi.FLAG_ANALYTIC_DERIVATIVES)):
+            g3, el3, prof3, ga3 = acrobot_run(other, 4096, 5.0, steps, args.warmup, fl)
+            st3, bt3 = stage_table(g3, prof3, 4096, so)
+            assert ga3 is None or bool(torch.isfinite(ga3).all())
+            extra["acrobot_T500_B4096_lim5_" + label] = {
+                "workload": "acrobot T=499 B=4096 per GPU, u in [-5,5], %s%s, fixed-work iterations (BASELINE configs[3] "
+                            "per-GPU shard; x %d GPUs)" % (other, ", exact model derivatives instead of finite differences" if fl else
+                                                             ("; finite differences taken in double from the float knot" if other == "f32" else ""), world),
+                "dtype": other, "value": world * 4096 * T * steps / el3, "unit": "trajectory-timesteps/s", "ms_per_step": el3 / steps * 1e3,
+                "n_gpus": world, "stages": st3, "roofline": roofline_of(st3, bt3, 4096)}
+            g3.close()
+    if not args.no_extra_configs and world == 1:
+        # BASELINE configs[1]: acrobot B=1024, limits +-5
+        g4, el4, prof4, _ = acrobot_run("f64", 1024, 5.0, steps, args.warmup, gather=False)
+        st4, bt4 = stage_table(g4, prof4, 1024, 8)
+        g4.close()
+        extra["acrobot_T500_B1024_lim5_f64"] = {"workload": "acrobot T=499 B=1024, u in [-5,5], fp64 (BASELINE configs[1])",
+                                                "value": 1024 * T * steps / el4, "unit": "trajectory-timesteps/s",
+                                                "ms_per_step": el4 / steps * 1e3, "stages": st4}
+        # BASELINE configs[4]: synthetic LQ n=32 m=16 T=200 B=8192, limits +-1: the generic wave-per-trajectory path
+        nq, mq, Tq, Bq = 32, 16, 200, 8192
+        flop_ts = 4 * nq ** 3 + 10 * nq * nq * mq + 6 * nq * mq * mq + mq ** 3   # backward flops / timestep
+        rq = np.random.default_rng(0)
+        x0q = rq.uniform(-1, 1, (Bq, nq))
+        for label, fl, itq in (("fd", 0, 3), ("analytic", capi.FLAG_ANALYTIC_DERIVATIVES, 6)):
+            gq = BatchILQR("lq", Bq, Tq, dt, u_min=-1.0, u_max=1.0, lq=lq_mats(nq, mq), device=local_rank, stream=stream,
+                           flags=capi.FLAG_FIXED_WORK | fl, params=dict(max_iter=itq + 2))
+            gq.init_traj(x0q, np.zeros((Bq, Tq, mq)))
+            gq.iterate(1)
+            gq.profile(True)
+            gq.profile_reset()
+            barrier()
+            t0 = time.perf_counter()
+            gq.iterate(itq)
+            barrier()
+            elq = time.perf_counter() - t0
+            pq = gq.profile_read()
+            assert gq.count_running() == Bq
+            names = {i: gq.lib.ilqr_stage_kernel_name(gq.h, i).decode() for i in range(capi.NUM_STAGES)}
+            stq = {k: {"kernel": names[capi.STAGE_NAMES.index(k)], "ms_per_launch": ms / ln, "launches": ln} for k, (ms, ln) in pq.items() if ln}
+            bw = stq["backward"]["ms_per_launch"] * 1e-3
+            gq.close()
+            extra["lq_n32_m16_T200_B8192_" + label] = {
+                "workload": "synthetic LQ n=32 m=16 T=200 B=8192, u in [-1,1], fp64, %s derivatives, fixed-work iterations "
+                            "(BASELINE configs[4])" % ("finite-difference" if not fl else "exact"),
+                "value": Bq * Tq * itq / elq, "unit": "trajectory-timesteps/s", "ms_per_step": elq / itq * 1e3, "stages": stq,
+                "roofline": {"bound": "mfma", "kernel": "k_backward_w", "achieved": flop_ts * Bq * Tq / bw / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": flop_ts * Bq * Tq / bw / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                             "algorithmic_flops_per_timestep": flop_ts, "avg_launch_ms": bw * 1e3}}
 
     if rank == 0:
         costs = gathered.cpu().numpy()
         assert np.all(np.isfinite(costs)), "non-finite cost in the gathered result"
-        steps = args.steps
         value = world * B * T * steps / elapsed
-        bytes_ts = algorithmic_bytes_per_timestep(n, m)
-        bytes_ts_backward_only = bytes_ts["backward"]
-        stages = {}
-        for name, (ms, launches) in prof.items():
-            if launches:
-                stages[name] = {"ms_per_launch": ms / launches, "launches": launches,
-                                "algorithmic_GBps": bytes_ts[name] * B * T / (ms / launches * 1e-3) / 1e9}
-        name_of = {i: g.lib.ilqr_stage_kernel_name(g.h, i).decode() for i in range(capi.NUM_STAGES)}
-        if name_of[capi.STAGE_NAMES.index("backward")] == "k_sweep_backward":
-            # one kernel does the derivative sweep AND the backward pass of the tile
-            bytes_ts["backward"] = bytes_ts["sweep_backward"]
-            stages["backward"]["algorithmic_GBps"] = bytes_ts["backward"] * B * T / (stages["backward"]["ms_per_launch"] * 1e-3) / 1e9
-            stages["backward"]["includes"] = "derivative sweep (fused kernel)"
-        dom = max(stages, key=lambda k: stages[k]["ms_per_launch"])
-        dom_kernel = name_of[capi.STAGE_NAMES.index(dom)]
-        achieved = stages[dom]["algorithmic_GBps"]
-        traffic, traffic_src = pmc_traffic(dom_kernel)
+        bytes_bw = algorithmic_bytes_per_timestep(n, m, s_bytes)["backward"]
+        roof = roofline_of(stages, bytes_ts, B)
         out = {
             "metric": "iLQR iterations/sec (batch x T timesteps/sec), acrobot T=500 batch=4096",
             "value": value, "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": steps,
             "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "acrobot n=4 m=1 T=499 transitions (500 knots) B=%d per GPU, u in [-%.1f,%.1f] "
-                                   "(box-QP clamps active), fp64, full iteration = FD derivatives + backward/box-QP "
-                                   "+ 11-alpha rollouts + accept, fixed work" % (B, lim, lim),
+                                   "(box-QP clamps active), %s, full iteration = FD derivatives + backward/box-QP "
+                                   "+ 11-alpha rollouts + accept, fixed work" % (B, lim, lim, args.dtype),
                        "batch_per_gpu": B, "T": T, "parallelism": "batch-sharded x%d, no data-path collective; "
                        "one all_gather of per-trajectory costs at the end" % world},
-            "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": bytes_ts[dom] * B * T,
-                         "avg_launch_ms": stages[dom]["ms_per_launch"]},
+            "roofline": roof,
+            "roofline_issue": issue_roofline(roof["kernel"]),
             "stages": stages,
             # north star "backward-pass throughput": k_backward_q alone on fixed derivative records
             "backward_only": {"kernel": "k_backward_q", "ms_per_launch": bw_ms,
                               "timesteps_per_s": B * T / (bw_ms * 1e-3) * world,
-                              "algorithmic_GBps": bytes_ts_backward_only * B * T / (bw_ms * 1e-3) / 1e9,
-                              "frac_of_hbm_peak": bytes_ts_backward_only * B * T / (bw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                              "algorithmic_GBps": bytes_bw * B * T / (bw_ms * 1e-3) / 1e9,
+                              "frac_of_hbm_peak": bytes_bw * B * T / (bw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "final_cost_mean": float(np.mean(costs)),
+            "configs": extra,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, T, dt, lim)

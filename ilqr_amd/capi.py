@@ -4,9 +4,10 @@ import os
 
 from . import _build
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MODEL_ACROBOT, MODEL_DOUBLE_INTEGRATOR, MODEL_LQ, MODEL_HOST = 0, 1, 2, 3
 FLAG_FIXED_WORK, FLAG_BACKWARD_THREAD_PER_TRAJ, FLAG_BACKWARD_LANE_GROUP, FLAG_UNFUSED, FLAG_ANALYTIC_DERIVATIVES = 1, 2, 4, 8, 16
+DTYPE_F64, DTYPE_F32 = 0, 1
 NUM_STAGES = 4
 STAGE_NAMES = ("derivatives", "backward", "rollout", "accept")
 
@@ -24,7 +25,7 @@ class Params(C.Structure):
 class Desc(C.Structure):
     _fields_ = [("abi_version", C.c_int), ("model", C.c_int), ("nx", C.c_int), ("nu", C.c_int),
                 ("T", C.c_int), ("B", C.c_int), ("dt", C.c_double), ("device", C.c_int),
-                ("flags", C.c_int), ("u_min", _dp), ("u_max", _dp), ("goal", _dp),
+                ("flags", C.c_int), ("dtype", C.c_int), ("u_min", _dp), ("u_max", _dp), ("goal", _dp),
                 ("lq_A", _dp), ("lq_B", _dp), ("lq_Q", _dp), ("lq_R", _dp), ("lq_Qf", _dp),
                 ("stream", C.c_void_p), ("params", C.POINTER(Params))]
 

@@ -33,24 +33,44 @@ ILQR_HD double recip(double a) {
   return 1.0 / a;
 #endif
 }
+// fp32: v_rcp_f32 (1 ulp) + one Newton step
+ILQR_HD float recip(float a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r = __builtin_amdgcn_rcpf(a);
+  const float e = __builtin_fmaf(-a, r, 1.0f);
+  return __builtin_fmaf(r, e, r);
+#else
+  return 1.0f / a;
+#endif
+}
+// type-directed math (an unqualified fabs / fmin / fmax / sqrt on a float silently picks the double
+// function in a host pass and wherever only the C declarations are visible)
+ILQR_HD double sqrt_of(double a) { return __builtin_sqrt(a); }
+ILQR_HD float sqrt_of(float a) { return __builtin_sqrtf(a); }
+ILQR_HD double abs_of(double a) { return __builtin_fabs(a); }
+ILQR_HD float abs_of(float a) { return __builtin_fabsf(a); }
+ILQR_HD double min_of(double a, double b) { return __builtin_fmin(a, b); }
+ILQR_HD float min_of(float a, float b) { return __builtin_fminf(a, b); }
+ILQR_HD double max_of(double a, double b) { return __builtin_fmax(a, b); }
+ILQR_HD float max_of(float a, float b) { return __builtin_fmaxf(a, b); }
 
-template <int M>
-ILQR_HD void clamp_to_limits(const double* x, const double* lo, const double* hi, double* out) {
+template <int M, class real>
+ILQR_HD void clamp_to_limits(const real* x, const real* lo, const real* hi, real* out) {
 #pragma unroll
   for (int i = 0; i < M; i++) {  // include/boxqp.h:48-51  upper.cwiseMin(x.cwiseMax(lower))
-    const double a = (x[i] < lo[i]) ? lo[i] : x[i];
+    const real a = (x[i] < lo[i]) ? lo[i] : x[i];
     out[i] = (hi[i] < a) ? hi[i] : a;
   }
 }
 
-template <int M>
-ILQR_HD double quad_cost(const double* Q, const double* c, const double* x) {
-  double quad = 0, lin = 0;  // include/boxqp.h:53-55   ((0.5 x')Q) x + x.c
+template <int M, class real>
+ILQR_HD real quad_cost(const real* Q, const real* c, const real* x) {
+  real quad = 0, lin = 0;  // include/boxqp.h:53-55   ((0.5 x')Q) x + x.c
 #pragma unroll
   for (int j = 0; j < M; j++) {
-    double r = 0;
+    real r = 0;
 #pragma unroll
-    for (int i = 0; i < M; i++) r += (0.5 * x[i]) * Q[i + M * j];
+    for (int i = 0; i < M; i++) r += (real(0.5) * x[i]) * Q[i + M * j];
     quad += r * x[j];
   }
 #pragma unroll
@@ -58,11 +78,11 @@ ILQR_HD double quad_cost(const double* Q, const double* c, const double* x) {
   return quad + lin;
 }
 
-template <int M>
-ILQR_HD void matvec(const double* Q, const double* x, double* y) {
+template <int M, class real>
+ILQR_HD void matvec(const real* Q, const real* x, real* y) {
 #pragma unroll
   for (int i = 0; i < M; i++) {
-    double s = 0;
+    real s = 0;
 #pragma unroll
     for (int j = 0; j < M; j++) s += Q[i + M * j] * x[j];
     y[i] = s;
@@ -71,30 +91,30 @@ ILQR_HD void matvec(const double* Q, const double* x, double* y) {
 
 // src/boxqp.cpp:143-178.  Returns failed; x_opt/v_opt are written unless the direction is not
 // a descent direction (:151-154).
-template <int M>
-ILQR_HD bool quadclamp_line_search(const double* x0, const double* dir, const double* Q,
-                                                      const double* c, const double* lo, const double* hi,
-                                                      double* x_opt, double& v_opt) {
-  double grad[M], xr[M], xc[M];
+template <int M, class real>
+ILQR_HD bool quadclamp_line_search(const real* x0, const real* dir, const real* Q,
+                                                      const real* c, const real* lo, const real* hi,
+                                                      real* x_opt, real& v_opt) {
+  real grad[M], xr[M], xc[M];
   matvec<M>(Q, x0, grad);
-  double slope = 0;
+  real slope = 0;
 #pragma unroll
   for (int i = 0; i < M; i++) slope += dir[i] * (grad[i] + c[i]);
   if (slope >= 0) return true;
-  double step = 1;
+  real step = 1;
 #pragma unroll
   for (int i = 0; i < M; i++) xr[i] = x0[i] + step * dir[i];
   clamp_to_limits<M>(xr, lo, hi, xc);
-  double v = quad_cost<M>(Q, c, xc);
-  const double old_v = quad_cost<M>(Q, c, x0);
+  real v = quad_cost<M>(Q, c, xc);
+  const real old_v = quad_cost<M>(Q, c, x0);
   bool failed = false;
-  while ((v - old_v) / (step * slope) < kArmijo) {
-    step *= kStepDec;
+  while ((v - old_v) / (step * slope) < real(kArmijo)) {
+    step *= real(kStepDec);
 #pragma unroll
     for (int i = 0; i < M; i++) xr[i] = x0[i] + step * dir[i];
     clamp_to_limits<M>(xr, lo, hi, xc);
     v = quad_cost<M>(Q, c, xc);
-    if (step < kMinStep) {
+    if (step < real(kMinStep)) {
       failed = true;
       break;
     }
@@ -106,31 +126,31 @@ ILQR_HD bool quadclamp_line_search(const double* x0, const double* dir, const do
 }
 
 // Eigen 3.3.4 llt_inplace<Lower>::unblocked on the leading nf x nf block (ld = M).
-template <int M>
-ILQR_HD void llt_lower(int nf, double* A) {
+template <int M, class real>
+ILQR_HD void llt_lower(int nf, real* A) {
   bool stop = false;
 #pragma unroll
   for (int k = 0; k < M; k++) {
     if (k < nf && !stop) {
-      double x = A[k + M * k];
-      double sq = 0;
+      real x = A[k + M * k];
+      real sq = 0;
 #pragma unroll
       for (int j = 0; j < M; j++)
         if (j < k) sq += A[k + M * j] * A[k + M * j];
       if (k > 0) x -= sq;
-      if (x <= 0.0) {
+      if (x <= real(0)) {
         stop = true;
       } else {
-        x = sqrt(x);
+        x = sqrt_of(x);
         A[k + M * k] = x;
 #pragma unroll
         for (int i = 0; i < M; i++)
           if (i > k && i < nf) {
-            double s = 0;
+            real s = 0;
 #pragma unroll
             for (int j = 0; j < M; j++)
               if (j < k) s += A[i + M * j] * A[k + M * j];
-            double v = A[i + M * k];
+            real v = A[i + M * k];
             if (k > 0) v -= s;
             A[i + M * k] = v / x;
           }
@@ -141,20 +161,20 @@ ILQR_HD void llt_lower(int nf, double* A) {
 
 // Minv = R^-1 R^-T for the upper-triangular leading nf x nf block of R (ld = M).
 // (The reference: two PartialPivLU inverses and a product, boxqp.cpp:105-112, ilqr_core.cpp:379.)
-template <int M>
-ILQR_HD void rinv_rinvT(int nf, const double* R, double* Minv) {
-  double Ri[M * M];
+template <int M, class real>
+ILQR_HD void rinv_rinvT(int nf, const real* R, real* Minv) {
+  real Ri[M * M];
 #pragma unroll
   for (int e = 0; e < M * M; e++) Ri[e] = 0;
 #pragma unroll
   for (int j = 0; j < M; j++) {
     if (j < nf) {
-      Ri[j + M * j] = 1.0 / R[j + M * j];
+      Ri[j + M * j] = real(1) / R[j + M * j];
 #pragma unroll
       for (int ii = 0; ii < M; ii++) {
         const int i = j - 1 - ii;  // i = j-1 .. 0
         if (i >= 0) {
-          double s = 0;
+          real s = 0;
 #pragma unroll
           for (int l = 0; l < M; l++)
             if (l > i && l <= j) s += R[i + M * l] * Ri[l + M * j];
@@ -167,7 +187,7 @@ ILQR_HD void rinv_rinvT(int nf, const double* R, double* Minv) {
   for (int i = 0; i < M; i++)
 #pragma unroll
     for (int j = 0; j < M; j++) {
-      double s = 0;
+      real s = 0;
 #pragma unroll
       for (int l = 0; l < M; l++)
         if (l < nf) s += Ri[i + M * l] * Ri[j + M * l];
@@ -175,28 +195,28 @@ ILQR_HD void rinv_rinvT(int nf, const double* R, double* Minv) {
     }
 }
 
-template <int M>
+template <int M, class real = double>
 struct BoxQPResult {
   int result;
-  double x[M];
+  real x[M];
   int v_free[M];  // 0/1 mask of free dims at exit
-  double R[M * M]; // compact upper factor: leading nfR x nfR block, ld = M
+  real R[M * M]; // compact upper factor: leading nfR x nfR block, ld = M
   int nfR;
 };
 
 // src/boxqp.cpp:26-139
-template <int M>
-ILQR_HD void box_qp(const double* Q, const double* c, const double* x0, const double* lo,
-                                       const double* hi, BoxQPResult<M>& res) {
-  double x[M], grad[M], gc[M], search[M], tmp[M];
-  double clamped[M], old_clamped[M];
+template <int M, class real>
+ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo,
+                                       const real* hi, BoxQPResult<M, real>& res) {
+  real x[M], grad[M], gc[M], search[M], tmp[M];
+  real clamped[M], old_clamped[M];
   clamp_to_limits<M>(x0, lo, hi, x);  // :35
-  double val;
+  real val;
   {  // :36  x'Qx + x.c (no 1/2)
-    double quad = 0, lin = 0;
+    real quad = 0, lin = 0;
 #pragma unroll
     for (int j = 0; j < M; j++) {
-      double r = 0;
+      real r = 0;
 #pragma unroll
       for (int i = 0; i < M; i++) r += x[i] * Q[i + M * j];
       quad += r * x[j];
@@ -205,7 +225,7 @@ ILQR_HD void box_qp(const double* Q, const double* c, const double* x0, const do
     for (int i = 0; i < M; i++) lin += x[i] * c[i];
     val = quad + lin;
   }
-  double oldvalue = 0;
+  real oldvalue = 0;
   int result = 0;
   int nfR = 0;
 #pragma unroll
@@ -218,7 +238,7 @@ ILQR_HD void box_qp(const double* Q, const double* c, const double* x0, const do
   for (int e = 0; e < M * M; e++) res.R[e] = 0;
 
   for (int iter = 0; iter <= kQpMaxIter; iter++) {  // :50
-    if (iter > 0 && (oldvalue - val) < kMinRelImprove * fabs(oldvalue)) {  // :54-57
+    if (iter > 0 && (oldvalue - val) < real(kMinRelImprove) * abs_of(oldvalue)) {  // :54-57
       result = 4;
       break;
     }
@@ -228,14 +248,14 @@ ILQR_HD void box_qp(const double* Q, const double* c, const double* x0, const do
     oldvalue = val;
 
     bool all_clamped = true;
-    double dsum = 0;
+    real dsum = 0;
     int rank[M];
     int nf = 0;
 #pragma unroll
     for (int i = 0; i < M; i++) {  // :62-71
       old_clamped[i] = clamped[i];
-      const bool cl = (fabs(x[i] - lo[i]) < kClampTol && grad[i] > 0) || (fabs(x[i] - hi[i]) < kClampTol && grad[i] < 0);
-      clamped[i] = cl ? 1.0 : 0.0;
+      const bool cl = (abs_of(x[i] - lo[i]) < real(kClampTol) && grad[i] > 0) || (abs_of(x[i] - hi[i]) < real(kClampTol) && grad[i] < 0);
+      clamped[i] = cl ? real(1) : real(0);
       res.v_free[i] = cl ? 0 : 1;
       all_clamped = all_clamped && cl;
       dsum += old_clamped[i] - clamped[i];
@@ -248,7 +268,7 @@ ILQR_HD void box_qp(const double* Q, const double* c, const double* x0, const do
     }
 
     if (iter == 0 || dsum != 0) {  // :80
-      double Qf[M * M];
+      real Qf[M * M];
 #pragma unroll
       for (int e = 0; e < M * M; e++) Qf[e] = 0;
       // extract_bool_rowsandcols (eigen_helpers.h:46-61): Qf[rank[i]][rank[j]] = Q[i][j] for free i,j
@@ -256,7 +276,7 @@ ILQR_HD void box_qp(const double* Q, const double* c, const double* x0, const do
       for (int a = 0; a < M; a++)
 #pragma unroll
         for (int b = 0; b < M; b++) {
-          double v = 0;
+          real v = 0;
 #pragma unroll
           for (int i = 0; i < M; i++)
 #pragma unroll
@@ -268,15 +288,15 @@ ILQR_HD void box_qp(const double* Q, const double* c, const double* x0, const do
 #pragma unroll
       for (int a = 0; a < M; a++)
 #pragma unroll
-        for (int b = 0; b < M; b++) res.R[a + M * b] = (a <= b && b < nf) ? Qf[b + M * a] : 0.0;  // :86-88
+        for (int b = 0; b < M; b++) res.R[a + M * b] = (a <= b && b < nf) ? Qf[b + M * a] : real(0);  // :86-88
       nfR = nf;
     }
 
-    double gn2 = 0;  // :93-97
+    real gn2 = 0;  // :93-97
 #pragma unroll
     for (int i = 0; i < M; i++)
       if (res.v_free[i]) gn2 += grad[i] * grad[i];
-    if (sqrt(gn2) < kMinGrad) {
+    if (sqrt_of(gn2) < real(kMinGrad)) {
       result = 5;
       break;
     }
@@ -289,11 +309,11 @@ ILQR_HD void box_qp(const double* Q, const double* c, const double* x0, const do
     for (int i = 0; i < M; i++) gc[i] += c[i];
 
     // :103-119  search(free) = -(R^-1 R^-T) gc(free) - x(free)
-    double Minv[M * M], gfree[M], xfree[M], sfree[M];
+    real Minv[M * M], gfree[M], xfree[M], sfree[M];
     rinv_rinvT<M>(nfR, res.R, Minv);
 #pragma unroll
     for (int a = 0; a < M; a++) {
-      double g = 0, xx = 0;
+      real g = 0, xx = 0;
 #pragma unroll
       for (int i = 0; i < M; i++)
         if (res.v_free[i] && rank[i] == a) {
@@ -305,7 +325,7 @@ ILQR_HD void box_qp(const double* Q, const double* c, const double* x0, const do
     }
 #pragma unroll
     for (int a = 0; a < M; a++) {
-      double s = 0;
+      real s = 0;
 #pragma unroll
       for (int l = 0; l < M; l++)
         if (l < nfR) s += -Minv[a + M * l] * gfree[l];
@@ -313,14 +333,14 @@ ILQR_HD void box_qp(const double* Q, const double* c, const double* x0, const do
     }
 #pragma unroll
     for (int i = 0; i < M; i++) {
-      double s = 0;
+      real s = 0;
 #pragma unroll
       for (int a = 0; a < M; a++)
         if (res.v_free[i] && rank[i] == a) s = sfree[a];
       search[i] = s;
     }
 
-    double lx[M], lv = 0;
+    real lx[M], lv = 0;
     const bool failed = quadclamp_line_search<M>(x, search, Q, c, lo, hi, lx, lv);  // :121
     if (failed) {  // :122-125
       result = 2;
@@ -349,53 +369,54 @@ ILQR_HD void box_qp(const double* Q, const double* c, const double* x0, const do
 //   - grad_clamped = Q*(x*0) + c is taken as c.
 // Outputs: x (= k), free (v_free[0]), minv = (R^-1 R^-T) of the factor held at exit.
 // ------------------------------------------------------------------------------------------
-ILQR_HD int box_qp_scalar(double Q, double c, double x0, double lo, double hi, double& x_out, int& free_out,
-                          double& minv_out) {
-  double x = (x0 < lo) ? lo : x0;
+template <class real>
+ILQR_HD int box_qp_scalar(real Q, real c, real x0, real lo, real hi, real& x_out, int& free_out,
+                          real& minv_out) {
+  real x = (x0 < lo) ? lo : x0;
   x = (hi < x) ? hi : x;
-  double val = (x * Q) * x + x * c;  // boxqp.cpp:36 (no 1/2)
-  double oldvalue = 0;
-  const double minv = (Q > 0.0) ? 1.0 / Q : 1.0 / (Q * Q);
+  real val = (x * Q) * x + x * c;  // boxqp.cpp:36 (no 1/2)
+  real oldvalue = 0;
+  const real minv = (Q > real(0)) ? real(1) / Q : real(1) / (Q * Q);
   int result = 0;
   int free_ = 0;
   for (int iter = 0; iter <= kQpMaxIter; iter++) {
-    if (iter > 0 && (oldvalue - val) < kMinRelImprove * fabs(oldvalue)) {
+    if (iter > 0 && (oldvalue - val) < real(kMinRelImprove) * abs_of(oldvalue)) {
       result = 4;
       break;
     }
-    const double grad = Q * x + c;
+    const real grad = Q * x + c;
     oldvalue = val;
-    const bool cl = (fabs(x - lo) < kClampTol && grad > 0) || (fabs(x - hi) < kClampTol && grad < 0);
+    const bool cl = (abs_of(x - lo) < real(kClampTol) && grad > 0) || (abs_of(x - hi) < real(kClampTol) && grad < 0);
     if (cl) {
       free_ = 0;
       result = 6;
       break;
     }
     free_ = 1;
-    if (fabs(grad) < kMinGrad) {
+    if (abs_of(grad) < real(kMinGrad)) {
       result = 5;
       break;
     }
-    const double search = -minv * c - x;
-    const double slope = search * grad;
+    const real search = -minv * c - x;
+    const real slope = search * grad;
     if (slope >= 0) {
       result = 2;
       break;
     }
-    double step = 1;
-    double xc = x + step * search;
+    real step = 1;
+    real xc = x + step * search;
     xc = (xc < lo) ? lo : xc;
     xc = (hi < xc) ? hi : xc;
-    double v = ((0.5 * xc) * Q) * xc + xc * c;
-    const double old_v = ((0.5 * x) * Q) * x + x * c;
+    real v = ((real(0.5) * xc) * Q) * xc + xc * c;
+    const real old_v = ((real(0.5) * x) * Q) * x + x * c;
     bool failed = false;
-    while ((v - old_v) > kArmijo * (step * slope)) {
-      step *= kStepDec;
+    while ((v - old_v) > real(kArmijo) * (step * slope)) {
+      step *= real(kStepDec);
       xc = x + step * search;
       xc = (xc < lo) ? lo : xc;
       xc = (hi < xc) ? hi : xc;
-      v = ((0.5 * xc) * Q) * xc + xc * c;
-      if (step < kMinStep) {
+      v = ((real(0.5) * xc) * Q) * xc + xc * c;
+      if (step < real(kMinStep)) {
         failed = true;
         break;
       }
@@ -430,41 +451,45 @@ ILQR_HD int box_qp_scalar(double Q, double c, double x0, double lo, double hi, d
 //   qp1_continue  iterations 1, 2, ... for the QPs that leave through none of the six exits
 // box_qp_scalar_fast composes them sequentially (host tests).  qp1_finish returns -1 when the
 // QP has to go on: the caller then runs qp1_continue.
-struct QP1State {
-  double Q, c, lo, hi;
-  double x, val0, g0, minv, search, slope, old_v;
-  double x1, v1, step;
+template <class real>
+struct QP1StateT {
+  real Q, c, lo, hi;
+  real x, val0, g0, minv, search, slope, old_v;
+  real x1, v1, step;
   bool clA, exB, exC, early, ls_failed;
 };
 
-ILQR_HD double qp1_value(const QP1State& q, double xx) { return ((0.5 * xx) * q.Q) * xx + xx * q.c; }
-ILQR_HD double qp1_trial(const QP1State& q, double step) { return fmin(fmax(q.x + step * q.search, q.lo), q.hi); }
+template <class real>
+ILQR_HD real qp1_value(const QP1StateT<real>& q, real xx) { return ((real(0.5) * xx) * q.Q) * xx + xx * q.c; }
+template <class real>
+ILQR_HD real qp1_trial(const QP1StateT<real>& q, real step) { return min_of(max_of(q.x + step * q.search, q.lo), q.hi); }
 // Armijo test of boxqp.cpp:161 without the division (step*slope < 0 on this path)
-ILQR_HD bool qp1_armijo_fails(const QP1State& q, double v, double step) {
-  return (v - q.old_v) > kArmijo * (step * q.slope);
+template <class real>
+ILQR_HD bool qp1_armijo_fails(const QP1StateT<real>& q, real v, real step) {
+  return (v - q.old_v) > real(kArmijo) * (step * q.slope);
 }
 
-template <bool EVAL_UNIT = true>
-ILQR_HD void qp1_begin(double Q, double c, double x0, double lo, double hi, QP1State& q) {
+template <bool EVAL_UNIT = true, class real>
+ILQR_HD void qp1_begin(real Q, real c, real x0, real lo, real hi, QP1StateT<real>& q) {
   q.Q = Q;
   q.c = c;
   q.lo = lo;
   q.hi = hi;
-  q.x = fmin(fmax(x0, lo), hi);  // == clamp_to_limits for non-NaN input
+  q.x = min_of(max_of(x0, lo), hi);  // == clamp_to_limits for non-NaN input
   q.val0 = (q.x * Q) * q.x + q.x * c;  // boxqp.cpp:36 (no 1/2)
   q.g0 = Q * q.x + c;
-  const double den = (Q > 0.0) ? Q : Q * Q;
+  const real den = (Q > real(0)) ? Q : Q * Q;
   q.minv = recip(den);
   // (bitwise & | on purpose: no short-circuit branches in the wavefront's instruction stream)
-  q.clA = ((fabs(q.x - lo) < kClampTol) & (q.g0 > 0)) | ((fabs(q.x - hi) < kClampTol) & (q.g0 < 0));
-  q.exB = fabs(q.g0) < kMinGrad;
+  q.clA = ((abs_of(q.x - lo) < real(kClampTol)) & (q.g0 > 0)) | ((abs_of(q.x - hi) < real(kClampTol)) & (q.g0 < 0));
+  q.exB = abs_of(q.g0) < real(kMinGrad);
   q.search = -q.minv * c - q.x;
   q.slope = q.search * q.g0;
   q.exC = q.slope >= 0;
   q.early = q.clA | q.exB | q.exC;
   q.step = 1;
   if (EVAL_UNIT) {
-    q.x1 = qp1_trial(q, 1.0);
+    q.x1 = qp1_trial(q, real(1));
     q.v1 = qp1_value(q, q.x1);
   } else {
     q.x1 = q.x;
@@ -474,26 +499,28 @@ ILQR_HD void qp1_begin(double Q, double c, double x0, double lo, double hi, QP1S
   q.ls_failed = false;
 }
 
-ILQR_HD void qp1_backtrack_seq(QP1State& q) {  // boxqp.cpp:161-173
+template <class real>
+ILQR_HD void qp1_backtrack_seq(QP1StateT<real>& q) {  // boxqp.cpp:161-173
   while (!q.early && qp1_armijo_fails(q, q.v1, q.step)) {
-    q.step *= kStepDec;
+    q.step *= real(kStepDec);
     q.x1 = qp1_trial(q, q.step);
     q.v1 = qp1_value(q, q.x1);
     // A trial that lands on x itself (the step is below half an ulp of x: the search direction is
     // rounding noise) has v1 == old_v, and so has every shorter step: the reference's loop keeps
     // failing the test until step < minStep (:167-171).  Same outcome, ~90 trips earlier.
-    if (q.step < kMinStep || q.x1 == q.x) {
+    if (q.step < real(kMinStep) || q.x1 == q.x) {
       q.ls_failed = true;
       break;
     }
   }
 }
 
-ILQR_HD int qp1_finish(const QP1State& q, double& x_out, int& free_out, double& minv_out) {
-  const bool exD = (q.val0 - q.v1) < kMinRelImprove * fabs(q.val0);
-  const double g1 = q.Q * q.x1 + q.c;
-  const bool clE = ((fabs(q.x1 - q.lo) < kClampTol) & (g1 > 0)) | ((fabs(q.x1 - q.hi) < kClampTol) & (g1 < 0));
-  const bool exF = fabs(g1) < kMinGrad;
+template <class real>
+ILQR_HD int qp1_finish(const QP1StateT<real>& q, real& x_out, int& free_out, real& minv_out) {
+  const bool exD = (q.val0 - q.v1) < real(kMinRelImprove) * abs_of(q.val0);
+  const real g1 = q.Q * q.x1 + q.c;
+  const bool clE = ((abs_of(q.x1 - q.lo) < real(kClampTol)) & (g1 > 0)) | ((abs_of(q.x1 - q.hi) < real(kClampTol)) & (g1 < 0));
+  const bool exF = abs_of(g1) < real(kMinGrad);
   minv_out = q.minv;
   // the reference's order of tests, as selects (no branches)
   const bool stay = q.clA | q.exB | q.exC | q.ls_failed;  // x is not updated
@@ -514,25 +541,25 @@ ILQR_HD int qp1_finish(const QP1State& q, double& x_out, int& free_out, double& 
 // the bound: the Newton target stays outside, so they creep towards the bound over several
 // iterations.  Restarting the literal loop from iteration 0 for them (as the first version did)
 // made their wavefront the slowest of the launch once a solve had run ~20 iterations.
-template <class LineSearch>
-ILQR_HD int qp1_continue(QP1State& q, LineSearch line_search, double& x_out, int& free_out) {
-  double x = q.x1, val = q.v1, oldvalue = q.val0;
+template <class real, class LineSearch>
+ILQR_HD int qp1_continue(QP1StateT<real>& q, LineSearch line_search, real& x_out, int& free_out) {
+  real x = q.x1, val = q.v1, oldvalue = q.val0;
   int result = 0, free_ = 1;
   for (int iter = 1; iter <= kQpMaxIter; iter++) {
-    if ((oldvalue - val) < kMinRelImprove * fabs(oldvalue)) {  // boxqp.cpp:54-57 (iter > 0 here)
+    if ((oldvalue - val) < real(kMinRelImprove) * abs_of(oldvalue)) {  // boxqp.cpp:54-57 (iter > 0 here)
       result = 4;
       break;
     }
-    const double grad = q.Q * x + q.c;
+    const real grad = q.Q * x + q.c;
     oldvalue = val;
-    const bool cl = ((fabs(x - q.lo) < kClampTol) & (grad > 0)) | ((fabs(x - q.hi) < kClampTol) & (grad < 0));
+    const bool cl = ((abs_of(x - q.lo) < real(kClampTol)) & (grad > 0)) | ((abs_of(x - q.hi) < real(kClampTol)) & (grad < 0));
     if (cl) {  // :74-77
       free_ = 0;
       result = 6;
       break;
     }
     free_ = 1;
-    if (fabs(grad) < kMinGrad) {  // :93-97
+    if (abs_of(grad) < real(kMinGrad)) {  // :93-97
       result = 5;
       break;
     }
@@ -560,31 +587,34 @@ ILQR_HD int qp1_continue(QP1State& q, LineSearch line_search, double& x_out, int
   free_out = free_;
   return result;
 }
-ILQR_HD void qp1_line_search_seq(QP1State& q) {
+template <class real>
+ILQR_HD void qp1_line_search_seq(QP1StateT<real>& q) {
   q.step = 1;
-  q.x1 = qp1_trial(q, 1.0);
+  q.x1 = qp1_trial(q, real(1));
   q.v1 = qp1_value(q, q.x1);
   qp1_backtrack_seq(q);
 }
 
-ILQR_HD int box_qp_scalar_fast(double Q, double c, double x0, double lo, double hi, double& x_out, int& free_out,
-                               double& minv_out) {
-  QP1State q;
+template <class real>
+ILQR_HD int box_qp_scalar_fast(real Q, real c, real x0, real lo, real hi, real& x_out, int& free_out,
+                               real& minv_out) {
+  QP1StateT<real> q;
   qp1_begin(Q, c, x0, lo, hi, q);
   qp1_backtrack_seq(q);
   int result = qp1_finish(q, x_out, free_out, minv_out);
-  if (result < 0) result = qp1_continue(q, [](QP1State& s) { qp1_line_search_seq(s); }, x_out, free_out);
+  if (result < 0) result = qp1_continue(q, [](QP1StateT<real>& s) { qp1_line_search_seq(s); }, x_out, free_out);
   return result;
 }
 
 // step sizes of the backtracking loop, exactly as it produces them: s[0] = 1, s[k+1] = s[k]*0.6
-struct StepTable {
-  double s[104];
-  constexpr StepTable() : s() {
-    double v = 1.0;
+template <class real>
+struct StepTableT {
+  real s[104];
+  constexpr StepTableT() : s() {
+    real v = 1;
     for (int k = 0; k < 104; k++) {
       s[k] = v;
-      v = v * kStepDec;
+      v = v * real(kStepDec);
     }
   }
 };

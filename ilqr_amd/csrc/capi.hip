@@ -53,12 +53,20 @@ struct StageTimer {
 
 struct ilqr_batch {
   int model, nx, nu, T, B, Bp, ntiles, device, flags;
+  int dtype = ILQR_DTYPE_F64;   // arithmetic of the nx = 4 device models (ilqr_desc.dtype)
   double dt;
   ilqr_params params;
+  // fp64 handle: its models.  fp32 handle: the double-precision TWINS the finite differences are taken in
+  // (kernels.hpp, derivatives_of_knot), built from the float models' own parameter values
   AcrobotModel acrobot;
   DoubleIntegratorModel dint;
+  AcrobotModelT<float> acrobot_f;          // fp32 handle: what the rollouts integrate
+  DoubleIntegratorModelT<float> dint_f;
   LqModel lq;                   // ILQR_MODEL_LQ: padded matrices on the device
+  // v is the view every entry point addresses arrays through; for an fp32 handle its trajectory pointers hold
+  // the addresses of FLOAT arrays (never dereferenced as double: kernels get vf, the same addresses typed float*)
   BatchView v;
+  BatchViewT<float> vf;
   SolverParams sp;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -87,6 +95,41 @@ struct ilqr_batch {
 };
 
 static int rec_of(const ilqr_batch* h) { return rec_size(h->nx, h->nu); }
+static size_t elem_size(const ilqr_batch* h) { return h->dtype == ILQR_DTYPE_F32 ? sizeof(float) : sizeof(double); }
+// the float view of an fp32 handle: same addresses as v, typed
+static void sync_float_view(ilqr_batch* h) {
+  const BatchView& v = h->v;
+  BatchViewT<float>& f = h->vf;
+  f.B = v.B; f.Bp = v.Bp; f.ntiles = v.ntiles; f.T = v.T; f.dt = v.dt;
+  f.x0 = (float*)v.x0; f.xs = (float*)v.xs; f.us = (float*)v.us; f.kff = (float*)v.kff; f.Kfb = (float*)v.Kfb;
+  f.D = (float*)v.D; f.cand_u = (float*)v.cand_u; f.cand_x = (float*)v.cand_x; f.nch = v.nch;
+  f.cost_c = v.cost_c; f.cost = v.cost; f.lambda = v.lambda; f.dlambda = v.dlambda; f.dV = v.dV; f.gnorm = v.gnorm;
+  f.status = v.status; f.iters = v.iters; f.flg_change = v.flg_change; f.alpha_idx = v.alpha_idx; f.diverge = v.diverge;
+  f.backpass_done = v.backpass_done; f.n_running = v.n_running; f.dbg = v.dbg; f.analytic = v.analytic;
+}
+// f(view, model, model the finite differences are taken in) for the handle's device model and arithmetic
+template <class F>
+static int with_model(ilqr_batch* h, F&& f) {
+  if (h->dtype == ILQR_DTYPE_F32) {
+    switch (h->model) {
+      case ILQR_MODEL_ACROBOT: return f(h->vf, h->acrobot_f, h->acrobot);
+      case ILQR_MODEL_DOUBLE_INTEGRATOR: return f(h->vf, h->dint_f, h->dint);
+      default: break;
+    }
+  } else {
+    switch (h->model) {
+      case ILQR_MODEL_ACROBOT: return f(h->v, h->acrobot, h->acrobot);
+      case ILQR_MODEL_DOUBLE_INTEGRATOR: return f(h->v, h->dint, h->dint);
+      default: break;
+    }
+  }
+  return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device kernels of this kind", h->model);
+}
+// f(view) for the handle's arithmetic
+template <class F>
+static int with_view(ilqr_batch* h, F&& f) {
+  return h->dtype == ILQR_DTYPE_F32 ? f(h->vf) : f(h->v);
+}
 // ILQR_MODEL_HOST: the model exists only as host code; nothing but the backward pass runs here
 static bool host_model(const ilqr_batch* h) { return h->model == ILQR_MODEL_HOST; }
 static int no_device_model();
@@ -102,6 +145,17 @@ static int dev_alloc(ilqr_batch* h, T** p, size_t n) {
   HIPCHK(hipMemsetAsync(q, 0, std::max<size_t>(n, 1) * sizeof(T), h->stream));
   h->allocs.push_back(q);
   *p = (T*)q;
+  return 0;
+}
+
+// trajectory arrays: n elements of the handle's arithmetic (the pointer keeps the view's nominal double* type)
+static int dev_alloc_real(ilqr_batch* h, double** p, size_t n) {
+  void* q = nullptr;
+  const size_t bytes = std::max<size_t>(n, 1) * elem_size(h);
+  HIPCHK(hipMalloc(&q, bytes));
+  HIPCHK(hipMemsetAsync(q, 0, bytes, h->stream));
+  h->allocs.push_back(q);
+  *p = (double*)q;
   return 0;
 }
 
@@ -176,7 +230,7 @@ static int ensure_staging(ilqr_batch* h, size_t elems) {
   return 0;
 }
 // canonical host [B][S][E] -> tiled device  (AoS handles: the canonical layout IS the device layout)
-static int upload(ilqr_batch* h, const double* src, double* dst_tiled, int S, int E) {
+static int upload(ilqr_batch* h, const double* src, void* dst_tiled, int S, int E) {
   const size_t n = (size_t)h->B * S * E;
   if (h->aos) {
     HIPCHK(hipMemcpyAsync(dst_tiled, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -186,12 +240,15 @@ static int upload(ilqr_batch* h, const double* src, double* dst_tiled, int S, in
   if (int rc = ensure_staging(h, n)) return rc;
   HIPCHK(hipMemcpyAsync(h->staging, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   const size_t nt = (size_t)h->ntiles * S * E * TW;
-  hipLaunchKernelGGL(k_pack, dim3(grid_for(nt, 256)), dim3(256), 0, h->stream, h->staging, dst_tiled, h->B, h->ntiles, S, E);
+  if (h->dtype == ILQR_DTYPE_F32)
+    hipLaunchKernelGGL(k_pack<float>, dim3(grid_for(nt, 256)), dim3(256), 0, h->stream, h->staging, (float*)dst_tiled, h->B, h->ntiles, S, E);
+  else
+    hipLaunchKernelGGL(k_pack<double>, dim3(grid_for(nt, 256)), dim3(256), 0, h->stream, h->staging, (double*)dst_tiled, h->B, h->ntiles, S, E);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));  // staging is reused by the next call
   return 0;
 }
-static int download(ilqr_batch* h, const double* src_tiled, double* dst, int S, int E) {
+static int download(ilqr_batch* h, const void* src_tiled, double* dst, int S, int E) {
   const size_t n = (size_t)h->B * S * E;
   if (h->aos) {
     HIPCHK(hipMemcpyAsync(dst, src_tiled, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -199,7 +256,10 @@ static int download(ilqr_batch* h, const double* src_tiled, double* dst, int S, 
     return 0;
   }
   if (int rc = ensure_staging(h, n)) return rc;
-  hipLaunchKernelGGL(k_unpack, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, src_tiled, h->staging, h->B, S, E);
+  if (h->dtype == ILQR_DTYPE_F32)
+    hipLaunchKernelGGL(k_unpack<float>, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, (const float*)src_tiled, h->staging, h->B, S, E);
+  else
+    hipLaunchKernelGGL(k_unpack<double>, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, (const double*)src_tiled, h->staging, h->B, S, E);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(dst, h->staging, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -228,8 +288,10 @@ static int upload_rec(ilqr_batch* h, const double* src, int off, int E) {
     return 0;
   }
   const size_t nt = (size_t)h->ntiles * S * E * TW;
-  hipLaunchKernelGGL(k_pack_rec, dim3(grid_for(nt, 256)), dim3(256), 0, h->stream, h->staging, h->v.D, h->B, h->ntiles, S,
-                     rec_of(h), off, E);
+  if (h->dtype == ILQR_DTYPE_F32)
+    hipLaunchKernelGGL(k_pack_rec<float>, dim3(grid_for(nt, 256)), dim3(256), 0, h->stream, h->staging, h->vf.D, h->B, h->ntiles, S, rec_of(h), off, E);
+  else
+    hipLaunchKernelGGL(k_pack_rec<double>, dim3(grid_for(nt, 256)), dim3(256), 0, h->stream, h->staging, h->v.D, h->B, h->ntiles, S, rec_of(h), off, E);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
@@ -245,7 +307,10 @@ static int download_rec(ilqr_batch* h, double* dst, int off, int E) {
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
   }
-  hipLaunchKernelGGL(k_unpack_rec, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, h->v.D, h->staging, h->B, S, rec_of(h), off, E);
+  if (h->dtype == ILQR_DTYPE_F32)
+    hipLaunchKernelGGL(k_unpack_rec<float>, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, h->vf.D, h->staging, h->B, S, rec_of(h), off, E);
+  else
+    hipLaunchKernelGGL(k_unpack_rec<double>, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, h->v.D, h->staging, h->B, S, rec_of(h), off, E);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(dst, h->staging, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -269,22 +334,22 @@ static int scalars_to_dev(ilqr_batch* h, const T* host, T* dev) {
 // kernel launchers (dispatch on the device model)
 // ------------------------------------------------------------------------------------------
 // cand = true: controls + checkpoint states go to the candidate buffers; false: straight into xs/us (init)
-template <class M>
-static int launch_rollout_t(ilqr_batch* h, const M& m, bool gains, bool cand, const AlphaSet& al, int n_alpha,
+template <class V, class M>
+static int launch_rollout_t(ilqr_batch* h, const V& v, const M& m, bool gains, bool cand, const AlphaSet& al, int n_alpha,
                             double* cost_out, int mode, bool with_accept) {
   const int aw = (n_alpha + 3) / 4;  // wavefronts per tile: 4 alphas each
   dim3 grid(h->ntiles), block(64 * aw);
   const bool deep = h->ntiles <= h->num_cus;  // one block per CU: deep prefetch (see k_rollout)
   if (gains && cand && with_accept && deep)
-    hipLaunchKernelGGL((k_rollout<M, true, true, 8, true>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode, h->sp, h->commit_idx);
+    hipLaunchKernelGGL((k_rollout<M, true, true, 8, true>), grid, block, 0, h->stream, v, m, al, n_alpha, cost_out, mode, h->sp, h->commit_idx);
   else if (gains && cand && with_accept)
-    hipLaunchKernelGGL((k_rollout<M, true, true, 4, true>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode, h->sp, h->commit_idx);
+    hipLaunchKernelGGL((k_rollout<M, true, true, 4, true>), grid, block, 0, h->stream, v, m, al, n_alpha, cost_out, mode, h->sp, h->commit_idx);
   else if (gains && cand && deep)
-    hipLaunchKernelGGL((k_rollout<M, true, true, 8>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode, h->sp, nullptr);
+    hipLaunchKernelGGL((k_rollout<M, true, true, 8>), grid, block, 0, h->stream, v, m, al, n_alpha, cost_out, mode, h->sp, nullptr);
   else if (gains && cand)
-    hipLaunchKernelGGL((k_rollout<M, true, true, 4>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode, h->sp, nullptr);
+    hipLaunchKernelGGL((k_rollout<M, true, true, 4>), grid, block, 0, h->stream, v, m, al, n_alpha, cost_out, mode, h->sp, nullptr);
   else if (!gains && !cand)
-    hipLaunchKernelGGL((k_rollout<M, false, false>), grid, block, 0, h->stream, h->v, m, al, n_alpha, cost_out, mode, h->sp, nullptr);
+    hipLaunchKernelGGL((k_rollout<M, false, false>), grid, block, 0, h->stream, v, m, al, n_alpha, cost_out, mode, h->sp, nullptr);
   else
     return fail(ILQR_ERR_INVALID, "unsupported rollout variant");
   HIPCHK(hipGetLastError());
@@ -336,11 +401,7 @@ static int launch_rollout(ilqr_batch* h, bool gains, bool cand, const AlphaSet& 
     if (rc) return rc;
     return timer_end(h, ILQR_STAGE_ROLLOUT, ev);
   }
-  switch (h->model) {
-    case ILQR_MODEL_ACROBOT: rc = launch_rollout_t(h, h->acrobot, gains, cand, al, n_alpha, cost_out, mode, with_accept); break;
-    case ILQR_MODEL_DOUBLE_INTEGRATOR: rc = launch_rollout_t(h, h->dint, gains, cand, al, n_alpha, cost_out, mode, with_accept); break;
-    default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device rollout", h->model);
-  }
+  rc = with_model(h, [&](auto& v, auto& m, auto&) { return launch_rollout_t(h, v, m, gains, cand, al, n_alpha, cost_out, mode, with_accept); });
   if (rc) return rc;
   return timer_end(h, ILQR_STAGE_ROLLOUT, ev);
 }
@@ -350,11 +411,11 @@ static int launch_commit(ilqr_batch* h) {
   if (h->model == ILQR_MODEL_LQ)  // no stored candidates on the generic path: re-run the accepted rollout in place
     return launch_rollout_g(h, h->lq, RG_COMMIT, line_search_alphas(), h->v.cost, 0, 0);
   dim3 grid((h->T + 1 + 15) / 16, h->ntiles), block(256);
-  switch (h->model) {
-    case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_commit<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, h->commit_idx); break;
-    case ILQR_MODEL_DOUBLE_INTEGRATOR: hipLaunchKernelGGL((k_commit<DoubleIntegratorModel>), grid, block, 0, h->stream, h->v, h->dint, h->commit_idx); break;
-    default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device rollout", h->model);
-  }
+  if (int rc = with_model(h, [&](auto& v, auto& m, auto&) {
+        hipLaunchKernelGGL((k_commit<std::decay_t<decltype(m)>>), grid, block, 0, h->stream, v, m, h->commit_idx);
+        return 0;
+      }))
+    return rc;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -400,11 +461,11 @@ static int launch_derivatives(ilqr_batch* h, int force) {
     HIPCHK(hipGetLastError());
     return timer_end(h, ILQR_STAGE_DERIVATIVES, ev);
   }
-  switch (h->model) {
-    case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_derivatives<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, force, ci); break;
-    case ILQR_MODEL_DOUBLE_INTEGRATOR: hipLaunchKernelGGL((k_derivatives<DoubleIntegratorModel>), grid, block, 0, h->stream, h->v, h->dint, force, ci); break;
-    default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device derivatives", h->model);
-  }
+  if (int rc = with_model(h, [&](auto& v, auto& m, auto& fdm) {
+        hipLaunchKernelGGL((k_derivatives<std::decay_t<decltype(m)>, std::decay_t<decltype(fdm)>>), grid, block, 0, h->stream, v, m, fdm, force, ci);
+        return 0;
+      }))
+    return rc;
   HIPCHK(hipGetLastError());
   // the kernel above performed the copy on the way; commit_idx is rewritten for every trajectory
   // by the next k_accept and only read while commit_pending is set, so it needs no reset here
@@ -426,18 +487,18 @@ static int launch_backward(ilqr_batch* h, int mode) {
                        h->records_partial ? h->const_rec : nullptr);
   } else if (use_quad_backward(h)) {
     dim3 grid(h->ntiles), block(64);  // one wavefront = one tile of 16 trajectories x 4 lanes
-    switch (h->model) {
-      case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_backward_q<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, h->sp, mode); break;
-      case ILQR_MODEL_DOUBLE_INTEGRATOR: hipLaunchKernelGGL((k_backward_q<DoubleIntegratorModel>), grid, block, 0, h->stream, h->v, h->dint, h->sp, mode); break;
-      default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device backward pass yet", h->model);
-    }
+    if (int rc = with_model(h, [&](auto& v, auto& m, auto&) {
+          hipLaunchKernelGGL((k_backward_q<std::decay_t<decltype(m)>>), grid, block, 0, h->stream, v, m, h->sp, mode);
+          return 0;
+        }))
+      return rc;
   } else {
     dim3 grid(h->Bp / 64), block(64);
-    switch (h->model) {
-      case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_backward_t<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, h->sp, mode); break;
-      case ILQR_MODEL_DOUBLE_INTEGRATOR: hipLaunchKernelGGL((k_backward_t<DoubleIntegratorModel>), grid, block, 0, h->stream, h->v, h->dint, h->sp, mode); break;
-      default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device backward pass yet", h->model);
-    }
+    if (int rc = with_model(h, [&](auto& v, auto& m, auto&) {
+          hipLaunchKernelGGL((k_backward_t<std::decay_t<decltype(m)>>), grid, block, 0, h->stream, v, m, h->sp, mode);
+          return 0;
+        }))
+      return rc;
   }
   HIPCHK(hipGetLastError());
   return timer_end(h, ILQR_STAGE_BACKWARD, ev);
@@ -459,23 +520,23 @@ static int fused_variant(const ilqr_batch* h) {  // 0: two kernels, 1: one block
 }
 static bool use_fused_sweep(const ilqr_batch* h) { return fused_variant(h) != 0; }
 constexpr int kRingKbTwoBlocks = 60;
-template <class M>
-static void launch_sweep_backward_t(ilqr_batch* h, const M& m, int variant, int mode, int force, const int* ci) {
+template <class V, class M, class MFD>
+static void launch_sweep_backward_t(ilqr_batch* h, const V& v, const M& m, const MFD& fdm, int variant, int mode, int force, const int* ci) {
   if (variant == 2)
-    hipLaunchKernelGGL((k_sweep_backward<M, 1, kRingKbTwoBlocks>), dim3(h->ntiles), dim3(64 * 2), 0, h->stream, h->v, m, h->sp, mode, force, ci);
+    hipLaunchKernelGGL((k_sweep_backward<M, 1, kRingKbTwoBlocks, MFD>), dim3(h->ntiles), dim3(64 * 2), 0, h->stream, v, m, fdm, h->sp, mode, force, ci);
   else
-    hipLaunchKernelGGL((k_sweep_backward<M>), dim3(h->ntiles), dim3(64 * (1 + kProducers)), 0, h->stream, h->v, m, h->sp, mode, force, ci);
+    hipLaunchKernelGGL((k_sweep_backward<M, kProducers, ILQR_RING_KB, MFD>), dim3(h->ntiles), dim3(64 * (1 + kProducers)), 0, h->stream, v, m, fdm, h->sp, mode, force, ci);
 }
 static int launch_sweep_backward(ilqr_batch* h, int mode, int force) {
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_BACKWARD, &ev)) return rc;
   const int variant = fused_variant(h);
   const int* ci = h->commit_pending ? h->commit_idx : nullptr;
-  switch (h->model) {
-    case ILQR_MODEL_ACROBOT: launch_sweep_backward_t(h, h->acrobot, variant, mode, force, ci); break;
-    case ILQR_MODEL_DOUBLE_INTEGRATOR: launch_sweep_backward_t(h, h->dint, variant, mode, force, ci); break;
-    default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device backward pass yet", h->model);
-  }
+  if (int rc = with_model(h, [&](auto& v, auto& m, auto& fdm) {
+        launch_sweep_backward_t(h, v, m, fdm, variant, mode, force, ci);
+        return 0;
+      }))
+    return rc;
   HIPCHK(hipGetLastError());
   h->commit_pending = false;  // the producers performed the copy on the way (see launch_derivatives)
   return timer_end(h, ILQR_STAGE_BACKWARD, ev);
@@ -486,7 +547,7 @@ static int launch_sweep_backward(ilqr_batch* h, int mode, int force) {
 static int launch_accept(ilqr_batch* h) {
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_ACCEPT, &ev)) return rc;
-  hipLaunchKernelGGL(k_accept, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->sp, h->commit_idx);
+  hipLaunchKernelGGL(k_accept<double>, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->sp, h->commit_idx);  // (scalars only)
   HIPCHK(hipGetLastError());
   h->commit_pending = true;
   return timer_end(h, ILQR_STAGE_ACCEPT, ev);
@@ -605,6 +666,10 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     h->own_stream = true;
   }
   h->model = d->model;
+  h->dtype = d->dtype;
+  if (d->dtype != ILQR_DTYPE_F64 && d->dtype != ILQR_DTYPE_F32) return fail(ILQR_ERR_INVALID, "dtype %d: ILQR_DTYPE_F64 or ILQR_DTYPE_F32", d->dtype);
+  if (d->dtype == ILQR_DTYPE_F32 && d->model != ILQR_MODEL_ACROBOT && d->model != ILQR_MODEL_DOUBLE_INTEGRATOR)
+    return fail(ILQR_ERR_UNSUPPORTED, "fp32 is available for the nx = 4 device models (acrobot, double integrator); the generic nx <= 32 path is fp64");
   h->nx = d->nx;
   h->nu = d->nu;
   h->T = d->T;
@@ -626,6 +691,12 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     m.goal[1] = m.goal[2] = m.goal[3] = 0;
     m.u_min[0] = d->u_min ? d->u_min[0] : -5.0;
     m.u_max[0] = d->u_max ? d->u_max[0] : 5.0;
+    if (h->dtype == ILQR_DTYPE_F32) {  // the float model, and its parameters' float values in the double twin
+      AcrobotModelT<float>& f = h->acrobot_f;
+      for (int i = 0; i < 4; i++) m.goal[i] = (double)(f.goal[i] = (float)m.goal[i]);
+      m.u_min[0] = (double)(f.u_min[0] = (float)m.u_min[0]);
+      m.u_max[0] = (double)(f.u_max[0] = (float)m.u_max[0]);
+    }
   } else if (d->model == ILQR_MODEL_DOUBLE_INTEGRATOR) {
     REQUIRE(d->nx == 4 && d->nu == 2, "double integrator is nx=4 nu=2 (include/double_integrator.h:16-17), got %d/%d", d->nx, d->nu);
     DoubleIntegratorModel& m = h->dint;
@@ -634,6 +705,14 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     for (int j = 0; j < 2; j++) {
       m.u_min[j] = d->u_min ? d->u_min[j] : -0.5;
       m.u_max[j] = d->u_max ? d->u_max[j] : 0.5;
+    }
+    if (h->dtype == ILQR_DTYPE_F32) {
+      DoubleIntegratorModelT<float>& f = h->dint_f;
+      for (int i = 0; i < 4; i++) m.goal[i] = (double)(f.goal[i] = (float)m.goal[i]);
+      for (int j = 0; j < 2; j++) {
+        m.u_min[j] = (double)(f.u_min[j] = (float)m.u_min[j]);
+        m.u_max[j] = (double)(f.u_max[j] = (float)m.u_max[j]);
+      }
     }
   } else if (d->model == ILQR_MODEL_HOST || d->model == ILQR_MODEL_LQ) {
     // Generic dimensions: trajectory-contiguous layout, one wavefront per trajectory in the backward
@@ -709,15 +788,15 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
       if (hipMemcpyAsync(h->d_umax, d->u_max, nu * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = 1;
     }
   } else {
-  rc |= dev_alloc(h, &v.x0, nt * nx * TW);
-  rc |= dev_alloc(h, &v.xs, nt * T1 * nx * TW);
-  rc |= dev_alloc(h, &v.us, nt * T * nu * TW);
-  rc |= dev_alloc(h, &v.kff, nt * T * nu * TW);
-  rc |= dev_alloc(h, &v.Kfb, nt * T * nu * nx * TW);
-  rc |= dev_alloc(h, &v.D, nt * T1 * REC * TW);
+  rc |= dev_alloc_real(h, &v.x0, nt * nx * TW);
+  rc |= dev_alloc_real(h, &v.xs, nt * T1 * nx * TW);
+  rc |= dev_alloc_real(h, &v.us, nt * T * nu * TW);
+  rc |= dev_alloc_real(h, &v.kff, nt * T * nu * TW);
+  rc |= dev_alloc_real(h, &v.Kfb, nt * T * nu * nx * TW);
+  rc |= dev_alloc_real(h, &v.D, nt * T1 * REC * TW);
   v.nch = h->T / CT + 1;
-  rc |= dev_alloc(h, &v.cand_u, (size_t)NALPHA * nt * T * nu * TW);
-  rc |= dev_alloc(h, &v.cand_x, (size_t)NALPHA * nt * v.nch * nx * TW);
+  rc |= dev_alloc_real(h, &v.cand_u, (size_t)NALPHA * nt * T * nu * TW);
+  rc |= dev_alloc_real(h, &v.cand_x, (size_t)NALPHA * nt * v.nch * nx * TW);
   rc |= dev_alloc(h, &v.cost_c, (size_t)NALPHA * Bp);
   }
   rc |= dev_alloc(h, &v.cost, Bp);
@@ -736,6 +815,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   if (!rc && hipMemsetAsync(h->commit_idx, 0xFF, Bp * sizeof(int), h->stream) != hipSuccess) rc = 1;
   rc |= dev_alloc(h, &v.dbg, 1024);
   if (rc) return ILQR_ERR_HIP;
+  sync_float_view(h);
 
   h->sp.max_iter = h->params.max_iter;
   h->sp.tol_fun = h->params.tol_fun;
@@ -746,7 +826,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   h->sp.z_min = h->params.z_min;
   h->sp.fixed_work = (h->flags & ILQR_FLAG_FIXED_WORK) ? 1 : 0;
 
-  hipLaunchKernelGGL(k_reset_state, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
+  hipLaunchKernelGGL(k_reset_state<double>, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
                      h->params.dlambda_init);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -806,11 +886,11 @@ int ilqr_init_traj(ilqr_batch* h, const double* x0, const double* u0, double* co
   if (int rc = upload(h, u0, h->v.us, h->T, h->nu)) return rc;  // us = u_0, ilqr_core.cpp:17
   // ilqr_core.cpp:23-48: zero derivative/gain arrays; statics lambda/dlambda as for a fresh process
   const size_t T = h->T, T1 = h->T + 1;
-  HIPCHK(hipMemsetAsync(h->v.D, 0, dev_elems(h, T1, rec_of(h)) * sizeof(double), h->stream));
-  HIPCHK(hipMemsetAsync(h->v.kff, 0, dev_elems(h, T, h->nu) * sizeof(double), h->stream));
-  HIPCHK(hipMemsetAsync(h->v.Kfb, 0, dev_elems(h, T, h->nu * h->nx) * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(h->v.D, 0, dev_elems(h, T1, rec_of(h)) * elem_size(h), h->stream));
+  HIPCHK(hipMemsetAsync(h->v.kff, 0, dev_elems(h, T, h->nu) * elem_size(h), h->stream));
+  HIPCHK(hipMemsetAsync(h->v.Kfb, 0, dev_elems(h, T, h->nu * h->nx) * elem_size(h), h->stream));
   if (int rc = forget_pending(h)) return rc;
-  hipLaunchKernelGGL(k_reset_state, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
+  hipLaunchKernelGGL(k_reset_state<double>, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
                      h->params.dlambda_init);
   HIPCHK(hipGetLastError());
   // ilqr_core.cpp:20: open-loop rollout (K is empty); writes xs, us, cost in place
@@ -904,7 +984,7 @@ int ilqr_warm_start(ilqr_batch* h, const double* x0) {
   std::vector<double> lam(h->B), dlam(h->B);
   if (int rc = scalars_to_host(h, h->v.lambda, lam.data())) return rc;
   if (int rc = scalars_to_host(h, h->v.dlambda, dlam.data())) return rc;
-  hipLaunchKernelGGL(k_reset_state, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, 1.0, 1.0);
+  hipLaunchKernelGGL(k_reset_state<double>, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, 1.0, 1.0);
   HIPCHK(hipGetLastError());
   if (int rc = scalars_to_dev(h, lam.data(), h->v.lambda)) return rc;
   if (int rc = scalars_to_dev(h, dlam.data(), h->v.dlambda)) return rc;
@@ -996,12 +1076,12 @@ int ilqr_reset_state(ilqr_batch* h, int warm) {
     if (int rc = scalars_to_host(h, h->v.dlambda, dlam.data())) return rc;
   } else {
     const size_t T = h->T, T1 = h->T + 1;
-    HIPCHK(hipMemsetAsync(h->v.D, 0, dev_elems(h, T1, rec_of(h)) * sizeof(double), h->stream));
-    HIPCHK(hipMemsetAsync(h->v.kff, 0, dev_elems(h, T, h->nu) * sizeof(double), h->stream));
-    HIPCHK(hipMemsetAsync(h->v.Kfb, 0, dev_elems(h, T, h->nu * h->nx) * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->v.D, 0, dev_elems(h, T1, rec_of(h)) * elem_size(h), h->stream));
+    HIPCHK(hipMemsetAsync(h->v.kff, 0, dev_elems(h, T, h->nu) * elem_size(h), h->stream));
+    HIPCHK(hipMemsetAsync(h->v.Kfb, 0, dev_elems(h, T, h->nu * h->nx) * elem_size(h), h->stream));
     if (int rc = forget_pending(h)) return rc;
   }
-  hipLaunchKernelGGL(k_reset_state, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
+  hipLaunchKernelGGL(k_reset_state<double>, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
                      h->params.dlambda_init);
   HIPCHK(hipGetLastError());
   if (warm) {
@@ -1121,11 +1201,11 @@ int ilqr_get_candidate(ilqr_batch* h, int a, double* xs, double* us) {
   double* dxs = h->staging;
   double* dus = h->staging + nx_el;
   const dim3 grid(grid_for((size_t)h->B * (h->T + 1), 256)), block(256);
-  switch (h->model) {
-    case ILQR_MODEL_ACROBOT: hipLaunchKernelGGL((k_unpack_cand<AcrobotModel>), grid, block, 0, h->stream, h->v, h->acrobot, a, dxs, dus); break;
-    case ILQR_MODEL_DOUBLE_INTEGRATOR: hipLaunchKernelGGL((k_unpack_cand<DoubleIntegratorModel>), grid, block, 0, h->stream, h->v, h->dint, a, dxs, dus); break;
-    default: return fail(ILQR_ERR_UNSUPPORTED, "model %d has no device rollout", h->model);
-  }
+  if (int rc = with_model(h, [&](auto& v, auto& m, auto&) {
+        hipLaunchKernelGGL((k_unpack_cand<std::decay_t<decltype(m)>>), grid, block, 0, h->stream, v, m, a, dxs, dus);
+        return 0;
+      }))
+    return rc;
   HIPCHK(hipGetLastError());
   if (xs) HIPCHK(hipMemcpyAsync(xs, dxs, nx_el * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (us) HIPCHK(hipMemcpyAsync(us, dus, nu_el * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -91,18 +91,24 @@ struct SolverParams {
 };
 
 // Raw views of a batch's device state, passed by value to kernels.
-struct BatchView {
+// `real` is the handle's arithmetic (ilqr_desc.dtype): double -- the reference's -- or float (BASELINE.json
+// configs[3]).  Everything per knot (states, controls, gains, derivative records, line-search candidates)
+// is stored and computed in `real`; the per-trajectory scalars that are accumulated over the horizon or
+// carried across iterations (costs, dV, gradient norm, lambda / dlambda) stay double in both modes -- a
+// float sum of 499 stage costs would not resolve the cost CHANGES the line search and tolFun test on.
+template <class real>
+struct BatchViewT {
   int B, Bp, ntiles, T;
   double dt;
   // trajectories
-  double* x0;   // [tile][1][nx][TW]
-  double* xs;   // [tile][T+1][nx][TW]
-  double* us;   // [tile][T][nu][TW]
-  double* kff;  // [tile][T][nu][TW]
-  double* Kfb;  // [tile][T][nu*nx][TW]
-  double* D;    // derivative records, pair-interleaved [tile][T+1][REC/2][TW][2]  (didx)
-  double* cand_u; // line-search candidates: every control      [NALPHA][tile][T][nu][TW]
-  double* cand_x; //                         checkpoint states  [NALPHA][tile][NCH][nx][TW]
+  real* x0;   // [tile][1][nx][TW]
+  real* xs;   // [tile][T+1][nx][TW]
+  real* us;   // [tile][T][nu][TW]
+  real* kff;  // [tile][T][nu][TW]
+  real* Kfb;  // [tile][T][nu*nx][TW]
+  real* D;    // derivative records, pair-interleaved [tile][T+1][REC/2][TW][2]  (didx)
+  real* cand_u; // line-search candidates: every control      [NALPHA][tile][T][nu][TW]
+  real* cand_x; //                         checkpoint states  [NALPHA][tile][NCH][nx][TW]
   int nch;        // NCH = T/CT + 1
   double* cost_c; // [NALPHA][Bp]
   // per-trajectory scalars [Bp]
@@ -121,5 +127,6 @@ struct BatchView {
   long long* dbg;     // phase-timing scratch (only used by -DILQR_PHASE_TIMING experiment builds)
   int analytic;       // ILQR_FLAG_ANALYTIC_DERIVATIVES: the models' exact derivatives instead of finite differences
 };
+using BatchView = BatchViewT<double>;  // (the generic nx <= 32 path, generic.hpp / backward_wave.hpp, is fp64 only)
 
 }  // namespace ilqr

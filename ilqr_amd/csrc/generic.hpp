@@ -32,6 +32,7 @@ typedef const __attribute__((address_space(4))) double cmem_d;
 // matrices are row-major and zero-padded to the maximum dimensions.  Sums run left to right
 // over the column index (the padding adds exact zeros at the end of every sum).
 struct LqModel {
+  using real = double;  // the generic path is fp64 only
   static constexpr int NX = GN, NU = GM;
   int nx, nu;
   const double *A, *Bm, *Q, *R, *Qf;  // device: [GN][GN], [GN][GM], [GN][GN], [GM][GM], [GN][GN]

@@ -23,7 +23,8 @@ namespace ilqr {
 // layout conversion
 // ------------------------------------------------------------------------------------------
 // canonical src[b][s][e]  ->  tiled dst[tile][s][e][l]      (one thread per tiled element)
-__global__ void k_pack(const double* __restrict__ src, double* __restrict__ dst, int B, int ntiles, int S, int E) {
+template <class real>
+__global__ void k_pack(const double* __restrict__ src, real* __restrict__ dst, int B, int ntiles, int S, int E) {
   const size_t n = (size_t)ntiles * S * E * TW;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int l = (int)(i % TW);
@@ -33,23 +34,25 @@ __global__ void k_pack(const double* __restrict__ src, double* __restrict__ dst,
     const int s = (int)(r % S);
     const int tile = (int)(r / S);
     const int b = tile * TW + l;
-    dst[i] = (b < B) ? src[((size_t)b * S + s) * E + e] : 0.0;
+    dst[i] = (b < B) ? (real)src[((size_t)b * S + s) * E + e] : real(0);
   }
 }
 // tiled src -> canonical dst   (one thread per canonical element; reads are line-strided but
 // this path only serves getters)
-__global__ void k_unpack(const double* __restrict__ src, double* __restrict__ dst, int B, int S, int E) {
+template <class real>
+__global__ void k_unpack(const real* __restrict__ src, double* __restrict__ dst, int B, int S, int E) {
   const size_t n = (size_t)B * S * E;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int e = (int)(i % E);
     size_t r = i / E;
     const int s = (int)(r % S);
     const int b = (int)(r / S);
-    dst[i] = src[tidx(b / TW, s, e, b % TW, S, E)];
+    dst[i] = (double)src[tidx(b / TW, s, e, b % TW, S, E)];
   }
 }
 // tiled record sub-range [off, off+E) of a record of size REC  <->  canonical [B][S][E]
-__global__ void k_pack_rec(const double* __restrict__ src, double* __restrict__ dst, int B, int ntiles, int S,
+template <class real>
+__global__ void k_pack_rec(const double* __restrict__ src, real* __restrict__ dst, int B, int ntiles, int S,
                            int REC, int off, int E) {
   const size_t n = (size_t)ntiles * S * E * TW;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -60,10 +63,11 @@ __global__ void k_pack_rec(const double* __restrict__ src, double* __restrict__ 
     const int s = (int)(r % S);
     const int tile = (int)(r / S);
     const int b = tile * TW + l;
-    dst[didx(tile, s, off + e, l, S, REC)] = (b < B) ? src[((size_t)b * S + s) * E + e] : 0.0;
+    dst[didx(tile, s, off + e, l, S, REC)] = (b < B) ? (real)src[((size_t)b * S + s) * E + e] : real(0);
   }
 }
-__global__ void k_unpack_rec(const double* __restrict__ src, double* __restrict__ dst, int B, int S, int REC,
+template <class real>
+__global__ void k_unpack_rec(const real* __restrict__ src, double* __restrict__ dst, int B, int S, int REC,
                              int off, int E) {
   const size_t n = (size_t)B * S * E;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -71,14 +75,15 @@ __global__ void k_unpack_rec(const double* __restrict__ src, double* __restrict_
     size_t r = i / E;
     const int s = (int)(r % S);
     const int b = (int)(r / S);
-    dst[i] = src[didx(b / TW, s, off + e, b % TW, S, REC)];
+    dst[i] = (double)src[didx(b / TW, s, off + e, b % TW, S, REC)];
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // per-trajectory state reset (init_traj, ilqr_core.cpp:11-56; statics of ilqr.h:17-18)
 // ------------------------------------------------------------------------------------------
-__global__ void k_reset_state(BatchView v, double lambda0, double dlambda0) {
+template <class real>
+__global__ void k_reset_state(BatchViewT<real> v, double lambda0, double dlambda0) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= v.Bp) return;
   v.lambda[b] = lambda0;
@@ -101,8 +106,8 @@ __global__ void k_reset_state(BatchView v, double lambda0, double dlambda0) {
 // line-search selection + lambda schedule + termination (ilqr_core.cpp:185-282)
 // ------------------------------------------------------------------------------------------
 // STEP 3/4 for trajectory b; cost_of(a) = cost of its candidate a
-template <class CostOf>
-__device__ __forceinline__ void accept_one(const BatchView& v, const SolverParams& sp, int b, CostOf cost_of,
+template <class View, class CostOf>
+__device__ __forceinline__ void accept_one(const View& v, const SolverParams& sp, int b, CostOf cost_of,
                                            int* __restrict__ commit_idx) {
   if (b >= v.Bp) return;
   int commit = -1;
@@ -158,13 +163,14 @@ __device__ __forceinline__ void accept_one(const BatchView& v, const SolverParam
   }
   commit_idx[b] = commit;
 }
-__global__ void k_accept(BatchView v, SolverParams sp, int* __restrict__ commit_idx) {
+template <class real>
+__global__ void k_accept(BatchViewT<real> v, SolverParams sp, int* __restrict__ commit_idx) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   accept_one(v, sp, b, [&](int a) { return v.cost_c[(size_t)a * v.Bp + b]; }, commit_idx);
 }
 
 struct AlphaSet {
-  double a[NALPHA];
+  double a[NALPHA];  // include/ilqr.h:24 as written; a kernel rounds it to its arithmetic once
 };
 
 // One thread per (trajectory, alpha).  A wavefront = one tile of 16 trajectories x 4 alphas
@@ -181,9 +187,10 @@ struct AlphaSet {
 // ACCEPT: the block also performs STEP 3/4 for its 16 trajectories once its three wavefronts have
 // their costs (k_accept's work without a launch of its own; sp, commit_idx are only used then).
 template <class M, bool GAINS, bool CAND, int PD = 4, bool ACCEPT = false>
-__global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet alphas, int n_alpha,
+__global__ __launch_bounds__(192) void k_rollout(BatchViewT<typename M::real> v, M model, AlphaSet alphas, int n_alpha,
                                                  double* __restrict__ cost_out, int mode, SolverParams sp,
                                                  int* __restrict__ commit_idx) {
+  using real = typename M::real;
   __shared__ double lds_cost[ACCEPT ? NALPHA * TW : 1];
   constexpr int NX = M::NX, NU = M::NU;
   const int wave = threadIdx.x >> 6;
@@ -198,13 +205,13 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
   if (!ACCEPT && !active) return;
   if (active) {
   const int T = v.T;
-  const double alpha = alphas.a[a < NALPHA ? a : NALPHA - 1];
-  const double dt = v.dt;
+  const real alpha = (real)alphas.a[a < NALPHA ? a : NALPHA - 1];
+  const real dt = (real)v.dt;
 
-  double x[NX];
+  real x[NX];
 #pragma unroll
   for (int i = 0; i < NX; i++) x[i] = v.x0[tidx(tile, 0, i, l, 1, NX)];
-  double total = 0;
+  double total = 0;  // (the sum over the horizon is a per-trajectory accumulator: double in both modes, common.hpp)
 
   // The nominal controls / gains / states of step t do not depend on the rollout's own state,
   // and one step of arithmetic (~600 cycles) is far shorter than an HBM round trip under load
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
   // spills).  Depth 8 costs 266 registers, i.e. one block per CU; when the tiles outnumber the CUs
   // the launcher picks depth 4 (136 registers, several blocks per CU hide the latency instead).
   struct StepIn {
-    double u[NU], k[GAINS ? NU : 1], K[GAINS ? NU * NX : 1], xnom[GAINS ? NX : 1];
+    real u[NU], k[GAINS ? NU : 1], K[GAINS ? NU * NX : 1], xnom[GAINS ? NX : 1];
   };
   auto load_step = [&](int t, StepIn& d) __attribute__((always_inline)) {
     t = (t < T) ? t : T - 1;  // tail: harmless re-load instead of a branch
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
 #else
 #define ILQR_RMARK(k)
 #endif
-  auto emit_knot = [&](int t, const double* xx, const double* uu) __attribute__((always_inline)) {  // knot t = (x_t, u_t)
+  auto emit_knot = [&](int t, const real* xx, const real* uu) __attribute__((always_inline)) {  // knot t = (x_t, u_t)
     if (CAND) {
       const int ta = a * v.ntiles + tile;
       if (t < T) {
@@ -259,14 +266,14 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
   };
   auto do_step = [&](int t, const StepIn& d) __attribute__((always_inline)) {
     ILQR_RMARK(0)  // loop control + prefetch issue
-    double u[NU];
+    real u[NU];
 #pragma unroll
     for (int j = 0; j < NU; j++) u[j] = d.u[j];
     if (GAINS) {
 #pragma unroll
       for (int j = 0; j < NU; j++) {
         u[j] += d.k[j] * alpha;  // :190
-        double acc = 0;
+        real acc = 0;
 #pragma unroll
         for (int i = 0; i < NX; i++) acc += d.K[j + NU * i] * (x[i] - d.xnom[i]);
         u[j] += acc;  // :316
@@ -274,8 +281,8 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
     }
     emit_knot(t, x, u);
     ILQR_RMARK(1)  // wait for inputs + feedback + knot store
-    total += model.cost(x, u);  // :324
-    double x1[NX];
+    total += (double)model.cost(x, u);  // :324
+    real x1[NX];
     integrate_dynamics(model, x, u, dt, x1);  // :325
     ILQR_RMARK(2)  // cost + dynamics
 #pragma unroll
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
     do_step(t, cur);
   }
   {  // knot T: the final state (no control)
-    double uz[NU];
+    real uz[NU];
 #pragma unroll
     for (int q = 0; q < NU; q++) uz[q] = 0;
     emit_knot(T, x, uz);
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
   if (v.dbg && threadIdx.x == 0 && tile < 3 && GAINS)
     for (int q = 0; q < 4; q++) v.dbg[512 - 16 + tile * 4 + q] = rph[q];
 #endif
-  total += model.final_cost(x);  // :335
+  total += (double)model.final_cost(x);  // :335
   cost_out[(size_t)a * v.Bp + b] = total;
   if (ACCEPT) lds_cost[a * TW + l] = total;
   }  // if (active)
@@ -324,13 +331,14 @@ __global__ __launch_bounds__(192) void k_rollout(BatchView v, M model, AlphaSet 
 // from the checkpoint at knot (t/CT)*CT with the rollout's own step (include/model.h:12-15).  The
 // CT-1 controls of the chunk are fetched up front (one memory round trip), the steps run predicated.
 template <class M>
-__device__ __forceinline__ void candidate_knot(const BatchView& v, const M& model, int a, int tile, int t, int l,
-                                               double* x, double* u) {
+__device__ __forceinline__ void candidate_knot(const BatchViewT<typename M::real>& v, const M& model, int a, int tile, int t, int l,
+                                               typename M::real* x, typename M::real* u) {
+  using real = typename M::real;
   constexpr int NX = M::NX, NU = M::NU;
   const int T = v.T, ta = a * v.ntiles + tile, c = t / CT, off = t - c * CT;
 #pragma unroll
   for (int i = 0; i < NX; i++) x[i] = v.cand_x[tidx(ta, c, i, l, v.nch, NX)];
-  double uq[CT][NU];
+  real uq[CT][NU];
 #pragma unroll
   for (int q = 0; q < CT; q++) {
     const int tq = (c * CT + q < T) ? c * CT + q : T - 1;
@@ -342,8 +350,8 @@ __device__ __forceinline__ void candidate_knot(const BatchView& v, const M& mode
 #pragma unroll
   for (int q = 0; q < CT; q++) {
     if (q < off) {
-      double x1[NX];
-      integrate_dynamics(model, x, uq[q], v.dt, x1);
+      real x1[NX];
+      integrate_dynamics(model, x, uq[q], (real)v.dt, x1);
 #pragma unroll
       for (int i = 0; i < NX; i++) x[i] = x1[i];
     }
@@ -356,19 +364,20 @@ __device__ __forceinline__ void candidate_knot(const BatchView& v, const M& mode
 
 // candidate `a` -> canonical xs [B][T+1][nx], us [B][T][nu]   (getter only)
 template <class M>
-__global__ void k_unpack_cand(BatchView v, M model, int a, double* __restrict__ xs, double* __restrict__ us) {
+__global__ void k_unpack_cand(BatchViewT<typename M::real> v, M model, int a, double* __restrict__ xs, double* __restrict__ us) {
+  using real = typename M::real;
   constexpr int NX = M::NX, NU = M::NU;
   const int T = v.T;
   const size_t n = (size_t)v.B * (T + 1);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int t = (int)(i % (T + 1));
     const int b = (int)(i / (T + 1));
-    double x[NX], u[NU];
+    real x[NX], u[NU];
     candidate_knot(v, model, a, b / TW, t, b % TW, x, u);
     if (xs)
-      for (int e = 0; e < NX; e++) xs[((size_t)b * (T + 1) + t) * NX + e] = x[e];
+      for (int e = 0; e < NX; e++) xs[((size_t)b * (T + 1) + t) * NX + e] = (double)x[e];
     if (us && t < T)
-      for (int e = 0; e < NU; e++) us[((size_t)b * T + t) * NU + e] = u[e];
+      for (int e = 0; e < NU; e++) us[((size_t)b * T + t) * NU + e] = (double)u[e];
   }
 }
 
@@ -376,39 +385,39 @@ __global__ void k_unpack_cand(BatchView v, M model, int a, double* __restrict__ 
 // finite-difference derivatives
 // ------------------------------------------------------------------------------------------
 // include/finite_diff.h:67-86 applied to a scalar functor of an N-vector.
-template <int N, class F>
-__device__ __forceinline__ void fd_hessian(const double* x, F f, double* out /* N x N col-major */) {
+template <int N, class real, class F>
+__device__ __forceinline__ void fd_hessian(const real* x, F f, real* out /* N x N col-major */) {
 #pragma unroll
   for (int i = 0; i < N; i++)
 #pragma unroll
     for (int j = i; j < N; j++) {
-      double pp[N], pm[N], mp[N], mm[N];
+      real pp[N], pm[N], mp[N], mm[N];
 #pragma unroll
       for (int l = 0; l < N; l++) pp[l] = pm[l] = mp[l] = mm[l] = x[l];
-      pp[i] += kEps;
-      pp[j] += kEps;
-      pm[i] += kEps;
-      pm[j] -= kEps;
-      mp[i] -= kEps;
-      mp[j] += kEps;
-      mm[i] -= kEps;
-      mm[j] -= kEps;
-      const double v = (f(pp) - f(mp) - f(pm) + f(mm)) / (4 * kEps * kEps);
+      pp[i] += real(kEps);
+      pp[j] += real(kEps);
+      pm[i] += real(kEps);
+      pm[j] -= real(kEps);
+      mp[i] -= real(kEps);
+      mp[j] += real(kEps);
+      mm[i] -= real(kEps);
+      mm[j] -= real(kEps);
+      const real v = (f(pp) - f(mp) - f(pm) + f(mm)) / real(4 * kEps * kEps);
       out[i + N * j] = v;
       out[j + N * i] = v;
     }
 }
 // include/finite_diff.h:22-33
-template <int N, class F>
-__device__ __forceinline__ void fd_gradient(const double* x, F f, double* out) {
+template <int N, class real, class F>
+__device__ __forceinline__ void fd_gradient(const real* x, F f, real* out) {
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    double p[N], m[N];
+    real p[N], m[N];
 #pragma unroll
     for (int l = 0; l < N; l++) p[l] = m[l] = x[l];
-    p[i] += kEps;
-    m[i] -= kEps;
-    out[i] = (f(p) - f(m)) / (2 * kEps);
+    p[i] += real(kEps);
+    m[i] -= real(kEps);
+    out[i] = (f(p) - f(m)) / real(2 * kEps);
   }
 }
 
@@ -424,21 +433,30 @@ __device__ __forceinline__ void fd_gradient(const double* x, F f, double* out) {
 #ifndef ILQR_RING_KB
 #define ILQR_RING_KB 150  // one block per CU; the two-blocks-per-CU variant of k_sweep_backward uses 60
 #endif
-template <int NX, int NU, int RING_KB = ILQR_RING_KB>
+template <int NX, int NU, class real, int RING_KB = ILQR_RING_KB>
 struct RingSlot {
   static constexpr int US = Rec<NX, NU>::SIZE;               // controls follow the record
   static constexpr int PAIRS = (Rec<NX, NU>::SIZE + NU + 1) / 2;
-  static constexpr int DOUBLES = PAIRS * 2 * TW;             // per slot
-  static constexpr int SLOTS = ((RING_KB * 1024 / 8) / DOUBLES) / 4 * 4;  // ring size: what fits in RING_KB of LDS
+  static constexpr int ELEMS = PAIRS * 2 * TW;               // per slot, in units of `real`
+  static constexpr int SLOTS = ((RING_KB * 1024 / (int)sizeof(real)) / ELEMS) / 4 * 4;  // ring size: what fits in RING_KB of LDS
 };
 
-template <class M, bool RING = false>
-__device__ __forceinline__ void derivatives_of_knot(const BatchView& v, const M& model, int force,
+// MFD / fdm: the model in the arithmetic the finite differences are TAKEN in.  For an fp64 handle that is
+// the model itself.  For an fp32 handle it is its double-precision twin: eps = 1e-3 second differences of
+// a cost of O(1e3) are rounding noise in float (1e3 x 6e-8 / 4e-6 = 15 against Hessian entries of 800), so
+// the knot (float) is widened, the sweep below runs in double exactly as for an fp64 handle, and the record
+// is rounded to float when stored.  Rollouts, the commit and the analytic route stay in the handle's own
+// arithmetic (`model`).
+template <class M, bool RING = false, class MFD = M>
+__device__ __forceinline__ void derivatives_of_knot(const BatchViewT<typename M::real>& v, const M& model, const MFD& fdm, int force,
                                                     const int* __restrict__ commit_idx, int tile, int t, int l,
-                                                    double* rs = nullptr) {
+                                                    typename M::real* rs = nullptr) {
+  using real = typename M::real;
+  using fdr = typename MFD::real;
+  using RSl = RingSlot<M::NX, M::NU, real>;
   constexpr int NX = M::NX, NU = M::NU;
   using R = Rec<NX, NU>;
-  typedef double double2_t __attribute__((ext_vector_type(2)));
+  typedef real real2_t __attribute__((ext_vector_type(2)));
   const int b = tile * TW + l;
   const int T = v.T;
   if (t > T || b >= v.B) return;
@@ -448,122 +466,130 @@ __device__ __forceinline__ void derivatives_of_knot(const BatchView& v, const M&
     // A running trajectory whose last line search failed keeps its derivatives (flgChange = 0,
     // ilqr_core.cpp:115): the backward pass still wants them, so the ring gets a copy.
     if (RING && v.status[b] == 0) {
-      const double* D0 = v.D + didx(tile, t, 0, l, T + 1, R::SIZE);
+      const real* D0 = v.D + didx(tile, t, 0, l, T + 1, R::SIZE);
 #pragma unroll
       for (int e = 0; e < R::SIZE; e += 2)
-        *reinterpret_cast<double2_t*>(rs + (e >> 1) * (2 * TW)) = *reinterpret_cast<const double2_t*>(D0 + (size_t)(e >> 1) * (2 * TW));
+        *reinterpret_cast<real2_t*>(rs + (e >> 1) * (2 * TW)) = *reinterpret_cast<const real2_t*>(D0 + (size_t)(e >> 1) * (2 * TW));
 #pragma unroll
       for (int j = 0; j < NU; j++)
-        rs[((RingSlot<NX, NU>::US + j) >> 1) * (2 * TW) + ((RingSlot<NX, NU>::US + j) & 1)] = (t < T) ? v.us[tidx(tile, t, j, l, T, NU)] : 0.0;
+        rs[((RSl::US + j) >> 1) * (2 * TW) + ((RSl::US + j) & 1)] = (t < T) ? v.us[tidx(tile, t, j, l, T, NU)] : real(0);
     }
     return;
   }
-  const double dt = v.dt;
+  const real dt = (real)v.dt;
 
-  double x[NX], u[NU];
+  real xk[NX], uk[NU];  // the knot as stored
   {
     if (ci >= 0) {  // knot t of the accepted candidate
-      candidate_knot(v, model, ci, tile, t, l, x, u);
+      candidate_knot(v, model, ci, tile, t, l, xk, uk);
     } else {
 #pragma unroll
-      for (int i = 0; i < NX; i++) x[i] = v.xs[tidx(tile, t, i, l, T + 1, NX)];
+      for (int i = 0; i < NX; i++) xk[i] = v.xs[tidx(tile, t, i, l, T + 1, NX)];
 #pragma unroll
-      for (int j = 0; j < NU; j++) u[j] = (t < T) ? v.us[tidx(tile, t, j, l, T, NU)] : 0.0;  // derivatives.cpp:35-38
+      for (int j = 0; j < NU; j++) uk[j] = (t < T) ? v.us[tidx(tile, t, j, l, T, NU)] : real(0);  // derivatives.cpp:35-38
     }
     if (ci >= 0) {  // the pending commit of ilqr_core.cpp:210-213 ("accept": xs, us keep the new rollout)
 #pragma unroll
-      for (int i = 0; i < NX; i++) v.xs[tidx(tile, t, i, l, T + 1, NX)] = x[i];
+      for (int i = 0; i < NX; i++) v.xs[tidx(tile, t, i, l, T + 1, NX)] = xk[i];
       if (t < T) {
 #pragma unroll
-        for (int j = 0; j < NU; j++) v.us[tidx(tile, t, j, l, T, NU)] = u[j];
+        for (int j = 0; j < NU; j++) v.us[tidx(tile, t, j, l, T, NU)] = uk[j];
       }
     }
   }
   if (!want) return;  // (finished trajectory whose last candidate was committed above)
 
-  double* D = v.D + didx(tile, t, 0, l, T + 1, R::SIZE);
-  auto put = [&](int e, double val) {
+  real* D = v.D + didx(tile, t, 0, l, T + 1, R::SIZE);
+  auto put = [&](int e, fdr val_) {
+    const real val = (real)val_;
     D[(size_t)(e >> 1) * (2 * TW) + (e & 1)] = val;
     if (RING) rs[(e >> 1) * (2 * TW) + (e & 1)] = val;
   };
-  auto put2 = [&](int e, double v0, double v1) {  // e even: one 16-byte store
-    double2_t w;
-    w.x = v0;
-    w.y = v1;
-    *reinterpret_cast<double2_t*>(D + (size_t)(e >> 1) * (2 * TW)) = w;
-    if (RING) *reinterpret_cast<double2_t*>(rs + (e >> 1) * (2 * TW)) = w;
+  auto put2 = [&](int e, fdr v0, fdr v1) {  // e even: one store of a pair
+    real2_t w;
+    w.x = (real)v0;
+    w.y = (real)v1;
+    *reinterpret_cast<real2_t*>(D + (size_t)(e >> 1) * (2 * TW)) = w;
+    if (RING) *reinterpret_cast<real2_t*>(rs + (e >> 1) * (2 * TW)) = w;
   };
   if (RING) {
 #pragma unroll
-    for (int j = 0; j < NU; j++) rs[((RingSlot<NX, NU>::US + j) >> 1) * (2 * TW) + ((RingSlot<NX, NU>::US + j) & 1)] = u[j];
+    for (int j = 0; j < NU; j++) rs[((RSl::US + j) >> 1) * (2 * TW) + ((RSl::US + j) & 1)] = uk[j];
   }
 
   if (v.analytic) {  // opt-in: the model's exact derivatives (wave-uniform branch)
-    double rec[R::SIZE];
-    model.analytic_record(x, u, dt, t == T, rec);
+    real rec[R::SIZE];
+    model.analytic_record(xk, uk, dt, t == T, rec);
 #pragma unroll
-    for (int e = 0; e < R::SIZE; e += 2) put2(e, rec[e], rec[e + 1]);
+    for (int e = 0; e < R::SIZE; e += 2) put2(e, (fdr)rec[e], (fdr)rec[e + 1]);
     return;
   }
+  // the knot in the finite differences' arithmetic (a no-op unless the handle is fp32)
+  fdr x[NX], u[NU];
+#pragma unroll
+  for (int i = 0; i < NX; i++) x[i] = (fdr)xk[i];
+#pragma unroll
+  for (int j = 0; j < NU; j++) u[j] = (fdr)uk[j];
+  const fdr dtf = (fdr)dt;
   if (t < T) {
     // fx, fu: central differences of the Euler map (derivatives.cpp:19-25, finite_diff.h:35-47)
 #pragma unroll
     for (int i = 0; i < NX; i++) {
-      double p[NX], m[NX], fp[NX], fm[NX];
+      fdr p[NX], m[NX], fp[NX], fm[NX];
 #pragma unroll
       for (int q = 0; q < NX; q++) p[q] = m[q] = x[q];
-      p[i] += kEps;
-      m[i] -= kEps;
-      integrate_dynamics(model, p, u, dt, fp);
-      integrate_dynamics(model, m, u, dt, fm);
+      p[i] += fdr(kEps);
+      m[i] -= fdr(kEps);
+      integrate_dynamics(fdm, p, u, dtf, fp);
+      integrate_dynamics(fdm, m, u, dtf, fm);
 #pragma unroll
       for (int r = 0; r < NX; r += 2)
-        put2(R::FX + r + NX * i, (fp[r] - fm[r]) / (2 * kEps), (fp[r + 1] - fm[r + 1]) / (2 * kEps));
+        put2(R::FX + r + NX * i, (fp[r] - fm[r]) / fdr(2 * kEps), (fp[r + 1] - fm[r + 1]) / fdr(2 * kEps));
     }
 #pragma unroll
     for (int i = 0; i < NU; i++) {
-      double p[NU], m[NU], fp[NX], fm[NX];
+      fdr p[NU], m[NU], fp[NX], fm[NX];
 #pragma unroll
       for (int q = 0; q < NU; q++) p[q] = m[q] = u[q];
-      p[i] += kEps;
-      m[i] -= kEps;
-      integrate_dynamics(model, x, p, dt, fp);
-      integrate_dynamics(model, x, m, dt, fm);
+      p[i] += fdr(kEps);
+      m[i] -= fdr(kEps);
+      integrate_dynamics(fdm, x, p, dtf, fp);
+      integrate_dynamics(fdm, x, m, dtf, fm);
 #pragma unroll
       for (int r = 0; r < NX; r += 2)
-        put2(R::FU + r + NX * i, (fp[r] - fm[r]) / (2 * kEps), (fp[r + 1] - fm[r + 1]) / (2 * kEps));
+        put2(R::FU + r + NX * i, (fp[r] - fm[r]) / fdr(2 * kEps), (fp[r + 1] - fm[r + 1]) / fdr(2 * kEps));
     }
     // cx, cu (derivatives.cpp:44-47)
-    double g[NX > NU ? NX : NU];
-    fd_gradient<NX>(x, [&](const double* xx) { return model.cost(xx, u); }, g);
+    fdr g[NX > NU ? NX : NU];
+    fd_gradient<NX>(x, [&](const fdr* xx) { return fdm.cost(xx, u); }, g);
 #pragma unroll
     for (int i = 0; i < NX; i += 2) put2(R::CX + i, g[i], g[i + 1]);
-    fd_gradient<NU>(u, [&](const double* uu) { return model.cost(x, uu); }, g);
+    fd_gradient<NU>(u, [&](const fdr* uu) { return fdm.cost(x, uu); }, g);
 #pragma unroll
     for (int i = 0; i < NU; i++) put(R::CU + i, g[i]);
     // cxx (derivatives.cpp:76-96)
-    double H[NX * NX];
-    fd_hessian<NX>(x, [&](const double* xx) { return model.cost(xx, u); }, H);
+    fdr H[NX * NX];
+    fd_hessian<NX>(x, [&](const fdr* xx) { return fdm.cost(xx, u); }, H);
 #pragma unroll
     for (int e = 0; e < NX * NX; e += 2) put2(R::CXX + e, H[e], H[e + 1]);
   } else {
 #pragma unroll
-    for (int e = 0; e < NX * NX + NX * NU; e += 2) put2(R::FX + e, 0.0, 0.0);  // fx[T], fu[T] stay zero
-    double g[NX];
-    fd_gradient<NX>(x, [&](const double* xx) { return model.final_cost(xx); }, g);  // :49
+    for (int e = 0; e < NX * NX + NX * NU; e += 2) put2(R::FX + e, fdr(0), fdr(0));  // fx[T], fu[T] stay zero
+    fdr g[NX];
+    fd_gradient<NX>(x, [&](const fdr* xx) { return fdm.final_cost(xx); }, g);  // :49
 #pragma unroll
     for (int i = 0; i < NX; i += 2) put2(R::CX + i, g[i], g[i + 1]);
 #pragma unroll
-    for (int i = 0; i < NU; i++) put(R::CU + i, 0.0);  // :50-51
-    double H[NX * NX];
-    fd_hessian<NX>(x, [&](const double* xx) { return model.final_cost(xx); }, H);  // :92
+    for (int i = 0; i < NU; i++) put(R::CU + i, fdr(0));  // :50-51
+    fdr H[NX * NX];
+    fd_hessian<NX>(x, [&](const fdr* xx) { return fdm.final_cost(xx); }, H);  // :92
 #pragma unroll
     for (int e = 0; e < NX * NX; e += 2) put2(R::CXX + e, H[e], H[e + 1]);
   }
   // cuu at every t, with u = 0 at t = T (derivatives.cpp:98-112)
   {
-    double H[NU * NU];
-    fd_hessian<NU>(u, [&](const double* uu) { return model.cost(x, uu); }, H);
+    fdr H[NU * NU];
+    fd_hessian<NU>(u, [&](const fdr* uu) { return fdm.cost(x, uu); }, H);
 #pragma unroll
     for (int e = 0; e < NU * NU; e++) put(R::CUU + e, H[e]);
   }
@@ -572,32 +598,32 @@ __device__ __forceinline__ void derivatives_of_knot(const BatchView& v, const M&
   for (int i = 0; i < NX; i++)
 #pragma unroll
     for (int j = 0; j < NU; j++) {
-      double px[NX], mx[NX], pu[NU], mu[NU];
+      fdr px[NX], mx[NX], pu[NU], mu[NU];
 #pragma unroll
       for (int q = 0; q < NX; q++) px[q] = mx[q] = x[q];
 #pragma unroll
       for (int q = 0; q < NU; q++) pu[q] = mu[q] = u[q];
-      px[i] += kEps;
-      mx[i] -= kEps;
-      pu[j] += kEps;
-      mu[j] -= kEps;
-      double val;
+      px[i] += fdr(kEps);
+      mx[i] -= fdr(kEps);
+      pu[j] += fdr(kEps);
+      mu[j] -= fdr(kEps);
+      fdr val;
       if (t < T)
-        val = (model.cost(px, pu) - model.cost(mx, pu) - model.cost(px, mu) + model.cost(mx, mu)) / (4 * (kEps * kEps));
+        val = (fdm.cost(px, pu) - fdm.cost(mx, pu) - fdm.cost(px, mu) + fdm.cost(mx, mu)) / fdr(4 * (kEps * kEps));
       else  // :140 (the reference's own "TODO this is wrong"; value is never consumed)
-        val = (model.final_cost(px) - model.final_cost(mx) - model.final_cost(px) + model.final_cost(mx)) /
-              (4 * (kEps * kEps));
+        val = (fdm.final_cost(px) - fdm.final_cost(mx) - fdm.final_cost(px) + fdm.final_cost(mx)) /
+              (4 * (fdr(kEps) * fdr(kEps)));
       put(R::CXU + i + NX * j, val);
     }
 }
 
 // grid = (ceil((T+1)/16), ntiles), block = 256 = 16 time steps x 16 trajectories
-template <class M>
-__global__ __launch_bounds__(256) void k_derivatives(BatchView v, M model, int force, const int* __restrict__ commit_idx) {
+template <class M, class MFD = M>
+__global__ __launch_bounds__(256) void k_derivatives(BatchViewT<typename M::real> v, M model, MFD fdm, int force, const int* __restrict__ commit_idx) {
   const int l = threadIdx.x & (TW - 1);
   const int t = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *v.n_running = 0;  // k_accept of this iteration recounts
-  derivatives_of_knot(v, model, force, commit_idx, (int)blockIdx.y, t, l);
+  derivatives_of_knot<M, false, MFD>(v, model, fdm, force, commit_idx, (int)blockIdx.y, t, l);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -607,7 +633,8 @@ __global__ __launch_bounds__(256) void k_derivatives(BatchView v, M model, int f
 // mode 1: STEP 2 of the outer loop for running trajectories: retry with increased lambda while
 //         the pass diverges (ilqr_core.cpp:136-150), then the gradient-norm test (:153-159).
 template <class M>
-__global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverParams sp, int mode) {
+__global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> v, M model, SolverParams sp, int mode) {
+  using real = typename M::real;
   constexpr int NX = M::NX, NU = M::NU;
   using R = Rec<NX, NU>;
   const int b = blockIdx.x * 64 + threadIdx.x;
@@ -616,14 +643,14 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
   const int tile = b / TW, l = b % TW;
   const int T = v.T;
   double lambda = v.lambda[b], dlambda = v.dlambda[b];
-  const double* Dt = v.D + didx(tile, 0, 0, l, T + 1, R::SIZE);
+  const real* Dt = v.D + didx(tile, 0, 0, l, T + 1, R::SIZE);
   auto rec = [&](int t, int e) { return Dt[((size_t)t * (R::SIZE / 2) + (e >> 1)) * (2 * TW) + (e & 1)]; };
 
   int diverge = 0;
   bool done = false;
-  double dV0 = 0, dV1 = 0;
+  double dV0 = 0, dV1 = 0;  // (per-trajectory accumulators: double in both modes)
   while (true) {
-    double Vx[NX], Vxx[NX * NX], kprev[NU];
+    real Vx[NX], Vxx[NX * NX], kprev[NU];
 #pragma unroll
     for (int i = 0; i < NX; i++) Vx[i] = rec(T, R::CX + i);  // :353
 #pragma unroll
@@ -634,7 +661,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
     diverge = 0;
 
     for (int i = T - 1; i >= 0; i--) {
-      double fx[NX * NX], fu[NX * NU], cx[NX], cu[NU], cxx[NX * NX], cxu[NX * NU], cuu[NU * NU], us[NU];
+      real fx[NX * NX], fu[NX * NU], cx[NX], cu[NU], cxx[NX * NX], cxu[NX * NU], cuu[NU * NU], us[NU];
 #pragma unroll
       for (int e = 0; e < NX * NX; e++) fx[e] = rec(i, R::FX + e);
 #pragma unroll
@@ -652,19 +679,19 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
 #pragma unroll
       for (int j = 0; j < NU; j++) us[j] = v.us[tidx(tile, i, j, l, T, NU)];
 
-      double Qx[NX], Qu[NU], Qxx[NX * NX], Qux[NU * NX], Quu[NU * NU], QuuF[NU * NU];
-      double A1[NX * NX], A2[NU * NX];
+      real Qx[NX], Qu[NU], Qxx[NX * NX], Qux[NU * NX], Quu[NU * NU], QuuF[NU * NU];
+      real A1[NX * NX], A2[NU * NX];
       // :359-360
 #pragma unroll
       for (int a = 0; a < NX; a++) {
-        double acc = 0;
+        real acc = 0;
 #pragma unroll
         for (int q = 0; q < NX; q++) acc += fx[q + NX * a] * Vx[q];
         Qx[a] = cx[a] + acc;
       }
 #pragma unroll
       for (int a = 0; a < NU; a++) {
-        double acc = 0;
+        real acc = 0;
 #pragma unroll
         for (int q = 0; q < NX; q++) acc += fu[q + NX * a] * Vx[q];
         Qu[a] = cu[a] + acc;
@@ -674,7 +701,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
       for (int a = 0; a < NX; a++)
 #pragma unroll
         for (int c = 0; c < NX; c++) {
-          double acc = 0;
+          real acc = 0;
 #pragma unroll
           for (int q = 0; q < NX; q++) acc += fx[q + NX * a] * Vxx[q + NX * c];
           A1[a + NX * c] = acc;
@@ -683,7 +710,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
       for (int a = 0; a < NX; a++)
 #pragma unroll
         for (int c = 0; c < NX; c++) {
-          double acc = 0;
+          real acc = 0;
 #pragma unroll
           for (int q = 0; q < NX; q++) acc += A1[a + NX * q] * fx[q + NX * c];
           Qxx[a + NX * c] = cxx[a + NX * c] + acc;
@@ -693,7 +720,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
       for (int a = 0; a < NU; a++)
 #pragma unroll
         for (int c = 0; c < NX; c++) {
-          double acc = 0;
+          real acc = 0;
 #pragma unroll
           for (int q = 0; q < NX; q++) acc += fu[q + NX * a] * Vxx[q + NX * c];
           A2[a + NU * c] = acc;
@@ -702,7 +729,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
       for (int a = 0; a < NU; a++)
 #pragma unroll
         for (int c = 0; c < NX; c++) {
-          double acc = 0;
+          real acc = 0;
 #pragma unroll
           for (int q = 0; q < NX; q++) acc += A2[a + NU * q] * fx[q + NX * c];
           Qux[a + NU * c] = cxu[c + NX * a] + acc;
@@ -712,21 +739,21 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
       for (int a = 0; a < NU; a++)
 #pragma unroll
         for (int c = 0; c < NU; c++) {
-          double acc = 0;
+          real acc = 0;
 #pragma unroll
           for (int q = 0; q < NX; q++) acc += A2[a + NU * q] * fu[q + NX * c];
           Quu[a + NU * c] = cuu[a + NU * c] + acc;
-          QuuF[a + NU * c] = (cuu[a + NU * c] + ((a == c) ? lambda : 0.0)) + acc;
+          QuuF[a + NU * c] = (cuu[a + NU * c] + ((a == c) ? (real)lambda : real(0))) + acc;
         }
 
       // :369
-      double lo[NU], hi[NU];
+      real lo[NU], hi[NU];
 #pragma unroll
       for (int j = 0; j < NU; j++) {
         lo[j] = model.u_min[j] - us[j];
         hi[j] = model.u_max[j] - us[j];
       }
-      BoxQPResult<NU> qp;
+      BoxQPResult<NU, real> qp;
       box_qp<NU>(QuuF, Qu, kprev, lo, hi, qp);
       if (qp.result < 1) {  // :371
         diverge = i;
@@ -734,7 +761,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
       }
 
       // :373-385
-      double K[NU * NX];
+      real K[NU * NX];
 #pragma unroll
       for (int e = 0; e < NU * NX; e++) K[e] = 0;
       {
@@ -745,15 +772,15 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
           nf += qp.v_free[j] ? 1 : 0;
         }
         if (nf > 0) {
-          double Minv[NU * NU];
+          real Minv[NU * NU];
           rinv_rinvT<NU>(qp.nfR, qp.R, Minv);
           const int nuse = (nf < qp.nfR) ? nf : qp.nfR;
 #pragma unroll
           for (int c = 0; c < NX; c++) {
-            double qf[NU];  // rows_w_ind(Qux_reg, v_free)(:, c)
+            real qf[NU];  // rows_w_ind(Qux_reg, v_free)(:, c)
 #pragma unroll
             for (int a = 0; a < NU; a++) {
-              double val = 0;
+              real val = 0;
 #pragma unroll
               for (int j = 0; j < NU; j++)
                 if (qp.v_free[j] && rank[j] == a) val = Qux[j + NU * c];
@@ -762,11 +789,11 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
 #pragma unroll
             for (int j = 0; j < NU; j++) {
               if (qp.v_free[j] && rank[j] < nuse) {
-                double acc = 0;
+                real acc = 0;
 #pragma unroll
                 for (int a = 0; a < NU; a++)
                   if (a < nuse) {
-                    double mrow = 0;  // Minv[rank[j]][a]
+                    real mrow = 0;  // Minv[rank[j]][a]
 #pragma unroll
                     for (int r = 0; r < NU; r++)
                       if (r == rank[j]) mrow = Minv[r + NU * a];
@@ -781,36 +808,36 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
 
       // :388-389
       {
-        double d0 = 0;
+        real d0 = 0;
 #pragma unroll
         for (int j = 0; j < NU; j++) d0 += qp.x[j] * Qu[j];
-        dV0 += d0;
-        double d1 = 0;
+        dV0 += (double)d0;
+        real d1 = 0;
 #pragma unroll
         for (int c = 0; c < NU; c++) {
-          double r = 0;
+          real r = 0;
 #pragma unroll
-          for (int a = 0; a < NU; a++) r += (0.5 * qp.x[a]) * Quu[a + NU * c];
+          for (int a = 0; a < NU; a++) r += (real(0.5) * qp.x[a]) * Quu[a + NU * c];
           d1 += r * qp.x[c];
         }
-        dV1 += d1;
+        dV1 += (double)d1;
       }
       // :391-393
       {
-        double T1[NX * NU];  // K' Quu  (NX x NU)
+        real T1[NX * NU];  // K' Quu  (NX x NU)
 #pragma unroll
         for (int a = 0; a < NX; a++)
 #pragma unroll
           for (int c = 0; c < NU; c++) {
-            double acc = 0;
+            real acc = 0;
 #pragma unroll
             for (int q = 0; q < NU; q++) acc += K[q + NU * a] * Quu[q + NU * c];
             T1[a + NX * c] = acc;
           }
-        double Vxn[NX], Vn[NX * NX];
+        real Vxn[NX], Vn[NX * NX];
 #pragma unroll
         for (int a = 0; a < NX; a++) {
-          double t1 = 0, t2 = 0, t3 = 0;
+          real t1 = 0, t2 = 0, t3 = 0;
 #pragma unroll
           for (int c = 0; c < NU; c++) {
             t1 += T1[a + NX * c] * qp.x[c];
@@ -823,7 +850,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
         for (int a = 0; a < NX; a++)
 #pragma unroll
           for (int c = 0; c < NX; c++) {
-            double t1 = 0, t2 = 0, t3 = 0;
+            real t1 = 0, t2 = 0, t3 = 0;
 #pragma unroll
             for (int q = 0; q < NU; q++) {
               t1 += T1[a + NX * q] * K[q + NU * c];
@@ -836,7 +863,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
         for (int a = 0; a < NX; a++) {
           Vx[a] = Vxn[a];
 #pragma unroll
-          for (int c = 0; c < NX; c++) Vxx[a + NX * c] = 0.5 * (Vn[a + NX * c] + Vn[c + NX * a]);
+          for (int c = 0; c < NX; c++) Vxx[a + NX * c] = real(0.5) * (Vn[a + NX * c] + Vn[c + NX * a]);
         }
       }
       // :396-397
@@ -874,13 +901,13 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchView v, M model, SolverP
   // :153 / :405-412  gnorm = mean_t max_j |k_j| / (|u_j| + 1), ascending t like std::accumulate
   double acc = 0;
   for (int t = 0; t < T; t++) {
-    double mx = 0;
+    real mx = 0;
 #pragma unroll
     for (int j = 0; j < NU; j++) {
-      const double val = fabs(v.kff[tidx(tile, t, j, l, T, NU)]) / (fabs(v.us[tidx(tile, t, j, l, T, NU)]) + 1);
+      const real val = abs_of(v.kff[tidx(tile, t, j, l, T, NU)]) / (abs_of(v.us[tidx(tile, t, j, l, T, NU)]) + 1);
       mx = (j == 0 || val > mx) ? val : mx;
     }
-    acc += mx;
+    acc += (double)mx;
   }
   const double gnorm = acc / T;
   v.gnorm[b] = gnorm;
@@ -905,6 +932,9 @@ __device__ __forceinline__ double dpp_swap1(double x) {
   hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float dpp_swap1(float x) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xf, 0xf, true));
+}
 template <int SRC>
 __device__ __forceinline__ double quad_bcast(double x) {
   constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);  // quad_perm:[SRC,SRC,SRC,SRC]
@@ -913,14 +943,24 @@ __device__ __forceinline__ double quad_bcast(double x) {
   hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ void quad_gather(double x, double out[4]) {
+template <int SRC>
+__device__ __forceinline__ float quad_bcast(float x) {  // fp32: one v_mov_b32 dpp per broadcast instead of two
+  constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), ctrl, 0xf, 0xf, true));
+}
+template <class real>
+__device__ __forceinline__ void quad_gather(real x, real out[4]) {
   out[0] = quad_bcast<0>(x);
   out[1] = quad_bcast<1>(x);
   out[2] = quad_bcast<2>(x);
   out[3] = quad_bcast<3>(x);
 }
 
-__device__ __constant__ const StepTable kStepTable{};
+// backtracking step sizes as the reference's loop produces them, in each arithmetic (boxqp.hpp)
+__device__ __constant__ const StepTableT<double> kStepTable{};
+__device__ __constant__ const StepTableT<float> kStepTableF{};
+__device__ __forceinline__ const double* step_table(double) { return kStepTable.s; }
+__device__ __forceinline__ const float* step_table(float) { return kStepTableF.s; }
 
 // Quad-parallel Armijo line search for the scalar QP (all four lanes of a quad hold the same
 // QP1State).  The reference's loop (boxqp.cpp:156-173) tries step_k = 0.6^k for k = 0, 1, 2, ...
@@ -933,20 +973,21 @@ __device__ __constant__ const StepTable kStepTable{};
 // table, and the first passing candidate whose predecessor is known to fail is taken.  Anything
 // else (estimate off, Q <= 0, k near the minStep cut-off) returns false and the caller runs the
 // sequential loop: the result is the reference's either way.
-__device__ __forceinline__ bool qp1_search_quad(QP1State& q, int s, int lane, const double* __restrict__ lds_steps) {
-  const double bound = (q.search > 0) ? q.hi : q.lo;
-  const double v_b = qp1_value(q, bound);
+template <class real>
+__device__ __forceinline__ bool qp1_search_quad(QP1StateT<real>& q, int s, int lane, const real* __restrict__ lds_steps) {
+  const real bound = (q.search > 0) ? q.hi : q.lo;
+  const real v_b = qp1_value(q, bound);
   // fp32 estimates: f = fraction of the step inside the box, r = Armijo threshold on the bound
   const float f = (float)(bound - q.x) * __builtin_amdgcn_rcpf((float)q.search);  // 1-ulp v_rcp_f32: only an estimate
-  const float r = (float)(v_b - q.old_v) * __builtin_amdgcn_rcpf((float)(kArmijo * q.slope));
+  const float r = (float)(v_b - q.old_v) * __builtin_amdgcn_rcpf((float)(real(kArmijo) * q.slope));
   const float thr = fmaxf(f, r);
   int kg = (int)ceilf(__log2f(thr) * -1.35691545f);  // log(thr)/log(0.6)
-  const bool sane = (q.Q > 0.0) & (thr > 0.f) & (thr < 1.f) & (kg >= 1) & (kg <= 96);
+  const bool sane = (q.Q > real(0)) & (thr > 0.f) & (thr < 1.f) & (kg >= 1) & (kg <= 96);
   const int k1 = (sane & (kg > 2)) ? kg - 1 : 1;
   const int my_k = (s == 0) ? 0 : k1 + s - 1;
-  const double my_step = lds_steps[my_k];
-  const double my_x1 = qp1_trial(q, my_step);
-  const double my_v1 = qp1_value(q, my_x1);
+  const real my_step = lds_steps[my_k];
+  const real my_x1 = qp1_trial(q, my_step);
+  const real my_v1 = qp1_value(q, my_x1);
   const bool my_pass = !qp1_armijo_fails(q, my_v1, my_step);
   const unsigned long long bal = __ballot(my_pass);
   const unsigned int m4 = (unsigned int)(bal >> (lane & ~3)) & 0xFu;
@@ -967,7 +1008,7 @@ __device__ __forceinline__ bool qp1_search_quad(QP1State& q, int s, int lane, co
   // Armijo ratio is 0 at every k, and the reference's loop runs its ~100 trips down to minStep and
   // reports failure (boxqp.cpp:167-171).  Same outcome, without the trips -- late in a solve this
   // was a quarter of the steps of the slowest tiles.
-  const bool stuck = (qp1_trial(q, 1.0) == q.x) & !q.early;
+  const bool stuck = (qp1_trial(q, real(1)) == q.x) & !q.early;
   // The same once the search direction is rounding noise (late in a solve Quu reaches 1e12+ and x
   // sits on the optimum to an ulp: search ~ 1e-19): steps 1 and 0.6 still move x by an ulp, from
   // 0.36 on the trial IS x.  With the window at k = 1, 2, 3 every k <= 3 has been tested exactly;
@@ -978,15 +1019,15 @@ __device__ __forceinline__ bool qp1_search_quad(QP1State& q, int s, int lane, co
   return ok | q.early | stuck | dead;
 }
 
-template <int NU>
+template <int NU, class real>
 struct QuadStep {  // what lane (l, s) needs of one derivative record
-  double fx[16];     // full fx (replicated over s)
-  double fxc[4];     // fx[:, s] again, loaded by address so no register array is indexed by s
-  double fu[4 * NU]; // full fu
-  double cu[NU], cuu[NU * NU], us[NU];
-  double cx;         // cx[s]
-  double cxx[4];     // cxx[:, s]
-  double cxu[NU];    // cxu[s, :]
+  real fx[16];     // full fx (replicated over s)
+  real fxc[4];     // fx[:, s] again, loaded by address so no register array is indexed by s
+  real fu[4 * NU]; // full fu
+  real cu[NU], cuu[NU * NU], us[NU];
+  real cx;         // cx[s]
+  real cxx[4];     // cxx[:, s]
+  real cxu[NU];    // cxu[s, :]
 };
 
 // The body of the quad backward pass for one tile, run by ONE wavefront (lane = 4*l + s).
@@ -996,9 +1037,10 @@ struct QuadStep {  // what lane (l, s) needs of one derivative record
 // ring != nullptr: the FIRST pass reads each knot from LDS slot (T - t) % SLOTS, where the producers
 // put it; lambda-retry passes (and ring == nullptr) read the records from HBM.
 template <class M, class Gate, int RING_KB = ILQR_RING_KB>
-__device__ __forceinline__ void backward_quad(const BatchView& v, const M& model, const SolverParams& sp, int mode,
-                                              int tile, int lane, const double* __restrict__ lds_steps, Gate gate,
-                                              const double* ring = nullptr) {
+__device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>& v, const M& model, const SolverParams& sp, int mode,
+                                              int tile, int lane, const typename M::real* __restrict__ lds_steps, Gate gate,
+                                              const typename M::real* ring = nullptr) {
+  using real = typename M::real;
   static_assert(M::NX == 4, "quad kernel: one lane per state dimension");
   constexpr int NX = 4, NU = M::NU;
   using R = Rec<NX, NU>;
@@ -1008,39 +1050,39 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
   if (mode == 1 && v.status[b] != 0) return;   // quad-uniform
   const int T = v.T;
   double lambda = v.lambda[b], dlambda = v.dlambda[b];
-  typedef double double2_t __attribute__((ext_vector_type(2)));
-  const double* __restrict__ Dt = v.D + didx(tile, 0, 0, l, T + 1, R::SIZE);
-  const double* __restrict__ ust = v.us + tidx(tile, 0, 0, l, T, NU);
-  double* __restrict__ kt = v.kff + tidx(tile, 0, 0, l, T, NU);
-  double* __restrict__ Kt = v.Kfb + tidx(tile, 0, 0, l, T, NU * NX);
+  typedef real real2_t __attribute__((ext_vector_type(2)));
+  const real* __restrict__ Dt = v.D + didx(tile, 0, 0, l, T + 1, R::SIZE);
+  const real* __restrict__ ust = v.us + tidx(tile, 0, 0, l, T, NU);
+  real* __restrict__ kt = v.kff + tidx(tile, 0, 0, l, T, NU);
+  real* __restrict__ Kt = v.Kfb + tidx(tile, 0, 0, l, T, NU * NX);
 
-  using RS = RingSlot<NX, NU, RING_KB>;
+  using RS = RingSlot<NX, NU, real, RING_KB>;
   bool from_ring = (ring != nullptr);  // cleared when a pass has to be repeated
   // what lane (l, s) needs of knot t, given accessors for element pairs (e even) / single elements
-  auto fill = [&](auto pair, auto one, QuadStep<NU>& d) __attribute__((always_inline)) {
+  auto fill = [&](auto pair, auto one, QuadStep<NU, real>& d) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = 0; e < 16; e += 2) {
-      const double2_t w = pair(R::FX + e);
+      const real2_t w = pair(R::FX + e);
       d.fx[e] = w.x;
       d.fx[e + 1] = w.y;
     }
 #pragma unroll
     for (int q = 0; q < 4; q += 2) {
-      const double2_t w = pair(R::FX + q + 4 * s);
+      const real2_t w = pair(R::FX + q + 4 * s);
       d.fxc[q] = w.x;
       d.fxc[q + 1] = w.y;
     }
 #pragma unroll
     for (int e = 0; e < 4 * NU; e += 2) {
-      const double2_t w = pair(R::FU + e);
+      const real2_t w = pair(R::FU + e);
       d.fu[e] = w.x;
       d.fu[e + 1] = w.y;
     }
     {  // cu and cuu are adjacent: nu(nu+1) doubles, an even count at an even offset
-      double tail[NU + NU * NU];
+      real tail[NU + NU * NU];
 #pragma unroll
       for (int e = 0; e < NU + NU * NU; e += 2) {
-        const double2_t w = pair(R::CU + e);
+        const real2_t w = pair(R::CU + e);
         tail[e] = w.x;
         tail[e + 1] = w.y;
       }
@@ -1052,7 +1094,7 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
     d.cx = one(R::CX + s);
 #pragma unroll
     for (int i = 0; i < 4; i += 2) {
-      const double2_t w = pair(R::CXX + i + 4 * s);
+      const real2_t w = pair(R::CXX + i + 4 * s);
       d.cxx[i] = w.x;
       d.cxx[i + 1] = w.y;
     }
@@ -1061,21 +1103,21 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
   };
   // (explicit address spaces: with generic pointers hipcc merges the two sources' loads into flat
   // instructions, which wait on vmcnt and lgkmcnt alike)
-  typedef const __attribute__((address_space(3))) double lds_cd;
-  typedef const __attribute__((address_space(3))) double2_t lds_cd2;
-  auto load = [&](auto tag, int t, QuadStep<NU>& d) __attribute__((always_inline)) {
+  typedef const __attribute__((address_space(3))) real lds_cd;
+  typedef const __attribute__((address_space(3))) real2_t lds_cd2;
+  auto load = [&](auto tag, int t, QuadStep<NU, real>& d) __attribute__((always_inline)) {
     constexpr bool RP = decltype(tag)::value;
     gate(t, RP);
     if constexpr (RP) {  // ds_read_b128 / b64 from the producers' slot
-      lds_cd* r = (lds_cd*)(ring + ((T - t) % RS::SLOTS) * RS::DOUBLES + l * 2);
+      lds_cd* r = (lds_cd*)(ring + ((T - t) % RS::SLOTS) * RS::ELEMS + l * 2);
       auto pair = [&](int e) { return *(lds_cd2*)(r + (e >> 1) * (2 * TW)); };
       auto one = [&](int e) { return r[(e >> 1) * (2 * TW) + (e & 1)]; };
       fill(pair, one, d);
 #pragma unroll
       for (int a = 0; a < NU; a++) d.us[a] = one(RS::US + a);
     } else {  // 16-byte / 8-byte global loads of the record in HBM
-      const double* r = Dt + (unsigned)(t * ((R::SIZE / 2) * 2 * TW));  // in-tile offsets fit 32 bits
-      auto pair = [&](int e) { return *reinterpret_cast<const double2_t*>(r + (unsigned)((e >> 1) * (2 * TW))); };
+      const real* r = Dt + (unsigned)(t * ((R::SIZE / 2) * 2 * TW));  // in-tile offsets fit 32 bits
+      auto pair = [&](int e) { return *reinterpret_cast<const real2_t*>(r + (unsigned)((e >> 1) * (2 * TW))); };
       auto one = [&](int e) { return r[(unsigned)((e >> 1) * (2 * TW) + (e & 1))]; };
       fill(pair, one, d);
 #pragma unroll
@@ -1087,12 +1129,13 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
   constexpr int kWaitLds = 0xC07F;                // s_waitcnt lgkmcnt(0) only (vmcnt = 63, expcnt = 7)
   int diverge = 0;
   bool done = false;
-  double dV0 = 0, dV1 = 0, gacc = 0;
+  double dV0 = 0, dV1 = 0, gacc = 0;  // per-trajectory accumulators: double in both modes
   // one backward_pass() at the current lambda; tag = std::true_type: knots come from the ring
   auto one_pass = [&](auto tag) __attribute__((always_inline)) {
     constexpr bool RP = decltype(tag)::value;
     // carried state: full Vxx / Vx in every lane
-    double Vx[4], Vxx[16], kprev[NU];
+    real Vx[4], Vxx[16], kprev[NU];
+    const real lam_r = (real)lambda;  // the regularisation of this pass in the handle's arithmetic (:367)
     {
       gate(T, RP);
       if constexpr (RP) {
@@ -1102,7 +1145,7 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
 #pragma unroll
         for (int e = 0; e < 16; e++) Vxx[e] = r[((R::CXX + e) >> 1) * (2 * TW) + ((R::CXX + e) & 1)];  // :354
       } else {
-        const double* r = Dt + (size_t)T * (R::SIZE / 2) * (2 * TW);
+        const real* r = Dt + (size_t)T * (R::SIZE / 2) * (2 * TW);
 #pragma unroll
         for (int i = 0; i < 4; i++) Vx[i] = r[(size_t)((R::CX + i) >> 1) * (2 * TW) + ((R::CX + i) & 1)];  // :353
 #pragma unroll
@@ -1124,74 +1167,74 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
 #define ILQR_MARK(k)
 #endif
     // one Riccati step; returns false if the box-QP reports failure (ilqr_core.cpp:371)
-    auto step = [&](int i, const QuadStep<NU>& d) -> bool {
+    auto step = [&](int i, const QuadStep<NU, real>& d) -> bool {
       ILQR_MARK(0)  // load issue + loop overhead
       // W = Vxx' * fx[:, s]   (column s)
-      double W[4];
+      real W[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        double acc = 0;
+        real acc = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) acc += Vxx[r + 4 * q] * d.fxc[q];
         W[r] = acc;
       }
       // Qxx[:, s] = cxx[:, s] + fx' W      :361
-      double Qxxc[4];
+      real Qxxc[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        double acc = 0;
+        real acc = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) acc += d.fx[q + 4 * r] * W[q];
         Qxxc[r] = d.cxx[r] + acc;
       }
       // Qx[s] = cx[s] + fx[:, s]' Vx'      :359
-      double Qxs;
+      real Qxs;
       {
-        double acc = 0;
+        real acc = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) acc += d.fxc[q] * Vx[q];
         Qxs = d.cx + acc;
       }
       // Qux[:, s] = cxu[s, :]' + fu' W     :362/:366
-      double Quxc[NU];
+      real Quxc[NU];
 #pragma unroll
       for (int a = 0; a < NU; a++) {
-        double acc = 0;
+        real acc = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) acc += d.fu[q + 4 * a] * W[q];
         Quxc[a] = d.cxu[a] + acc;
       }
       // replicated: Qu, wv = Vxx' fu, Quu, QuuF     :360, :363, :367
-      double Qu[NU], Quu[NU * NU], QuuF[NU * NU];
+      real Qu[NU], Quu[NU * NU], QuuF[NU * NU];
 #pragma unroll
       for (int a = 0; a < NU; a++) {
-        double acc = 0;
+        real acc = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) acc += d.fu[q + 4 * a] * Vx[q];
         Qu[a] = d.cu[a] + acc;
       }
 #pragma unroll
       for (int c = 0; c < NU; c++) {
-        double wv[4];
+        real wv[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          double acc = 0;
+          real acc = 0;
 #pragma unroll
           for (int q = 0; q < 4; q++) acc += Vxx[r + 4 * q] * d.fu[q + 4 * c];
           wv[r] = acc;
         }
 #pragma unroll
         for (int a = 0; a < NU; a++) {
-          double acc = 0;
+          real acc = 0;
 #pragma unroll
           for (int q = 0; q < 4; q++) acc += d.fu[q + 4 * a] * wv[q];
           Quu[a + NU * c] = d.cuu[a + NU * c] + acc;
-          QuuF[a + NU * c] = (d.cuu[a + NU * c] + ((a == c) ? lambda : 0.0)) + acc;
+          QuuF[a + NU * c] = (d.cuu[a + NU * c] + ((a == c) ? lam_r : real(0))) + acc;
         }
       }
       ILQR_MARK(1)  // Q-function products
       // :369  box-QP (replicated in the quad)
-      double lo[NU], hi[NU];
+      real lo[NU], hi[NU];
 #pragma unroll
       for (int a = 0; a < NU; a++) {
         lo[a] = model.u_min[a] - d.us[a];
@@ -1199,20 +1242,20 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
       }
       // :371  a failed QP ends the pass.  No early return: the rest of the step is computed
       // anyway (its results are discarded) so that the vmcnt wait below sits on every path.
-      struct { double x[NU]; } qp;
-      double Kc[NU];
+      struct { real x[NU]; } qp;
+      real Kc[NU];
       bool ok;
       if constexpr (NU == 1) {
         int free0;
-        double minv;
-        QP1State q1;
+        real minv;
+        QP1StateT<real> q1;
         qp1_begin<false>(QuuF[0], Qu[0], kprev[0], lo[0], hi[0], q1);
         if (!qp1_search_quad(q1, s, lane, lds_steps)) {  // fallback: rare
 #ifdef ILQR_PHASE_TIMING
           xc[2] += 1;
 #endif
           q1.step = 1;
-          q1.x1 = qp1_trial(q1, 1.0);
+          q1.x1 = qp1_trial(q1, real(1));
           q1.v1 = qp1_value(q1, q1.x1);
           qp1_backtrack_seq(q1);
         }
@@ -1227,7 +1270,7 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
         if (result < 0)  // the QP goes on (rare early in a solve, a quarter of the steps of some tiles later)
           result = qp1_continue(
               q1,
-              [&](QP1State& qs) __attribute__((always_inline)) {
+              [&](QP1StateT<real>& qs) __attribute__((always_inline)) {
 #ifdef ILQR_PHASE_TIMING
                 xc[1] += 1;
 #endif
@@ -1235,8 +1278,8 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
 #ifdef ILQR_PHASE_TIMING
                   xc[2] += 1;
                   if (v.dbg && s == 0) {
-                    const double bnd = (qs.search > 0) ? qs.hi : qs.lo;
-                    double* dd = reinterpret_cast<double*>(v.dbg + 768);
+                    const real bnd = (qs.search > 0) ? qs.hi : qs.lo;
+                    real* dd = reinterpret_cast<real*>(v.dbg + 768);
                     dd[0] = qs.search; dd[1] = bnd - qs.x; dd[2] = qp1_value(qs, bnd) - qs.old_v; dd[3] = qs.slope; dd[4] = qs.Q; dd[5] = qs.x; dd[6] = bnd;
                   }
 #endif
@@ -1248,9 +1291,9 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
               },
               qp.x[0], free0);
         ok = result >= 1;
-        Kc[0] = free0 ? -minv * Quxc[0] : 0.0;  // :373-385
+        Kc[0] = free0 ? -minv * Quxc[0] : real(0);  // :373-385
       } else {
-        BoxQPResult<NU> r;
+        BoxQPResult<NU, real> r;
         box_qp<NU>(QuuF, Qu, kprev, lo, hi, r);
         ok = r.result >= 1;
 #pragma unroll
@@ -1266,12 +1309,12 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
           nf += r.v_free[a] ? 1 : 0;
         }
         if (nf > 0) {
-          double Minv[NU * NU], qf[NU];
+          real Minv[NU * NU], qf[NU];
           rinv_rinvT<NU>(r.nfR, r.R, Minv);
           const int nuse = (nf < r.nfR) ? nf : r.nfR;
 #pragma unroll
           for (int a = 0; a < NU; a++) {
-            double val = 0;
+            real val = 0;
 #pragma unroll
             for (int j = 0; j < NU; j++)
               if (r.v_free[j] && rank[j] == a) val = Quxc[j];
@@ -1280,11 +1323,11 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
 #pragma unroll
           for (int j = 0; j < NU; j++)
             if (r.v_free[j] && rank[j] < nuse) {
-              double acc = 0;
+              real acc = 0;
 #pragma unroll
               for (int a = 0; a < NU; a++)
                 if (a < nuse) {
-                  double mrow = 0;
+                  real mrow = 0;
 #pragma unroll
                   for (int rr = 0; rr < NU; rr++)
                     if (rr == rank[j]) mrow = Minv[rr + NU * a];
@@ -1298,33 +1341,33 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
       ILQR_MARK(2)  // box-QP + K
       // :388-389
       {
-        double d0 = 0;
+        real d0 = 0;
 #pragma unroll
         for (int a = 0; a < NU; a++) d0 += qp.x[a] * Qu[a];
-        if (ok) dV0 += d0;
-        double d1 = 0;
+        if (ok) dV0 += (double)d0;
+        real d1 = 0;
 #pragma unroll
         for (int c = 0; c < NU; c++) {
-          double r = 0;
+          real r = 0;
 #pragma unroll
-          for (int a = 0; a < NU; a++) r += (0.5 * qp.x[a]) * Quu[a + NU * c];
+          for (int a = 0; a < NU; a++) r += (real(0.5) * qp.x[a]) * Quu[a + NU * c];
           d1 += r * qp.x[c];
         }
-        if (ok) dV1 += d1;
+        if (ok) dV1 += (double)d1;
       }
       // T1s[c] = (K' Quu)[s, c]
-      double T1s[NU];
+      real T1s[NU];
 #pragma unroll
       for (int c = 0; c < NU; c++) {
-        double acc = 0;
+        real acc = 0;
 #pragma unroll
         for (int q = 0; q < NU; q++) acc += Kc[q] * Quu[q + NU * c];
         T1s[c] = acc;
       }
       // :391  Vx[s]
-      double Vxs;
+      real Vxs;
       {
-        double t1 = 0, t2 = 0, t3 = 0;
+        real t1 = 0, t2 = 0, t3 = 0;
 #pragma unroll
         for (int c = 0; c < NU; c++) {
           t1 += T1s[c] * qp.x[c];
@@ -1334,7 +1377,7 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
         Vxs = ((Qxs + t1) + t2) + t3;
       }
       // exchange K, Qux, K'Quu columns inside the quad
-      double Kall[NU][4], Qall[NU][4], T1all[NU][4];
+      real Kall[NU][4], Qall[NU][4], T1all[NU][4];
 #pragma unroll
       for (int a = 0; a < NU; a++) {
         quad_gather(Kc[a], Kall[a]);
@@ -1344,16 +1387,16 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
       for (int c = 0; c < NU; c++)  // (K'Quu)[r, c] for every r, from the gathered K (no third exchange)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          double acc = 0;
+          real acc = 0;
 #pragma unroll
           for (int q = 0; q < NU; q++) acc += Kall[q][r] * Quu[q + NU * c];
           T1all[c][r] = acc;
         }
       // :392  Vn[r, s] = Qxx[r,s] + (K'Quu)[r,:] K[:,s] + K[:,r]' Qux[:,s] + Qux[:,r]' K[:,s]
-      double Vn[4];
+      real Vn[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        double t1 = 0, t2 = 0, t3 = 0;
+        real t1 = 0, t2 = 0, t3 = 0;
 #pragma unroll
         for (int q = 0; q < NU; q++) {
           t1 += T1all[q][r] * Kc[q];
@@ -1363,10 +1406,10 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
         Vn[r] = ((Qxxc[r] + t1) + t2) + t3;
       }
       // all-gather, then :393 symmetrise (every lane keeps the full matrix)
-      double Vf[16];
+      real Vf[16];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        double col[4];
+        real col[4];
         quad_gather(Vn[r], col);  // col[c] = Vn[r, c]
 #pragma unroll
         for (int c = 0; c < 4; c++) Vf[r + 4 * c] = col[c];
@@ -1378,7 +1421,7 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
         Vxx[r + 4 * r] = Vf[r + 4 * r];
 #pragma unroll
         for (int c = r + 1; c < 4; c++) {
-          const double sym = 0.5 * (Vf[r + 4 * c] + Vf[c + 4 * r]);
+          const real sym = real(0.5) * (Vf[r + 4 * c] + Vf[c + 4 * r]);
           Vxx[r + 4 * c] = sym;
           Vxx[c + 4 * r] = sym;
         }
@@ -1386,13 +1429,13 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
       quad_gather(Vxs, Vx);
       // :405-412 term of the gradient norm for this step (summed here in descending t)
       {
-        double mx = 0;
+        real mx = 0;
 #pragma unroll
         for (int a = 0; a < NU; a++) {
-          const double val = fabs(qp.x[a]) * recip(fabs(d.us[a]) + 1);
+          const real val = abs_of(qp.x[a]) * recip(abs_of(d.us[a]) + 1);
           mx = (a == 0 || val > mx) ? val : mx;
         }
-        if (ok) gacc += mx;
+        if (ok) gacc += (double)mx;
       }
       ILQR_MARK(3)  // value-function update + quad exchanges
       // the prefetch issued at the top of this step has had the whole step to land.  From HBM:
@@ -1431,7 +1474,7 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
       //   -> issue this step's stores (never waited for).
       // The explicit wait + sched_barriers keep hipcc from parking its own vmcnt(0) right behind
       // the freshly issued prefetch, which would expose one HBM round trip per step.
-      QuadStep<NU> A, Bd;
+      QuadStep<NU, real> A, Bd;
       int i = T - 1;
       load(tag, i, A);
       __builtin_amdgcn_s_waitcnt(kWaitAll & kWaitLds);
@@ -1499,7 +1542,7 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
     __builtin_amdgcn_s_waitcnt(0);
     acc = 0;
     for (int t0 = 0; t0 < T; t0 += 8) {
-      double kv[8][NU], uv[8][NU];
+      real kv[8][NU], uv[8][NU];
 #pragma unroll
       for (int j = 0; j < 8; j++)
 #pragma unroll
@@ -1510,13 +1553,13 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
         }
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        double mx = 0;
+        real mx = 0;
 #pragma unroll
         for (int a = 0; a < NU; a++) {
-          const double val = fabs(kv[j][a]) / (fabs(uv[j][a]) + 1);
+          const real val = abs_of(kv[j][a]) / (abs_of(uv[j][a]) + 1);
           mx = (a == 0 || val > mx) ? val : mx;
         }
-        if (t0 + j < T) acc += mx;
+        if (t0 + j < T) acc += (double)mx;
       }
     }
   }
@@ -1538,15 +1581,18 @@ __device__ __forceinline__ void backward_quad(const BatchView& v, const M& model
   }
 }
 
-__device__ __forceinline__ void load_step_table(double* lds_steps) {
-  for (int k = threadIdx.x; k < 104; k += blockDim.x) lds_steps[k] = kStepTable.s[k];
+template <class real>
+__device__ __forceinline__ void load_step_table(real* lds_steps) {
+  const real* tab = step_table(real(0));
+  for (int k = threadIdx.x; k < 104; k += blockDim.x) lds_steps[k] = tab[k];
   __syncthreads();
 }
 
 // stage call / records already in HBM: grid = ntiles, block = 64
 template <class M>
-__global__ __launch_bounds__(64) void k_backward_q(BatchView v, M model, SolverParams sp, int mode) {
-  __shared__ double lds_steps[104];  // backtracking step sizes (per-lane indexed -> LDS, not constant cache)
+__global__ __launch_bounds__(64) void k_backward_q(BatchViewT<typename M::real> v, M model, SolverParams sp, int mode) {
+  using real = typename M::real;
+  __shared__ real lds_steps[104];  // backtracking step sizes (per-lane indexed -> LDS, not constant cache)
   load_step_table(lds_steps);
   backward_quad(v, model, sp, mode, (int)blockIdx.x, (int)threadIdx.x, lds_steps, [](int, bool) {});
 }
@@ -1576,16 +1622,17 @@ constexpr int kProducers = ILQR_PRODUCERS;
 #ifndef ILQR_LEAD_ROUNDS
 #define ILQR_LEAD_ROUNDS 1
 #endif
-template <class M, int kProd = kProducers, int RING_KB = ILQR_RING_KB>
-__global__ __launch_bounds__(64 * (1 + kProd)) void k_sweep_backward(BatchView v, M model, SolverParams sp, int mode, int force,
+template <class M, int kProd = kProducers, int RING_KB = ILQR_RING_KB, class MFD = M>
+__global__ __launch_bounds__(64 * (1 + kProd)) void k_sweep_backward(BatchViewT<typename M::real> v, M model, MFD fdm, SolverParams sp, int mode, int force,
                                                         const int* __restrict__ commit_idx) {
+  using real = typename M::real;
   constexpr int kProducers = kProd;               // (shadows the default: everything below is per instantiation)
   constexpr int kKnotsPerRound = 4 * kProducers;  // 4 knots per producer wavefront
   constexpr int kLeadKnots = ILQR_LEAD_ROUNDS * kKnotsPerRound;  // producers stay at most this far ahead of the consumer
-  using RS = RingSlot<M::NX, M::NU, RING_KB>;
+  using RS = RingSlot<M::NX, M::NU, real, RING_KB>;
   static_assert(RS::SLOTS >= kLeadKnots + 4, "the ring must hold the producers' lead plus the four knots in production");
-  __shared__ double lds_steps[104];
-  __shared__ double ring[RS::SLOTS * RS::DOUBLES];  // knot j = T - t lives in slot j % SLOTS
+  __shared__ real lds_steps[104];
+  __shared__ real ring[RS::SLOTS * RS::ELEMS];  // knot j = T - t lives in slot j % SLOTS
   __shared__ int rounds_done[kProducers];    // rounds whose records are in the ring
   __shared__ int rounds_stored[kProducers];  // rounds whose records (and committed knots) have reached HBM
   __shared__ int consumer_at;  // knots j < consumer_at are in the backward pass's registers (slots free)
@@ -1650,7 +1697,7 @@ __global__ __launch_bounds__(64 * (1 + kProd)) void k_sweep_backward(BatchView v
       }
       const int t = T - (j0 + sub);
       if (t >= 0)
-        derivatives_of_knot<M, true>(v, model, force, commit_idx, tile, t, l, ring + ((j0 + sub) % RS::SLOTS) * RS::DOUBLES + l * 2);
+        derivatives_of_knot<M, true, MFD>(v, model, fdm, force, commit_idx, tile, t, l, ring + ((j0 + sub) % RS::SLOTS) * RS::ELEMS + l * 2);
       // LDS operations of a wavefront complete in order: once its writes are done the round is visible
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
       if (lane == 0) __hip_atomic_store(&rounds_done[w], r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1665,7 +1712,8 @@ __global__ __launch_bounds__(64 * (1 + kProd)) void k_sweep_backward(BatchView v
 // ------------------------------------------------------------------------------------------
 // copy candidate commit_idx[b] into the nominal trajectory.  block 256 = 16 traj x 16 steps.
 template <class M>
-__global__ __launch_bounds__(256) void k_commit(BatchView v, M model, const int* __restrict__ commit_idx) {
+__global__ __launch_bounds__(256) void k_commit(BatchViewT<typename M::real> v, M model, const int* __restrict__ commit_idx) {
+  using real = typename M::real;
   constexpr int NX = M::NX, NU = M::NU;
   const int l = threadIdx.x & (TW - 1);
   const int t = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -1675,7 +1723,7 @@ __global__ __launch_bounds__(256) void k_commit(BatchView v, M model, const int*
   if (t > T || b >= v.B) return;
   const int a = commit_idx[b];
   if (a < 0) return;
-  double x[NX], u[NU];
+  real x[NX], u[NU];
   candidate_knot(v, model, a, tile, t, l, x, u);
 #pragma unroll
   for (int i = 0; i < NX; i++) v.xs[tidx(tile, t, i, l, T + 1, NX)] = x[i];

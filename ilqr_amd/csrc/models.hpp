@@ -45,40 +45,59 @@ __device__ __forceinline__ void sincos_shared(double x, double& s_out, double& c
   c_out = ((q + 1) & 2) ? -ca : ca;
 }
 
+// fp32 flavour of the above: j = rint(x 2/pi), r = x - j pi/2 in three FMAs (pi/2 split in three floats),
+// minimax polynomials on [-pi/4, pi/4] (the classic single-precision kernels): ~1 ulp for |x| <= 1e4.
+__device__ __forceinline__ void sincos_shared(float x, float& s_out, float& c_out) {
+  const float j = __builtin_rintf(x * 6.36619772e-01f);
+  float r = __builtin_fmaf(-j, 1.57079601e+00f, x);   // pi/2, leading bits (exact product with |j| < 2^11)
+  r = __builtin_fmaf(-j, 3.13916473e-07f, r);         // next
+  r = __builtin_fmaf(-j, 5.39030253e-15f, r);         // rest
+  const float z = r * r;
+  const float sr = r + (z * r) * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+  const float cr = (1.0f - 0.5f * z) + (z * z) * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+  const int q = (int)j & 3;
+  const float sa = (q & 1) ? cr : sr;
+  const float ca = (q & 1) ? sr : cr;
+  s_out = (q & 2) ? -sa : sa;
+  c_out = ((q + 1) & 2) ? -ca : ca;
+}
+
 // include/acrobot.h  (n=4, m=1).  I1=I2=l1=l2=m1=m2=1, lc1=lc2=.5, g=9.81 (:19-25).
-struct AcrobotModel {
+template <class real_>
+struct AcrobotModelT {
+  using real = real_;
   static constexpr int NX = 4;
   static constexpr int NU = 1;
-  double goal[4];  // acrobot.h:21  (3.1415, 0, 0, 0)
-  double u_min[1], u_max[1];
+  real goal[4];  // acrobot.h:21  (3.1415, 0, 0, 0)
+  real u_min[1], u_max[1];
 
-  __device__ __forceinline__ void dynamics(const double* x, const double* u, double* dx) const {
-    const double I1 = 1, I2 = 1, l1 = 1, l2 = 1, m1 = 1, m2 = 1, g = 9.81;
-    const double lc1 = 0.5 * l1, lc2 = 0.5 * l2;
-    const double q0 = x[0], q1 = x[1], qd0 = x[2], qd1 = x[3];
+  __device__ __forceinline__ void dynamics(const real* x, const real* u, real* dx) const {
+    const real I1 = 1, I2 = 1, l1 = 1, l2 = 1, m1 = 1, m2 = 1, g = real(9.81);
+    const real lc1 = real(0.5) * l1, lc2 = real(0.5) * l2;
+    const real q0 = x[0], q1 = x[1], qd0 = x[2], qd1 = x[3];
     // the four trig values of acrobot.h:44,55,65,66 from two shared-reduction evaluations;
     // sin(q0+q1) by the angle-sum identity (about 2e-16 absolute)
-    double s1, c1, s2, c2;
+    real s1, c1, s2, c2;
     sincos_shared(q0, s1, c1);
     sincos_shared(q1, s2, c2);
-    const double s12 = s1 * c2 + c1 * s2;
+    const real s12 = s1 * c2 + c1 * s2;
     // H(q), acrobot.h:43-51
-    const double H00 = I1 + I2 + m2 * l1 * l1 + 2 * m2 * l1 * lc2 * c2;
-    const double H01 = I2 + m2 * l1 * lc2 * c2;
-    const double H10 = H01;
-    const double H11 = I2;
+    const real H00 = I1 + I2 + m2 * l1 * l1 + 2 * m2 * l1 * lc2 * c2;
+    const real H01 = I2 + m2 * l1 * lc2 * c2;
+    const real H10 = H01;
+    const real H11 = I2;
     // C(q,qd), acrobot.h:53-61
-    const double C00 = -2 * m2 * l1 * lc2 * s2 * qd1;
-    const double C01 = -m2 * l2 * lc2 * s2 * qd1;
-    const double C10 = m2 * l1 * lc2 * s2 * qd0;
+    const real C00 = -2 * m2 * l1 * lc2 * s2 * qd1;
+    const real C01 = -m2 * l2 * lc2 * s2 * qd1;
+    const real C10 = m2 * l1 * lc2 * s2 * qd0;
     // G(q), acrobot.h:63-70
-    const double G0 = m1 * g * lc1 * s1 + m2 * g * (l1 * s1 + lc2 * s12);
-    const double G1 = m2 * g * lc2 * s12;
+    const real G0 = m1 * g * lc1 * s1 + m2 * g * (l1 * s1 + lc2 * s12);
+    const real G1 = m2 * g * lc2 * s12;
     // rhs = (0,u) - C*qd - G, acrobot.h:80
-    const double r0 = (0.0 - (C00 * qd0 + C01 * qd1)) - G0;
-    const double r1 = (u[0] - (C10 * qd0)) - G1;
+    const real r0 = (real(0.0) - (C00 * qd0 + C01 * qd1)) - G0;
+    const real r1 = (u[0] - (C10 * qd0)) - G1;
     // H^-1 as Eigen's fixed 2x2 inverse (LU/InverseImpl.h:76-96): invdet then 4 products
-    const double invdet = 1.0 / (H00 * H11 - H10 * H01);
+    const real invdet = real(1.0) / (H00 * H11 - H10 * H01);
     dx[0] = qd0;
     dx[1] = qd1;
     dx[2] = (H11 * invdet) * r0 + (-H01 * invdet) * r1;
@@ -89,48 +108,48 @@ struct AcrobotModel {
   // qdd = H^-1 r with r = (0,u) - C qd - G, so d qdd / dz = H^-1 (dr/dz - (dH/dz) qdd); the Euler map
   // has fx = I + dt df/dx, fu = dt df/du.  t = T follows the conventions of derivatives.cpp
   // (fx = fu = 0, cx / cxx from final_cost, cu = 0, cuu from cost(x_T, .), cxu = 0).
-  __device__ __forceinline__ void analytic_record(const double* x, const double* u, double dt, bool last, double* rec) const {
+  __device__ __forceinline__ void analytic_record(const real* x, const real* u, real dt, bool last, real* rec) const {
     using R = Rec<4, 1>;
 #pragma unroll
-    for (int e = 0; e < R::SIZE; e++) rec[e] = 0.0;
-    rec[R::CUU] = 2 * 0.1 * 0.1;  // d2/du2 of Kr^2 u^2
+    for (int e = 0; e < R::SIZE; e++) rec[e] = real(0);
+    rec[R::CUU] = 2 * real(0.1) * real(0.1);  // d2/du2 of Kr^2 u^2
     if (last) {
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        rec[R::CX + i] = -2.0 * 400.0 * (goal[i] - x[i]);  // Ks^2 = Kd^2 = 400
-        rec[R::CXX + i + 4 * i] = 2.0 * 400.0;
+        rec[R::CX + i] = -real(2.0) * real(400.0) * (goal[i] - x[i]);  // Ks^2 = Kd^2 = 400
+        rec[R::CXX + i + 4 * i] = real(2.0) * real(400.0);
       }
       return;
     }
-    const double g = 9.81, b = 0.5;  // b = m2 l1 lc2
-    const double qd0 = x[2], qd1 = x[3];
-    double s1, c1, s2, c2;
+    const real g = real(9.81), b = real(0.5);  // b = m2 l1 lc2
+    const real qd0 = x[2], qd1 = x[3];
+    real s1, c1, s2, c2;
     sincos_shared(x[0], s1, c1);
     sincos_shared(x[1], s2, c2);
-    const double s12 = s1 * c2 + c1 * s2, c12 = c1 * c2 - s1 * s2;
-    const double H00 = 3.0 + 2 * b * c2, H01 = 1.0 + b * c2, H11 = 1.0;
-    const double Cq0 = -2 * b * s2 * qd1 * qd0 - b * s2 * qd1 * qd1, Cq1 = b * s2 * qd0 * qd0;
-    const double G0 = g * (1.5 * s1 + 0.5 * s12), G1 = 0.5 * g * s12;
-    const double r0 = -Cq0 - G0, r1 = u[0] - Cq1 - G1;
-    const double invdet = 1.0 / (H00 * H11 - H01 * H01);
-    const double a0 = invdet * (H11 * r0 - H01 * r1), a1 = invdet * (-H01 * r0 + H00 * r1);  // qdd
-    double dr[5][2];  // columns q0, q1, qd0, qd1, u of dr/dz - (dH/dz) qdd
-    dr[0][0] = -g * (1.5 * c1 + 0.5 * c12);
-    dr[0][1] = -0.5 * g * c12;
+    const real s12 = s1 * c2 + c1 * s2, c12 = c1 * c2 - s1 * s2;
+    const real H00 = real(3.0) + 2 * b * c2, H01 = real(1.0) + b * c2, H11 = real(1.0);
+    const real Cq0 = -2 * b * s2 * qd1 * qd0 - b * s2 * qd1 * qd1, Cq1 = b * s2 * qd0 * qd0;
+    const real G0 = g * (real(1.5) * s1 + real(0.5) * s12), G1 = real(0.5) * g * s12;
+    const real r0 = -Cq0 - G0, r1 = u[0] - Cq1 - G1;
+    const real invdet = real(1.0) / (H00 * H11 - H01 * H01);
+    const real a0 = invdet * (H11 * r0 - H01 * r1), a1 = invdet * (-H01 * r0 + H00 * r1);  // qdd
+    real dr[5][2];  // columns q0, q1, qd0, qd1, u of dr/dz - (dH/dz) qdd
+    dr[0][0] = -g * (real(1.5) * c1 + real(0.5) * c12);
+    dr[0][1] = -real(0.5) * g * c12;
     {
-      const double dC0 = -2 * b * c2 * qd1 * qd0 - b * c2 * qd1 * qd1, dC1 = b * c2 * qd0 * qd0;
-      const double dG = 0.5 * g * c12;
-      const double dH00 = -2 * b * s2, dH01 = -b * s2;
+      const real dC0 = -2 * b * c2 * qd1 * qd0 - b * c2 * qd1 * qd1, dC1 = b * c2 * qd0 * qd0;
+      const real dG = real(0.5) * g * c12;
+      const real dH00 = -2 * b * s2, dH01 = -b * s2;
       dr[1][0] = -dC0 - dG - (dH00 * a0 + dH01 * a1);
       dr[1][1] = -dC1 - dG - (dH01 * a0);
     }
     dr[2][0] = 2 * b * s2 * qd1;
     dr[2][1] = -2 * b * s2 * qd0;
     dr[3][0] = 2 * b * s2 * qd0 + 2 * b * s2 * qd1;
-    dr[3][1] = 0.0;
-    dr[4][0] = 0.0;
-    dr[4][1] = 1.0;
-    double dq[5][2];
+    dr[3][1] = real(0.0);
+    dr[4][0] = real(0.0);
+    dr[4][1] = real(1.0);
+    real dq[5][2];
 #pragma unroll
     for (int z = 0; z < 5; z++) {
       dq[z][0] = invdet * (H11 * dr[z][0] - H01 * dr[z][1]);
@@ -139,7 +158,7 @@ struct AcrobotModel {
     // fx = I + dt * [[0,0,1,0],[0,0,0,1],[d qdd0/dx],[d qdd1/dx]]   (element (r, c) at r + 4 c)
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-      rec[R::FX + c + 4 * c] = 1.0;
+      rec[R::FX + c + 4 * c] = real(1.0);
       rec[R::FX + 2 + 4 * c] += dt * dq[c][0];
       rec[R::FX + 3 + 4 * c] += dt * dq[c][1];
     }
@@ -147,41 +166,43 @@ struct AcrobotModel {
     rec[R::FX + 1 + 4 * 3] += dt;
     rec[R::FU + 2] = dt * dq[4][0];
     rec[R::FU + 3] = dt * dq[4][1];
-    rec[R::CU] = 2 * 0.1 * 0.1 * u[0];
+    rec[R::CU] = 2 * real(0.1) * real(0.1) * u[0];
   }
 
   // acrobot.h:83-92: Ks = Kd = 0, Kr = 0.1 -> the state terms are exact zeros for finite x
-  __device__ __forceinline__ double cost(const double* x, const double* u) const {
+  __device__ __forceinline__ real cost(const real* x, const real* u) const {
     (void)x;
-    const double Kr = 0.1;
+    const real Kr = real(0.1);
     return Kr * Kr * (u[0] * u[0]);
   }
   // acrobot.h:94-100: Ks = Kd = 20
-  __device__ __forceinline__ double final_cost(const double* x) const {
-    const double q0 = goal[0] - x[0], q1 = goal[1] - x[1];
-    const double qd0 = goal[2] - x[2], qd1 = goal[3] - x[3];
-    const double Ks = 20.0, Kd = 20.0;
+  __device__ __forceinline__ real final_cost(const real* x) const {
+    const real q0 = goal[0] - x[0], q1 = goal[1] - x[1];
+    const real qd0 = goal[2] - x[2], qd1 = goal[3] - x[3];
+    const real Ks = real(20.0), Kd = real(20.0);
     return Ks * Ks * (q0 * q0 + q1 * q1) + Kd * Kd * (qd0 * qd0 + qd1 * qd1);
   }
 };
 
 // include/double_integrator.h  (n=4, m=2), mass = 1, Hx = diag(1,1,.2,.2), Hu = I.
-struct DoubleIntegratorModel {
+template <class real_>
+struct DoubleIntegratorModelT {
+  using real = real_;
   static constexpr int NX = 4;
   static constexpr int NU = 2;
-  double goal[4];
-  double u_min[2], u_max[2];
+  real goal[4];
+  real u_min[2], u_max[2];
 
-  __device__ __forceinline__ void dynamics(const double* x, const double* u, double* dx) const {
-    const double mass = 1.0;  // double_integrator.h:29-37
+  __device__ __forceinline__ void dynamics(const real* x, const real* u, real* dx) const {
+    const real mass = real(1.0);  // double_integrator.h:29-37
     dx[0] = x[2];
     dx[1] = x[3];
     dx[2] = u[0] / mass;
     dx[3] = u[1] / mass;
   }
-  __device__ __forceinline__ double quad(const double* x, double scale) const {
-    const double hx[4] = {1, 1, 0.2, 0.2};
-    double d[4], r[4];
+  __device__ __forceinline__ real quad(const real* x, real scale) const {
+    const real hx[4] = {1, 1, real(0.2), real(0.2)};
+    real d[4], r[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       d[i] = goal[i] - x[i];
@@ -190,45 +211,48 @@ struct DoubleIntegratorModel {
     return (r[0] * d[0] + r[2] * d[2]) + (r[1] * d[1] + r[3] * d[3]);
   }
   // exact derivatives (opt-in, see AcrobotModel::analytic_record): linear dynamics, quadratic costs
-  __device__ __forceinline__ void analytic_record(const double* x, const double* u, double dt, bool last, double* rec) const {
+  __device__ __forceinline__ void analytic_record(const real* x, const real* u, real dt, bool last, real* rec) const {
     using R = Rec<4, 2>;
-    const double hx[4] = {1, 1, 0.2, 0.2};
+    const real hx[4] = {1, 1, real(0.2), real(0.2)};
 #pragma unroll
-    for (int e = 0; e < R::SIZE; e++) rec[e] = 0.0;
-    const double scale = last ? 10.0 : 1.0;
+    for (int e = 0; e < R::SIZE; e++) rec[e] = real(0);
+    const real scale = last ? real(10.0) : real(1.0);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      rec[R::CX + i] = -2.0 * scale * hx[i] * (goal[i] - x[i]);
-      rec[R::CXX + i + 4 * i] = 2.0 * scale * hx[i];
+      rec[R::CX + i] = -real(2.0) * scale * hx[i] * (goal[i] - x[i]);
+      rec[R::CXX + i + 4 * i] = real(2.0) * scale * hx[i];
     }
-    rec[R::CUU + 0] = 2.0;  // cuu at every t (at t = T from cost(x_T, .))
-    rec[R::CUU + 3] = 2.0;
+    rec[R::CUU + 0] = real(2.0);  // cuu at every t (at t = T from cost(x_T, .))
+    rec[R::CUU + 3] = real(2.0);
     if (last) return;
 #pragma unroll
-    for (int c = 0; c < 4; c++) rec[R::FX + c + 4 * c] = 1.0;
+    for (int c = 0; c < 4; c++) rec[R::FX + c + 4 * c] = real(1.0);
     rec[R::FX + 0 + 4 * 2] = dt;
     rec[R::FX + 1 + 4 * 3] = dt;
     rec[R::FU + 2 + 4 * 0] = dt;  // mass = 1
     rec[R::FU + 3 + 4 * 1] = dt;
-    rec[R::CU + 0] = 2.0 * u[0];
-    rec[R::CU + 1] = 2.0 * u[1];
+    rec[R::CU + 0] = real(2.0) * u[0];
+    rec[R::CU + 1] = real(2.0) * u[1];
   }
   // double_integrator.h:39-43
-  __device__ __forceinline__ double cost(const double* x, const double* u) const {
-    return quad(x, 1.0) + (u[0] * u[0] + u[1] * u[1]);
+  __device__ __forceinline__ real cost(const real* x, const real* u) const {
+    return quad(x, real(1.0)) + (u[0] * u[0] + u[1] * u[1]);
   }
   // double_integrator.h:45-48
-  __device__ __forceinline__ double final_cost(const double* x) const { return quad(x, 10.0); }
+  __device__ __forceinline__ real final_cost(const real* x) const { return quad(x, real(10.0)); }
 };
 
 // include/model.h:12-15  x1 = x + dynamics(x,u)*dt
 template <class M>
-__device__ __forceinline__ void integrate_dynamics(const M& m, const double* x, const double* u, double dt,
-                                                   double* x1) {
-  double dx[M::NX];
+__device__ __forceinline__ void integrate_dynamics(const M& m, const typename M::real* x, const typename M::real* u, typename M::real dt,
+                                                   typename M::real* x1) {
+  typename M::real dx[M::NX];
   m.dynamics(x, u, dx);
 #pragma unroll
   for (int i = 0; i < M::NX; i++) x1[i] = x[i] + dx[i] * dt;
 }
+
+using AcrobotModel = AcrobotModelT<double>;
+using DoubleIntegratorModel = DoubleIntegratorModelT<double>;
 
 }  // namespace ilqr

@@ -15,7 +15,7 @@
  *     gives the message of the calling thread's last failure.
  *   - T is the number of transitions (= u0.size(), src/ilqr_core.cpp:12); state arrays have
  *     T+1 knot points.  "acrobot T=500" of BASELINE.json is T = 499 here (500 knots).
- *   - Host-side array layouts ("canonical"), all double, row-major over the leading indices:
+ *   - Host-side array layouts ("canonical"), all double (also for fp32 handles), row-major over the leading indices:
  *         x0 [B][nx]          u0,us,k [B][T][nu]        xs [B][T+1][nx]
  *         K  [B][T][nu*nx]    each K_t column-major nu x nx  (Eigen MatrixXd default)
  *         fx,cxx [B][T+1][nx*nx]   fu,cxu [B][T+1][nx*nu]   cuu [B][T+1][nu*nu]   (column-major)
@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ILQR_AMD_ABI_VERSION 1
+#define ILQR_AMD_ABI_VERSION 2 /* 2: ilqr_desc.dtype */
 
 typedef struct ilqr_batch ilqr_batch; /* opaque: owns all device memory of one batch */
 
@@ -63,6 +63,15 @@ enum ilqr_model_id {
                                        ilqr_accept_candidates), the backward pass / box-QPs / accept logic run on the
                                        device; rollout and finite-difference entry points return ILQR_ERR_UNSUPPORTED */
 };
+
+/* Arithmetic of the device models (BASELINE.json configs[3] asks for fp32; the reference is fp64 only).
+ * ILQR_DTYPE_F32 (acrobot, double integrator): every per-knot quantity -- states, controls, gains, derivative
+ * records, the Riccati recursion and the box-QP -- is stored and computed in float; the per-trajectory
+ * scalars (cost, dV, gradient norm, lambda) stay double, and the finite differences are taken in double
+ * from the float knot (eps = 1e-3 second differences of an O(1e3) cost are pure rounding noise in float)
+ * and rounded to float when stored.  The ABI's arrays are double in both modes; the conversion happens on
+ * the device when they are packed into / unpacked from the handle's layout. */
+enum ilqr_dtype { ILQR_DTYPE_F64 = 0, ILQR_DTYPE_F32 = 1 };
 
 /* where a trajectory's outer loop stands (src/ilqr_core.cpp:103-288) */
 enum ilqr_traj_status {
@@ -114,6 +123,7 @@ typedef struct ilqr_desc {
   double dt;       /* iLQR::dt, include/ilqr.h:30 */
   int device;      /* HIP device ordinal */
   int flags;       /* enum ilqr_flags */
+  int dtype;       /* enum ilqr_dtype; 0 = fp64, the reference's arithmetic */
   const double* u_min; /* [nu] Model::u_min (include/model.h:17); NULL = the model's default */
   const double* u_max; /* [nu] */
   const double* goal;  /* [nx] DoubleIntegrator(goal) (double_integrator.h:14); NULL = (1,.5,0,0); acrobot ignores it */

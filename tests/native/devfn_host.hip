@@ -34,3 +34,31 @@ extern "C" int devfn_box_qp_scalar(double Q, double c, double x0, double lo, dou
 extern "C" int devfn_box_qp_scalar_fast(double Q, double c, double x0, double lo, double hi, double* x, int* fr, double* minv) {
   return box_qp_scalar_fast(Q, c, x0, lo, hi, *x, *fr, *minv);
 }
+
+// ---- the same device functions instantiated for float (the product's fp32 mode) ----
+template <int M>
+static int run_f(const float* Q, const float* c, const float* x0, const float* lo, const float* hi, float* x, int* vfree) {
+  BoxQPResult<M, float> r;
+  box_qp<M>(Q, c, x0, lo, hi, r);
+  for (int i = 0; i < M; i++) {
+    x[i] = r.x[i];
+    vfree[i] = r.v_free[i];
+  }
+  return r.result;
+}
+extern "C" int devfn_box_qp_f32(int m, const float* Q, const float* c, const float* x0, const float* lo, const float* hi, float* x,
+                                int* vfree) {
+  switch (m) {
+    case 1: return run_f<1>(Q, c, x0, lo, hi, x, vfree);
+    case 2: return run_f<2>(Q, c, x0, lo, hi, x, vfree);
+    case 3: return run_f<3>(Q, c, x0, lo, hi, x, vfree);
+    case 4: return run_f<4>(Q, c, x0, lo, hi, x, vfree);
+    default: return -100;
+  }
+}
+extern "C" int devfn_box_qp_scalar_f32(float Q, float c, float x0, float lo, float hi, float* x, int* fr, float* minv) {
+  return box_qp_scalar(Q, c, x0, lo, hi, *x, *fr, *minv);
+}
+extern "C" int devfn_box_qp_scalar_fast_f32(float Q, float c, float x0, float lo, float hi, float* x, int* fr, float* minv) {
+  return box_qp_scalar_fast(Q, c, x0, lo, hi, *x, *fr, *minv);
+}

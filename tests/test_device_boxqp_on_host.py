@@ -82,3 +82,41 @@ def test_scalar_solver_and_fast_path(oracle, dev):
                 n_tie += 1  # clamp membership decided by a rounding-noise gradient (boxqp.h:61-64)
             assert (Q > 0) == (abs(mv.value - 1.0 / Q) <= 1e-15 * abs(1.0 / Q)) or Q <= 0
     assert n_tie <= 4
+
+
+def test_float_instantiation_against_the_fp32_oracle(oracle, dev):
+    """The box-QP sources instantiated for float (the product's fp32 mode, BASELINE configs[3]) against the
+    oracle's float build (liboracle_ilqr_f32.so): same results up to float rounding; the float-noise ties
+    (clamp membership / stall exit decided by the last bit) are counted."""
+    fp = C.POINTER(C.c_float)
+    for f in (dev.devfn_box_qp_scalar_f32, dev.devfn_box_qp_scalar_fast_f32):
+        f.argtypes = [C.c_float] * 5 + [fp, ip, fp]
+    rng = np.random.default_rng(8)
+    n_tie, N = 0, 6000
+    with oracle.flavour("f32"):
+        for t in range(N):
+            m = 1 + t % 4
+            A = rng.normal(size=(m, m))
+            Q = (A @ A.T + 0.2 * np.eye(m)).astype(np.float32)
+            c = (rng.normal(size=m) * 2).astype(np.float32)
+            x0 = rng.normal(size=m).astype(np.float32)
+            lo = (-rng.uniform(0.05, 1.5, size=m)).astype(np.float32)
+            hi = rng.uniform(0.05, 1.5, size=m).astype(np.float32)
+            ro = oracle.boxqp(Q, c, x0, lo, hi)
+            q = np.ascontiguousarray(Q.T).ravel()
+            x = np.zeros(m, dtype=np.float32)
+            vf = np.zeros(m, dtype=np.int32)
+            r = dev.devfn_box_qp_f32(m, q.ctypes.data_as(fp), c.ctypes.data_as(fp), x0.ctypes.data_as(fp), lo.ctypes.data_as(fp),
+                                     hi.ctypes.data_as(fp), x.ctypes.data_as(fp), vf.ctypes.data_as(ip))
+            same = np.array_equal(vf, ro["v_free"]) and np.allclose(x, ro["x_opt"], rtol=2e-4, atol=2e-5)
+            if not same or (r != ro["result"] and {int(r), int(ro["result"])} != {2, 4}):
+                assert r >= 1 and ro["result"] >= 1
+                n_tie += 1
+            if m == 1:
+                for fn in (dev.devfn_box_qp_scalar_f32, dev.devfn_box_qp_scalar_fast_f32):
+                    xs, fr, mv = C.c_float(), C.c_int(), C.c_float()
+                    rs = fn(float(Q[0, 0]), float(c[0]), float(x0[0]), float(lo[0]), float(hi[0]), C.byref(xs), C.byref(fr), C.byref(mv))
+                    assert rs >= 0
+                    if fr.value != ro["v_free"][0] or abs(xs.value - ro["x_opt"][0]) > 2e-5 + 2e-4 * abs(xs.value):
+                        n_tie += 1
+    assert n_tie <= N // 100, n_tie

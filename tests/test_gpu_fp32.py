@@ -1,0 +1,172 @@
+"""The fp32 mode of the device path (BASELINE.json configs[3]: acrobot T=500, fp32; ilqr_desc.dtype = ILQR_DTYPE_F32)
+through the C ABI.  The reference has no fp32 build, so parity is stated two ways:
+  (a) against the oracle's FLOAT twin (oracle flavour "f32": the same restatement compiled with float for every
+      per-knot quantity, double for the per-trajectory accumulators, finite differences in double -- exactly the
+      product's split), stage by stage with teacher forcing and per-knot gains, tolerance TOL32 = 1e-4; a
+      trajectory beyond that must be a proven tie or be limited by float conditioning, judged against the fp64
+      oracle as the yardstick (tests/parity.py, one precision down from the fp64 tests);
+  (b) against the fp64 oracle (= the reference's arithmetic) with the tolerance float can deliver, stated per
+      stage below."""
+import numpy as np
+import pytest
+
+from tests.parity import TOL32, assert_free_run, check_backward, walk_both, walk_iterations
+from tests.util import acrobot_x0, integrator_x0, mat, relerr, relerr_abs
+
+pytestmark = pytest.mark.gpu
+DT = 0.02
+CASES = [("acrobot", 70, 60, 5.0), ("acrobot", 70, 60, 1.5), ("integrator", 33, 40, 0.5)]
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+def make(oracle, name, B, T, lim, **kw):
+    from ilqr_amd import BatchILQR
+    if name == "acrobot":
+        om = oracle.Model("acrobot", u_lim=lim)
+        g = BatchILQR("acrobot", B, T, DT, u_min=-lim, u_max=lim, dtype="f32", **kw)
+        x0 = f32(acrobot_x0(B))
+    else:
+        goal = [1.0, 0.5, 0.0, 0.0]
+        om = oracle.Model("integrator", goal=goal, u_lim=lim)
+        g = BatchILQR("integrator", B, T, DT, u_min=-lim, u_max=lim, goal=goal, dtype="f32", **kw)
+        x0 = f32(integrator_x0(B))
+    return om, om.twin("f32"), g, x0
+
+
+@pytest.mark.parametrize("name,B,T,lim", CASES)
+def test_rollout_and_derivatives(oracle, name, B, T, lim):
+    om, om32, g, x0 = make(oracle, name, B, T, lim)
+    u0 = f32(np.random.default_rng(7).normal(size=(B, T, om.nu)) * 0.3)
+    cost = g.init_traj(x0, u0)
+    xs, us = g.trajectory()
+    with oracle.flavour("f32"):
+        xs32, us32, c32 = oracle.batch_rollout(om32, x0, u0, DT)
+    assert np.array_equal(us, u0)
+    # (a) float twin: two float integrations of T Euler steps (different sin/cos, FMA contraction)
+    assert relerr(xs, xs32) < TOL32 and np.max(np.abs(cost - c32) / np.abs(c32)) < TOL32
+    # (b) fp64 oracle: float rounding of T steps on chaotic dynamics
+    xs64, _, c64 = oracle.batch_rollout(om, x0, u0, DT)
+    assert relerr(xs, xs64) < 1e-3 and np.max(np.abs(cost - c64) / np.abs(c64)) < 1e-4
+    # finite differences: taken in double from the float knot on both sides, stored as float
+    g.set_trajectory(x0=x0, xs=xs32, us=us32, cost=c32)
+    g.compute_derivatives()
+    d = g.derivatives()
+    with oracle.flavour("f32"):
+        d32 = oracle.batch_derivatives(om32, xs32, us32, DT)
+    d64 = oracle.batch_derivatives(om, np.asarray(xs32, dtype=np.float64), np.asarray(us32, dtype=np.float64), DT)
+    for k in ("fx", "fu", "cx", "cu", "cxx", "cuu"):
+        r32 = d32[k] if k in ("cx", "cu") else mat(d32[k])
+        r64 = d64[k] if k in ("cx", "cu") else mat(d64[k])
+        assert relerr_abs(d[k], r32, 1e-2) < 1e-6, k       # same double arithmetic, one float rounding
+        assert relerr_abs(d[k], r64, 1e-2) < 2e-6, k       # the reference's records to float precision
+    assert np.all(d["fx"][:, T] == 0) and np.all(d["cu"][:, T] == 0)
+
+
+@pytest.mark.parametrize("lam", [1.0, 1e-3, 0.0])
+@pytest.mark.parametrize("name,B,T,lim", CASES)
+def test_backward_teacher_forced(oracle, name, B, T, lim, lam):
+    om, om32, g, x0 = make(oracle, name, B, T, lim)
+    u0 = f32(np.random.default_rng(7).normal(size=(B, T, om.nu)))
+    with oracle.flavour("f32"):
+        xs, us, cost = oracle.batch_rollout(om32, x0, u0, DT)
+        do = oracle.batch_derivatives(om32, xs, us, DT)
+        k_prev = f32(np.random.default_rng(11).normal(size=(B, T, om.nu)) * 0.2)
+        ro = oracle.batch_backward(om32, us, do, k_prev=k_prev, lam=lam)
+    g.set_trajectory(x0=x0, xs=xs, us=us, cost=cost)
+    g.set_derivatives(**{k: (do[k] if k in ("cx", "cu") else mat(do[k])) for k in do})
+    g.set_gains(k=k_prev, K=np.zeros((B, T, om.nu, om.nx)))
+    g.set_lambda(lam, 1.0)
+    div = g.backward_pass()
+    k, K = g.gains()
+    r = check_backward(oracle, om, us, {kk: np.asarray(v, dtype=np.float64) for kk, v in do.items()}, k_prev, lam, k, K, g.dV(), div, ro,
+                       max_ties=max(2, B // 8), precision="f32")
+    print("fp32 backward", name, lim, lam, {kk: v for kk, v in r.items() if kk != "good"})
+    assert r["good"].sum() > 0
+
+
+@pytest.mark.parametrize("name,B,T,lim,scale,iters", [("acrobot", 64, 120, 1.5, 1.0, 6), ("acrobot", 32, 499, 5.0, 0.01, 4),
+                                                       ("integrator", 33, 99, 0.5, 1.0, 6)])
+def test_iterations_teacher_forced(oracle, name, B, T, lim, scale, iters):
+    """Whole iterations, every one started from the float twin's state: accepted alpha, lambda schedule, status,
+    per-knot gains and cost for every trajectory -- or a proven tie / float conditioning (tests/parity.py)."""
+    om, om32, g, x0 = make(oracle, name, B, T, lim)
+    if name == "acrobot":
+        x0 = f32(acrobot_x0(B, scale=scale))
+    u0 = np.zeros((B, T, om.nu))
+    r = walk_iterations(oracle, om, g, x0, u0, DT, iters, precision="f32")
+    g.close()
+    print("fp32 walk", name, r)
+    ties = r["ties_backward"] + r["ties_search"] + r["ties_stop"]
+    assert r["checked"] >= B * 2
+    # float: a cost change of rounding size is 1e-7 of the cost instead of 1e-16, the 1e-4 clamp band is 1700 ulps
+    # wide instead of 1e12 -- ties are no longer rare events once a solve is near its optimum
+    assert ties + r["conditioned_branch"] <= max(4, r["checked"] // 3), r
+    assert r["cond_over10"] <= max(2, r["checked"] // 20), r
+    # and at the headline horizon, once lambda has decayed, float stops resolving the gains of some trajectories
+    # at all (the float ORACLE is then > 1 % per knot away from the fp64 answer): bounded, and reported in DESIGN.md
+    assert r["unresolved"] <= r["checked"] // 8, r
+
+
+def test_solution_quality_against_fp64(oracle):
+    """(b) end to end: what fp32 does to a solve.  Same problems, 10 iterations, fp32 device vs fp64 oracle: costs
+    within 1e-3 for the trajectories that take the same branches (most), never worse than a few percent."""
+    from ilqr_amd import BatchILQR
+    B, T, lim = 64, 200, 5.0
+    om = oracle.Model("acrobot", u_lim=lim)
+    x0 = f32(acrobot_x0(B, scale=0.3))
+    u0 = np.zeros((B, T, 1))
+    g = BatchILQR("acrobot", B, T, DT, u_min=-lim, u_max=lim, dtype="f32", params=dict(max_iter=10))
+    c0 = g.init_traj(x0, u0)
+    g.generate_trajectory()
+    cost = g.cost()
+    ro = oracle.batch_solve(om, x0, u0, DT, max_iters=10)
+    rel = np.abs(cost - ro["cost"]) / ro["cost"]
+    print("fp32 vs fp64 after 10 iterations: median %.2e, 90%% %.2e, max %.2e" % (np.median(rel), np.quantile(rel, 0.9), rel.max()))
+    assert np.all(np.isfinite(cost)) and np.all(cost <= c0 * (1 + 1e-6))
+    assert np.median(rel) < 1e-3 and (rel < 5e-2).mean() > 0.9
+
+
+@pytest.mark.parametrize("B", [5, 48, 200])
+def test_fused_equals_unfused(B):
+    from ilqr_amd import BatchILQR, capi
+    T = 120
+    x0 = acrobot_x0(B, scale=0.3, seed=5)
+    out = []
+    for fl in (0, capi.FLAG_UNFUSED):
+        g = BatchILQR("acrobot", B, T, DT, u_min=-1.5, u_max=1.5, flags=fl, dtype="f32")
+        g.init_traj(x0, np.zeros((B, T, 1)))
+        g.iterate(6)
+        xs, us = g.trajectory()
+        k, K = g.gains()
+        d = g.derivatives()
+        st, it, al = g.status()
+        out.append(dict(xs=xs, us=us, k=k, K=K, cost=g.cost(), st=st, it=it, al=al, lam=g.lambdas()[0], gn=g.gnorm(), **d))
+        g.close()
+    for n in out[0]:
+        assert np.array_equal(out[0][n], out[1][n], equal_nan=True), n
+    # stored values are floats
+    assert np.array_equal(out[0]["xs"], f32(out[0]["xs"])) and np.array_equal(out[0]["K"], f32(out[0]["K"]))
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[3] per-GPU shard (acrobot T=499, B=4096, fp32): size-independent properties."""
+    from ilqr_amd import BatchILQR
+    B, T, lim = 4096, 499, 5.0
+    g = BatchILQR("acrobot", B, T, DT, u_min=-lim, u_max=lim, dtype="f32")
+    x0 = f32(acrobot_x0(B))
+    x0[1] = x0[0]
+    x0[B - 1] = x0[0]
+    c0 = g.init_traj(x0, np.zeros((B, T, 1)))
+    g.iterate(3)
+    cost = g.cost()
+    st, it, al = g.status()
+    xs, us = g.trajectory()
+    k, K = g.gains()
+    assert np.all(np.isfinite(cost)) and np.all(cost <= c0 * (1 + 1e-6))
+    assert cost[0] == cost[1] == cost[B - 1]
+    assert np.array_equal(xs[0], xs[1]) and np.array_equal(K[0], K[B - 1])
+    assert np.array_equal(xs[:, 0], x0)
+    assert (al >= 0).mean() > 0.5 and (g.dV()[:, 0] <= 0).mean() > 0.9
