@@ -9,7 +9,13 @@ SOURCES = [os.path.join(CSRC, "capi.hip")]
 HEADERS = [os.path.join(CSRC, f) for f in ("common.hpp", "models.hpp", "boxqp.hpp", "kernels.hpp", "backward_wave.hpp", "generic.hpp")] + \
           [os.path.join(os.path.dirname(PKG), "include", "ilqr_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+# -fno-slp-vectorize: the SLP vectoriser turns the float dot products of the Riccati step into v_pk_mul_f32 +
+# scalar adds instead of FMA chains (fp32 backward kernel 0.64 -> 0.60 ms); there is no packed fp64 arithmetic
+# for it to find, so the fp64 kernels do not change.
+# (-ffp-contract stays at hipcc's default: =on measured 2-10 % slower.  Candidate states are re-integrated from
+# checkpoints by several kernels; tests/test_gpu_fused_sweep.py::test_committed_trajectory_is_the_rollout_that_was_scored
+# pins that they all reproduce the scored rollout bit for bit.)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize"]
 
 
 HASHFILE = LIB + ".srchash"

@@ -442,6 +442,7 @@ ILQR_HD int box_qp_scalar(real Q, real c, real x0, real lo, real hi, real& x_out
 //   A  all clamped at iter 0 (result 6, ~85 % with u in [-1.5,1.5])
 //   B  |grad| < minGrad at iter 0 (5)       C  not a descent direction (2)
 //   D  no improvement at iter 1 (4)         E  clamped at iter 1 (6)       F  |grad| < minGrad at iter 1 (5)
+//   G  iter 1's direction is not a descent direction (2) -- the usual exit of an interior Newton step in float
 // The evaluation is split in three so that the kernel can replace the sequential Armijo
 // backtracking (a Newton step truncated by a bound to < ~10 % of its length fails the test at
 // step 1 -- ~10 % of the QPs, i.e. most wavefronts) by a quad-parallel search:
@@ -521,10 +522,16 @@ ILQR_HD int qp1_finish(const QP1StateT<real>& q, real& x_out, int& free_out, rea
   const real g1 = q.Q * q.x1 + q.c;
   const bool clE = ((abs_of(q.x1 - q.lo) < real(kClampTol)) & (g1 > 0)) | ((abs_of(q.x1 - q.hi) < real(kClampTol)) & (g1 < 0));
   const bool exF = abs_of(g1) < real(kMinGrad);
+  // G: iteration 1's own search direction is not a descent direction (boxqp.cpp:150-153 -> result 2, x kept).
+  // After an interior Newton step x1 IS the optimum to rounding, so search = -minv c - x1 is 0 or an ulp of
+  // either sign.  In fp64 exit F fires first (|g1| ~ 1e-16 |c|); in float |g1| ~ 1e-7 |c| never passes
+  // minGrad = 1e-8, and without this exit every unclamped step paid the data-dependent continue loop.
+  const real slope1 = (-q.minv * q.c - q.x1) * g1;
+  const bool exG = slope1 >= real(0);
   minv_out = q.minv;
   // the reference's order of tests, as selects (no branches)
   const bool stay = q.clA | q.exB | q.exC | q.ls_failed;  // x is not updated
-  const int inner = exD ? 4 : (clE ? 6 : (exF ? 5 : -1));
+  const int inner = exD ? 4 : (clE ? 6 : (exF ? 5 : (exG ? 2 : -1)));
   const int outer = q.clA ? 6 : (q.exB ? 5 : 2);
   x_out = stay ? q.x : q.x1;
   free_out = (q.clA | (!stay & !exD & clE)) ? 0 : 1;

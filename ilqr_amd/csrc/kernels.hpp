@@ -1020,14 +1020,19 @@ __device__ __forceinline__ bool qp1_search_quad(QP1StateT<real>& q, int s, int l
 }
 
 template <int NU, class real>
-struct QuadStep {  // what lane (l, s) needs of one derivative record
-  real fx[16];     // full fx (replicated over s)
-  real fxc[4];     // fx[:, s] again, loaded by address so no register array is indexed by s
-  real fu[4 * NU]; // full fu
-  real cu[NU], cuu[NU * NU], us[NU];
-  real cx;         // cx[s]
-  real cxx[4];     // cxx[:, s]
-  real cxu[NU];    // cxu[s, :]
+struct QuadStep {  // what lane (l, s) needs of one derivative record, AS LOADED: element pairs stay pairs until the
+  // step that consumes them unpacks them.  (Unpacked into scalars at load time, the two halves of one 8-byte
+  // load flowed into separate loop-carried registers; for float hipcc then put a copy -- and the s_waitcnt vmcnt
+  // it needs -- right behind the freshly issued prefetch: one exposed HBM round trip per step.)
+  typedef real pair_t __attribute__((ext_vector_type(2)));
+  pair_t fx[8];                        // full fx (replicated over s)
+  pair_t fxc[2];                       // fx[:, s] again, loaded by address so no register array is indexed by s
+  pair_t fu[2 * NU];                   // full fu
+  pair_t tail[(NU + NU * NU) / 2];     // cu, cuu
+  pair_t cxx[2];                       // cxx[:, s]
+  real us[NU];
+  real cx;                             // cx[s]
+  real cxu[NU];                        // cxu[s, :]
 };
 
 // The body of the quad backward pass for one tile, run by ONE wavefront (lane = 4*l + s).
@@ -1061,43 +1066,16 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
   // what lane (l, s) needs of knot t, given accessors for element pairs (e even) / single elements
   auto fill = [&](auto pair, auto one, QuadStep<NU, real>& d) __attribute__((always_inline)) {
 #pragma unroll
-    for (int e = 0; e < 16; e += 2) {
-      const real2_t w = pair(R::FX + e);
-      d.fx[e] = w.x;
-      d.fx[e + 1] = w.y;
-    }
+    for (int e = 0; e < 16; e += 2) d.fx[e >> 1] = pair(R::FX + e);
 #pragma unroll
-    for (int q = 0; q < 4; q += 2) {
-      const real2_t w = pair(R::FX + q + 4 * s);
-      d.fxc[q] = w.x;
-      d.fxc[q + 1] = w.y;
-    }
+    for (int q = 0; q < 4; q += 2) d.fxc[q >> 1] = pair(R::FX + q + 4 * s);
 #pragma unroll
-    for (int e = 0; e < 4 * NU; e += 2) {
-      const real2_t w = pair(R::FU + e);
-      d.fu[e] = w.x;
-      d.fu[e + 1] = w.y;
-    }
-    {  // cu and cuu are adjacent: nu(nu+1) doubles, an even count at an even offset
-      real tail[NU + NU * NU];
+    for (int e = 0; e < 4 * NU; e += 2) d.fu[e >> 1] = pair(R::FU + e);
 #pragma unroll
-      for (int e = 0; e < NU + NU * NU; e += 2) {
-        const real2_t w = pair(R::CU + e);
-        tail[e] = w.x;
-        tail[e + 1] = w.y;
-      }
-#pragma unroll
-      for (int e = 0; e < NU; e++) d.cu[e] = tail[e];
-#pragma unroll
-      for (int e = 0; e < NU * NU; e++) d.cuu[e] = tail[NU + e];
-    }
+    for (int e = 0; e < NU + NU * NU; e += 2) d.tail[e >> 1] = pair(R::CU + e);  // cu and cuu are adjacent: nu(nu+1) elements, an even count at an even offset
     d.cx = one(R::CX + s);
 #pragma unroll
-    for (int i = 0; i < 4; i += 2) {
-      const real2_t w = pair(R::CXX + i + 4 * s);
-      d.cxx[i] = w.x;
-      d.cxx[i + 1] = w.y;
-    }
+    for (int i = 0; i < 4; i += 2) d.cxx[i >> 1] = pair(R::CXX + i + 4 * s);
 #pragma unroll
     for (int a = 0; a < NU; a++) d.cxu[a] = one(R::CXU + s + 4 * a);
   };
@@ -1167,8 +1145,46 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
 #define ILQR_MARK(k)
 #endif
     // one Riccati step; returns false if the box-QP reports failure (ilqr_core.cpp:371)
-    auto step = [&](int i, const QuadStep<NU, real>& d) -> bool {
+    auto step = [&](int i, const QuadStep<NU, real>& raw) -> bool {
       ILQR_MARK(0)  // load issue + loop overhead
+      struct {  // the record, unpacked (register renames: the loads have landed, see QuadStep)
+        real fx[16], fxc[4], fu[4 * NU], cu[NU], cuu[NU * NU], us[NU], cx, cxx[4], cxu[NU];
+      } d;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        d.fx[2 * e] = raw.fx[e].x;
+        d.fx[2 * e + 1] = raw.fx[e].y;
+      }
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        d.fxc[2 * e] = raw.fxc[e].x;
+        d.fxc[2 * e + 1] = raw.fxc[e].y;
+        d.cxx[2 * e] = raw.cxx[e].x;
+        d.cxx[2 * e + 1] = raw.cxx[e].y;
+      }
+#pragma unroll
+      for (int e = 0; e < 2 * NU; e++) {
+        d.fu[2 * e] = raw.fu[e].x;
+        d.fu[2 * e + 1] = raw.fu[e].y;
+      }
+      {
+        real tail[NU + NU * NU];
+#pragma unroll
+        for (int e = 0; e < (NU + NU * NU) / 2; e++) {
+          tail[2 * e] = raw.tail[e].x;
+          tail[2 * e + 1] = raw.tail[e].y;
+        }
+#pragma unroll
+        for (int e = 0; e < NU; e++) d.cu[e] = tail[e];
+#pragma unroll
+        for (int e = 0; e < NU * NU; e++) d.cuu[e] = tail[NU + e];
+      }
+      d.cx = raw.cx;
+#pragma unroll
+      for (int a = 0; a < NU; a++) {
+        d.cxu[a] = raw.cxu[a];
+        d.us[a] = raw.us[a];
+      }
       // W = Vxx' * fx[:, s]   (column s)
       real W[4];
 #pragma unroll
