@@ -76,6 +76,12 @@ struct ilqr_batch {
   // per knot only cx, cu; records_partial says that D holds no matrices for t < T right now
   double* const_rec = nullptr;
   bool records_partial = false;
+  // nx = 4 device models: D (0.75 GB per 4096 acrobot trajectories) is allocated the first time somebody wants
+  // records in HBM -- the stage calls, the two-kernel route, the getters.  ilqr_iterate's fused kernel keeps them
+  // in LDS (kernels.hpp) and leaves D as it was: recs says what D holds.
+  //   REC_ZERO  what init_traj leaves (ilqr_core.cpp:39-45): zeros        REC_VALID  the records of the nominal
+  //   REC_STALE iterations have run since: whoever asks gets them computed from the current nominal
+  enum { REC_ZERO, REC_VALID, REC_STALE } recs = REC_ZERO;
   size_t staging_elems = 0;
   std::vector<void*> allocs;
   bool initialised = false;  // init_traj / set_trajectory has run
@@ -265,8 +271,23 @@ static int download(ilqr_batch* h, const void* src_tiled, double* dst, int S, in
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
-// D as the getters and ilqr_set_derivatives expect it: fill in the constant matrices the partial sweep skipped
+static int launch_derivatives(ilqr_batch* h, int force);
+// the record array of a tiled handle, allocated (zero-filled) on first use
+static int ensure_records(ilqr_batch* h) {
+  if (h->aos || h->v.D) return 0;
+  if (int rc = dev_alloc_real(h, &h->v.D, (size_t)h->ntiles * (h->T + 1) * rec_of(h) * TW)) return rc;
+  sync_float_view(h);
+  return 0;
+}
+// D as the getters, the stage calls and ilqr_set_derivatives expect it.  LQ handles: fill in the constant
+// matrices the partial sweep skipped.  nx = 4 handles: have the sweep compute the records of the current nominal
+// trajectory if iterations have run since D was last written.
 static int materialise_records(ilqr_batch* h) {
+  if (!h->aos) {
+    if (int rc = ensure_records(h)) return rc;
+    if (h->recs == ilqr_batch::REC_STALE) return launch_derivatives(h, 1);
+    return 0;
+  }
   if (!h->records_partial) return 0;
   const int nchunk = (h->T + 1 + kAnalyticChunk - 1) / kAnalyticChunk;
   hipLaunchKernelGGL(k_analytic_lq, dim3(h->B * nchunk), dim3(64), 0, h->stream, h->v, h->lq, 1, 2, h->const_rec, kAnalyticChunk);
@@ -276,6 +297,7 @@ static int materialise_records(ilqr_batch* h) {
 static int upload_rec(ilqr_batch* h, const double* src, int off, int E) {
   if (int rc = materialise_records(h)) return rc;
   h->records_partial = false;  // the caller's blocks replace the model's: every knot reads its own record again
+  h->recs = ilqr_batch::REC_VALID;
 
   const int S = h->T + 1;
   const size_t n = (size_t)h->B * S * E;
@@ -442,6 +464,8 @@ static int forget_pending(ilqr_batch* h) {
 }
 
 static int launch_derivatives(ilqr_batch* h, int force) {
+  if (int rc = ensure_records(h)) return rc;
+  h->recs = ilqr_batch::REC_VALID;
   if (h->model == ILQR_MODEL_LQ)  // the generic sweep has no fused commit: rebuild the accepted rollout first
     if (int rc = flush_commit(h)) return rc;
   std::pair<hipEvent_t, hipEvent_t> ev;
@@ -480,6 +504,8 @@ static bool use_quad_backward(const ilqr_batch* h) {
 }
 
 static int launch_backward(ilqr_batch* h, int mode) {
+  if (!h->aos)
+    if (int rc = materialise_records(h)) return rc;
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_BACKWARD, &ev)) return rc;
   if (h->aos) {
@@ -539,6 +565,7 @@ static int launch_sweep_backward(ilqr_batch* h, int mode, int force) {
     return rc;
   HIPCHK(hipGetLastError());
   h->commit_pending = false;  // the producers performed the copy on the way (see launch_derivatives)
+  h->recs = ilqr_batch::REC_STALE;  // the records lived in LDS only
   return timer_end(h, ILQR_STAGE_BACKWARD, ev);
 }
 
@@ -793,7 +820,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   rc |= dev_alloc_real(h, &v.us, nt * T * nu * TW);
   rc |= dev_alloc_real(h, &v.kff, nt * T * nu * TW);
   rc |= dev_alloc_real(h, &v.Kfb, nt * T * nu * nx * TW);
-  rc |= dev_alloc_real(h, &v.D, nt * T1 * REC * TW);
+  v.D = nullptr;  // on first use (ensure_records)
   v.nch = h->T / CT + 1;
   rc |= dev_alloc_real(h, &v.cand_u, (size_t)NALPHA * nt * T * nu * TW);
   rc |= dev_alloc_real(h, &v.cand_x, (size_t)NALPHA * nt * v.nch * nx * TW);
@@ -886,7 +913,8 @@ int ilqr_init_traj(ilqr_batch* h, const double* x0, const double* u0, double* co
   if (int rc = upload(h, u0, h->v.us, h->T, h->nu)) return rc;  // us = u_0, ilqr_core.cpp:17
   // ilqr_core.cpp:23-48: zero derivative/gain arrays; statics lambda/dlambda as for a fresh process
   const size_t T = h->T, T1 = h->T + 1;
-  HIPCHK(hipMemsetAsync(h->v.D, 0, dev_elems(h, T1, rec_of(h)) * elem_size(h), h->stream));
+  if (h->v.D) HIPCHK(hipMemsetAsync(h->v.D, 0, dev_elems(h, T1, rec_of(h)) * elem_size(h), h->stream));
+  h->recs = ilqr_batch::REC_ZERO;
   HIPCHK(hipMemsetAsync(h->v.kff, 0, dev_elems(h, T, h->nu) * elem_size(h), h->stream));
   HIPCHK(hipMemsetAsync(h->v.Kfb, 0, dev_elems(h, T, h->nu * h->nx) * elem_size(h), h->stream));
   if (int rc = forget_pending(h)) return rc;
@@ -926,6 +954,7 @@ int ilqr_iterate(ilqr_batch* h, int n_iters) {
       if (int rc = launch_accept(h)) return rc;                         // STEP 3/4
     }
   }
+  if (!h->aos && n_iters > 0) h->recs = ilqr_batch::REC_STALE;  // (D lags the nominal after an accept, on every route)
   return flush_commit(h);  // the last iteration's accepted trajectories
 }
 
@@ -1076,7 +1105,8 @@ int ilqr_reset_state(ilqr_batch* h, int warm) {
     if (int rc = scalars_to_host(h, h->v.dlambda, dlam.data())) return rc;
   } else {
     const size_t T = h->T, T1 = h->T + 1;
-    HIPCHK(hipMemsetAsync(h->v.D, 0, dev_elems(h, T1, rec_of(h)) * elem_size(h), h->stream));
+    if (h->v.D) HIPCHK(hipMemsetAsync(h->v.D, 0, dev_elems(h, T1, rec_of(h)) * elem_size(h), h->stream));
+    h->recs = ilqr_batch::REC_ZERO;
     HIPCHK(hipMemsetAsync(h->v.kff, 0, dev_elems(h, T, h->nu) * elem_size(h), h->stream));
     HIPCHK(hipMemsetAsync(h->v.Kfb, 0, dev_elems(h, T, h->nu * h->nx) * elem_size(h), h->stream));
     if (int rc = forget_pending(h)) return rc;

@@ -450,7 +450,7 @@ struct RingSlot {
 template <class M, bool RING = false, class MFD = M>
 __device__ __forceinline__ void derivatives_of_knot(const BatchViewT<typename M::real>& v, const M& model, const MFD& fdm, int force,
                                                     const int* __restrict__ commit_idx, int tile, int t, int l,
-                                                    typename M::real* rs = nullptr) {
+                                                    typename M::real* rs = nullptr, bool records = true) {
   using real = typename M::real;
   using fdr = typename MFD::real;
   using RSl = RingSlot<M::NX, M::NU, real>;
@@ -461,21 +461,13 @@ __device__ __forceinline__ void derivatives_of_knot(const BatchViewT<typename M:
   const int T = v.T;
   if (t > T || b >= v.B) return;
   const int ci = commit_idx ? commit_idx[b] : -1;
-  const bool want = force || (v.status[b] == 0 && v.flg_change[b]);
-  if (ci < 0 && !want) {
-    // A running trajectory whose last line search failed keeps its derivatives (flgChange = 0,
-    // ilqr_core.cpp:115): the backward pass still wants them, so the ring gets a copy.
-    if (RING && v.status[b] == 0) {
-      const real* D0 = v.D + didx(tile, t, 0, l, T + 1, R::SIZE);
-#pragma unroll
-      for (int e = 0; e < R::SIZE; e += 2)
-        *reinterpret_cast<real2_t*>(rs + (e >> 1) * (2 * TW)) = *reinterpret_cast<const real2_t*>(D0 + (size_t)(e >> 1) * (2 * TW));
-#pragma unroll
-      for (int j = 0; j < NU; j++)
-        rs[((RSl::US + j) >> 1) * (2 * TW) + ((RSl::US + j) & 1)] = (t < T) ? v.us[tidx(tile, t, j, l, T, NU)] : real(0);
-    }
-    return;
-  }
+  // Stand-alone sweep (k_derivatives): the records live in HBM, and a trajectory whose last line search failed
+  // keeps them (flgChange = 0, ilqr_core.cpp:115).  Fused sweep (RING): the records exist ONLY in the LDS ring,
+  // for as long as the backward wavefront needs them -- every running trajectory's are recomputed each time
+  // (they are a function of the nominal trajectory: same values), nothing is written to HBM but the commit.
+  // (records == false: the caller only wants the pending commit performed -- a fused sweep whose backward pass has moved on)
+  const bool want = records && (force || (v.status[b] == 0 && (RING || v.flg_change[b])));
+  if (ci < 0 && !want) return;
   const real dt = (real)v.dt;
 
   real xk[NX], uk[NU];  // the knot as stored
@@ -499,18 +491,22 @@ __device__ __forceinline__ void derivatives_of_knot(const BatchViewT<typename M:
   }
   if (!want) return;  // (finished trajectory whose last candidate was committed above)
 
-  real* D = v.D + didx(tile, t, 0, l, T + 1, R::SIZE);
+  real* D = RING ? nullptr : v.D + didx(tile, t, 0, l, T + 1, R::SIZE);
   auto put = [&](int e, fdr val_) {
     const real val = (real)val_;
-    D[(size_t)(e >> 1) * (2 * TW) + (e & 1)] = val;
-    if (RING) rs[(e >> 1) * (2 * TW) + (e & 1)] = val;
+    if (RING)
+      rs[(e >> 1) * (2 * TW) + (e & 1)] = val;
+    else
+      D[(size_t)(e >> 1) * (2 * TW) + (e & 1)] = val;
   };
   auto put2 = [&](int e, fdr v0, fdr v1) {  // e even: one store of a pair
     real2_t w;
     w.x = (real)v0;
     w.y = (real)v1;
-    *reinterpret_cast<real2_t*>(D + (size_t)(e >> 1) * (2 * TW)) = w;
-    if (RING) *reinterpret_cast<real2_t*>(rs + (e >> 1) * (2 * TW)) = w;
+    if (RING)
+      *reinterpret_cast<real2_t*>(rs + (e >> 1) * (2 * TW)) = w;
+    else
+      *reinterpret_cast<real2_t*>(D + (size_t)(e >> 1) * (2 * TW)) = w;
   };
   if (RING) {
 #pragma unroll
@@ -1036,14 +1032,25 @@ struct QuadStep {  // what lane (l, s) needs of one derivative record, AS LOADED
 };
 
 // The body of the quad backward pass for one tile, run by ONE wavefront (lane = 4*l + s).
-// gate(t) returns once the derivative record and the nominal control of knot t may be read: a
+// gate.wait(t) returns once the derivative record and the nominal control of knot t may be read: a
 // no-op when the records were written by an earlier kernel (k_backward_q), a wait on the
 // co-resident producer wavefronts in k_sweep_backward.
 // ring != nullptr: the FIRST pass reads each knot from LDS slot (T - t) % SLOTS, where the producers
 // put it; lambda-retry passes (and ring == nullptr) read the records from HBM.
+// A Gate says where the records come from.  NoGate: they are in HBM (k_backward_q, written by k_derivatives).
+// RingGate (k_sweep_backward): the producer wavefronts of the block compute them into the LDS ring, pass after
+// pass -- a lambda-retry pass is a second sweep, nothing is ever read back from HBM.
+struct NoGate {
+  static constexpr bool kRing = false;
+  __device__ __forceinline__ void begin_pass() {}
+  __device__ __forceinline__ void wait(int) {}
+  __device__ __forceinline__ int slot(int) const { return 0; }
+  __device__ __forceinline__ void finish() {}
+};
+
 template <class M, class Gate, int RING_KB = ILQR_RING_KB>
 __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>& v, const M& model, const SolverParams& sp, int mode,
-                                              int tile, int lane, const typename M::real* __restrict__ lds_steps, Gate gate,
+                                              int tile, int lane, const typename M::real* __restrict__ lds_steps, Gate& gate,
                                               const typename M::real* ring = nullptr) {
   using real = typename M::real;
   static_assert(M::NX == 4, "quad kernel: one lane per state dimension");
@@ -1056,13 +1063,13 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
   const int T = v.T;
   double lambda = v.lambda[b], dlambda = v.dlambda[b];
   typedef real real2_t __attribute__((ext_vector_type(2)));
-  const real* __restrict__ Dt = v.D + didx(tile, 0, 0, l, T + 1, R::SIZE);
+  const real* __restrict__ Dt = Gate::kRing ? nullptr : v.D + didx(tile, 0, 0, l, T + 1, R::SIZE);
   const real* __restrict__ ust = v.us + tidx(tile, 0, 0, l, T, NU);
   real* __restrict__ kt = v.kff + tidx(tile, 0, 0, l, T, NU);
   real* __restrict__ Kt = v.Kfb + tidx(tile, 0, 0, l, T, NU * NX);
 
   using RS = RingSlot<NX, NU, real, RING_KB>;
-  bool from_ring = (ring != nullptr);  // cleared when a pass has to be repeated
+  constexpr bool RP = Gate::kRing;  // records (and the knot's control) come from the LDS ring
   // what lane (l, s) needs of knot t, given accessors for element pairs (e even) / single elements
   auto fill = [&](auto pair, auto one, QuadStep<NU, real>& d) __attribute__((always_inline)) {
 #pragma unroll
@@ -1083,11 +1090,10 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
   // instructions, which wait on vmcnt and lgkmcnt alike)
   typedef const __attribute__((address_space(3))) real lds_cd;
   typedef const __attribute__((address_space(3))) real2_t lds_cd2;
-  auto load = [&](auto tag, int t, QuadStep<NU, real>& d) __attribute__((always_inline)) {
-    constexpr bool RP = decltype(tag)::value;
-    gate(t, RP);
+  auto load = [&](int t, QuadStep<NU, real>& d) __attribute__((always_inline)) {
+    gate.wait(t);
     if constexpr (RP) {  // ds_read_b128 / b64 from the producers' slot
-      lds_cd* r = (lds_cd*)(ring + ((T - t) % RS::SLOTS) * RS::ELEMS + l * 2);
+      lds_cd* r = (lds_cd*)(ring + gate.slot(t) * RS::ELEMS + l * 2);
       auto pair = [&](int e) { return *(lds_cd2*)(r + (e >> 1) * (2 * TW)); };
       auto one = [&](int e) { return r[(e >> 1) * (2 * TW) + (e & 1)]; };
       fill(pair, one, d);
@@ -1108,16 +1114,16 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
   int diverge = 0;
   bool done = false;
   double dV0 = 0, dV1 = 0, gacc = 0;  // per-trajectory accumulators: double in both modes
-  // one backward_pass() at the current lambda; tag = std::true_type: knots come from the ring
-  auto one_pass = [&](auto tag) __attribute__((always_inline)) {
-    constexpr bool RP = decltype(tag)::value;
+  // one backward_pass() at the current lambda
+  auto one_pass = [&]() __attribute__((always_inline)) {
+    gate.begin_pass();
     // carried state: full Vxx / Vx in every lane
     real Vx[4], Vxx[16], kprev[NU];
     const real lam_r = (real)lambda;  // the regularisation of this pass in the handle's arithmetic (:367)
     {
-      gate(T, RP);
+      gate.wait(T);
       if constexpr (RP) {
-        lds_cd* r = (lds_cd*)(ring + l * 2);  // knot T sits in slot 0
+        lds_cd* r = (lds_cd*)(ring + gate.slot(T) * RS::ELEMS + l * 2);
 #pragma unroll
         for (int i = 0; i < 4; i++) Vx[i] = r[((R::CX + i) >> 1) * (2 * TW) + ((R::CX + i) & 1)];  // :353
 #pragma unroll
@@ -1492,16 +1498,16 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       // the freshly issued prefetch, which would expose one HBM round trip per step.
       QuadStep<NU, real> A, Bd;
       int i = T - 1;
-      load(tag, i, A);
+      load(i, A);
       __builtin_amdgcn_s_waitcnt(kWaitAll & kWaitLds);
       while (true) {
         __builtin_amdgcn_sched_barrier(0);
-        if (i >= 1) load(tag, i - 1, Bd);
+        if (i >= 1) load(i - 1, Bd);
         __builtin_amdgcn_sched_barrier(0);
         if (!step(i, A)) break;
         if (--i < 0) break;
         __builtin_amdgcn_sched_barrier(0);
-        if (i >= 1) load(tag, i - 1, A);
+        if (i >= 1) load(i - 1, A);
         __builtin_amdgcn_sched_barrier(0);
         if (!step(i, Bd)) break;
         if (--i < 0) break;
@@ -1530,10 +1536,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
   };
 
   while (true) {
-    if (from_ring)
-      one_pass(std::true_type{});
-    else
-      one_pass(std::false_type{});
+    one_pass();
     if (mode == 0) {
       done = (diverge == 0);
       break;
@@ -1542,8 +1545,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       dlambda = fmax(dlambda * sp.lambda_factor, sp.lambda_factor);
       lambda = fmax(lambda * dlambda, sp.lambda_min);
       if (lambda > sp.lambda_max) break;
-      from_ring = false;  // the ring has moved on: the repeated pass reads the records from HBM
-      continue;
+      continue;  // (a fused sweep produces the records again: Gate::begin_pass)
     }
     done = true;
     break;
@@ -1610,27 +1612,10 @@ __global__ __launch_bounds__(64) void k_backward_q(BatchViewT<typename M::real> 
   using real = typename M::real;
   __shared__ real lds_steps[104];  // backtracking step sizes (per-lane indexed -> LDS, not constant cache)
   load_step_table(lds_steps);
-  backward_quad(v, model, sp, mode, (int)blockIdx.x, (int)threadIdx.x, lds_steps, [](int, bool) {});
+  NoGate gate;
+  backward_quad(v, model, sp, mode, (int)blockIdx.x, (int)threadIdx.x, lds_steps, gate);
 }
 
-// STEP 1 + STEP 2 of one iteration in ONE kernel (ilqr_iterate).  The quad backward pass keeps a
-// single wavefront per tile busy with one long dependent chain, i.e. one of the four SIMDs of a
-// CU; the finite-difference sweep is independent per knot.  So a block is one tile with four
-// wavefronts: wavefront 0 runs backward_quad, wavefronts 1..3 are PRODUCERS that compute the
-// derivative records of the tile's knots in descending t (4 knots x 16 trajectories per
-// wavefront and round), perform the pending commit of the accepted candidate on the way
-// (derivatives_of_knot), and publish their progress in LDS.  The consumer follows a few hundred
-// cycles behind the first round and never waits again (a producer round of 4 time steps costs
-// about as much as ONE backward step).  Each record goes into an LDS ring slot, from where the
-// backward wavefront reads it (ds_read: no HBM round trip, no vmcnt wait in its loop), AND to HBM
-// in the didx layout, where a lambda-retry pass and the getters find it as the stand-alone
-// kernels would have left it.  Workgroup-scope release/acquire is all the ordering needed.
-//   grid = ntiles, block = 64 * (1 + kProducers), LDS ~150 KB (one block per CU)
-// Two instantiations are shipped: <3 producers, 150 KB ring> = one block per CU, for batches of up to
-// 16 x #CU trajectories, and <1 producer, 60 KB ring> = two blocks (four wavefronts) per CU for up to
-// twice that -- one producer cannot quite feed a backward wavefront (0.66 instead of 0.55 ms per tile
-// at T = 499), but two tiles per CU side by side beat the two-kernel route (B = 8192: 1.26 against
-// 1.42 ms per iteration).
 #ifndef ILQR_PRODUCERS
 #define ILQR_PRODUCERS 3
 #endif
@@ -1638,89 +1623,146 @@ constexpr int kProducers = ILQR_PRODUCERS;
 #ifndef ILQR_LEAD_ROUNDS
 #define ILQR_LEAD_ROUNDS 1
 #endif
+// LDS of one tile's sweep + backward pass
+template <class real, int NX, int NU, int kProd, int RING_KB>
+struct SweepShared {
+  using RS = RingSlot<NX, NU, real, RING_KB>;
+  real steps[104];                    // backtracking step sizes (per-lane indexed -> LDS, not constant cache)
+  real ring[RS::SLOTS * RS::ELEMS];   // knot with running index G lives in slot G % SLOTS
+  int rounds_done[kProd];             // rounds (counted across passes) whose records are in the ring
+  int consumer_at;                    // running index of the knot the backward pass waits for (everything below is consumed)
+  int passes_started;                 // backward passes begun; -1 once the tile's backward wavefront is through
+  unsigned long long pass_lanes;      // exec mask of the backward wavefront in the current pass (bit 4 l = trajectory l)
+};
+
+// The consumer side of the ring (see NoGate).  Knots are numbered by a RUNNING index G = pass * N + (T - t),
+// N = knots per pass rounded up to whole producer rounds: passes follow each other seamlessly in the ring.
+template <class SH, int kProd>
+struct RingGate {
+  static constexpr bool kRing = true;
+  static constexpr int kKnotsPerRound = 4 * kProd;
+  SH& sh;
+  const int T, nrounds, N;
+  int pass = -1, have = 0;
+#ifdef ILQR_PHASE_TIMING
+  long long spins = 0;
+#endif
+  __device__ __forceinline__ RingGate(SH& s, int T_) : sh(s), T(T_), nrounds((T_ + 1 + kKnotsPerRound - 1) / kKnotsPerRound), N(nrounds * kKnotsPerRound) {}
+  __device__ __forceinline__ void begin_pass() {  // wave-uniform among the lanes still in the pass loop
+    pass++;
+    have = pass * N;
+    __hip_atomic_store(&sh.pass_lanes, __ballot(1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&sh.passes_started, pass + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __device__ __forceinline__ int slot(int t) const { return (pass * N + (T - t)) % SH::RS::SLOTS; }
+  __device__ __forceinline__ void wait(int t) {
+    const int j = T - t, G = pass * N + j;
+    if (G < have) return;
+    const int round = pass * nrounds + j / kKnotsPerRound, w = (j % kKnotsPerRound) / 4;
+    __hip_atomic_store(&sh.consumer_at, G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(&sh.rounds_done[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= round) {
+      __builtin_amdgcn_s_sleep(2);
+#ifdef ILQR_PHASE_TIMING
+      spins++;
+#endif
+    }
+    have = pass * N + (j / kKnotsPerRound) * kKnotsPerRound + (w + 1) * 4;
+  }
+  __device__ __forceinline__ void finish() {  // releases the producers (also from a pass abandoned half way)
+    __hip_atomic_store(&sh.consumer_at, 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&sh.passes_started, -1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+};
+
+// STEP 1 + STEP 2 of one iteration for ONE tile, run by a block of 1 + kProd wavefronts (k_sweep_backward is
+// this and nothing else).  The quad backward pass keeps a single wavefront per tile busy with one long dependent
+// chain, i.e. one of the four SIMDs of a CU; the finite-difference sweep is independent per knot.  So wavefront
+// 0 runs backward_quad, wavefronts 1..kProd are PRODUCERS that compute the derivative records of the tile's
+// knots in descending t (4 knots x 16 trajectories per wavefront and round) into an LDS ring, perform the
+// pending commit of the accepted candidate on the way (derivatives_of_knot, first pass only), and publish their
+// progress in LDS.  The consumer follows a few hundred cycles behind the first round and never waits again (a
+// producer round of 4 time steps costs about as much as ONE backward step): ds_read, no HBM round trip, no
+// vmcnt wait in its loop.  The records never reach HBM: a lambda-retry pass (ilqr_core.cpp:136-150) makes the
+// producers sweep again, for the trajectories that retry; whoever else wants records (getters, stage calls)
+// has k_derivatives compute them.  Workgroup-scope release/acquire is all the ordering needed.
+template <class M, int kProd, int RING_KB, class MFD, class SH>
+__device__ __forceinline__ void sweep_backward_tile(const BatchViewT<typename M::real>& v, const M& model, const MFD& fdm, const SolverParams& sp,
+                                                    int mode, int force, const int* __restrict__ commit_idx, int tile, SH& sh) {
+  using real = typename M::real;
+  constexpr int kKnotsPerRound = 4 * kProd;                      // 4 knots per producer wavefront
+  constexpr int kLeadKnots = ILQR_LEAD_ROUNDS * kKnotsPerRound;  // producers stay at most this far ahead of the consumer
+  using RS = typename SH::RS;
+  static_assert(RS::SLOTS >= kLeadKnots + 4, "the ring must hold the producers' lead plus the four knots in production");
+  if (threadIdx.x < kProd) sh.rounds_done[threadIdx.x] = 0;
+  if (threadIdx.x == kProd) {
+    sh.consumer_at = 0;
+    sh.passes_started = 0;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int T = v.T;
+  if (wave == 0) {
+    __builtin_amdgcn_s_setprio(3);
+    RingGate<SH, kProd> gate(sh, T);
+    backward_quad<M, decltype(gate), RING_KB>(v, model, sp, mode, tile, lane, sh.steps, gate, sh.ring);
+#ifdef ILQR_PHASE_TIMING
+    if (v.dbg && lane == 0 && tile < 64) v.dbg[tile * 8 + 7] = gate.spins;
+#endif
+    gate.finish();
+    __builtin_amdgcn_s_setprio(0);
+  } else {
+    // Producers pace themselves to the consumer (a bounded lead is what keeps a ring slot from being
+    // overwritten before it is read; running flat out they also took issue slots from nobody but saturated
+    // the CU's store path when the records still went to HBM).  A round is published as soon as its LDS
+    // writes are done.
+    const int w = wave - 1;
+    const int l = lane & (TW - 1), sub = lane >> 4;
+    const int nrounds = (T + 1 + kKnotsPerRound - 1) / kKnotsPerRound, N = nrounds * kKnotsPerRound;
+    for (int pass = 0;; pass++) {
+      unsigned long long lanes = ~0ull;
+      if (pass > 0) {  // a retry pass exists only if the backward wavefront starts one
+        int started;
+        while ((started = __hip_atomic_load(&sh.passes_started, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >= 0 && started <= pass)
+          __builtin_amdgcn_s_sleep(8);
+        if (started < 0) break;
+        lanes = __hip_atomic_load(&sh.pass_lanes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      const bool mine = (lanes >> (4 * l)) & 1ull;  // does trajectory l take part in this pass?
+      for (int r = 0; r < nrounds; r++) {
+        const int j0 = r * kKnotsPerRound + w * 4, G0 = pass * N + j0;
+        while (G0 > __hip_atomic_load(&sh.consumer_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + kLeadKnots)
+          __builtin_amdgcn_s_sleep(8);
+        // Has the backward wavefront left this pass behind (abandoned it at a failed box-QP, or is through)?
+        // Then its remaining records are of no use -- but the first pass still owes the commit of every knot.
+        const int started = __hip_atomic_load(&sh.passes_started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool moved_on = (started < 0) | (started > pass + 1);
+        if (moved_on && (pass > 0 || commit_idx == nullptr)) break;
+        const int t = T - (j0 + sub);
+        if (t >= 0 && (pass == 0 || mine))
+          derivatives_of_knot<M, true, MFD>(v, model, fdm, force, pass == 0 ? commit_idx : nullptr, tile, t, l,
+                                            sh.ring + ((G0 + sub) % RS::SLOTS) * RS::ELEMS + l * 2, !moved_on);
+        // LDS operations of a wavefront complete in order: once its writes are done the round is visible
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        if (lane == 0) __hip_atomic_store(&sh.rounds_done[w], pass * nrounds + r + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+}
+
+//   grid = ntiles, block = 64 * (1 + kProd), LDS ~150 KB (one block per CU)
+// Two instantiations are shipped: <3 producers, 150 KB ring> = one block per CU, for batches of up to
+// 16 x #CU trajectories, and <1 producer, 60 KB ring> = two blocks (four wavefronts) per CU for up to
+// twice that -- one producer cannot quite feed a backward wavefront (0.66 instead of 0.55 ms per tile
+// at T = 499), but two tiles per CU side by side beat the two-kernel route (B = 8192: 1.26 against
+// 1.42 ms per iteration).
 template <class M, int kProd = kProducers, int RING_KB = ILQR_RING_KB, class MFD = M>
 __global__ __launch_bounds__(64 * (1 + kProd)) void k_sweep_backward(BatchViewT<typename M::real> v, M model, MFD fdm, SolverParams sp, int mode, int force,
                                                         const int* __restrict__ commit_idx) {
   using real = typename M::real;
-  constexpr int kProducers = kProd;               // (shadows the default: everything below is per instantiation)
-  constexpr int kKnotsPerRound = 4 * kProducers;  // 4 knots per producer wavefront
-  constexpr int kLeadKnots = ILQR_LEAD_ROUNDS * kKnotsPerRound;  // producers stay at most this far ahead of the consumer
-  using RS = RingSlot<M::NX, M::NU, real, RING_KB>;
-  static_assert(RS::SLOTS >= kLeadKnots + 4, "the ring must hold the producers' lead plus the four knots in production");
-  __shared__ real lds_steps[104];
-  __shared__ real ring[RS::SLOTS * RS::ELEMS];  // knot j = T - t lives in slot j % SLOTS
-  __shared__ int rounds_done[kProducers];    // rounds whose records are in the ring
-  __shared__ int rounds_stored[kProducers];  // rounds whose records (and committed knots) have reached HBM
-  __shared__ int consumer_at;  // knots j < consumer_at are in the backward pass's registers (slots free)
-  if (threadIdx.x < kProducers) rounds_done[threadIdx.x] = rounds_stored[threadIdx.x] = 0;
-  if (threadIdx.x == kProducers) consumer_at = 0;
-  load_step_table(lds_steps);  // (barrier)
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tile = blockIdx.x;
-  const int T = v.T;
-  if (wave == 0) {
-    __builtin_amdgcn_s_setprio(3);
-#ifdef ILQR_PHASE_TIMING
-    long long gate_spins = 0;
-#endif
-    int have = 0, have_hbm = 0;  // knots j < have are in the ring / < have_hbm are readable from HBM
-    auto gate = [&](int t, bool from_ring) __attribute__((always_inline)) {  // wave-uniform
-      const int j = T - t;
-      const int round = j / kKnotsPerRound, w = (j % kKnotsPerRound) / 4;
-      if (from_ring) {
-        if (j < have) return;
-        __hip_atomic_store(&consumer_at, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(&rounds_done[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= round) {
-          __builtin_amdgcn_s_sleep(2);
-#ifdef ILQR_PHASE_TIMING
-          gate_spins++;
-#endif
-        }
-        have = round * kKnotsPerRound + (w + 1) * 4;
-      } else {  // a repeated pass (lambda retry) reads what the producers stored to HBM
-        if (j < have_hbm) return;
-        if (j >= have) __hip_atomic_store(&consumer_at, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(&rounds_stored[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= round)
-          __builtin_amdgcn_s_sleep(2);
-        have_hbm = round * kKnotsPerRound + (w + 1) * 4;
-        if (have_hbm > have) have = have_hbm;
-      }
-    };
-    backward_quad<M, decltype(gate), RING_KB>(v, model, sp, mode, tile, lane, lds_steps, gate, ring);
-#ifdef ILQR_PHASE_TIMING
-    if (v.dbg && lane == 0 && tile < 64) v.dbg[tile * 8 + 7] = gate_spins;
-#endif
-    // (a pass abandoned at lambdaMax never asks for the remaining knots: release the producers)
-    __hip_atomic_store(&consumer_at, 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  } else {
-    // Producers pace themselves to the consumer: running flat out they would saturate the CU's
-    // store path for the first third of the kernel (the sweep alone is HBM-write-bound) and the
-    // backward wavefront's own stores would queue behind theirs; a bounded lead also is what keeps
-    // a ring slot from being overwritten before it is read.  A round is published for the ring as
-    // soon as its LDS writes are done; its HBM stores drain while the wavefront waits for its next
-    // turn and are published (rounds_stored) just before the next round starts.
-    const int w = wave - 1;
-    const int l = lane & (TW - 1), sub = lane >> 4;
-    if (tile == 0 && threadIdx.x == 64) *v.n_running = 0;  // k_accept of this iteration recounts
-    const int nrounds = (T + 1 + kKnotsPerRound - 1) / kKnotsPerRound;
-    for (int r = 0; r < nrounds; r++) {
-      const int j0 = r * kKnotsPerRound + w * 4;
-      while (j0 > __hip_atomic_load(&consumer_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + kLeadKnots)
-        __builtin_amdgcn_s_sleep(8);
-      if (r > 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // round r-1 has reached the L2
-        if (lane == 0) __hip_atomic_store(&rounds_stored[w], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      const int t = T - (j0 + sub);
-      if (t >= 0)
-        derivatives_of_knot<M, true, MFD>(v, model, fdm, force, commit_idx, tile, t, l, ring + ((j0 + sub) % RS::SLOTS) * RS::ELEMS + l * 2);
-      // LDS operations of a wavefront complete in order: once its writes are done the round is visible
-      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-      if (lane == 0) __hip_atomic_store(&rounds_done[w], r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_store(&rounds_stored[w], nrounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
+  __shared__ SweepShared<real, M::NX, M::NU, kProd, RING_KB> sh;
+  load_step_table(sh.steps);  // (barrier)
+  if (blockIdx.x == 0 && threadIdx.x == 64) *v.n_running = 0;  // k_accept of this iteration recounts
+  sweep_backward_tile<M, kProd, RING_KB, MFD>(v, model, fdm, sp, mode, force, commit_idx, (int)blockIdx.x, sh);
 }
 
 // ------------------------------------------------------------------------------------------
