@@ -41,10 +41,10 @@ def algorithmic_bytes_per_timestep(n, m, s=8):
         # (SURVEY's nominal figure charges the reads to every alpha: 11 x 92 B; that is not what reaches HBM.)
         "rollout": ((2 * m + m * n + n) + 11 * (m + n / 8.0)) * s,                        # acrobot fp64 204
         "accept": 2 * (n + m) * s,                                                       # commit copy
-        # k_sweep_backward (ilqr_iterate): the sweep's records reach the backward wavefront through LDS, so
-        # HBM sees: candidate u + 1/8 checkpoint x read, committed x,u written, the record written (retry
-        # passes / getters read it there), K and k written, the nominal u read.              acrobot fp64 468
-        "sweep_backward": (m + n / 8.0 + (n + m) + (2 * n * n + 2 * n * m + m * m + n + m) + (m * n + m) + m) * s,
+        # fused sweep + backward (k_sweep_backward / the first phase of k_solve_tile): the records live in LDS
+        # only, so HBM sees: candidate u + 1/8 checkpoint x read, committed x,u written, K and k written, the
+        # nominal u read.                                                                    acrobot fp64 100
+        "sweep_backward": (m + n / 8.0 + (n + m) + (m * n + m) + m) * s,
     }
 
 
@@ -220,24 +220,33 @@ def main():
         assert g.count_running() == B, "fixed-work run lost trajectories: the throughput figure would be inflated"
         return g, elapsed, prof, gathered
 
-    def stage_table(g, prof, B, s_bytes):
+    def stage_table(g, prof, B, s_bytes, iters_per_call):
         bytes_ts = algorithmic_bytes_per_timestep(n, m, s_bytes)
         name_of = {i: g.lib.ilqr_stage_kernel_name(g.h, i).decode() for i in range(capi.NUM_STAGES)}
         fused = name_of[capi.STAGE_NAMES.index("backward")] == "k_sweep_backward"
         if fused:  # one kernel does the derivative sweep AND the backward pass of the tile
             bytes_ts["backward"] = bytes_ts["sweep_backward"]
+        # the persistent kernel: every iteration of the call, both phases (the commit of the last accepts is k_commit)
+        bytes_ts["solve"] = (bytes_ts["sweep_backward"] + bytes_ts["rollout"]) * iters_per_call
         stages = {}
+        persistent = prof.get("solve", (0, 0))[1] > 0
         for name, (ms, launches) in prof.items():
             if launches:
                 stages[name] = {"kernel": name_of[capi.STAGE_NAMES.index(name)], "ms_per_launch": ms / launches, "launches": launches,
                                 "algorithmic_bytes_per_timestep": bytes_ts[name],
                                 "algorithmic_GBps": bytes_ts[name] * B * T / (ms / launches * 1e-3) / 1e9}
+                if persistent and name in ("backward", "rollout"):
+                    stages[name]["kernel"] = "k_solve_tile"
+                    stages[name]["clock"] = "the kernel's own per-phase clock, mean over tiles and per iteration (not a launch)"
         if fused:
-            stages["backward"]["includes"] = "derivative sweep (fused kernel)"
+            stages["backward"]["includes"] = "derivative sweep (fused)"
+        if persistent:
+            stages["solve"]["iterations_per_launch"] = iters_per_call
         return stages, bytes_ts
 
     def roofline_of(stages, bytes_ts, B):
-        dom = max(stages, key=lambda k: stages[k]["ms_per_launch"])
+        real_launches = {k: v for k, v in stages.items() if "clock" not in v}
+        dom = max(real_launches, key=lambda k: stages[k]["ms_per_launch"])
         kern = stages[dom]["kernel"]
         achieved = stages[dom]["algorithmic_GBps"]
         traffic, traffic_src = pmc_traffic(kern)
@@ -246,6 +255,7 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_ts[dom] * B * T, "avg_launch_ms": stages[dom]["ms_per_launch"],
                 "limiter": "neither roofline: one dependent Riccati chain per tile, bound by VALU issue + latency "
                            "(see roofline_issue); HBM is the contract's nominal bound for this byte-light path"}
+
 
     # ---------------- headline: BASELINE.json metric, configs[2] ----------------
     B, lim, steps = args.batch, args.limit, args.steps
@@ -264,7 +274,7 @@ def main():
         capi.check(g.lib.ilqr_backward_pass(g.h, None))
     bw_ms = g.profile_read()["backward"][0] / R
     g.profile(False)
-    stages, bytes_ts = stage_table(g, prof, B, s_bytes)
+    stages, bytes_ts = stage_table(g, prof, B, s_bytes, steps)
     g.close()
 
     # ---------------- the other configurations (each a fixed-work run of its own) ----------------
@@ -273,7 +283,7 @@ def main():
         # late in a solve: iterations 4..103 of the same workload -- box-QPs leave the fast path
         # once lambda has reached 0, the launch lasts as long as its slowest tile
         g2, el2, prof2, _ = acrobot_run(args.dtype, B, lim, 100, args.warmup, args.flags, gather=False)
-        st2, _ = stage_table(g2, prof2, B, s_bytes)
+        st2, _ = stage_table(g2, prof2, B, s_bytes, 100)
         g2.close()
         extra["late_solve"] = {"workload": "the headline workload, 100 timed iterations (4..103 of the solve)",
                                "late_ms_per_step": el2 / 100 * 1e3, "value": world * B * T * 100 / el2,
@@ -284,7 +294,7 @@ def main():
         so = 4 if other == "f32" else 8
         for label, fl in ((other, 0), (other + "_analytic", capi.FLAG_ANALYTIC_DERIVATIVES)):
             g3, el3, prof3, ga3 = acrobot_run(other, 4096, 5.0, steps, args.warmup, fl)
-            st3, bt3 = stage_table(g3, prof3, 4096, so)
+            st3, bt3 = stage_table(g3, prof3, 4096, so, steps)
             assert ga3 is None or bool(torch.isfinite(ga3).all())
             extra["acrobot_T500_B4096_lim5_" + label] = {
                 "workload": "acrobot T=499 B=4096 per GPU, u in [-5,5], %s%s, fixed-work iterations (BASELINE configs[3] "
@@ -296,7 +306,7 @@ def main():
     if not args.no_extra_configs and world == 1:
         # BASELINE configs[1]: acrobot B=1024, limits +-5
         g4, el4, prof4, _ = acrobot_run("f64", 1024, 5.0, steps, args.warmup, gather=False)
-        st4, bt4 = stage_table(g4, prof4, 1024, 8)
+        st4, bt4 = stage_table(g4, prof4, 1024, 8, steps)
         g4.close()
         extra["acrobot_T500_B1024_lim5_f64"] = {"workload": "acrobot T=499 B=1024, u in [-5,5], fp64 (BASELINE configs[1])",
                                                 "value": 1024 * T * steps / el4, "unit": "trajectory-timesteps/s",

@@ -71,6 +71,8 @@ struct ilqr_batch {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int* commit_idx = nullptr;
+  long long* phase_ticks = nullptr;  // [ntiles][3] per-tile clocks of k_solve_tile: sweep+backward, rollouts+accept, iterations
+  double wall_clock_khz = 100000.0;
   double* staging = nullptr;  // device scratch for canonical <-> tiled conversion
   // LQ model with exact derivatives: the sweep writes one copy of the constant matrices (const_rec) and
   // per knot only cx, cu; records_partial says that D holds no matrices for t < T right now
@@ -363,11 +365,11 @@ static int launch_rollout_t(ilqr_batch* h, const V& v, const M& m, bool gains, b
   dim3 grid(h->ntiles), block(64 * aw);
   const bool deep = h->ntiles <= h->num_cus;  // one block per CU: deep prefetch (see k_rollout)
   if (gains && cand && with_accept && deep)
-    hipLaunchKernelGGL((k_rollout<M, true, true, 8, true>), grid, block, 0, h->stream, v, m, al, n_alpha, cost_out, mode, h->sp, h->commit_idx);
+    hipLaunchKernelGGL((k_rollout<M, true, true, kDeepPrefetch<M>, true>), grid, block, 0, h->stream, v, m, al, n_alpha, cost_out, mode, h->sp, h->commit_idx);
   else if (gains && cand && with_accept)
     hipLaunchKernelGGL((k_rollout<M, true, true, 4, true>), grid, block, 0, h->stream, v, m, al, n_alpha, cost_out, mode, h->sp, h->commit_idx);
   else if (gains && cand && deep)
-    hipLaunchKernelGGL((k_rollout<M, true, true, 8>), grid, block, 0, h->stream, v, m, al, n_alpha, cost_out, mode, h->sp, nullptr);
+    hipLaunchKernelGGL((k_rollout<M, true, true, kDeepPrefetch<M>>), grid, block, 0, h->stream, v, m, al, n_alpha, cost_out, mode, h->sp, nullptr);
   else if (gains && cand)
     hipLaunchKernelGGL((k_rollout<M, true, true, 4>), grid, block, 0, h->stream, v, m, al, n_alpha, cost_out, mode, h->sp, nullptr);
   else if (!gains && !cand)
@@ -580,6 +582,32 @@ static int launch_accept(ilqr_batch* h) {
   return timer_end(h, ILQR_STAGE_ACCEPT, ev);
 }
 
+// Whole iterations per tile in one persistent kernel (k_solve_tile): the one-block-per-CU regime of the fused
+// kernel.  ILQR_FLAG_STAGED / ILQR_AMD_STAGED=1: per-stage launches instead (A/B runs, the bit-identity tests).
+static bool use_persistent(const ilqr_batch* h) {
+  if (h->aos || (h->flags & ILQR_FLAG_STAGED) || getenv("ILQR_AMD_STAGED")) return false;
+  return fused_variant(h) == 1;
+}
+static AlphaSet line_search_alphas();
+static int launch_solve_tiles(ilqr_batch* h, int n_iters) {
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  HIPCHK(hipMemsetAsync(h->v.n_running, 0, sizeof(int), h->stream));
+  if (int rc = timer_begin(h, ILQR_STAGE_SOLVE, &ev)) return rc;
+  const AlphaSet al = line_search_alphas();
+  const int pending = h->commit_pending ? 1 : 0;
+  long long* ticks = h->profile ? h->phase_ticks : nullptr;
+  if (int rc = with_model(h, [&](auto& v, auto& m, auto& fdm) {
+        hipLaunchKernelGGL((k_solve_tile<std::decay_t<decltype(m)>, std::decay_t<decltype(fdm)>>), dim3(h->ntiles), dim3(256), 0, h->stream, v, m, fdm,
+                           al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
+        return 0;
+      }))
+    return rc;
+  HIPCHK(hipGetLastError());
+  h->commit_pending = true;   // the last iteration's accepts (flushed by the caller)
+  h->recs = ilqr_batch::REC_STALE;
+  return timer_end(h, ILQR_STAGE_SOLVE, ev);
+}
+
 static AlphaSet line_search_alphas() {
   AlphaSet a;
   for (int i = 0; i < NALPHA; i++) a.a[i] = kAlphaHost[i];
@@ -683,6 +711,10 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   if (d->device < 0 || d->device >= ndev) return fail(ILQR_ERR_NO_DEVICE, "device %d out of range (%d visible)", d->device, ndev);
   HIPCHK(hipSetDevice(d->device));
   HIPCHK(hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, d->device));
+  {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, d->device) == hipSuccess && khz > 0) h->wall_clock_khz = khz;
+  }
   if (const char* e = getenv("ILQR_AMD_NUM_CUS"))  // tests: exercise the batch-size thresholds of the route selection on small batches
     if (atoi(e) > 0) h->num_cus = atoi(e);
   h->device = d->device;
@@ -839,6 +871,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   rc |= dev_alloc(h, &v.backpass_done, Bp);
   rc |= dev_alloc(h, &v.n_running, 1);
   rc |= dev_alloc(h, &h->commit_idx, Bp);
+  rc |= dev_alloc(h, &h->phase_ticks, 3 * (size_t)h->ntiles);
   if (!rc && hipMemsetAsync(h->commit_idx, 0xFF, Bp * sizeof(int), h->stream) != hipSuccess) rc = 1;
   rc |= dev_alloc(h, &v.dbg, 1024);
   if (rc) return ILQR_ERR_HIP;
@@ -939,6 +972,10 @@ int ilqr_iterate(ilqr_batch* h, int n_iters) {
     explicit Chain(ilqr_batch* hh) : h(hh) { h->chain_timers = true; h->chain_event = nullptr; }
     ~Chain() { h->chain_timers = false; h->chain_event = nullptr; }
   } chain(h);
+  if (use_persistent(h) && n_iters > 0) {
+    if (int rc = launch_solve_tiles(h, n_iters)) return rc;
+    return flush_commit(h);
+  }
   for (int it = 0; it < n_iters; it++) {
     if (use_fused_sweep(h)) {
       if (int rc = launch_sweep_backward(h, 1, h->sp.fixed_work)) return rc;  // STEP 1 + STEP 2
@@ -973,7 +1010,7 @@ int ilqr_generate_trajectory(ilqr_batch* h) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
   if (!h->initialised) return fail(ILQR_ERR_STATE, "generate_trajectory needs x0/xs/us (asserts of ilqr_core.cpp:80-82)");
   int done_iters = 0;
-  const int chunk = 10;
+  const int chunk = use_persistent(h) ? std::max(1, h->params.max_iter) : 10;  // (a persistent tile stops by itself)
   while (done_iters < h->params.max_iter) {
     const int n = std::min(chunk, h->params.max_iter - done_iters);
     if (int rc = ilqr_iterate(h, n)) return rc;
@@ -1262,14 +1299,37 @@ int ilqr_profile_reset(ilqr_batch* h) {
     t.ms = 0;
     t.launches = 0;
   }
+  HIPCHK(hipMemsetAsync(h->phase_ticks, 0, 3 * (size_t)h->ntiles * sizeof(long long), h->stream));
   return 0;
 }
 int ilqr_profile_read(ilqr_batch* h, double ms_out[ILQR_NUM_STAGES], int launches_out[ILQR_NUM_STAGES]) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
   if (int rc = timers_drain(h)) return rc;
+  double ms[ILQR_NUM_STAGES];
+  int ln[ILQR_NUM_STAGES];
   for (int s = 0; s < ILQR_NUM_STAGES; s++) {
-    if (ms_out) ms_out[s] = h->timers[s].ms;
-    if (launches_out) launches_out[s] = h->timers[s].launches;
+    ms[s] = h->timers[s].ms;
+    ln[s] = h->timers[s].launches;
+  }
+  if (h->timers[ILQR_STAGE_SOLVE].launches > 0) {  // the persistent kernel's own phase clocks: mean over tiles
+    std::vector<long long> tk(3 * (size_t)h->ntiles);
+    HIPCHK(hipMemcpyAsync(tk.data(), h->phase_ticks, tk.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double sweep = 0, roll = 0, its = 0;
+    for (int t = 0; t < h->ntiles; t++) {
+      sweep += (double)tk[3 * t];
+      roll += (double)tk[3 * t + 1];
+      its += (double)tk[3 * t + 2];
+    }
+    const double to_ms = 1.0 / h->wall_clock_khz / h->ntiles;  // ticks -> ms, mean over tiles
+    ms[ILQR_STAGE_BACKWARD] += sweep * to_ms;
+    ms[ILQR_STAGE_ROLLOUT] += roll * to_ms;
+    ln[ILQR_STAGE_BACKWARD] += (int)(its / h->ntiles + 0.5);
+    ln[ILQR_STAGE_ROLLOUT] += (int)(its / h->ntiles + 0.5);
+  }
+  for (int s = 0; s < ILQR_NUM_STAGES; s++) {
+    if (ms_out) ms_out[s] = ms[s];
+    if (launches_out) launches_out[s] = ln[s];
   }
   return 0;
 }
@@ -1282,6 +1342,7 @@ const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
       return (h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t";
     case ILQR_STAGE_ROLLOUT: return (h && h->aos) ? (lq_thread_rollout() ? "k_rollout_g" : "k_rollout_lq") : "k_rollout";
     case ILQR_STAGE_ACCEPT: return "k_accept";
+    case ILQR_STAGE_SOLVE: return (h && use_persistent(h)) ? "k_solve_tile" : "";
     default: return "";
   }
 }

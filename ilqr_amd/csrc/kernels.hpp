@@ -108,7 +108,7 @@ __global__ void k_reset_state(BatchViewT<real> v, double lambda0, double dlambda
 // STEP 3/4 for trajectory b; cost_of(a) = cost of its candidate a
 template <class View, class CostOf>
 __device__ __forceinline__ void accept_one(const View& v, const SolverParams& sp, int b, CostOf cost_of,
-                                           int* __restrict__ commit_idx) {
+                                           int* __restrict__ commit_idx, bool count_running = true) {
   if (b >= v.Bp) return;
   int commit = -1;
   if (b < v.B && v.status[b] == 0) {
@@ -159,7 +159,7 @@ __device__ __forceinline__ void accept_one(const View& v, const SolverParams& sp
     // whatever max_iter says.
     if (status == 0 && !sp.fixed_work && it >= sp.max_iter) status = 4;
     v.status[b] = status;
-    if (status == 0) atomicAdd(v.n_running, 1);
+    if (status == 0 && count_running) atomicAdd(v.n_running, 1);
   }
   commit_idx[b] = commit;
 }
@@ -186,19 +186,24 @@ struct AlphaSet {
 // backward pass succeeded.
 // ACCEPT: the block also performs STEP 3/4 for its 16 trajectories once its three wavefronts have
 // their costs (k_accept's work without a launch of its own; sp, commit_idx are only used then).
-template <class M, bool GAINS, bool CAND, int PD = 4, bool ACCEPT = false>
-__global__ __launch_bounds__(192) void k_rollout(BatchViewT<typename M::real> v, M model, AlphaSet alphas, int n_alpha,
-                                                 double* __restrict__ cost_out, int mode, SolverParams sp,
-                                                 int* __restrict__ commit_idx) {
+// Prefetch depth of the rollout when a tile has a CU to itself: 8 steps for the acrobot (10 doubles per step: 160
+// registers of ring), 4 for the double integrator (16 per step: at depth 8 the ring alone is 256 registers, the
+// kernel spills -- and inside k_solve_tile the spilled build produced wrong rollouts from knot 59 on).
+template <class M>
+constexpr int kDeepPrefetch = (M::NU * M::NX + M::NX + 2 * M::NU <= 10) ? 8 : 4;
+
+// (the body of k_rollout for one tile: the persistent kernel k_solve_tile runs it too, with a fourth, idle wavefront)
+template <class M, bool GAINS, bool CAND, int PD, bool ACCEPT>
+__device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>& v, const M& model, const AlphaSet& alphas, int n_alpha,
+                                             double* __restrict__ cost_out, int mode, const SolverParams& sp,
+                                             int* __restrict__ commit_idx, int tile, double* lds_cost, bool count_running = true) {
   using real = typename M::real;
-  __shared__ double lds_cost[ACCEPT ? NALPHA * TW : 1];
   constexpr int NX = M::NX, NU = M::NU;
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int l = lane & (TW - 1);
   const int a_sub = lane >> 4;
   const int a = wave * 4 + a_sub;
-  const int tile = blockIdx.x;
   const int b = tile * TW + l;
   bool active = (b < v.B) && (a < n_alpha);
   if (active && mode == 1) active = (v.status[b] == 0 && v.backpass_done[b]);
@@ -323,8 +328,16 @@ __global__ __launch_bounds__(192) void k_rollout(BatchViewT<typename M::real> v,
   if constexpr (ACCEPT) {
     __syncthreads();
     if (threadIdx.x < TW)
-      accept_one(v, sp, tile * TW + (int)threadIdx.x, [&](int aa) { return lds_cost[aa * TW + threadIdx.x]; }, commit_idx);
+      accept_one(v, sp, tile * TW + (int)threadIdx.x, [&](int aa) { return lds_cost[aa * TW + threadIdx.x]; }, commit_idx, count_running);
   }
+}
+
+template <class M, bool GAINS, bool CAND, int PD = 4, bool ACCEPT = false>
+__global__ __launch_bounds__(192) void k_rollout(BatchViewT<typename M::real> v, M model, AlphaSet alphas, int n_alpha,
+                                                 double* __restrict__ cost_out, int mode, SolverParams sp,
+                                                 int* __restrict__ commit_idx) {
+  __shared__ double lds_cost[ACCEPT ? NALPHA * TW : 1];
+  rollout_tile<M, GAINS, CAND, PD, ACCEPT>(v, model, alphas, n_alpha, cost_out, mode, sp, commit_idx, (int)blockIdx.x, lds_cost);
 }
 
 // Knot t of candidate `a` of trajectory (tile, l): the control as stored, the state re-integrated
@@ -1763,6 +1776,69 @@ __global__ __launch_bounds__(64 * (1 + kProd)) void k_sweep_backward(BatchViewT<
   load_step_table(sh.steps);  // (barrier)
   if (blockIdx.x == 0 && threadIdx.x == 64) *v.n_running = 0;  // k_accept of this iteration recounts
   sweep_backward_tile<M, kProd, RING_KB, MFD>(v, model, fdm, sp, mode, force, commit_idx, (int)blockIdx.x, sh);
+}
+
+// Whole iterations of the outer loop (ilqr_core.cpp:103-288) for ONE tile, start to finish, in one launch: the
+// block alternates between the fused sweep + backward pass (STEP 1 + 2) and the 11-alpha rollouts with the
+// accept logic (STEP 3 + 4), n_iters times or until all of its 16 trajectories have left their loops.  Tiles
+// never wait for each other: launched per stage, every iteration lasted as long as its SLOWEST tile, twice --
+// and late in a solve one tile in 256 is always repeating a backward pass at a raised lambda (ilqr_core.cpp:
+// 136-150) or sitting in the slow paths of a box-QP, a different one every time; per tile those passes add up
+// to little.  Everything a tile's phases hand each other (gains, status, lambda, candidates, commit indices)
+// goes through global memory written and read by wavefronts of the same block, ordered by the block barrier.
+//   grid = ntiles, block = 256; one block per CU (about 290 registers x 4 wavefronts, 150 KB of LDS)
+// Between the phases of a persistent tile: what one wavefront of the block stored to global memory is read by
+// another a moment later, at addresses this CU has read before (gains, the previous iteration's candidates, the
+// nominal trajectory).  The LLVM memory model orders that at workgroup scope without waiting for the stores or
+// touching the L1 (the wavefronts of a block share a CU); the phases hand over megabytes twice per iteration,
+// so this barrier does not lean on it: stores are waited for (vmcnt(0)) and the CU's vector L1 is invalidated.
+__device__ __forceinline__ void phase_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+template <class M, class MFD>
+__global__ __launch_bounds__(256) void k_solve_tile(BatchViewT<typename M::real> v, M model, MFD fdm, AlphaSet alphas, SolverParams sp, int n_iters,
+                                                    int force, int* __restrict__ commit_idx, int commit_pending, long long* __restrict__ phase_ticks) {
+  using real = typename M::real;
+  __shared__ SweepShared<real, M::NX, M::NU, kProducers, ILQR_RING_KB> sh;
+  __shared__ double lds_cost[NALPHA * TW];
+  __shared__ int tile_running;
+  load_step_table(sh.steps);  // (barrier)
+  const int tile = blockIdx.x;
+  long long t_sweep = 0, t_roll = 0, t0 = 0;
+  const bool timing = (phase_ticks != nullptr) & (threadIdx.x == 0);
+  int it = 0;
+  for (; it < n_iters; it++) {
+    if (timing) t0 = wall_clock64();
+    sweep_backward_tile<M, kProducers, ILQR_RING_KB, MFD>(v, model, fdm, sp, 1, force, (it > 0 || commit_pending) ? commit_idx : nullptr, tile, sh);
+    phase_barrier();  // the tile's gains, lambda, status are in memory for its rollout wavefronts
+    if (timing) {
+      const long long t1 = wall_clock64();
+      t_sweep += t1 - t0;
+      t0 = t1;
+    }
+    rollout_tile<M, true, true, kDeepPrefetch<M>, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, commit_idx, tile, lds_cost, /*count_running=*/it == n_iters - 1);
+    if (threadIdx.x == 0) tile_running = 0;
+    phase_barrier();  // candidates, costs, status, commit indices are in memory for the next sweep
+    if (timing) t_roll += wall_clock64() - t0;
+    if (!sp.fixed_work) {  // has every trajectory of the tile left its loop?
+      const int b = tile * TW + (int)threadIdx.x;
+      if (threadIdx.x < TW && b < v.B && v.status[b] == 0) tile_running = 1;
+      __syncthreads();
+      if (!tile_running) {
+        it++;
+        break;
+      }
+    }
+  }
+  if (timing) {
+    phase_ticks[3 * tile + 0] += t_sweep;
+    phase_ticks[3 * tile + 1] += t_roll;
+    phase_ticks[3 * tile + 2] += it;
+  }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -19,6 +19,9 @@ namespace ilqr {
 // every rollout step.  NaN/Inf propagate to NaN as in libm; a finite |x| beyond ~1e9 (a rollout
 // that has already diverged -- the line search rejects it on cost) loses accuracy gracefully.
 __device__ __forceinline__ void sincos_shared(double x, double& s_out, double& c_out) {
+  // contraction by the source, not by the optimiser: every inlined copy of this function (rollout kernels, the
+  // persistent kernel, the commit / getter re-integration, the finite differences) must round identically
+#pragma clang fp contract(on)
   const double j = __builtin_rint(x * 6.36619772367581382433e-01);  // 2/pi
   double r = __builtin_fma(-j, 1.57079632679489655800e+00, x);      // pi/2, leading 53 bits
   r = __builtin_fma(-j, 6.12323399573676603587e-17, r);             // next 53 bits
@@ -48,6 +51,9 @@ __device__ __forceinline__ void sincos_shared(double x, double& s_out, double& c
 // fp32 flavour of the above: j = rint(x 2/pi), r = x - j pi/2 in three FMAs (pi/2 split in three floats),
 // minimax polynomials on [-pi/4, pi/4] (the classic single-precision kernels): ~1 ulp for |x| <= 1e4.
 __device__ __forceinline__ void sincos_shared(float x, float& s_out, float& c_out) {
+  // contraction by the source, not by the optimiser: every inlined copy of this function (rollout kernels, the
+  // persistent kernel, the commit / getter re-integration, the finite differences) must round identically
+#pragma clang fp contract(on)
   const float j = __builtin_rintf(x * 6.36619772e-01f);
   float r = __builtin_fmaf(-j, 1.57079601e+00f, x);   // pi/2, leading bits (exact product with |j| < 2^11)
   r = __builtin_fmaf(-j, 3.13916473e-07f, r);         // next
@@ -72,6 +78,9 @@ struct AcrobotModelT {
   real u_min[1], u_max[1];
 
   __device__ __forceinline__ void dynamics(const real* x, const real* u, real* dx) const {
+    // contraction by the source, not by the optimiser: every inlined copy of this function (rollout kernels, the
+    // persistent kernel, the commit / getter re-integration, the finite differences) must round identically
+#pragma clang fp contract(on)
     const real I1 = 1, I2 = 1, l1 = 1, l2 = 1, m1 = 1, m2 = 1, g = real(9.81);
     const real lc1 = real(0.5) * l1, lc2 = real(0.5) * l2;
     const real q0 = x[0], q1 = x[1], qd0 = x[2], qd1 = x[3];
@@ -171,12 +180,18 @@ struct AcrobotModelT {
 
   // acrobot.h:83-92: Ks = Kd = 0, Kr = 0.1 -> the state terms are exact zeros for finite x
   __device__ __forceinline__ real cost(const real* x, const real* u) const {
+    // contraction by the source, not by the optimiser: every inlined copy of this function (rollout kernels, the
+    // persistent kernel, the commit / getter re-integration, the finite differences) must round identically
+#pragma clang fp contract(on)
     (void)x;
     const real Kr = real(0.1);
     return Kr * Kr * (u[0] * u[0]);
   }
   // acrobot.h:94-100: Ks = Kd = 20
   __device__ __forceinline__ real final_cost(const real* x) const {
+    // contraction by the source, not by the optimiser: every inlined copy of this function (rollout kernels, the
+    // persistent kernel, the commit / getter re-integration, the finite differences) must round identically
+#pragma clang fp contract(on)
     const real q0 = goal[0] - x[0], q1 = goal[1] - x[1];
     const real qd0 = goal[2] - x[2], qd1 = goal[3] - x[3];
     const real Ks = real(20.0), Kd = real(20.0);
@@ -194,6 +209,9 @@ struct DoubleIntegratorModelT {
   real u_min[2], u_max[2];
 
   __device__ __forceinline__ void dynamics(const real* x, const real* u, real* dx) const {
+    // contraction by the source, not by the optimiser: every inlined copy of this function (rollout kernels, the
+    // persistent kernel, the commit / getter re-integration, the finite differences) must round identically
+#pragma clang fp contract(on)
     const real mass = real(1.0);  // double_integrator.h:29-37
     dx[0] = x[2];
     dx[1] = x[3];
@@ -201,6 +219,9 @@ struct DoubleIntegratorModelT {
     dx[3] = u[1] / mass;
   }
   __device__ __forceinline__ real quad(const real* x, real scale) const {
+    // contraction by the source, not by the optimiser: every inlined copy of this function (rollout kernels, the
+    // persistent kernel, the commit / getter re-integration, the finite differences) must round identically
+#pragma clang fp contract(on)
     const real hx[4] = {1, 1, real(0.2), real(0.2)};
     real d[4], r[4];
 #pragma unroll
@@ -236,6 +257,9 @@ struct DoubleIntegratorModelT {
   }
   // double_integrator.h:39-43
   __device__ __forceinline__ real cost(const real* x, const real* u) const {
+    // contraction by the source, not by the optimiser: every inlined copy of this function (rollout kernels, the
+    // persistent kernel, the commit / getter re-integration, the finite differences) must round identically
+#pragma clang fp contract(on)
     return quad(x, real(1.0)) + (u[0] * u[0] + u[1] * u[1]);
   }
   // double_integrator.h:45-48
@@ -246,6 +270,9 @@ struct DoubleIntegratorModelT {
 template <class M>
 __device__ __forceinline__ void integrate_dynamics(const M& m, const typename M::real* x, const typename M::real* u, typename M::real dt,
                                                    typename M::real* x1) {
+  // contraction by the source, not by the optimiser: every inlined copy of this function (rollout kernels, the
+  // persistent kernel, the commit / getter re-integration, the finite differences) must round identically
+#pragma clang fp contract(on)
   typename M::real dx[M::NX];
   m.dynamics(x, u, dx);
 #pragma unroll

@@ -98,7 +98,12 @@ enum ilqr_flags {
    * model's exact derivatives of the Euler map and of the costs instead of eps = 1e-3 central
    * differences.  Results then differ from the reference's by its finite differences' truncation and
    * rounding error (~1e-6 relative on the records), so parity claims are made WITHOUT this flag. */
-  ILQR_FLAG_ANALYTIC_DERIVATIVES = 16
+  ILQR_FLAG_ANALYTIC_DERIVATIVES = 16,
+  /* ilqr_iterate / ilqr_solve normally run whole iterations of a 16-trajectory tile in ONE persistent kernel
+   * (batches of up to 16 x #CU trajectories of an nx = 4 model: tiles never wait for each other).  This flag
+   * launches the stages of every iteration as kernels of their own instead (fused sweep + backward, then
+   * rollouts + accept), as larger batches do.  Same results bit for bit. */
+  ILQR_FLAG_STAGED = 32
 };
 
 /* Solver tunables = the compile-time constants of include/ilqr.h:14-24 (defaults shown). */
@@ -214,8 +219,11 @@ int ilqr_copy_cost_to_device(ilqr_batch* h, void* dst_device);
 
 /* ---- measurement --------------------------------------------------------------------------- */
 enum ilqr_stage { ILQR_STAGE_DERIVATIVES = 0, ILQR_STAGE_BACKWARD = 1, ILQR_STAGE_ROLLOUT = 2,
-                  ILQR_STAGE_ACCEPT = 3, ILQR_NUM_STAGES = 4 };
-/* HIP-event timing of every kernel launch of a stage, accumulated on the handle's stream. */
+                  ILQR_STAGE_ACCEPT = 3, ILQR_STAGE_SOLVE = 4, ILQR_NUM_STAGES = 5 };
+/* HIP-event timing of every kernel launch of a stage, accumulated on the handle's stream.  ILQR_STAGE_SOLVE is the
+ * persistent per-tile kernel of ilqr_iterate (one launch = all the iterations of the call); while it runs, the
+ * BACKWARD and ROLLOUT slots receive the kernel's own per-phase clocks (mean over tiles, one "launch" per
+ * iteration) so that the split stays visible. */
 int ilqr_profile_enable(ilqr_batch* h, int enable);
 int ilqr_profile_reset(ilqr_batch* h);
 /* total milliseconds and launch count per stage since the last reset (synchronises) */

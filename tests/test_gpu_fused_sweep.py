@@ -1,7 +1,9 @@
-"""ilqr_iterate runs the derivative sweep and the backward pass of an iteration in one kernel
-(k_sweep_backward: producer wavefronts + the quad backward wavefront of a tile share a CU); the
-stage calls, and ILQR_FLAG_UNFUSED, run them as two kernels.  Both routes execute the same device
-functions on the same data, so everything they leave behind must be bit-identical."""
+"""ilqr_iterate runs whole iterations of a tile in one persistent kernel (k_solve_tile: the fused sweep + backward
+pass, producer wavefronts + the quad backward wavefront of a tile sharing a CU and an LDS ring, then the rollouts
+and the accept logic, again and again); ILQR_FLAG_STAGED launches the same two phases as kernels of their own per
+iteration (k_sweep_backward, k_rollout); the stage calls, and ILQR_FLAG_UNFUSED, run sweep and backward pass as
+two kernels with the records in HBM.  All routes execute the same device functions on the same data, so
+everything they leave behind must be bit-identical."""
 import numpy as np
 import pytest
 
@@ -35,13 +37,14 @@ def test_acrobot_fused_equals_unfused(B, fixed):
     u0 = np.zeros((B, T, 1))
     base = capi.FLAG_FIXED_WORK if fixed else 0
     out = []
-    for fl in (0, capi.FLAG_UNFUSED):
+    for fl in (0, capi.FLAG_STAGED, capi.FLAG_UNFUSED):
         g = BatchILQR("acrobot", B, T, DT, u_min=-1.5, u_max=1.5, flags=base | fl)
         g.init_traj(x0, u0)
         g.iterate(6)
         out.append(_state(g))
         g.close()
     _same(out[0], out[1])
+    _same(out[0], out[2])
 
 
 def test_integrator_fused_equals_unfused_through_termination():
@@ -53,19 +56,24 @@ def test_integrator_fused_equals_unfused_through_termination():
     x0 = integrator_x0(B)
     u0 = np.zeros((B, T, 2))
     out = []
-    for fl in (0, capi.FLAG_UNFUSED):
+    for fl in (0, capi.FLAG_STAGED, capi.FLAG_UNFUSED):
         g = BatchILQR("integrator", B, T, DT, goal=[1.0, 0.5, 0.0, 0.0], flags=fl)
         g.generate_trajectory(x0, u0)
         assert g.count_running() == 0
         out.append(_state(g))
         g.close()
     _same(out[0], out[1])
+    _same(out[0], out[2])
 
 
 def test_stage_kernel_name_reports_the_fused_kernel():
     from ilqr_amd import BatchILQR, capi
     g = BatchILQR("acrobot", 16, 10, DT)
     assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("backward")) == b"k_sweep_backward"
+    assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("solve")) == b"k_solve_tile"
+    g.close()
+    g = BatchILQR("acrobot", 16, 10, DT, flags=capi.FLAG_STAGED)
+    assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("solve")) == b""
     g.close()
     g = BatchILQR("acrobot", 16, 10, DT, flags=capi.FLAG_UNFUSED)
     assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("backward")) == b"k_backward_q"
@@ -81,13 +89,14 @@ def test_short_horizons_fused_equals_unfused(T):
         x0 = acrobot_x0(B, scale=0.2, seed=T)
         u0 = np.full((B, T, 1), 0.3)
         out = []
-        for fl in (0, capi.FLAG_UNFUSED):
+        for fl in (0, capi.FLAG_STAGED, capi.FLAG_UNFUSED):
             g = BatchILQR("acrobot", B, T, DT, u_min=-1.0, u_max=1.0, flags=fl)
             g.init_traj(x0, u0)
             g.iterate(4)
             out.append(_state(g))
             g.close()
         _same(out[0], out[1])
+        _same(out[0], out[2])
         assert np.all(np.isfinite(out[0]["cost"]))
 
 
