@@ -91,16 +91,21 @@ def cpu_baseline(B_total, T, dt, lim, target_wall_s=4.0):
                       "threads" % (nb2, iters, t2, t2 * cores)}
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/): the
-    bench cannot run rocprofv3 on itself, so it quotes the last collected figures when present."""
+def pmc_traffic(kernel, iterations_per_launch=1):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/): the bench cannot run
+    rocprofv3 on itself, so it quotes the last collected figures when present (the persistent kernel's are kept per
+    iteration and scaled to the launch timed here)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
         return None, None
     try:
         d = json.load(open(path))
         e = d["kernels"].get(kernel)
-        return (e["hbm_bytes_per_launch"], d.get("source")) if e else (None, None)
+        if not e:
+            return None, None
+        if "hbm_bytes_per_iteration" in e:
+            return e["hbm_bytes_per_iteration"] * iterations_per_launch, d.get("source")
+        return e["hbm_bytes_per_launch"], d.get("source")
     except Exception:
         return None, None
 
@@ -112,11 +117,13 @@ def pmc_traffic(kernel):
 def issue_roofline(kernel):
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        e = json.load(open(path))["kernels"][kernel]
-        ipc = e["valu_insts_per_launch"] / (e["busy_simds"] * e["avg_launch_us"] * 1e-6 * e["sclk_hz"])
+        d = json.load(open(path))
+        e = d["kernels"][kernel]
+        ipc = e["valu_insts_per_iteration"] / (e["busy_simds"] * e["avg_iteration_us"] * 1e-6 * e["sclk_hz"])
         return {"bound": "valu_issue", "kernel": kernel, "achieved": ipc, "peak": 0.25, "unit": "VALU instructions / cycle / SIMD",
-                "frac": ipc / 0.25, "valu_insts_per_timestep": e["valu_insts_per_launch"] / e["timesteps_per_launch"],
-                "source": e.get("source")}
+                "frac": ipc / 0.25, "valu_insts_per_timestep": e["valu_insts_per_iteration"] / e["timesteps_per_iteration"],
+                "wait_fraction_of_wave_cycles": e.get("wait_fraction_of_wave_cycles"),
+                "lds_bank_conflict_fraction": e.get("lds_bank_conflict_fraction"), "source": d.get("source")}
     except Exception:
         return None
 
@@ -249,7 +256,7 @@ def main():
         dom = max(real_launches, key=lambda k: stages[k]["ms_per_launch"])
         kern = stages[dom]["kernel"]
         achieved = stages[dom]["algorithmic_GBps"]
-        traffic, traffic_src = pmc_traffic(kern)
+        traffic, traffic_src = pmc_traffic(kern, stages[dom].get("iterations_per_launch", 1))
         return {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_ts[dom] * B * T, "avg_launch_ms": stages[dom]["ms_per_launch"],

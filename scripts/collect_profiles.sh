@@ -1,23 +1,34 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for profiles/ on the GPU box (run through gpurun from the repo root).
 # usage: scripts/collect_profiles.sh rNN
+# Kernel-trace + stats in one run; every PMC counter set in a run of its own with --kernel-trace only
+# (MI355X_MICROARCH.md, HBM / rocprofv3 section).
 set -u
-R=${1:-r01}
+R=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --no-cpu-baseline"
+SHORT="$BENCH --no-extra-configs --steps 5 --warmup 3"
+# the whole default record (headline + configs) under the tracer
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o $R -- $BENCH --steps 20 --warmup 3 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+# the headline alone, 5 iterations per launch: durations in the units of the counter passes below
+rocprofv3 --kernel-trace --stats -d $OUT/stats5 -o $R -- $SHORT > /dev/null 2> $OUT/stats5.err
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o $R -- $BENCH --steps 5 --warmup 3 > /dev/null 2> $OUT/pmc_$C.err
+  rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o $R -- $SHORT > /dev/null 2> $OUT/pmc_$C.err
 done
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace -d $OUT/pmc_sq1 -o $R -- $BENCH --steps 5 --warmup 3 > /dev/null 2> $OUT/pmc_sq1.err
-rocprofv3 --pmc SQ_INSTS_VMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $OUT/pmc_sq2 -o $R -- $BENCH --steps 5 --warmup 3 > /dev/null 2> $OUT/pmc_sq2.err
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/pmc_sq3 -o $R -- $BENCH --steps 5 --warmup 3 > /dev/null 2> $OUT/pmc_sq3.err
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace -d $OUT/pmc_sq1 -o $R -- $SHORT > /dev/null 2> $OUT/pmc_sq1.err
+rocprofv3 --pmc SQ_INSTS_VMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $OUT/pmc_sq2 -o $R -- $SHORT > /dev/null 2> $OUT/pmc_sq2.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/pmc_sq3 -o $R -- $SHORT > /dev/null 2> $OUT/pmc_sq3.err
+# the per-stage route of the same workload (ILQR_FLAG_STAGED = 32): one launch per phase, for the per-phase traffic
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace -d $OUT/staged_pmc_$C -o $R -- $SHORT --flags 32 > /dev/null 2> $OUT/staged_pmc_$C.err
+done
+rocprofv3 --kernel-trace --stats -d $OUT/staged_stats -o $R -- $SHORT --flags 32 > /dev/null 2> $OUT/staged_stats.err
 cd $ROOT
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-for d in stats pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq1 pmc_sq2 pmc_sq3; do
+for d in stats stats5 pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq1 pmc_sq2 pmc_sq3 staged_pmc_FETCH_SIZE staged_pmc_WRITE_SIZE staged_stats; do
   f=$(find $OUT/$d -name "*.db" | head -1)
   [ -n "$f" ] && python scripts/prof_summary.py $f > $OUT/$d.txt 2>&1
 done
