@@ -127,7 +127,7 @@ ILQR_HD bool quadclamp_line_search(const real* x0, const real* dir, const real* 
 
 // Eigen 3.3.4 llt_inplace<Lower>::unblocked on the leading nf x nf block (ld = M).
 template <int M, class real>
-ILQR_HD void llt_lower(int nf, real* A) {
+ILQR_HD bool llt_lower(int nf, real* A) {  // returns true if a pivot was not positive (Eigen: info() != Success)
   bool stop = false;
 #pragma unroll
   for (int k = 0; k < M; k++) {
@@ -157,6 +157,7 @@ ILQR_HD void llt_lower(int nf, real* A) {
       }
     }
   }
+  return stop;
 }
 
 // Minv = R^-1 R^-T for the upper-triangular leading nf x nf block of R (ld = M).
@@ -207,7 +208,7 @@ struct BoxQPResult {
 // src/boxqp.cpp:26-139
 template <int M, class real>
 ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo,
-                                       const real* hi, BoxQPResult<M, real>& res) {
+                                       const real* hi, BoxQPResult<M, real>& res, bool detect_indefinite = false) {
   real x[M], grad[M], gc[M], search[M], tmp[M];
   real clamped[M], old_clamped[M];
   clamp_to_limits<M>(x0, lo, hi, x);  // :35
@@ -284,7 +285,11 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
               if (res.v_free[i] && res.v_free[j] && rank[i] == a && rank[j] == b) v = Q[i + M * j];
           Qf[a + M * b] = v;
         }
-      llt_lower<M>(nf, Qf);  // :85 (info() ignored)
+      const bool indefinite = llt_lower<M>(nf, Qf);  // :85 (info() ignored ...
+      if (detect_indefinite && indefinite) {       // ... unless the caller opted into the fix: result -1)
+        result = -1;
+        break;
+      }
 #pragma unroll
       for (int a = 0; a < M; a++)
 #pragma unroll
@@ -450,14 +455,17 @@ ILQR_HD int box_qp_scalar(real Q, real c, real x0, real lo, real hi, real& x_out
 //   qp1_backtrack_seq  the loop of boxqp.cpp:161-173 as written
 //   qp1_finish iteration 1's exit tests and the result ladder
 //   qp1_continue  iterations 1, 2, ... for the QPs that leave through none of the six exits
-// box_qp_scalar_fast composes them sequentially (host tests).  qp1_finish returns -1 when the
-// QP has to go on: the caller then runs qp1_continue.
+// box_qp_scalar_fast composes them sequentially (host tests).  qp1_finish returns kQpGoesOn when
+// the QP has to go on: the caller then runs qp1_continue.
+constexpr int kQpGoesOn = -100;  // qp1_finish: none of the fast path's exits applies (not a boxQP result code; -1 is: indefinite)
+
 template <class real>
 struct QP1StateT {
   real Q, c, lo, hi;
   real x, val0, g0, minv, search, slope, old_v;
   real x1, v1, step;
   bool clA, exB, exC, early, ls_failed;
+  bool indef;  // opt-in fix: Q <= 0 with a free dimension -> the Cholesky factorisation fails -> result -1
 };
 
 template <class real>
@@ -471,7 +479,7 @@ ILQR_HD bool qp1_armijo_fails(const QP1StateT<real>& q, real v, real step) {
 }
 
 template <bool EVAL_UNIT = true, class real>
-ILQR_HD void qp1_begin(real Q, real c, real x0, real lo, real hi, QP1StateT<real>& q) {
+ILQR_HD void qp1_begin(real Q, real c, real x0, real lo, real hi, QP1StateT<real>& q, bool detect_indefinite = false) {
   q.Q = Q;
   q.c = c;
   q.lo = lo;
@@ -487,7 +495,8 @@ ILQR_HD void qp1_begin(real Q, real c, real x0, real lo, real hi, QP1StateT<real
   q.search = -q.minv * c - q.x;
   q.slope = q.search * q.g0;
   q.exC = q.slope >= 0;
-  q.early = q.clA | q.exB | q.exC;
+  q.indef = detect_indefinite & !(Q > real(0));
+  q.early = q.clA | q.indef | q.exB | q.exC;
   q.step = 1;
   if (EVAL_UNIT) {
     q.x1 = qp1_trial(q, real(1));
@@ -530,9 +539,9 @@ ILQR_HD int qp1_finish(const QP1StateT<real>& q, real& x_out, int& free_out, rea
   const bool exG = slope1 >= real(0);
   minv_out = q.minv;
   // the reference's order of tests, as selects (no branches)
-  const bool stay = q.clA | q.exB | q.exC | q.ls_failed;  // x is not updated
-  const int inner = exD ? 4 : (clE ? 6 : (exF ? 5 : (exG ? 2 : -1)));
-  const int outer = q.clA ? 6 : (q.exB ? 5 : 2);
+  const bool stay = q.clA | q.indef | q.exB | q.exC | q.ls_failed;  // x is not updated
+  const int inner = exD ? 4 : (clE ? 6 : (exF ? 5 : (exG ? 2 : kQpGoesOn)));
+  const int outer = q.clA ? 6 : (q.indef ? -1 : (q.exB ? 5 : 2));  // (the factorisation comes before the gradient test, boxqp.cpp:80-97)
   x_out = stay ? q.x : q.x1;
   free_out = (q.clA | (!stay & !exD & clE)) ? 0 : 1;
   return stay ? outer : inner;
@@ -609,7 +618,7 @@ ILQR_HD int box_qp_scalar_fast(real Q, real c, real x0, real lo, real hi, real& 
   qp1_begin(Q, c, x0, lo, hi, q);
   qp1_backtrack_seq(q);
   int result = qp1_finish(q, x_out, free_out, minv_out);
-  if (result < 0) result = qp1_continue(q, [](QP1StateT<real>& s) { qp1_line_search_seq(s); }, x_out, free_out);
+  if (result == kQpGoesOn) result = qp1_continue(q, [](QP1StateT<real>& s) { qp1_line_search_seq(s); }, x_out, free_out);
   return result;
 }
 

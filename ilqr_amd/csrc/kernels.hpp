@@ -284,6 +284,10 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
         u[j] += acc;  // :316
       }
     }
+    if (sp.fixes & 1) {  // opt-in fix: "the right way" of ilqr_core.cpp:327-329 -- the clamped control is stored and integrated
+#pragma unroll
+      for (int j = 0; j < NU; j++) u[j] = min_of(max_of(u[j], model.u_min[j]), model.u_max[j]);
+    }
     emit_knot(t, x, u);
     ILQR_RMARK(1)  // wait for inputs + feedback + knot store
     total += (double)model.cost(x, u);  // :324
@@ -763,7 +767,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
         hi[j] = model.u_max[j] - us[j];
       }
       BoxQPResult<NU, real> qp;
-      box_qp<NU>(QuuF, Qu, kprev, lo, hi, qp);
+      box_qp<NU>(QuuF, Qu, kprev, lo, hi, qp, (sp.fixes & 2) != 0);
       if (qp.result < 1) {  // :371
         diverge = i;
         break;
@@ -1284,7 +1288,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         int free0;
         real minv;
         QP1StateT<real> q1;
-        qp1_begin<false>(QuuF[0], Qu[0], kprev[0], lo[0], hi[0], q1);
+        qp1_begin<false>(QuuF[0], Qu[0], kprev[0], lo[0], hi[0], q1, (sp.fixes & 2) != 0);
         if (!qp1_search_quad(q1, s, lane, lds_steps)) {  // fallback: rare
 #ifdef ILQR_PHASE_TIMING
           xc[2] += 1;
@@ -1297,12 +1301,12 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         int result = qp1_finish(q1, qp.x[0], free0, minv);
         ILQR_MARK(6)  // fast QP
 #ifdef ILQR_PHASE_TIMING
-        if (__any(result < 0)) ph[7] += 1;
+        if (__any(result == kQpGoesOn)) ph[7] += 1;
 #endif
 #ifdef ILQR_PHASE_TIMING
-        if (__any(result < 0)) xc[0] += 1;
+        if (__any(result == kQpGoesOn)) xc[0] += 1;
 #endif
-        if (result < 0)  // the QP goes on (rare early in a solve, a quarter of the steps of some tiles later)
+        if (result == kQpGoesOn)  // the QP goes on (rare early in a solve, a quarter of the steps of some tiles later)
           result = qp1_continue(
               q1,
               [&](QP1StateT<real>& qs) __attribute__((always_inline)) {
@@ -1329,7 +1333,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         Kc[0] = free0 ? -minv * Quxc[0] : real(0);  // :373-385
       } else {
         BoxQPResult<NU, real> r;
-        box_qp<NU>(QuuF, Qu, kprev, lo, hi, r);
+        box_qp<NU>(QuuF, Qu, kprev, lo, hi, r, (sp.fixes & 2) != 0);
         ok = r.result >= 1;
 #pragma unroll
         for (int a = 0; a < NU; a++) {

@@ -103,7 +103,15 @@ enum ilqr_flags {
    * (batches of up to 16 x #CU trajectories of an nx = 4 model: tiles never wait for each other).  This flag
    * launches the stages of every iteration as kernels of their own instead (fused sweep + backward, then
    * rollouts + accept), as larger batches do.  Same results bit for bit. */
-  ILQR_FLAG_STAGED = 32
+  ILQR_FLAG_STAGED = 32,
+  /* Opt-in, OFF by default because it changes results: two things the reference's own
+   * comments call for.  (1) The rollout clamps every control into [u_min, u_max] and stores / integrates the
+   * clamped one -- src/ilqr_core.cpp:327-329, "This is the right way" (the reference adds K (x - xs) to the
+   * box-QP's clamped feed-forward without re-clamping, README.md:9 "control-limited part not working").
+   * (2) A failed Cholesky factorisation of Quu on the free subspace ends the box-QP with result -1 and the
+   * backward pass reports divergence at that step (lambda is raised) -- src/boxqp.cpp:85-88 never looks at
+   * info() and goes on with the partial factor.  nx = 4 device models; the CPU oracle has the same switch. */
+  ILQR_FLAG_REFERENCE_FIXES = 64
 };
 
 /* Solver tunables = the compile-time constants of include/ilqr.h:14-24 (defaults shown). */

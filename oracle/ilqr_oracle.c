@@ -30,6 +30,13 @@ static orc_acc lambdaFactor = 1.6;
 static orc_acc lambdaMax = 1e11;
 static orc_acc lambdaMin = 1e-8;
 static orc_acc zMin = 0;
+/* The opt-in "fixes" of the product (ILQR_FLAG_REFERENCE_FIXES), mirrored here so that they can be
+ * parity-tested too.  OFF by default = the reference as it is.  bit 0: the rollout clamps every control into
+ * [u_min, u_max] and integrates the clamped one (the commented "right way", ilqr_core.cpp:327-329); bit 1: a
+ * failed Cholesky factorisation of Q[free,free] ends the box-QP with result -1 (the MATLAB original's
+ * `indef`), which the backward pass reports as divergence -> lambda is raised (boxqp.cpp:85-88 ignores info()). */
+static int referenceFixes = 0;
+void orc_set_fixes(int bits) { referenceFixes = bits; }
 void orc_set_params(orc_f64 tol_fun, orc_f64 tol_grad, orc_f64 lambda_factor, orc_f64 lambda_max,
                     orc_f64 lambda_min, orc_f64 z_min) {
   tolFun = tol_fun;
@@ -334,7 +341,11 @@ int orc_boxqp(int n, const orc_real* Q, const orc_real* c, const orc_real* x0, c
         if (v_free[i] != 0) idx[nf++] = i;
       for (int a = 0; a < nf; a++) /* include/eigen_helpers.h:46-61 */
         for (int b = 0; b < nf; b++) Qfree[a + nf * b] = Q[idx[a] + n * idx[b]];
-      orc_llt_lower_unblocked(nf, Qfree); /* :85, info() ignored */
+      const int llt_info = orc_llt_lower_unblocked(nf, Qfree); /* :85, info() ignored */
+      if ((referenceFixes & 2) && llt_info >= 0) { /* opt-in: not positive definite on the free subspace */
+        result = -1;
+        break;
+      }
       /* :86-88  R_free = matrixL().transpose(): dense upper triangle, zeros below */
       for (int a = 0; a < nf; a++)
         for (int b = 0; b < nf; b++) R_free[a + nf * b] = (a <= b) ? Qfree[b + nf * a] : (orc_real)0.0;
@@ -455,6 +466,8 @@ orc_acc orc_forward_pass(const orc_model* m, orc_traj* s, const orc_real* x0, co
         u_curr[a] += acc;
       }
     }
+    if (referenceFixes & 1) /* opt-in: "the right way", :327-329 */
+      for (int a = 0; a < mu; a++) u_curr[a] = (m->u_max[a] < ((u_curr[a] < m->u_min[a]) ? m->u_min[a] : u_curr[a])) ? m->u_max[a] : ((u_curr[a] < m->u_min[a]) ? m->u_min[a] : u_curr[a]);
     for (int a = 0; a < mu; a++) s->us[t * mu + a] = u_curr[a]; /* :323, no clamping */
     total_cost += m->cost(m, x_curr, u_curr);                   /* :324 */
     orc_integrate_dynamics(m, x_curr, u_curr, s->dt, xn);      /* :325 */

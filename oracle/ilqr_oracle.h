@@ -68,6 +68,9 @@ typedef ORC_REAL orc_fd;
 void orc_set_params(orc_f64 tol_fun, orc_f64 tol_grad, orc_f64 lambda_factor, orc_f64 lambda_max,
                     orc_f64 lambda_min, orc_f64 z_min);
 
+/* opt-in fixes (process-wide; 0 = the reference as it is): bit 0 clamped rollout, bit 1 Cholesky failure ends the box-QP */
+void orc_set_fixes(int bits);
+
 enum { ORC_MODEL_ACROBOT = 0, ORC_MODEL_DOUBLE_INTEGRATOR = 1, ORC_MODEL_LQ = 2 };
 
 /* status of a solve (where the outer loop of src/ilqr_core.cpp:103-288 left) */

@@ -167,6 +167,13 @@ def _pa(a):
     return a.ctypes.data_as(C.POINTER(_ac()))
 
 
+def set_fixes(bits=0):
+    """Opt-in fixes (ILQR_FLAG_REFERENCE_FIXES on the product side): 1 = clamped rollout, 2 = Cholesky failure ends the box-QP, 3 = both."""
+    for name in list(_libs) or ["f64"]:
+        with flavour(name):
+            lib().orc_set_fixes(int(bits))
+
+
 def set_params(tol_fun=1e-6, tol_grad=1e-6, lambda_factor=1.6, lambda_max=1e11, lambda_min=1e-8, z_min=0.0):
     """Solver tunables of include/ilqr.h:14-24 (process-wide in the oracle); no arguments = the reference's."""
     lib().orc_set_params(*[C.c_double(v) for v in (tol_fun, tol_grad, lambda_factor, lambda_max, lambda_min, z_min)])

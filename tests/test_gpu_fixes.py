@@ -1,0 +1,92 @@
+"""ILQR_FLAG_REFERENCE_FIXES (opt-in): the two things the reference's own comments call for --
+the clamped rollout (src/ilqr_core.cpp:327-329, "This is the right way") and a box-QP that reports a failed
+Cholesky factorisation (src/boxqp.cpp:85-88 ignores info()) -- against the oracle with the same switch
+(orc_set_fixes), and the property they exist for: the controls of a solve respect their limits."""
+import numpy as np
+import pytest
+
+from tests.parity import check_backward, walk_iterations
+from tests.util import acrobot_x0, integrator_x0, mat
+
+pytestmark = pytest.mark.gpu
+DT = 0.02
+
+
+@pytest.fixture
+def fixed_oracle(oracle):
+    oracle.set_fixes(3)
+    yield oracle
+    oracle.set_fixes(0)
+
+
+def build(oracle, name, B, T, lim, flags):
+    from ilqr_amd import BatchILQR
+    if name == "acrobot":
+        return oracle.Model("acrobot", u_lim=lim), BatchILQR("acrobot", B, T, DT, u_min=-lim, u_max=lim, flags=flags), acrobot_x0(B, scale=0.5)
+    goal = [1.0, 0.5, 0.0, 0.0]
+    return (oracle.Model("integrator", goal=goal, u_lim=lim), BatchILQR("integrator", B, T, DT, u_min=-lim, u_max=lim, goal=goal, flags=flags),
+            integrator_x0(B))
+
+
+@pytest.mark.parametrize("name,B,T,lim,iters", [("acrobot", 48, 150, 1.5, 6), ("integrator", 33, 60, 0.5, 6)])
+def test_iterations_with_the_fixes_match_the_oracle(fixed_oracle, name, B, T, lim, iters):
+    from ilqr_amd import capi
+    oracle = fixed_oracle
+    om, g, x0 = build(oracle, name, B, T, lim, capi.FLAG_REFERENCE_FIXES)
+    u0 = np.zeros((B, T, om.nu))
+    r = walk_iterations(oracle, om, g, x0, u0, DT, iters)
+    print("fixes walk", name, {k: v for k, v in r.items() if k != "tied"})
+    assert r["checked"] >= 2 * B and len(r["tied"]) <= max(2, r["checked"] // 10), r
+    # the point of the clamped rollout: the solve's controls stay inside their box ...
+    g.init_traj(x0, u0)
+    g.iterate(iters)
+    _, us = g.trajectory()
+    assert np.abs(us).max() <= lim
+    g.close()
+    # ... which the reference's own rollout does not guarantee (README.md:9, "control-limited part not working")
+    oracle.set_fixes(0)
+    ro = oracle.batch_solve(om, x0, u0, DT, max_iters=iters)
+    oracle.set_fixes(3)
+    if name == "acrobot":
+        assert np.abs(ro["us"]).max() > lim
+
+
+@pytest.mark.parametrize("name", ["acrobot", "integrator"])
+def test_indefinite_quu_is_reported_as_divergence(fixed_oracle, name):
+    """Quu made indefinite at a few knots (cuu shifted negative, lambda = 0), free controls: with the fix the box-QP
+    returns -1 there and backward_pass returns that knot (ilqr_core.cpp:371) -- same knot on both sides; without the
+    fix both sides carry on with Eigen's partial factor (covered by the default tests)."""
+    from ilqr_amd import capi
+    oracle = fixed_oracle
+    B, T, lim = 24, 40, 50.0   # wide limits: nothing is clamped, the factorisation is reached
+    om, g, x0 = build(oracle, name, B, T, lim, capi.FLAG_REFERENCE_FIXES)
+    rng = np.random.default_rng(5)
+    u0 = rng.normal(size=(B, T, om.nu)) * 0.2
+    xs, us, cost = oracle.batch_rollout(om, x0, u0, DT)
+    do = oracle.batch_derivatives(om, xs, us, DT)
+    bad_t = rng.integers(3, T - 3, size=B)
+    for b in range(0, B, 2):  # every other trajectory gets one indefinite knot
+        do["cuu"][b, bad_t[b]] -= 5.0 * np.eye(om.nu)
+    k_prev = np.zeros((B, T, om.nu))
+    ro = oracle.batch_backward(om, us, do, k_prev=k_prev, lam=0.0)
+    assert (ro["diverge"][0::2] == bad_t[0::2]).mean() > 0.7 and np.all(ro["diverge"][1::2] == 0)
+    g.set_trajectory(x0=x0, xs=xs, us=us, cost=cost)
+    g.set_derivatives(**{k: (do[k] if k in ("cx", "cu") else mat(do[k])) for k in do})
+    g.set_gains(k=k_prev, K=np.zeros((B, T, om.nu, om.nx)))
+    g.set_lambda(0.0, 1.0)
+    div = g.backward_pass()
+    assert np.array_equal(div, ro["diverge"])
+    k, K = g.gains()
+    check_backward(oracle, om, us, do, k_prev, 0.0, k, K, g.dV(), div, ro, max_ties=2)
+    # STEP 2 as a whole: the retry loop raises lambda until the pass goes through (ilqr_core.cpp:136-150)
+    g.backward_step()
+    lam, _ = g.lambdas()
+    assert np.all(lam[0::2][ro["diverge"][0::2] > 0] > 0) and np.all(lam[1::2] == 0)
+    g.close()
+
+
+def test_the_flag_is_off_by_default_and_rejected_where_not_implemented():
+    from ilqr_amd import BatchILQR, capi
+    from ilqr_amd.capi import ILQRError
+    with pytest.raises(ILQRError, match="nx = 4"):
+        BatchILQR("host", 2, 5, DT, nx=3, nu=2, u_min=[-1, -1], u_max=[1, 1], flags=capi.FLAG_REFERENCE_FIXES)
