@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <vector>
 
 #include "ilqr_amd.hpp"
 
@@ -81,6 +83,24 @@ int main(int argc, char** argv) {
       st[which] = solver.status();
       xs[which] = solver.states();
       us[which] = solver.controls();
+    }
+    if (argc > 2) {  // a batch of host-evaluated problems, model evaluated by 1 and by N host threads (-fopenmp)
+      const int threads = std::atoi(argv[2]), B = 6, its = iters > 0 ? iters : 4;
+      std::vector<double> bx0((size_t)B * 4), bu0((size_t)B * T * 2, 0.0), res[2];
+      for (int b = 0; b < B; b++)
+        for (int i = 0; i < 4; i++) bx0[(size_t)b * 4 + i] = x0v[i] + 0.1 * b * (i + 1);
+      for (int which = 0; which < 2; which++) {
+        BatchILQR batch(std::make_shared<MyIntegrator>(goal), B, T, 0.02);
+        batch.set_host_threads(which == 0 ? 1 : threads);
+        batch.init_traj(bx0, bu0);
+        batch.iterate(its);
+        res[which] = batch.states();
+        const std::vector<double> c = batch.cost();
+        res[which].insert(res[which].end(), c.begin(), c.end());
+      }
+      double d = 0;
+      for (size_t e = 0; e < res[0].size(); e++) d = std::max(d, std::fabs(res[0][e] - res[1][e]));
+      std::printf("host_threads  %d max_abs_diff %.3e\n", threads, d);
     }
     double dx = 0, du = 0;
     for (int t = 0; t <= T; t++)

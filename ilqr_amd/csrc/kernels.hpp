@@ -1284,6 +1284,8 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       struct { real x[NU]; } qp;
       real Kc[NU];
       bool ok;
+      int k_free = 0;      // (NU == 1: what K is scaled from, see the exchange below)
+      real k_minv = 0;
       if constexpr (NU == 1) {
         int free0;
         real minv;
@@ -1331,6 +1333,8 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
               qp.x[0], free0);
         ok = result >= 1;
         Kc[0] = free0 ? -minv * Quxc[0] : real(0);  // :373-385
+        k_free = free0;
+        k_minv = minv;
       } else {
         BoxQPResult<NU, real> r;
         box_qp<NU>(QuuF, Qu, kprev, lo, hi, r, (sp.fixes & 2) != 0);
@@ -1418,9 +1422,14 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       // exchange K, Qux, K'Quu columns inside the quad
       real Kall[NU][4], Qall[NU][4], T1all[NU][4];
 #pragma unroll
-      for (int a = 0; a < NU; a++) {
-        quad_gather(Kc[a], Kall[a]);
-        quad_gather(Quxc[a], Qall[a]);
+      for (int a = 0; a < NU; a++) quad_gather(Quxc[a], Qall[a]);  // (does not wait for the box-QP)
+      if constexpr (NU == 1) {
+        // K[0, r] = -minv Qux[0, r] in lane r; the same product of the same operands here: no second exchange
+#pragma unroll
+        for (int r = 0; r < 4; r++) Kall[0][r] = k_free ? -k_minv * Qall[0][r] : real(0);
+      } else {
+#pragma unroll
+        for (int a = 0; a < NU; a++) quad_gather(Kc[a], Kall[a]);
       }
 #pragma unroll
       for (int c = 0; c < NU; c++)  // (K'Quu)[r, c] for every r, from the gathered K (no third exchange)

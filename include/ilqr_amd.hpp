@@ -290,6 +290,12 @@ class BatchILQR {
   BatchILQR& operator=(const BatchILQR&) = delete;
 
   ilqr_batch* handle() { return h_; }
+  // Host-evaluated models (no device twin): how many host threads evaluate the model's virtuals -- rollouts and
+  // finite differences of different trajectories side by side (the reference's own, commented-out intent was
+  // `omp parallel for` over t: src/derivatives.cpp:18,32,84).  Default 1: Model's methods are non-const
+  // (include/model.h:8-10) and a user's subclass may keep state; a stateless model (both shipped ones are) can
+  // be called from many threads.  Takes effect when the including translation unit is compiled with -fopenmp.
+  void set_host_threads(int n) { host_threads_ = n < 1 ? 1 : n; }
   int batch() const { return B_; }
   int horizon() const { return T_; }
 
@@ -504,6 +510,9 @@ class BatchILQR {
     hx0_ = x0;
     host_alloc();
     std::vector<double> cost(B_);
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(host_threads_) schedule(dynamic) if (host_threads_ > 1)
+#endif
     for (int b = 0; b < B_; b++)
       cost[b] = host_forward(b, &u0[(size_t)b * T_ * m_], nullptr, nullptr, &hxs_[(size_t)b * (T_ + 1) * n_], &hus_[(size_t)b * T_ * m_]);
     check(ilqr_reset_state(h_, 0), "ilqr_reset_state");
@@ -531,11 +540,14 @@ class BatchILQR {
     std::vector<int> st(B_);
     check(ilqr_get_status(h_, st.data(), nullptr, nullptr), "ilqr_get_status");
     bool any = false;
+    for (int b = 0; b < B_; b++) any = any || (st[b] == ILQR_RUNNING && need_derivs_[b]);
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(host_threads_) schedule(dynamic) if (host_threads_ > 1)
+#endif
     for (int b = 0; b < B_; b++)
       if (st[b] == ILQR_RUNNING && need_derivs_[b]) {  // STEP 1, :115-120 (flgChange)
         host_derivatives(b);
         need_derivs_[b] = 0;
-        any = true;
       }
     if (any)
       check(ilqr_set_derivatives(h_, d_fx_.data(), d_fu_.data(), d_cx_.data(), d_cu_.data(), d_cxx_.data(), d_cxu_.data(), d_cuu_.data()),
@@ -544,24 +556,39 @@ class BatchILQR {
     check(ilqr_get_status(h_, st.data(), nullptr, nullptr), "ilqr_get_status");
     const std::vector<double> k = gains_k(), K = gains_K();
     static const double alphas[11] = {1.0000, 0.5012, 0.2512, 0.1259, 0.0631, 0.0316, 0.0158, 0.0079, 0.0040, 0.0020, 0.0010};
-    std::vector<double> cost_c((size_t)B_ * 11, 0.0), u_try((size_t)T_ * m_), xs_try((size_t)(T_ + 1) * n_), us_try((size_t)T_ * m_);
-    auto roll = [&](int b, double alpha) {  // :188-190
-      for (size_t e = 0; e < u_try.size(); e++) u_try[e] = hus_[(size_t)b * T_ * m_ + e] + k[(size_t)b * T_ * m_ + e] * alpha;
-      return host_forward(b, u_try.data(), &K[(size_t)b * T_ * m_ * n_], &hxs_[(size_t)b * (T_ + 1) * n_], xs_try.data(), us_try.data());
+    std::vector<double> cost_c((size_t)B_ * 11, 0.0);
+    struct Scratch {
+      std::vector<double> u_try, xs_try, us_try;
     };
+    auto roll = [&](int b, double alpha, Scratch& w) {  // :188-190
+      w.u_try.resize((size_t)T_ * m_);
+      w.xs_try.resize((size_t)(T_ + 1) * n_);
+      w.us_try.resize((size_t)T_ * m_);
+      for (size_t e = 0; e < w.u_try.size(); e++) w.u_try[e] = hus_[(size_t)b * T_ * m_ + e] + k[(size_t)b * T_ * m_ + e] * alpha;
+      return host_forward(b, w.u_try.data(), &K[(size_t)b * T_ * m_ * n_], &hxs_[(size_t)b * (T_ + 1) * n_], w.xs_try.data(), w.us_try.data());
+    };
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(host_threads_) schedule(dynamic) if (host_threads_ > 1)
+#endif
     for (int b = 0; b < B_; b++)
-      if (st[b] == ILQR_RUNNING)
-        for (int a = 0; a < 11; a++) cost_c[(size_t)b * 11 + a] = roll(b, alphas[a]);  // STEP 3 rollouts
+      if (st[b] == ILQR_RUNNING) {
+        Scratch w;
+        for (int a = 0; a < 11; a++) cost_c[(size_t)b * 11 + a] = roll(b, alphas[a], w);  // STEP 3 rollouts
+      }
     std::vector<int> acc(B_);
     check(ilqr_accept_candidates(h_, cost_c.data(), acc.data()), "ilqr_accept_candidates");  // STEP 3/4 decisions on the device
     bool moved = false;
+    for (int b = 0; b < B_; b++) moved = moved || acc[b] >= 0;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(host_threads_) schedule(dynamic) if (host_threads_ > 1)
+#endif
     for (int b = 0; b < B_; b++)
       if (acc[b] >= 0) {  // :210-213: xs, us keep the accepted rollout
-        roll(b, alphas[acc[b]]);
-        std::copy(xs_try.begin(), xs_try.end(), hxs_.begin() + (size_t)b * (T_ + 1) * n_);
-        std::copy(us_try.begin(), us_try.end(), hus_.begin() + (size_t)b * T_ * m_);
+        Scratch w;
+        roll(b, alphas[acc[b]], w);
+        std::copy(w.xs_try.begin(), w.xs_try.end(), hxs_.begin() + (size_t)b * (T_ + 1) * n_);
+        std::copy(w.us_try.begin(), w.us_try.end(), hus_.begin() + (size_t)b * T_ * m_);
         need_derivs_[b] = 1;
-        moved = true;
       }
     if (moved) check(ilqr_set_trajectory(h_, nullptr, hxs_.data(), hus_.data(), nullptr), "ilqr_set_trajectory");
   }
@@ -571,6 +598,7 @@ class BatchILQR {
   double dt_;
   ilqr_batch* h_;
   bool host_ = false;
+  int host_threads_ = 1;
   std::vector<double> hx0_, hxs_, hus_, d_fx_, d_fu_, d_cx_, d_cu_, d_cxx_, d_cxu_, d_cuu_;
   std::vector<char> need_derivs_;
 };

@@ -130,3 +130,20 @@ def test_host_only_model_matches_its_device_twin(tmp_path, iters):
     else:  # solved to termination: the absolute stopping tests may tie one iteration apart
         assert sth > 0 and std_ > 0 and abs(ith - itd) <= 1
         assert abs(ch - cd) < 1e-4 * abs(cd) and abs(cd - 356.168506469842) < 1e-4 * 356
+
+
+@pytest.mark.gpu
+def test_host_model_evaluated_by_several_threads(tmp_path):
+    """BatchILQR::set_host_threads: a batch of host-evaluated problems with the model's virtuals called from four
+    OpenMP threads gives exactly what one thread gives (trajectories are independent; include/ilqr_amd.hpp)."""
+    from ilqr_amd import _build
+    _build.build()
+    exe = str(tmp_path / "host_model_omp")
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-fopenmp", "-DILQR_AMD_NO_EIGEN", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "host_model.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "ilqr_amd", "lib"), "-lilqr_amd", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + os.path.join(ROOT, "ilqr_amd", "lib"), "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe, "3", "4"], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert r.returncode == 0, r.stderr
+    row = [l.split() for l in r.stdout.splitlines() if l.startswith("host_threads")][0]
+    assert int(row[1]) == 4 and float(row[3]) == 0.0
