@@ -885,8 +885,8 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   h->sp.lambda_min = h->params.lambda_min;
   h->sp.z_min = h->params.z_min;
   h->sp.fixed_work = (h->flags & ILQR_FLAG_FIXED_WORK) ? 1 : 0;
-  h->sp.fixes = (h->flags & ILQR_FLAG_REFERENCE_FIXES) ? 3 : 0;
-  if (h->sp.fixes && h->aos) return fail(ILQR_ERR_UNSUPPORTED, "ILQR_FLAG_REFERENCE_FIXES is implemented for the nx = 4 device models");
+  h->sp.fixes = ((h->flags & ILQR_FLAG_REFERENCE_FIXES) ? 3 : 0) | ((h->flags & ILQR_FLAG_REGULARIZE_VXX) ? 4 : 0);
+  if (h->sp.fixes && h->aos) return fail(ILQR_ERR_UNSUPPORTED, "ILQR_FLAG_REFERENCE_FIXES / ILQR_FLAG_REGULARIZE_VXX are implemented for the nx = 4 device models");
 
   hipLaunchKernelGGL(k_reset_state<double>, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
                      h->params.dlambda_init);

@@ -88,7 +88,7 @@ struct SolverParams {
   int max_iter;
   double tol_fun, tol_grad, lambda_factor, lambda_max, lambda_min, z_min;
   int fixed_work;
-  int fixes;  // ILQR_FLAG_REFERENCE_FIXES: bit 0 clamped rollout, bit 1 a failed Cholesky ends the box-QP (result -1)
+  int fixes;  // bit 0 clamped rollout, bit 1 a failed Cholesky ends the box-QP (ILQR_FLAG_REFERENCE_FIXES); bit 2 lambda on Vxx (ILQR_FLAG_REGULARIZE_VXX)
 };
 
 // Raw views of a batch's device state, passed by value to kernels.

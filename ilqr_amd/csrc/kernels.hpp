@@ -758,6 +758,31 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
           Quu[a + NU * c] = cuu[a + NU * c] + acc;
           QuuF[a + NU * c] = (cuu[a + NU * c] + ((a == c) ? (real)lambda : real(0))) + acc;
         }
+      // opt-in (sp.fixes & 4): lambda regularises Vxx' ([Tassa 2012] eq. 10) instead of Quu:
+      // Quu_reg = Quu + lambda fu'fu, Qux_reg = Qux + lambda fu'fx; the value update keeps Quu, Qux
+      real Quxr[NU * NX];
+#pragma unroll
+      for (int e = 0; e < NU * NX; e++) Quxr[e] = Qux[e];
+      if (sp.fixes & 4) {
+        const real lam = (real)lambda;
+#pragma unroll
+        for (int a = 0; a < NU; a++) {
+#pragma unroll
+          for (int c = 0; c < NU; c++) {
+            real acc = 0;
+#pragma unroll
+            for (int q = 0; q < NX; q++) acc += fu[q + NX * a] * fu[q + NX * c];
+            QuuF[a + NU * c] = Quu[a + NU * c] + lam * acc;
+          }
+#pragma unroll
+          for (int c = 0; c < NX; c++) {
+            real acc = 0;
+#pragma unroll
+            for (int q = 0; q < NX; q++) acc += fu[q + NX * a] * fx[q + NX * c];
+            Quxr[a + NU * c] = Qux[a + NU * c] + lam * acc;
+          }
+        }
+      }
 
       // :369
       real lo[NU], hi[NU];
@@ -796,7 +821,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
               real val = 0;
 #pragma unroll
               for (int j = 0; j < NU; j++)
-                if (qp.v_free[j] && rank[j] == a) val = Qux[j + NU * c];
+                if (qp.v_free[j] && rank[j] == a) val = Quxr[j + NU * c];
               qf[a] = val;
             }
 #pragma unroll
@@ -1271,6 +1296,27 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
           QuuF[a + NU * c] = (d.cuu[a + NU * c] + ((a == c) ? lam_r : real(0))) + acc;
         }
       }
+      // opt-in (sp.fixes & 4, see k_backward_t): Quu_reg = Quu + lambda fu'fu, Qux_reg[:, s] = Qux[:, s] + lambda fu'fx[:, s]
+      real Quxr[NU];
+#pragma unroll
+      for (int a = 0; a < NU; a++) Quxr[a] = Quxc[a];
+      const bool reg_vxx = (sp.fixes & 4) != 0;
+      if (reg_vxx) {
+#pragma unroll
+        for (int a = 0; a < NU; a++) {
+#pragma unroll
+          for (int c = 0; c < NU; c++) {
+            real acc = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc += d.fu[q + 4 * a] * d.fu[q + 4 * c];
+            QuuF[a + NU * c] = Quu[a + NU * c] + lam_r * acc;
+          }
+          real acc = 0;
+#pragma unroll
+          for (int q = 0; q < 4; q++) acc += d.fu[q + 4 * a] * d.fxc[q];
+          Quxr[a] = Quxc[a] + lam_r * acc;
+        }
+      }
       ILQR_MARK(1)  // Q-function products
       // :369  box-QP (replicated in the quad)
       real lo[NU], hi[NU];
@@ -1332,7 +1378,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
               },
               qp.x[0], free0);
         ok = result >= 1;
-        Kc[0] = free0 ? -minv * Quxc[0] : real(0);  // :373-385
+        Kc[0] = free0 ? -minv * Quxr[0] : real(0);  // :373-385
         k_free = free0;
         k_minv = minv;
       } else {
@@ -1360,7 +1406,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
             real val = 0;
 #pragma unroll
             for (int j = 0; j < NU; j++)
-              if (r.v_free[j] && rank[j] == a) val = Quxc[j];
+              if (r.v_free[j] && rank[j] == a) val = Quxr[j];
             qf[a] = val;
           }
 #pragma unroll
@@ -1423,7 +1469,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       real Kall[NU][4], Qall[NU][4], T1all[NU][4];
 #pragma unroll
       for (int a = 0; a < NU; a++) quad_gather(Quxc[a], Qall[a]);  // (does not wait for the box-QP)
-      if constexpr (NU == 1) {
+      if (NU == 1 && !reg_vxx) {
         // K[0, r] = -minv Qux[0, r] in lane r; the same product of the same operands here: no second exchange
 #pragma unroll
         for (int r = 0; r < 4; r++) Kall[0][r] = k_free ? -k_minv * Qall[0][r] : real(0);

@@ -111,7 +111,12 @@ enum ilqr_flags {
    * (2) A failed Cholesky factorisation of Quu on the free subspace ends the box-QP with result -1 and the
    * backward pass reports divergence at that step (lambda is raised) -- src/boxqp.cpp:85-88 never looks at
    * info() and goes on with the partial factor.  nx = 4 device models; the CPU oracle has the same switch. */
-  ILQR_FLAG_REFERENCE_FIXES = 64
+  ILQR_FLAG_REFERENCE_FIXES = 64,
+  /* Opt-in, OFF by default (third part of SURVEY.md 8f-4): lambda regularises the value Hessian instead of Quu --
+   * [Tassa 2012] eq. 10a/10b, Quu_reg = cuu + fu'(Vxx' + lambda I) fu, Qux_reg = cxu' + fu'(Vxx' + lambda I) fx --
+   * where the reference adds lambda I to Quu and notes "regularization is different" (src/ilqr_core.cpp:365-367).
+   * The value update keeps the unregularised Quu, Qux as in the reference.  nx = 4 device models. */
+  ILQR_FLAG_REGULARIZE_VXX = 128
 };
 
 /* Solver tunables = the compile-time constants of include/ilqr.h:14-24 (defaults shown). */

@@ -34,7 +34,8 @@ static orc_acc zMin = 0;
  * parity-tested too.  OFF by default = the reference as it is.  bit 0: the rollout clamps every control into
  * [u_min, u_max] and integrates the clamped one (the commented "right way", ilqr_core.cpp:327-329); bit 1: a
  * failed Cholesky factorisation of Q[free,free] ends the box-QP with result -1 (the MATLAB original's
- * `indef`), which the backward pass reports as divergence -> lambda is raised (boxqp.cpp:85-88 ignores info()). */
+ * `indef`), which the backward pass reports as divergence -> lambda is raised (boxqp.cpp:85-88 ignores info());
+ * bit 2: lambda regularises Vxx' ([Tassa 2012] eq. 10) instead of Quu (ilqr_core.cpp:365-367). */
 static int referenceFixes = 0;
 void orc_set_fixes(int bits) { referenceFixes = bits; }
 void orc_set_params(orc_f64 tol_fun, orc_f64 tol_grad, orc_f64 lambda_factor, orc_f64 lambda_max,
@@ -724,6 +725,26 @@ int orc_backward_pass(const orc_model* m, orc_traj* s) {
         Quu[a + mu * b] = cuu[a + mu * b] + f;
         QuuF[a + mu * b] = (cuu[a + mu * b] + ((a == b) ? (orc_real)s->lambda : (orc_real)0.0)) + f;
       }
+    /* opt-in (bit 2 of the fixes): regularise Vxx' instead of Quu -- [Tassa 2012] eq. 10a/10b, which :365 says the
+     * reference's lambda*I on Quu is "similar to": Quu_reg = cuu + fu'(Vxx' + lambda I) fu = Quu + lambda fu'fu,
+     * Qux_reg = cxu' + fu'(Vxx' + lambda I) fx = Qux + lambda fu'fx.  The value update keeps the unregularised Quu, Qux. */
+    orc_real Qux_reg[ORC_MAXM * ORC_MAXN];
+    for (int e = 0; e < mu * n; e++) Qux_reg[e] = Qux[e];
+    if (referenceFixes & 4) {
+      const orc_real lam = (orc_real)s->lambda;
+      for (int a = 0; a < mu; a++) {
+        for (int b = 0; b < mu; b++) {
+          orc_real acc = 0;
+          for (int l = 0; l < n; l++) acc += fu[l + n * a] * fu[l + n * b];
+          QuuF[a + mu * b] = Quu[a + mu * b] + lam * acc;
+        }
+        for (int j = 0; j < n; j++) {
+          orc_real acc = 0;
+          for (int l = 0; l < n; l++) acc += fu[l + n * a] * fx[l + n * j];
+          Qux_reg[a + mu * j] = Qux[a + mu * j] + lam * acc;
+        }
+      }
+    }
 
     /* :369  boxQP(QuuF, Qu, k[min(i+1,T-1)], u_min-us[i], u_max-us[i]) */
     const int iw = (i + 1 < T - 1) ? i + 1 : T - 1;
@@ -750,7 +771,7 @@ int orc_backward_pass(const orc_model* m, orc_traj* s) {
       for (int r = 0; r < nf && r < nfree; r++)
         for (int j = 0; j < n; j++) {
           orc_real acc = 0;
-          for (int l = 0; l < nfree && l < nf; l++) acc += -Minv[r + nfree * l] * Qux[idx[l] + mu * j];
+          for (int l = 0; l < nfree && l < nf; l++) acc += -Minv[r + nfree * l] * Qux_reg[idx[l] + mu * j];
           K_i[idx[r] + mu * j] = acc;
         }
     }

@@ -2,7 +2,8 @@
 
 Every case draws a model, batch size, horizon, control limit, initial conditions and an iteration
 count, then checks
-  * fused (k_sweep_backward) and two-kernel routes leave bit-identical state,
+  * the persistent tile kernel (k_solve_tile), the per-stage launches (k_sweep_backward + k_rollout) and the two-kernel
+    route (records in HBM) leave bit-identical state,
   * the thread-per-trajectory backward kernel agrees with the quad kernel (1e-6 on >= 90 % of the
     trajectories: the two differ in rounding, and a few acrobot iterations amplify that),
   * after `iters` iterations (normal mode, per-trajectory exits) iteration counts and statuses match
@@ -61,16 +62,18 @@ def main():
         u0 = rng.normal(size=(B, T, nu)) * float(rng.choice([0.0, 0.1, 0.6]))
         desc = "%s B=%d T=%d lim=%g iters=%d" % (name, B, T, lim, iters)
         outs = {}
-        for label, fl in (("fused", 0), ("unfused", capi.FLAG_UNFUSED), ("thread", capi.FLAG_UNFUSED | capi.FLAG_BACKWARD_THREAD_PER_TRAJ)):
+        for label, fl in (("fused", 0), ("staged", capi.FLAG_STAGED), ("unfused", capi.FLAG_UNFUSED),
+                          ("thread", capi.FLAG_UNFUSED | capi.FLAG_BACKWARD_THREAD_PER_TRAJ)):
             g = BatchILQR(name, B, T, DT, flags=fl, params=dict(max_iter=iters), **kw)
             g.init_traj(x0, u0)
             g.generate_trajectory()
             outs[label] = state(g)
             g.close()
-        for key in outs["fused"]:
-            if not np.array_equal(outs["fused"][key], outs["unfused"][key], equal_nan=True):
-                print("FAIL fused != unfused:", key, desc, "seed", seed)
-                return 1
+        for other in ("staged", "unfused"):  # persistent tile kernel == per-stage launches == two kernels with records in HBM
+            for key in outs["fused"]:
+                if not np.array_equal(outs["fused"][key], outs[other][key], equal_nan=True):
+                    print("FAIL persistent != %s:" % other, key, desc, "seed", seed)
+                    return 1
         same_thread = np.isclose(outs["thread"]["cost"], outs["unfused"]["cost"], rtol=1e-6, equal_nan=True)
         if (same_thread.mean() < 0.9 and B >= 10) or (B < 10 and (~same_thread).sum() > 1):
             print("FAIL thread-per-trajectory kernel deviates:", desc, same_thread.mean())

@@ -90,3 +90,36 @@ def test_the_flag_is_off_by_default_and_rejected_where_not_implemented():
     from ilqr_amd.capi import ILQRError
     with pytest.raises(ILQRError, match="nx = 4"):
         BatchILQR("host", 2, 5, DT, nx=3, nu=2, u_min=[-1, -1], u_max=[1, 1], flags=capi.FLAG_REFERENCE_FIXES)
+
+
+@pytest.mark.parametrize("name,B,T,lim", [("acrobot", 40, 120, 5.0), ("integrator", 33, 60, 0.5)])
+def test_vxx_regularisation_matches_the_oracle(oracle, name, B, T, lim):
+    """ILQR_FLAG_REGULARIZE_VXX: lambda on Vxx' ([Tassa 2012] eq. 10) instead of on Quu, both sides (orc_set_fixes(4)):
+    teacher-forced backward passes at lambda in {1, 10} and whole iterations."""
+    from ilqr_amd import capi
+    oracle.set_fixes(4)
+    try:
+        om, g, x0 = build(oracle, name, B, T, lim, capi.FLAG_REGULARIZE_VXX)
+        rng = np.random.default_rng(3)
+        u0 = rng.normal(size=(B, T, om.nu)) * 0.3
+        xs, us, cost = oracle.batch_rollout(om, x0, u0, DT)
+        do = oracle.batch_derivatives(om, xs, us, DT)
+        for lam in (1.0, 10.0):
+            ro = oracle.batch_backward(om, us, do, lam=lam)
+            g.set_trajectory(x0=x0, xs=xs, us=us, cost=cost)
+            g.set_derivatives(**{k: (do[k] if k in ("cx", "cu") else mat(do[k])) for k in do})
+            g.set_gains(k=np.zeros((B, T, om.nu)), K=np.zeros((B, T, om.nu, om.nx)))
+            g.set_lambda(lam, 1.0)
+            div = g.backward_pass()
+            k, K = g.gains()
+            check_backward(oracle, om, us, do, np.zeros((B, T, om.nu)), lam, k, K, g.dV(), div, ro, max_ties=max(1, B // 16))
+            # and it IS a different regularisation: the gains differ from the reference's lambda I on Quu
+            oracle.set_fixes(0)
+            r0 = oracle.batch_backward(om, us, do, lam=lam)
+            oracle.set_fixes(4)
+            assert np.abs(mat(r0["K"]) - mat(ro["K"])).max() > 1e-3 * np.abs(mat(ro["K"])).max()
+        r = walk_iterations(oracle, om, g, x0, np.zeros((B, T, om.nu)), DT, 4)
+        assert r["checked"] >= 2 * B and len(r["tied"]) <= max(2, r["checked"] // 10), r
+        g.close()
+    finally:
+        oracle.set_fixes(0)
