@@ -1790,6 +1790,7 @@ __device__ __forceinline__ void sweep_backward_tile(const BatchViewT<typename M:
     const int w = wave - 1;
     const int l = lane & (TW - 1), sub = lane >> 4;
     const int nrounds = (T + 1 + kKnotsPerRound - 1) / kKnotsPerRound, N = nrounds * kKnotsPerRound;
+    if (w < kProd)  // (a block may have more wavefronts than this phase uses: k_solve_tile's fourth one with two producers)
     for (int pass = 0;; pass++) {
       unsigned long long lanes = ~0ull;
       if (pass > 0) {  // a retry pass exists only if the backward wavefront starts one
