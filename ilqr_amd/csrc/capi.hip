@@ -670,6 +670,15 @@ void ilqr_destroy(ilqr_batch* h) {
                 (double)d[512 + worst * 4 + 0] / h->T, (double)d[512 + worst * 4 + 1] / h->T, (double)d[512 + worst * 4 + 2] / h->T,
                 (double)d[512 + worst * 4 + 3] / h->T);
       }
+      {
+        long long y[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < 16; t++)
+          for (int q = 0; q < 8; q++) y[q] += d[800 + t * 8 + q];
+        const double per = 16.0 * 16 * h->T;
+        fprintf(stderr, "[search fallbacks to the sequential loop, tiles 0..15, per QP] first search: estimate unusable %.4f (Q <= 0: %.4f) window all fail %.4f "
+                        "first window lane passes %.4f | searches of later QP iterations: %.4f (Q <= 0: %.4f) %.4f %.4f\n",
+                y[1] / per, y[0] / per, y[2] / per, y[3] / per, y[5] / per, y[4] / per, y[6] / per, y[7] / per);
+      }
       for (int t = 0; t < 3; t++) {
         fprintf(stderr, "[phase timing, tile %d, last backward pass] ", t * 20);
         for (int q = 0; q < 8; q++) fprintf(stderr, "%s %.2f  ", nm[q], (double)d[t * 20 * 8 + q] / h->T);

@@ -1003,7 +1003,7 @@ __device__ __forceinline__ const float* step_table(float) { return kStepTableF.s
 // Quad-parallel Armijo line search for the scalar QP (all four lanes of a quad hold the same
 // QP1State).  The reference's loop (boxqp.cpp:156-173) tries step_k = 0.6^k for k = 0, 1, 2, ...
 // until the Armijo test passes; a Newton step that a bound truncates to a tiny fraction needs
-// 10+ trips, and a wavefront pays for its slowest quad.  For Q > 0 the set of passing k is upward
+// 10+ trips, and a wavefront pays for its slowest quad.  The set of passing k is upward
 // closed (while the trial point sits on the bound the value is constant and the threshold shrinks
 // with the step; once it is inside the bound a Newton step always passes).  So the four lanes
 // evaluate four candidates in ONE instruction stream -- lane 0 the unit step, lanes 1..3 a window
@@ -1012,7 +1012,7 @@ __device__ __forceinline__ const float* step_table(float) { return kStepTableF.s
 // else (estimate off, Q <= 0, k near the minStep cut-off) returns false and the caller runs the
 // sequential loop: the result is the reference's either way.
 template <class real>
-__device__ __forceinline__ bool qp1_search_quad(QP1StateT<real>& q, int s, int lane, const real* __restrict__ lds_steps) {
+__device__ __forceinline__ bool qp1_search_quad(QP1StateT<real>& q, int s, int lane, const real* __restrict__ lds_steps, int* why = nullptr) {
   const real bound = (q.search > 0) ? q.hi : q.lo;
   const real v_b = qp1_value(q, bound);
   // fp32 estimates: f = fraction of the step inside the box, r = Armijo threshold on the bound
@@ -1020,7 +1020,11 @@ __device__ __forceinline__ bool qp1_search_quad(QP1StateT<real>& q, int s, int l
   const float r = (float)(v_b - q.old_v) * __builtin_amdgcn_rcpf((float)(real(kArmijo) * q.slope));
   const float thr = fmaxf(f, r);
   int kg = (int)ceilf(__log2f(thr) * -1.35691545f);  // log(thr)/log(0.6)
-  const bool sane = (q.Q > real(0)) & (thr > 0.f) & (thr < 1.f) & (kg >= 1) & (kg <= 96);
+  // (Q < 0 too -- Eigen's unchecked factor makes that a legal QP, and in float Quu = cuu + fu'Vxx fu cancels to <= 0
+  //  for a few trajectories late in a solve: along a descent direction the value change of a trial on the bound is a
+  //  negative constant N, the test passes iff step <= N / (0.1 slope), and an interior trial has ratio
+  //  1 + Q step search^2 / (2 slope) > 1: the passing set is upward closed for either sign of Q)
+  const bool sane = (q.Q != real(0)) & (thr > 0.f) & (thr < 1.f) & (kg >= 1) & (kg <= 96);
   const int k1 = (sane & (kg > 2)) ? kg - 1 : 1;
   const int my_k = (s == 0) ? 0 : k1 + s - 1;
   const real my_step = lds_steps[my_k];
@@ -1054,6 +1058,9 @@ __device__ __forceinline__ bool qp1_search_quad(QP1StateT<real>& q, int s, int l
   const unsigned int s4 = (unsigned int)(__ballot(my_x1 == q.x) >> (lane & ~3)) & 0xFu;
   const bool dead = (k1 == 1) & (m4 == 0u) & ((s4 & 8u) != 0u) & !q.early;
   q.ls_failed = q.ls_failed | stuck | dead;
+  // (experiment builds: why a search is handed to the sequential loop -- 1 estimate unusable and k = 0..3 all fail,
+  //  2 every window lane fails, 3 the first window lane already passes)
+  if (why) *why = (ok | q.early | stuck | dead) ? 0 : (!sane ? 1 : (w == 0u ? 2 : 3));
   return ok | q.early | stuck | dead;
 }
 
@@ -1187,6 +1194,8 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
 #ifdef ILQR_PHASE_TIMING
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long xc[4] = {0, 0, 0, 0};  // (per lane: counts of lane 0's own quad)
+    long long yc[4] = {0, 0, 0, 0};  // first-level fallbacks by reason (see qp1_search_quad), [0] = of reason 1 with Q <= 0
+    long long zc[4] = {0, 0, 0, 0};  // the same for the searches of qp1_continue
     long long tmark = clock64();
 #define ILQR_MARK(k) { __builtin_amdgcn_sched_barrier(0); const long long tn_ = clock64(); ph[k] += tn_ - tmark; tmark = tn_; __builtin_amdgcn_sched_barrier(0); }
 #else
@@ -1337,9 +1346,16 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         real minv;
         QP1StateT<real> q1;
         qp1_begin<false>(QuuF[0], Qu[0], kprev[0], lo[0], hi[0], q1, (sp.fixes & 2) != 0);
-        if (!qp1_search_quad(q1, s, lane, lds_steps)) {  // fallback: rare
 #ifdef ILQR_PHASE_TIMING
+        int why = 0;
+        if (!qp1_search_quad(q1, s, lane, lds_steps, &why)) {  // fallback: rare
           xc[2] += 1;
+          yc[why & 3] += 1;
+          if (why == 1) {
+            yc[0] += (q1.Q > real(0)) ? 0 : 1;  // of which: Q <= 0
+          }
+#else
+        if (!qp1_search_quad(q1, s, lane, lds_steps)) {  // fallback: rare
 #endif
           q1.step = 1;
           q1.x1 = qp1_trial(q1, real(1));
@@ -1361,7 +1377,14 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
 #ifdef ILQR_PHASE_TIMING
                 xc[1] += 1;
 #endif
+#ifdef ILQR_PHASE_TIMING
+                int why2 = 0;
+                if (!qp1_search_quad(qs, s, lane, lds_steps, &why2)) {
+                  zc[why2 & 3] += 1;
+                  if (why2 == 1) zc[0] += (qs.Q > real(0)) ? 0 : 1;
+#else
                 if (!qp1_search_quad(qs, s, lane, lds_steps)) {
+#endif
 #ifdef ILQR_PHASE_TIMING
                   xc[2] += 1;
                   if (v.dbg && s == 0) {
@@ -1596,6 +1619,29 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         m1 = o1 > m1 ? o1 : m1;
         m2 = o2 > m2 ? o2 : m2;
         m3 = o3 > m3 ? o3 : m3;
+      }
+      {  // tile totals of the fallback reasons (sum over quads / 4 lanes)
+        long long y0 = yc[0], y1 = yc[1], y2 = yc[2], y3 = yc[3], z0 = zc[0], z1 = zc[1], z2 = zc[2], z3 = zc[3];
+        for (int off = 1; off < 64; off <<= 1) {
+          y0 += __shfl_xor(y0, off, 64);
+          y1 += __shfl_xor(y1, off, 64);
+          y2 += __shfl_xor(y2, off, 64);
+          y3 += __shfl_xor(y3, off, 64);
+          z0 += __shfl_xor(z0, off, 64);
+          z1 += __shfl_xor(z1, off, 64);
+          z2 += __shfl_xor(z2, off, 64);
+          z3 += __shfl_xor(z3, off, 64);
+        }
+        if (v.dbg && lane == 0 && tile < 16) {
+          v.dbg[800 + tile * 8 + 0] = y0 / 4;
+          v.dbg[800 + tile * 8 + 1] = y1 / 4;
+          v.dbg[800 + tile * 8 + 2] = y2 / 4;
+          v.dbg[800 + tile * 8 + 3] = y3 / 4;
+          v.dbg[800 + tile * 8 + 4] = z0 / 4;
+          v.dbg[800 + tile * 8 + 5] = z1 / 4;
+          v.dbg[800 + tile * 8 + 6] = z2 / 4;
+          v.dbg[800 + tile * 8 + 7] = z3 / 4;
+        }
       }
       if (v.dbg && lane == 0 && tile < 64) {
         v.dbg[512 + tile * 4 + 0] = m0;
