@@ -1355,7 +1355,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
             yc[0] += (q1.Q > real(0)) ? 0 : 1;  // of which: Q <= 0
           }
 #else
-        if (!qp1_search_quad(q1, s, lane, lds_steps)) {  // fallback: rare
+        if (__builtin_expect(!qp1_search_quad(q1, s, lane, lds_steps), 0)) {  // fallback: rare, out of line
 #endif
           q1.step = 1;
           q1.x1 = qp1_trial(q1, real(1));
@@ -1383,7 +1383,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
                   zc[why2 & 3] += 1;
                   if (why2 == 1) zc[0] += (qs.Q > real(0)) ? 0 : 1;
 #else
-                if (!qp1_search_quad(qs, s, lane, lds_steps)) {
+                if (__builtin_expect(!qp1_search_quad(qs, s, lane, lds_steps), 0)) {
 #endif
 #ifdef ILQR_PHASE_TIMING
                   xc[2] += 1;
