@@ -345,7 +345,7 @@ def main():
                 "workload": "synthetic LQ n=32 m=16 T=200 B=8192, u in [-1,1], fp64, %s derivatives, fixed-work iterations "
                             "(BASELINE configs[4])" % ("finite-difference" if not fl else "exact"),
                 "value": Bq * Tq * itq / elq, "unit": "trajectory-timesteps/s", "ms_per_step": elq / itq * 1e3, "stages": stq,
-                "roofline": {"bound": "mfma", "kernel": "k_backward_w", "achieved": flop_ts * Bq * Tq / bw / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
+                "roofline": {"bound": "mfma", "kernel": stq["backward"]["kernel"], "achieved": flop_ts * Bq * Tq / bw / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": flop_ts * Bq * Tq / bw / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                              "algorithmic_flops_per_timestep": flop_ts, "avg_launch_ms": bw * 1e3}}
 

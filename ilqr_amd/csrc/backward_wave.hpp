@@ -172,7 +172,8 @@ __device__ __forceinline__ double w_quad_cost(int m, const double* Q, const doub
 #ifdef ILQR_PHASE_TIMING
 __device__ long long g_qp_count[8];  // [0] QPs, [1] iterations, [2] factorisations, [3] Armijo trips, [4..7] cycles: factor, inverse, search, rest
 #endif
-__device__ int w_box_qp(int m, WaveLds& L, int lane, int& nfR_out) {
+template <class LDS>
+__device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
 #ifdef ILQR_PHASE_TIMING
   long long qc[8] = {1, 0, 0, 0, 0, 0, 0, 0};
   long long qmark = clock64();

@@ -96,3 +96,44 @@ def test_non_positive_definite_quu(oracle, n, m, where):
     assert g.last["ok"].sum() >= 6, g.last  # (ties allowed as everywhere; "ok" includes trajectories where fp64 itself
     # cannot pin the answer: a first pivot < 0 leaves R = Q untouched and the "solve" amplifies rounding by 1e15)
     g.close()
+
+
+@pytest.mark.parametrize("n,m,lim,shift", [(32, 16, 0.2, None), (32, 16, 1.0, None), (17, 1, 0.3, None), (24, 7, 0.2, None),
+                                           (32, 16, 0.3, "middle"), (20, 16, 0.5, "first")])
+def test_register_kernel_equals_lds_kernel(oracle, n, m, lim, shift):
+    """k_backward_w2 (16 < nx <= 32: matrices in MFMA-layout registers, two wavefronts per SIMD) is a re-arrangement of
+    k_backward_w (matrices in LDS): transposed products, the same k-ordered FMA chains.  Gains, value terms, divergence
+    indices and gradient norms must be IDENTICAL, bit for bit -- mixed clamp sets, partial factors and stale
+    factors included (the non-positive-definite cases)."""
+    import os
+    from ilqr_amd import BatchILQR
+    om = lq_model(oracle, n, m, lim=lim)
+    B, T = 9, 14
+    rng = np.random.default_rng(5)
+    x0 = rng.uniform(-1, 1, (B, n))
+    u0 = rng.normal(size=(B, T, m)) * 0.5
+    xs, us, cost = oracle.batch_rollout(om, x0, u0, DT)
+    dv = oracle.batch_derivatives(om, xs, us, DT)
+    if shift is not None:
+        s = np.zeros(m)
+        s[{"first": 0, "middle": m // 2}[shift]] = -60.0
+        dv["cuu"] = dv["cuu"] + np.diag(s)[None, None]
+    k_prev = rng.normal(size=(B, T, m)) * 0.1
+    outs = []
+    for force_lds in (False, True):
+        if force_lds:
+            os.environ["ILQR_AMD_BACKWARD_W1"] = "1"
+        try:
+            g = BatchILQR("host", B, T, DT, nx=n, nu=m, u_min=om.u_min, u_max=om.u_max)
+            g.set_trajectory(x0=x0, xs=xs, us=us, cost=cost)
+            g.set_derivatives(**{k: (dv[k] if k in ("cx", "cu") else mat(dv[k])) for k in dv})
+            g.set_gains(k=k_prev, K=np.zeros((B, T, m, n)))
+            g.set_lambda(1e-3 if shift is None else 0.0, 1.0)
+            div = g.backward_pass()
+            k, K = g.gains()
+            outs.append(dict(div=np.asarray(div), k=k, K=K, dV=g.dV(), gnorm=g.gnorm()))
+            g.close()
+        finally:
+            os.environ.pop("ILQR_AMD_BACKWARD_W1", None)
+    for key in outs[0]:
+        assert np.array_equal(outs[0][key], outs[1][key], equal_nan=True), key
