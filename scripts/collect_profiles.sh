@@ -26,9 +26,16 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace -d $OUT/staged_pmc_$C -o $R -- $SHORT --flags 32 > /dev/null 2> $OUT/staged_pmc_$C.err
 done
 rocprofv3 --kernel-trace --stats -d $OUT/staged_stats -o $R -- $SHORT --flags 32 > /dev/null 2> $OUT/staged_stats.err
+# the generic path (configs[4]: LQ n=32, m=16, T=200, B=8192, exact derivatives): k_backward_w2 and, forced, k_backward_w
+LQ="python $ROOT/scripts/bench_lq.py 8192 2 16"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $OUT/lq_pmc_sq -o $R -- $LQ > /dev/null 2> $OUT/lq_pmc_sq.err
+rocprofv3 --pmc MeanOccupancyPerCU MeanOccupancyPerActiveCU --kernel-trace -d $OUT/lq_pmc_occ -o $R -- $LQ > /dev/null 2> $OUT/lq_pmc_occ.err
+ILQR_AMD_BACKWARD_W1=1 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $OUT/lq_w1_pmc_sq -o $R -- $LQ > /dev/null 2> $OUT/lq_w1_pmc_sq.err
+ILQR_AMD_BACKWARD_W1=1 rocprofv3 --pmc MeanOccupancyPerCU MeanOccupancyPerActiveCU --kernel-trace -d $OUT/lq_w1_pmc_occ -o $R -- $LQ > /dev/null 2> $OUT/lq_w1_pmc_occ.err
 cd $ROOT
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-for d in stats stats5 pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq1 pmc_sq2 pmc_sq3 staged_pmc_FETCH_SIZE staged_pmc_WRITE_SIZE staged_stats; do
+scripts/ubench/lat > $OUT/ubench_lat.txt 2>/dev/null
+for d in stats stats5 pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq1 pmc_sq2 pmc_sq3 staged_pmc_FETCH_SIZE staged_pmc_WRITE_SIZE staged_stats lq_pmc_sq lq_pmc_occ lq_w1_pmc_sq lq_w1_pmc_occ; do
   f=$(find $OUT/$d -name "*.db" | head -1)
   [ -n "$f" ] && python scripts/prof_summary.py $f > $OUT/$d.txt 2>&1
 done

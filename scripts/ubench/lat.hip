@@ -44,10 +44,10 @@ int main() {
 #define RUN(K) k<K><<<1, 64>>>(out, sink, 1.0000001, 0.999999); k<K><<<1, 64>>>(out, sink, 1.0000001, 0.999999); { hipError_t e = hipDeviceSynchronize(); fprintf(stderr, "kind %d: %s\n", K, hipGetErrorString(e)); }
   RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15)
   long long h[64]; hipMemcpy(h, out, 64 * 8, hipMemcpyDeviceToHost);
-  const char* nm[] = {"dep v_fma_f64", "4 indep v_fma_f64 chains", "dep v_fma_f32", "dep v_mul_f64", "dep v_add_f64", "dep s_nop+dpp mov", "indep cmp_f64+cndmask (2 instr)",
-                      "dep v_rcp_f64", "dep v_max_f64", "2 chains v_fma_f64 (per 2 instr x 65/64)", "dep bpermute+wait", "s_add", "fma_f64 + s_add (2 instr)",
+  const char* nm[] = {"dep v_fma_f64", "4 indep v_fma_f64 chains (per instr)", "dep v_fma_f32", "dep v_mul_f64", "dep v_add_f64", "dep s_nop+dpp mov", "indep cmp_f64+cndmask (2 instr)",
+                      "dep v_rcp_f64", "dep v_max_f64", "2 v_fma_f64 chains (per instr)", "dep bpermute+wait", "s_add", "fma_f64 + s_add (2 instr)",
                       "dep cmp+cndmask (2 instr)", "fma_f32 -> nop 1 -> dpp (3 instr)", "indep dpp mov"};
-  for (int i = 0; i < 16; i++) printf("%-45s %.2f ticks per asm statement (s_memtime, 100 MHz?)\n", nm[i], h[i] / (16.0 * 256));
+  for (int i = 0; i < 16; i++) printf("%-45s %.2f cycles (s_memtime) per statement\n", nm[i], h[i] / (16.0 * 256));
   int khz; hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, 0); printf("clock %d kHz\n", khz);
   hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0); printf("wall clock %d kHz\n", khz);
   return 0;
