@@ -1,5 +1,5 @@
-// backward_wave2.hpp -- the generic backward pass of backward_wave.hpp for 16 < nx <= 32 with the step's matrices
-// in REGISTERS, so that two wavefronts share a SIMD.
+// backward_wave2.hpp -- the generic backward pass of backward_wave.hpp with the step's matrices in REGISTERS, so that
+// two wavefronts (nx <= 32) or more (nx <= 16) share a SIMD.
 //
 // k_backward_w keeps every matrix of a step in LDS (39.6 KB per wavefront: four wavefronts per CU, one per SIMD) and
 // was measured latency-bound: the box-QP's dependent chains and the write -> read round trips between product
@@ -27,28 +27,34 @@
 
 namespace ilqr {
 
+template <int NT>  // NT = 16-row tiles covering n: 1 (n <= 16) or 2 (n <= 32)
 struct Wave2Lds {
-  double S[LDN * WN];      // Quu | QuuF | Minv (m x m, ld LDM) until T1'; then Vn for the symmetrisation
-  double Kbuf[LDM * WN];   // K (m x n, ld LDM): written only when the box-QP returns a stale factor or nothing free
-  double Tbuf[LDM * WN];   // Ri / the scattered Minv (m x m, ld LDM); Qux for the stale-factor path
+  static constexpr int N = 16 * NT, LD = N + 1;
+  static constexpr int S_LEN = (LD * N > 3 * LDM * WM) ? LD * N : 3 * LDM * WM;
+  double S[S_LEN];        // Quu | QuuF | Minv (m x m, ld LDM) until T1'; then Vn (ld LD) for the symmetrisation
+  double Kbuf[LDM * N];   // K (m x n, ld LDM): written only when the box-QP returns a stale factor or nothing free
+  double Tbuf[LDM * N];   // Ri / the scattered Minv (m x m, ld LDM); Qux for the stale-factor path
   __device__ __forceinline__ double* K() { return Kbuf; }
   __device__ __forceinline__ double* Quu() { return S; }
   __device__ __forceinline__ double* QuuF() { return S + LDM * WM; }
   __device__ __forceinline__ double* Minv() { return S + 2 * LDM * WM; }
   __device__ __forceinline__ double* Qf() { return Tbuf; }
   __device__ __forceinline__ double* Ri() { return Tbuf; }
-  double Vx[WN], cx[WN], Qx[WN];
+  double Vx[N], cx[N], Qx[N];
   double Qu[WM], x[WM], grad[WM], gc[WM], search[WM], lo[WM], hi[WM], clamped[WM], xc[WM], tmp[WM], kprev[WM],
       gfree[WM], xfree[WM];
   int vfree[WM], idx[WM];
 };
-static_assert(sizeof(Wave2Lds) <= 20 * 1024, "two wavefronts per SIMD: 8 x LDS <= 160 KB");
+static_assert(sizeof(Wave2Lds<2>) <= 20 * 1024, "two wavefronts per SIMD: 8 x LDS <= 160 KB");
+static_assert(sizeof(Wave2Lds<1>) <= 160 * 1024 / 12, "three wavefronts per SIMD: 12 x LDS <= 160 KB");
 
-// 16 < n <= 32, m <= 16.  Arguments as k_backward_w.
-__global__ __launch_bounds__(64, 2) void k_backward_w2(BatchView v, int n, int m, const double* __restrict__ u_min,
+// n <= 16 NT (NT = 1: three wavefronts per SIMD, NT = 2: two), m <= 16.  Arguments as k_backward_w.
+template <int NT>
+__global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w2(BatchView v, int n, int m, const double* __restrict__ u_min,
                                                        const double* __restrict__ u_max, SolverParams sp, int mode,
                                                        const double* __restrict__ const_rec) {
-  __shared__ Wave2Lds L;
+  __shared__ Wave2Lds<NT> L;
+  constexpr int LDX = Wave2Lds<NT>::LD;  // leading dimension of the n x n scratch
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
   if (b >= v.B) return;
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(64, 2) void k_backward_w2(BatchView v, int n, int m
   const int orow = lane >> 4, ocol = lane & 15;
   {
     double* z = reinterpret_cast<double*>(&L);
-    const int nz = (int)(sizeof(Wave2Lds) / sizeof(double));
+    const int nz = (int)(sizeof(Wave2Lds<NT>) / sizeof(double));
     for (int e = lane; e < nz; e += 64) z[e] = 0.0;
   }
   lds_sync();
@@ -76,10 +82,10 @@ __global__ __launch_bounds__(64, 2) void k_backward_w2(BatchView v, int n, int m
   const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
   // natural registers: X[ti][tj][r] = X(16 ti + 4 r + orow, 16 tj + ocol); k-step ks of a 32-long sum is [ks >> 2][.][ks & 3]
   struct RecA {
-    double fx[2][2][4], fu[2][4], cx, cu, us;
+    double fx[NT][NT][4], fu[NT][4], cx, cu, us;
   };
   struct RecB {
-    double cxx[2][4], cxu[4], cuu[4];  // one 16-column block
+    double cxx[NT][4], cxu[4], cuu[4];  // one 16-column block
   };
   // Addressing: every element of a record block is (lane part) + (wave-uniform part).  The lane parts are kept in
   // four registers and made opaque once per step (`asm volatile`): left alone, hipcc hoists all 52 guarded 64-bit
@@ -96,13 +102,13 @@ __global__ __launch_bounds__(64, 2) void k_backward_w2(BatchView v, int n, int m
     const double* rm = const_rec ? const_rec : r;
     asm volatile("" : "+v"(lb_nn));
 #pragma unroll
-    for (int ti = 0; ti < 2; ti++)
+    for (int ti = 0; ti < NT; ti++)
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
         const int a0 = 16 * ti + 4 * rr;
         const bool ain = a0 + orow < n;
 #pragma unroll
-        for (int tj = 0; tj < 2; tj++) q.fx[ti][tj][rr] = ldm(rm, ain && 16 * tj + ocol < n, lb_nn + (unsigned)(oFX + a0 + n * 16 * tj));
+        for (int tj = 0; tj < NT; tj++) q.fx[ti][tj][rr] = ldm(rm, ain && 16 * tj + ocol < n, lb_nn + (unsigned)(oFX + a0 + n * 16 * tj));
         q.fu[ti][rr] = ldm(rm, ain && ocol < m, lb_nn + (unsigned)(oFU + a0));
       }
     q.cx = ldm(r, lane < n, (unsigned)(oCX + lane));
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(64, 2) void k_backward_w2(BatchView v, int n, int m
     const double* r = const_rec ? const_rec : Db + (size_t)i * REC;
     asm volatile("" : "+v"(lb_nn), "+v"(lb_tn), "+v"(lb_mm));
 #pragma unroll
-    for (int ti = 0; ti < 2; ti++)
+    for (int ti = 0; ti < NT; ti++)
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
         const int a0 = 16 * ti + 4 * rr;
@@ -134,14 +140,14 @@ __global__ __launch_bounds__(64, 2) void k_backward_w2(BatchView v, int n, int m
   bool done = false;
   double dV0 = 0, dV1 = 0;
   while (true) {
-    double Vxx[2][2][4];
+    double Vxx[NT][NT][4];
     {  // :353-354
       const double* r = Db + (size_t)T * REC;
       for (int e = lane; e < n; e += 64) L.Vx[e] = r[oCX + e];
 #pragma unroll
-      for (int ti = 0; ti < 2; ti++)
+      for (int ti = 0; ti < NT; ti++)
 #pragma unroll
-        for (int tj = 0; tj < 2; tj++)
+        for (int tj = 0; tj < NT; tj++)
 #pragma unroll
           for (int rr = 0; rr < 4; rr++) {
             const int a0 = 16 * ti + 4 * rr;
@@ -172,28 +178,29 @@ __global__ __launch_bounds__(64, 2) void k_backward_w2(BatchView v, int n, int m
         L.tmp[lane] = cur.cu;
       }
       if (lane < n) L.cx[lane] = cur.cx;
-      double fx[2][2][4], fu[2][4];
+      double fx[NT][NT][4], fu[NT][4];
 #pragma unroll
-      for (int ti = 0; ti < 2; ti++)
+      for (int ti = 0; ti < NT; ti++)
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
           fu[ti][rr] = cur.fu[ti][rr];
 #pragma unroll
-          for (int tj = 0; tj < 2; tj++) fx[ti][tj][rr] = cur.fx[ti][tj][rr];
+          for (int tj = 0; tj < NT; tj++) fx[ti][tj][rr] = cur.fx[ti][tj][rr];
         }
       lds_sync();
       // :359-360 Qx = cx + fx'Vx, Qu = cu + fu'Vx -- B operand: Vx in every column
       {
-        double4_t qx[2];
-        double bv[8];
+        double4_t qx[NT];
+        double bv[4 * NT];
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++) bv[ks] = L.Vx[4 * ks + orow];
+        for (int ks = 0; ks < 4 * NT; ks++) bv[ks] = L.Vx[4 * ks + orow];
         double4_t qu = zero4;
-        qx[0] = qx[1] = zero4;
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++) {
-          qx[0] = mfma(fx[ks >> 2][0][ks & 3], bv[ks], qx[0]);
-          qx[1] = mfma(fx[ks >> 2][1][ks & 3], bv[ks], qx[1]);
+        for (int ti = 0; ti < NT; ti++) qx[ti] = zero4;
+#pragma unroll
+        for (int ks = 0; ks < 4 * NT; ks++) {
+#pragma unroll
+          for (int ti = 0; ti < NT; ti++) qx[ti] = mfma(fx[ks >> 2][ti][ks & 3], bv[ks], qx[ti]);
           qu = mfma(fu[ks >> 2][ks & 3], bv[ks], qu);
         }
         if (ocol == 0) {
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(64, 2) void k_backward_w2(BatchView v, int n, int m
           for (int rr = 0; rr < 4; rr++) {
             if (4 * rr + orow < m) L.Qu[4 * rr + orow] = L.tmp[4 * rr + orow] + qu[rr];
 #pragma unroll
-            for (int ti = 0; ti < 2; ti++) {
+            for (int ti = 0; ti < NT; ti++) {
               const int a = 16 * ti + 4 * rr + orow;
               if (a < n) L.Qx[a] = L.cx[a] + qx[ti][rr];
             }
@@ -210,43 +217,45 @@ __global__ __launch_bounds__(64, 2) void k_backward_w2(BatchView v, int n, int m
       }
       ILQR_W2MARK(0)
       // A1' = Vxx' fx (n x n), A2' = Vxx' fu (n x m)
-      double4_t a1t[2][2], a2t[2];
+      double4_t a1t[NT][NT], a2t[NT];
 #pragma unroll
-      for (int ti = 0; ti < 2; ti++) {
+      for (int ti = 0; ti < NT; ti++) {
         a2t[ti] = zero4;
 #pragma unroll
-        for (int tj = 0; tj < 2; tj++) a1t[ti][tj] = zero4;
+        for (int tj = 0; tj < NT; tj++) a1t[ti][tj] = zero4;
       }
 #pragma unroll
-      for (int ks = 0; ks < 8; ks++) {
+      for (int ks = 0; ks < 4 * NT; ks++) {
 #pragma unroll
-        for (int ti = 0; ti < 2; ti++) {
+        for (int ti = 0; ti < NT; ti++) {
 #pragma unroll
-          for (int tj = 0; tj < 2; tj++) a1t[ti][tj] = mfma(Vxx[ks >> 2][ti][ks & 3], fx[ks >> 2][tj][ks & 3], a1t[ti][tj]);
+          for (int tj = 0; tj < NT; tj++) a1t[ti][tj] = mfma(Vxx[ks >> 2][ti][ks & 3], fx[ks >> 2][tj][ks & 3], a1t[ti][tj]);
           a2t[ti] = mfma(Vxx[ks >> 2][ti][ks & 3], fu[ks >> 2][ks & 3], a2t[ti]);
         }
       }
       // :361 Qxx = cxx + A1 fx ; :362 Qux = cxu' + A2 fx ; :363/:367 Quu, QuuF = cuu (+ lambda I) + A2 fu
       ILQR_W2MARK(1)
-      double Qxx[2][2][4], Qux[2][4];
+      double Qxx[NT][NT][4], Qux[NT][4];
 #pragma unroll
-      for (int tj = 0; tj < 2; tj++) {  // one 16-column block of the outputs at a time (registers)
+      for (int tj = 0; tj < NT; tj++) {  // one 16-column block of the outputs at a time (registers)
         // (scheduling fences: left free, hipcc hoists both blocks' loads above the first products, runs out of
         //  registers there and turns every load into load -> vmcnt(0) -> scratch spill)
         __builtin_amdgcn_sched_barrier(0);
         RecB rec;
         load_rec_b(i, tj, rec);
         __builtin_amdgcn_sched_barrier(0);
-        double4_t qxx[2] = {zero4, zero4}, qux = zero4, quu = zero4;
+        double4_t qxx[NT], qux = zero4, quu = zero4;
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++) {
+        for (int ti = 0; ti < NT; ti++) qxx[ti] = zero4;
 #pragma unroll
-          for (int ti = 0; ti < 2; ti++) qxx[ti] = mfma(a1t[ks >> 2][ti][ks & 3], fx[ks >> 2][tj][ks & 3], qxx[ti]);
+        for (int ks = 0; ks < 4 * NT; ks++) {
+#pragma unroll
+          for (int ti = 0; ti < NT; ti++) qxx[ti] = mfma(a1t[ks >> 2][ti][ks & 3], fx[ks >> 2][tj][ks & 3], qxx[ti]);
           qux = mfma(a2t[ks >> 2][ks & 3], fx[ks >> 2][tj][ks & 3], qux);
           if (tj == 0) quu = mfma(a2t[ks >> 2][ks & 3], fu[ks >> 2][ks & 3], quu);
         }
 #pragma unroll
-        for (int ti = 0; ti < 2; ti++)
+        for (int ti = 0; ti < NT; ti++)
 #pragma unroll
           for (int rr = 0; rr < 4; rr++) {
             const int a = 16 * ti + 4 * rr + orow, c = 16 * tj + ocol;
@@ -280,7 +289,7 @@ __global__ __launch_bounds__(64, 2) void k_backward_w2(BatchView v, int n, int m
         break;
       }
       // :373-385  K rows of free dims, natural registers K[tj][r] = K(4 r + orow, 16 tj + ocol)
-      double K[2][4];
+      double K[NT][4];
       const unsigned long long free_mask = __ballot(lane < m && L.vfree[lane]);
       const int nf = __popcll(free_mask);
       if (nf > 0 && nf == nfR) {
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(64, 2) void k_backward_w2(BatchView v, int n, int m
         double aM[WM / 4];
         ld_operand<WM / 4>([&](int i2, int k) { return MF[i2 + LDM * k]; }, lane, aM);
 #pragma unroll
-        for (int tj = 0; tj < 2; tj++) {
+        for (int tj = 0; tj < NT; tj++) {
           double4_t acc = zero4;
 #pragma unroll
           for (int ks = 0; ks < WM / 4; ks++) acc = mfma(aM[ks], Qux[tj][ks], acc);
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(64, 2) void k_backward_w2(BatchView v, int n, int m
         if (lane < m && L.vfree[lane]) L.idx[__popcll(free_mask & ((1ull << lane) - 1ull))] = lane;
         for (int c = lane >> 4; c < n; c += 4) L.K()[(lane & 15) + LDM * c] = 0;
 #pragma unroll
-        for (int tj = 0; tj < 2; tj++)
+        for (int tj = 0; tj < NT; tj++)
 #pragma unroll
           for (int rr = 0; rr < 4; rr++) L.Tbuf[(4 * rr + orow) + LDM * (16 * tj + ocol)] = Qux[tj][rr];
         lds_sync();
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(64, 2) void k_backward_w2(BatchView v, int n, int m
         }
         lds_sync();
 #pragma unroll
-        for (int tj = 0; tj < 2; tj++)
+        for (int tj = 0; tj < NT; tj++)
 #pragma unroll
           for (int rr = 0; rr < 4; rr++) K[tj][rr] = L.K()[(4 * rr + orow) + LDM * (16 * tj + ocol)];
       }
@@ -344,12 +353,12 @@ __global__ __launch_bounds__(64, 2) void k_backward_w2(BatchView v, int n, int m
         dV1 += wave_sum_row0(part);
       }
       // T1' = Quu' K (m x n)
-      double4_t t1t[2];
+      double4_t t1t[NT];
       {
         double aQ[WM / 4];
         ld_operand<WM / 4>([&](int i2, int k) { return L.Quu()[k + LDM * i2]; }, lane, aQ);
 #pragma unroll
-        for (int tj = 0; tj < 2; tj++) {
+        for (int tj = 0; tj < NT; tj++) {
           t1t[tj] = zero4;
 #pragma unroll
           for (int ks = 0; ks < WM / 4; ks++) t1t[tj] = mfma(aQ[ks], K[tj][ks], t1t[tj]);
@@ -363,13 +372,13 @@ __global__ __launch_bounds__(64, 2) void k_backward_w2(BatchView v, int n, int m
           bx[ks] = L.x[4 * ks + orow];
           bq[ks] = L.Qu[4 * ks + orow];
         }
-        double qxv[2][4];
+        double qxv[NT][4];
 #pragma unroll
-        for (int ti = 0; ti < 2; ti++)
+        for (int ti = 0; ti < NT; ti++)
 #pragma unroll
           for (int rr = 0; rr < 4; rr++) qxv[ti][rr] = L.Qx[16 * ti + 4 * rr + orow];
 #pragma unroll
-        for (int ti = 0; ti < 2; ti++) {
+        for (int ti = 0; ti < NT; ti++) {
           double4_t s1 = zero4, s2 = zero4, s3 = zero4;
 #pragma unroll
           for (int ks = 0; ks < WM / 4; ks++) {
@@ -390,9 +399,9 @@ __global__ __launch_bounds__(64, 2) void k_backward_w2(BatchView v, int n, int m
       ILQR_W2MARK(5)
       // :392 Vn = ((Qxx + T1 K) + K'Qux) + Qux'K ; :393 Vxx = (Vn + Vn')/2 through S
 #pragma unroll
-      for (int ti = 0; ti < 2; ti++)
+      for (int ti = 0; ti < NT; ti++)
 #pragma unroll
-        for (int tj = 0; tj < 2; tj++) {
+        for (int tj = 0; tj < NT; tj++) {
           double4_t p1 = zero4, p2 = zero4, p3 = zero4;
 #pragma unroll
           for (int ks = 0; ks < WM / 4; ks++) {
@@ -404,24 +413,24 @@ __global__ __launch_bounds__(64, 2) void k_backward_w2(BatchView v, int n, int m
           for (int rr = 0; rr < 4; rr++) {
             const double vn = ((Qxx[ti][tj][rr] + p1[rr]) + p2[rr]) + p3[rr];
             Vxx[ti][tj][rr] = vn;
-            L.S[(16 * ti + 4 * rr + orow) + LDN * (16 * tj + ocol)] = vn;
+            L.S[(16 * ti + 4 * rr + orow) + LDX * (16 * tj + ocol)] = vn;
           }
         }
       lds_sync();
 #pragma unroll
-      for (int ti = 0; ti < 2; ti++)
+      for (int ti = 0; ti < NT; ti++)
 #pragma unroll
-        for (int tj = 0; tj < 2; tj++)
+        for (int tj = 0; tj < NT; tj++)
 #pragma unroll
           for (int rr = 0; rr < 4; rr++)
-            Vxx[ti][tj][rr] = 0.5 * (Vxx[ti][tj][rr] + L.S[(16 * tj + ocol) + LDN * (16 * ti + 4 * rr + orow)]);
+            Vxx[ti][tj][rr] = 0.5 * (Vxx[ti][tj][rr] + L.S[(16 * tj + ocol) + LDX * (16 * ti + 4 * rr + orow)]);
       // :396-397
       if (lane < m) {
         kb[(size_t)i * m + lane] = L.x[lane];
         L.kprev[lane] = L.x[lane];
       }
 #pragma unroll
-      for (int tj = 0; tj < 2; tj++)
+      for (int tj = 0; tj < NT; tj++)
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
           const int a = 4 * rr + orow, c = 16 * tj + ocol;

@@ -512,14 +512,16 @@ static int launch_backward(ilqr_batch* h, int mode) {
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_BACKWARD, &ev)) return rc;
   if (h->aos) {
-    // 16 < nx <= 32: the register-resident kernel, two wavefronts per SIMD (ILQR_AMD_BACKWARD_W1 forces the LDS kernel;
-    // the two give bit-identical results, tests/test_gpu_generic_backward.py)
-    if (h->nx > 16 && !getenv("ILQR_AMD_BACKWARD_W1"))
-      hipLaunchKernelGGL(k_backward_w2, dim3(h->B), dim3(64), getenv("ILQR_AMD_W2_PAD") ? atoi(getenv("ILQR_AMD_W2_PAD")) : 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode,
-                         h->records_partial ? h->const_rec : nullptr);
+    // the register-resident kernel, two (nx > 16) or more (nx <= 16) wavefronts per SIMD; ILQR_AMD_BACKWARD_W1 forces round
+    // 1's LDS kernel -- the two give bit-identical results (tests/test_gpu_generic_backward.py)
+    const size_t pad = getenv("ILQR_AMD_W2_PAD") ? (size_t)atoi(getenv("ILQR_AMD_W2_PAD")) : 0;  // (occupancy experiments)
+    const double* crec = h->records_partial ? h->const_rec : nullptr;
+    if (getenv("ILQR_AMD_BACKWARD_W1"))
+      hipLaunchKernelGGL(k_backward_w, dim3(h->B), dim3(64), 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
+    else if (h->nx > 16)
+      hipLaunchKernelGGL(k_backward_w2<2>, dim3(h->B), dim3(64), pad, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
     else
-      hipLaunchKernelGGL(k_backward_w, dim3(h->B), dim3(64), 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode,
-                         h->records_partial ? h->const_rec : nullptr);
+      hipLaunchKernelGGL(k_backward_w2<1>, dim3(h->B), dim3(64), pad, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
   } else if (use_quad_backward(h)) {
     dim3 grid(h->ntiles), block(64);  // one wavefront = one tile of 16 trajectories x 4 lanes
     if (int rc = with_model(h, [&](auto& v, auto& m, auto&) {
@@ -1355,7 +1357,7 @@ const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
   switch (stage) {
     case ILQR_STAGE_DERIVATIVES: return (h && h->aos) ? ((h->v.analytic) ? "k_analytic_lq" : "k_derivatives_g") : "k_derivatives";
     case ILQR_STAGE_BACKWARD:
-      if (h && h->aos) return (h->nx > 16 && !getenv("ILQR_AMD_BACKWARD_W1")) ? "k_backward_w2" : "k_backward_w";
+      if (h && h->aos) return getenv("ILQR_AMD_BACKWARD_W1") ? "k_backward_w" : "k_backward_w2";
       if (h && use_fused_sweep(h)) return "k_sweep_backward";  // what ilqr_iterate launches
       return (h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t";
     case ILQR_STAGE_ROLLOUT: return (h && h->aos) ? (lq_thread_rollout() ? "k_rollout_g" : "k_rollout_lq") : "k_rollout";

@@ -13,7 +13,7 @@ from tests.test_gpu_lq_end_to_end import lq_mats
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 extra_flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # e.g. 16 = exact derivatives
-n, m, T, DT = 32, 16, 200, 0.02
+n, m, T, DT = int(os.environ.get("LQ_N", 32)), int(os.environ.get("LQ_M", 16)), 200, 0.02  # (BASELINE configs[4]: 32, 16)
 mats = lq_mats(n, m)
 rng = np.random.default_rng(0)
 x0 = rng.uniform(-1, 1, (B, n))

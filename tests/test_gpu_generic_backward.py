@@ -99,9 +99,11 @@ def test_non_positive_definite_quu(oracle, n, m, where):
 
 
 @pytest.mark.parametrize("n,m,lim,shift", [(32, 16, 0.2, None), (32, 16, 1.0, None), (17, 1, 0.3, None), (24, 7, 0.2, None),
-                                           (32, 16, 0.3, "middle"), (20, 16, 0.5, "first")])
+                                           (32, 16, 0.3, "middle"), (20, 16, 0.5, "first"),
+                                           (6, 2, 0.2, None), (16, 4, 0.3, None), (12, 16, 0.2, None), (3, 1, 0.5, None),
+                                           (12, 16, 0.3, "middle"), (6, 2, 0.5, "first")])
 def test_register_kernel_equals_lds_kernel(oracle, n, m, lim, shift):
-    """k_backward_w2 (16 < nx <= 32: matrices in MFMA-layout registers, two wavefronts per SIMD) is a re-arrangement of
+    """k_backward_w2 (matrices in MFMA-layout registers; <2>: 16 < nx <= 32, two wavefronts per SIMD; <1>: nx <= 16, three) is a re-arrangement of
     k_backward_w (matrices in LDS): transposed products, the same k-ordered FMA chains.  Gains, value terms, divergence
     indices and gradient norms must be IDENTICAL, bit for bit -- mixed clamp sets, partial factors and stale
     factors included (the non-positive-definite cases)."""
