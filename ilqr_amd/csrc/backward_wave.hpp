@@ -156,11 +156,29 @@ __device__ __forceinline__ double dot_masked(int lo, int hi, FA a, FB b) {
   return s;
 }
 
+// The same sum over all N terms without the masks, for operands that are ZERO-PADDED beyond the range (both of
+// them: 0 * 0 adds nothing to the chain, so the value is dot_masked's bit for bit).  The box-QP's vectors (lanes
+// >= m are never written after the kernel's clear) and its m x m matrices (every 16 x 16 entry written each step,
+// zeros outside m x m) are; the masks were 4 of the 5 instructions of a term, a quarter of the kernel's VALU work.
+template <int N = WM, class FA, class FB>
+__device__ __forceinline__ double dot_padded(FA a, FB b) {
+  double av[N], bv[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    av[j] = a(j);
+    bv[j] = b(j);
+  }
+  double s = 0;
+#pragma unroll
+  for (int j = 0; j < N; j++) s = __builtin_fma(av[j], bv[j], s);
+  return s;
+}
+
 // 0.5 x'Qx + x.c with Q m x m (ld LDM), include/boxqp.h:53-55, evaluated ((0.5 x')Q) x + x.c
 __device__ __forceinline__ double w_quad_cost(int m, const double* Q, const double* c, const double* x, int lane) {
   double part = 0, lin = 0;
   if (lane < m) {
-    const double r = dot_masked(0, m, [&](int i) { return 0.5 * x[i]; }, [&](int i) { return Q[i + LDM * lane]; });
+    const double r = dot_padded([&](int i) { return 0.5 * x[i]; }, [&](int i) { return Q[i + LDM * lane]; });
     part = r * x[lane];
     lin = x[lane] * c[lane];
   }
@@ -196,7 +214,7 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
   {
     double part = 0, lin = 0;
     if (lane < m) {
-      const double r = dot_masked(0, m, [&](int i) { return L.x[i]; }, [&](int i) { return Q[i + LDM * lane]; });
+      const double r = dot_padded([&](int i) { return L.x[i]; }, [&](int i) { return Q[i + LDM * lane]; });
       part = r * L.x[lane];
       lin = L.x[lane] * c[lane];
     }
@@ -216,7 +234,7 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
     int cl = 1;
     double dd = 0;
     if (lane < m) {
-      const double s = dot_masked(0, m, [&](int j) { return Q[lane + LDM * j]; }, [&](int j) { return L.x[j]; });
+      const double s = dot_padded([&](int j) { return Q[lane + LDM * j]; }, [&](int j) { return L.x[j]; });
       const double g = s + c[lane];
       L.grad[lane] = g;
       const double oldcl = L.clamped[lane];  // (lane-local: first pass reads the 0 written above)
@@ -335,7 +353,7 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
     if (lane < m) L.tmp[lane] = L.x[lane] * L.clamped[lane];
     lds_sync();
     if (lane < m) {
-      const double s = dot_masked(0, m, [&](int j) { return Q[lane + LDM * j]; }, [&](int j) { return L.tmp[j]; });
+      const double s = dot_padded([&](int j) { return Q[lane + LDM * j]; }, [&](int j) { return L.tmp[j]; });
       L.gc[lane] = s + c[lane];
     }
     lds_sync();
@@ -361,7 +379,7 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
     {
       double sl = 0;
       if (lane < m) {
-        const double s = dot_masked(0, m, [&](int j) { return Q[lane + LDM * j]; }, [&](int j) { return L.x[j]; });
+        const double s = dot_padded([&](int j) { return Q[lane + LDM * j]; }, [&](int j) { return L.x[j]; });
         sl = L.search[lane] * (s + c[lane]);
       }
       const double slope = wave_sum_row0(sl);
@@ -445,7 +463,7 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
   // zero every LDS matrix once: the padding up to whole tiles must read as 0 in the products
   {
     double* z = reinterpret_cast<double*>(&L);
-    const int nz = (int)((offsetof(WaveLds, Vx)) / sizeof(double));
+    const int nz = (int)(sizeof(WaveLds) / sizeof(double));  // (the vectors too: dot_padded relies on zeros beyond m)
     for (int e = lane; e < nz; e += 64) z[e] = 0.0;
   }
   lds_sync();
@@ -766,7 +784,7 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
         const double d0 = wave_sum_row0(lane < m ? L.x[lane] * L.Qu[lane] : 0.0);
         double part = 0;
         if (lane < m) {
-          const double rr = dot_masked(0, m, [&](int a) { return 0.5 * L.x[a]; }, [&](int a) { return L.Quu()[a + LDM * lane]; });
+          const double rr = dot_padded([&](int a) { return 0.5 * L.x[a]; }, [&](int a) { return L.Quu()[a + LDM * lane]; });
           part = rr * L.x[lane];
         }
         dV0 += d0;

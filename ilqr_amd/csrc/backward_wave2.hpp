@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w2(BatchView v
         const double d0 = wave_sum_row0(lane < m ? L.x[lane] * L.Qu[lane] : 0.0);
         double part = 0;
         if (lane < m) {
-          const double rr = dot_masked(0, m, [&](int a) { return 0.5 * L.x[a]; }, [&](int a) { return L.Quu()[a + LDM * lane]; });
+          const double rr = dot_padded([&](int a) { return 0.5 * L.x[a]; }, [&](int a) { return L.Quu()[a + LDM * lane]; });
           part = rr * L.x[lane];
         }
         dV0 += d0;
