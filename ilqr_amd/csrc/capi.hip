@@ -16,6 +16,7 @@
 
 #include "backward_wave.hpp"
 #include "backward_wave2.hpp"
+#include "backward_hex.hpp"
 #include "generic.hpp"
 #include "kernels.hpp"
 
@@ -522,6 +523,14 @@ static int launch_backward(ilqr_batch* h, int mode) {
       hipLaunchKernelGGL(k_backward_w2<2>, dim3(h->B), dim3(64), pad, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
     else
       hipLaunchKernelGGL(k_backward_w2<1>, dim3(h->B), dim3(64), pad, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
+  } else if ((h->flags & ILQR_FLAG_BACKWARD_LANE_GROUP) && h->nx == 4 && h->nu == 1 && !(h->sp.fixes & 4)) {
+    dim3 grid(h->ntiles * 4), block(64);  // experiment: 16 lanes per trajectory, one wavefront = 4 trajectories (backward_hex.hpp)
+    if (int rc = with_model(h, [&](auto& v, auto& m, auto&) {
+          using MM = std::decay_t<decltype(m)>;
+          if constexpr (MM::NU == 1) hipLaunchKernelGGL((k_backward_h<MM>), grid, block, 0, h->stream, v, m, h->sp, mode);
+          return 0;
+        }))
+      return rc;
   } else if (use_quad_backward(h)) {
     dim3 grid(h->ntiles), block(64);  // one wavefront = one tile of 16 trajectories x 4 lanes
     if (int rc = with_model(h, [&](auto& v, auto& m, auto&) {

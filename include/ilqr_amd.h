@@ -87,7 +87,9 @@ enum ilqr_flags {
    * every trajectory and the three termination tests are disabled, so B*T*iters is exactly the
    * work done.  Accept/reject and the lambda schedule stay as in the reference. */
   ILQR_FLAG_FIXED_WORK = 1,
-  /* Backward-pass kernel choice: default picks by batch size. */
+  /* Backward-pass kernel of the stage call ilqr_backward_pass and of the two-kernel route (nx = 4 models; see
+   * DESIGN.md): the default is four lanes per trajectory; one thread per trajectory (the cross-check); sixteen
+   * lanes per trajectory (experiment, nu = 1: same results to rounding, not bit for bit). */
   ILQR_FLAG_BACKWARD_THREAD_PER_TRAJ = 2,
   ILQR_FLAG_BACKWARD_LANE_GROUP = 4,
   /* ilqr_iterate / ilqr_solve normally run the derivative sweep and the backward pass of an

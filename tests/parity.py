@@ -133,7 +133,7 @@ def twin_iterate(oracle, om, prec, x0, st, dt, fixed_work):
     return {kk: (_f64(v) if v.dtype.kind == "f" else v) for kk, v in r.items()}
 
 
-def check_backward(oracle, om, us, derivs, k_prev, lam, k, K, dV, div, ro, max_ties, precision="f64"):
+def check_backward(oracle, om, us, derivs, k_prev, lam, k, K, dV, div, ro, max_ties, precision="f64", max_over10=None):
     """One teacher-forced backward pass: device outputs (k, K [B][T][nu][nx], dV, div) against the oracle's
     `ro` (batch_backward) for every trajectory the oracle completes: per-knot gains and dV within tol and
     the same diverge flag -- or fp64 rounding shown to be the limit (conditioning_verdict) -- or a proven
@@ -169,7 +169,7 @@ def check_backward(oracle, om, us, derivs, k_prev, lam, k, K, dV, div, ro, max_t
             good[b] = True
     assert ties <= max_ties, (ties, max_ties)
     assert np.array_equal(div[good | ~conv], ro["diverge"][good | ~conv])
-    assert over10 <= max(1, B // 50), over10
+    assert over10 <= (max(1, B // 50) if max_over10 is None else max_over10), over10
     return dict(good=conv & good, ties=ties, conditioned=conditioned, cond_over10=over10)
 
 
