@@ -318,6 +318,30 @@ def main():
         extra["acrobot_T500_B1024_lim5_f64"] = {"workload": "acrobot T=499 B=1024, u in [-5,5], fp64 (BASELINE configs[1])",
                                                 "value": 1024 * T * steps / el4, "unit": "trajectory-timesteps/s",
                                                 "ms_per_step": el4 / steps * 1e3, "stages": st4}
+        # the reference's other shipped model, batched (north_star: "acrobot/double-integrator problems"; BASELINE configs[0]
+        # is its single-trajectory T=100 solve, a parity case): n=4, m=2 -- the generic m x m box-QP inside the quad kernel
+        Bd, Td, goal = 4096, 100, [1.0, 0.5, 0.0, 0.0]
+        gd = BatchILQR("integrator", Bd, Td, dt, u_min=-0.5, u_max=0.5, goal=goal, device=local_rank, stream=stream,
+                       flags=capi.FLAG_FIXED_WORK, params=dict(max_iter=args.warmup + steps + 1))
+        rd = np.random.default_rng(4321)
+        gd.init_traj(rd.uniform(-1, 1, size=(Bd, 4)) * np.array([1.5, 1.5, 0.5, 0.5]), np.zeros((Bd, Td, 2)))
+        gd.iterate(args.warmup)
+        gd.profile(True)
+        gd.profile_reset()
+        barrier()
+        t0 = time.perf_counter()
+        gd.iterate(steps)
+        barrier()
+        eld = time.perf_counter() - t0
+        pd_ = gd.profile_read()
+        assert gd.count_running() == Bd
+        named = {i: gd.lib.ilqr_stage_kernel_name(gd.h, i).decode() for i in range(capi.NUM_STAGES)}
+        extra["integrator_T100_B4096_lim0.5_f64"] = {
+            "workload": "double integrator (n=4, m=2) T=100 B=4096, u in [-0.5,0.5]^2, goal (1, 0.5, 0, 0), fp64, fixed-work iterations",
+            "value": Bd * Td * steps / eld, "unit": "trajectory-timesteps/s", "ms_per_step": eld / steps * 1e3,
+            "stages": {k: {"kernel": "k_solve_tile" if k in ("backward", "rollout", "solve") else named[capi.STAGE_NAMES.index(k)],
+                           "ms_per_launch": ms / ln, "launches": ln} for k, (ms, ln) in pd_.items() if ln}}
+        gd.close()
         # BASELINE configs[4]: synthetic LQ n=32 m=16 T=200 B=8192, limits +-1: the generic wave-per-trajectory path
         nq, mq, Tq, Bq = 32, 16, 200, 8192
         flop_ts = 4 * nq ** 3 + 10 * nq * nq * mq + 6 * nq * mq * mq + mq ** 3   # backward flops / timestep

@@ -12,9 +12,10 @@
 // Products are 4 FMAs instead of 16-32, there is no 32-move all-gather of Vxx: ~330 instructions per step.
 // The box-QP is backward_quad's (qp1_*, the quad Armijo search), evaluated by every quad of the row.
 // Sums run in rotated / tree order, so results differ from backward_quad's in the last bits (not bit-identical;
-// tests compare at 1e-9 on well-conditioned passes and against the oracle with the usual criteria).
+// tests/test_gpu_hex_backward.py compares the two to rounding and this one against the CPU restatement with the
+// usual per-knot criteria).
 //
-// Stage call only (records in HBM, ILQR_FLAG_BACKWARD_HEX): grid = 4 x tiles, one wavefront = 4 trajectories.
+// Stage call only (records in HBM, ILQR_FLAG_BACKWARD_LANE_GROUP): grid = 4 x tiles, one wavefront = 4 trajectories.
 #pragma once
 #include "kernels.hpp"
 

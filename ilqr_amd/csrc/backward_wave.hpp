@@ -24,6 +24,7 @@
 #pragma once
 #include <stddef.h>
 
+#include "boxqp.hpp"
 #include "common.hpp"
 
 namespace ilqr {
@@ -344,7 +345,7 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
     // :93-97
     {
       const double gn2 = wave_sum_row0((lane < m && !cl) ? L.grad[lane] * L.grad[lane] : 0.0);
-      if (sqrt(gn2) < kMinGrad) {
+      if (grad_norm_below_min(gn2)) {  // sqrt(gn2) < minGrad, boxqp.hpp
         result = 5;
         break;
       }

@@ -63,6 +63,12 @@ ILQR_HD void clamp_to_limits(const real* x, const real* lo, const real* hi, real
   }
 }
 
+// sqrt(gn2) < minGrad (boxqp.cpp:93-97, Eigen's norm()) without the square root: for a correctly rounded sqrt the
+// test is monotone in gn2, so it equals gn2 < y* with y* the smallest value whose root rounds to >= minGrad -- one ulp
+// below fl(1e-8^2) in double, found by search in float (tests/test_device_boxqp_on_host.py checks both against sqrt).
+ILQR_HD bool grad_norm_below_min(double gn2) { return gn2 < 0x1.cd2b297d889bcp-54; }
+ILQR_HD bool grad_norm_below_min(float gn2) { return gn2 < 0x1.cd2b28p-54f; }
+
 template <int M, class real>
 ILQR_HD real quad_cost(const real* Q, const real* c, const real* x) {
   real quad = 0, lin = 0;  // include/boxqp.h:53-55   ((0.5 x')Q) x + x.c
@@ -89,6 +95,14 @@ ILQR_HD void matvec(const real* Q, const real* x, real* y) {
   }
 }
 
+#if defined(ILQR_PHASE_TIMING) && defined(__HIPCC__) && !defined(ILQR_HOST_BUILD_OF_DEVICE_CODE)
+__device__ long long g_bq_count[4];  // (experiment builds) generic box-QP, thread 0 of block 0: QPs, iterations, factorisations, Armijo trips
+#endif
+#if defined(ILQR_PHASE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define ILQR_BQ_COUNT(k) { if (threadIdx.x == 0 && blockIdx.x == 0) g_bq_count[k] += 1; }
+#else
+#define ILQR_BQ_COUNT(k)
+#endif
 // src/boxqp.cpp:143-178.  Returns failed; x_opt/v_opt are written unless the direction is not
 // a descent direction (:151-154).
 template <int M, class real>
@@ -108,7 +122,10 @@ ILQR_HD bool quadclamp_line_search(const real* x0, const real* dir, const real* 
   real v = quad_cost<M>(Q, c, xc);
   const real old_v = quad_cost<M>(Q, c, x0);
   bool failed = false;
-  while ((v - old_v) / (step * slope) < real(kArmijo)) {
+  // (the reference's (v - old_v) / (step * slope) < armijo without the division: step * slope < 0 here, so the test is
+  //  (v - old_v) > armijo * (step * slope) up to the rounding of the quotient -- the scalar fast path's form, see below)
+  while ((v - old_v) > real(kArmijo) * (step * slope)) {
+    ILQR_BQ_COUNT(3)
     step *= real(kStepDec);
 #pragma unroll
     for (int i = 0; i < M; i++) xr[i] = x0[i] + step * dir[i];
@@ -238,7 +255,13 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
 #pragma unroll
   for (int e = 0; e < M * M; e++) res.R[e] = 0;
 
+  ILQR_BQ_COUNT(0)
+  real Minv[M * M];  // (R^-1 R^-T) of the factor held in res.R: the reference inverts R in every iteration (:105-112); R only
+#pragma unroll       // changes when the free set does, so the product is formed there and kept -- same values
+  for (int e = 0; e < M * M; e++) Minv[e] = 0;
+#pragma unroll 2  // (most QPs end in their second iteration: the loop-carried copies then sit on a back edge that is rarely taken)
   for (int iter = 0; iter <= kQpMaxIter; iter++) {  // :50
+    ILQR_BQ_COUNT(1)
     if (iter > 0 && (oldvalue - val) < real(kMinRelImprove) * abs_of(oldvalue)) {  // :54-57
       result = 4;
       break;
@@ -269,10 +292,18 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
     }
 
     if (iter == 0 || dsum != 0) {  // :80
+      ILQR_BQ_COUNT(2)
       real Qf[M * M];
 #pragma unroll
       for (int e = 0; e < M * M; e++) Qf[e] = 0;
       // extract_bool_rowsandcols (eigen_helpers.h:46-61): Qf[rank[i]][rank[j]] = Q[i][j] for free i,j
+      if constexpr (M == 2) {  // (the same selection written out: four selects instead of the 64 of the loops below)
+        const bool f0 = res.v_free[0] != 0, both = f0 && res.v_free[1] != 0;
+        Qf[0] = f0 ? Q[0] : Q[3];
+        Qf[1] = both ? Q[1] : real(0);
+        Qf[2] = both ? Q[2] : real(0);
+        Qf[3] = both ? Q[3] : real(0);
+      } else {
 #pragma unroll
       for (int a = 0; a < M; a++)
 #pragma unroll
@@ -285,6 +316,7 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
               if (res.v_free[i] && res.v_free[j] && rank[i] == a && rank[j] == b) v = Q[i + M * j];
           Qf[a + M * b] = v;
         }
+      }
       const bool indefinite = llt_lower<M>(nf, Qf);  // :85 (info() ignored ...
       if (detect_indefinite && indefinite) {       // ... unless the caller opted into the fix: result -1)
         result = -1;
@@ -295,13 +327,14 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
 #pragma unroll
         for (int b = 0; b < M; b++) res.R[a + M * b] = (a <= b && b < nf) ? Qf[b + M * a] : real(0);  // :86-88
       nfR = nf;
+      rinv_rinvT<M>(nfR, res.R, Minv);
     }
 
     real gn2 = 0;  // :93-97
 #pragma unroll
     for (int i = 0; i < M; i++)
       if (res.v_free[i]) gn2 += grad[i] * grad[i];
-    if (sqrt_of(gn2) < real(kMinGrad)) {
+    if (grad_norm_below_min(gn2)) {
       result = 5;
       break;
     }
@@ -314,8 +347,14 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
     for (int i = 0; i < M; i++) gc[i] += c[i];
 
     // :103-119  search(free) = -(R^-1 R^-T) gc(free) - x(free)
-    real Minv[M * M], gfree[M], xfree[M], sfree[M];
-    rinv_rinvT<M>(nfR, res.R, Minv);
+    real gfree[M], xfree[M], sfree[M];
+    if constexpr (M == 2) {
+      const bool f0 = res.v_free[0] != 0, both = f0 && res.v_free[1] != 0;
+      gfree[0] = f0 ? gc[0] : gc[1];
+      xfree[0] = f0 ? x[0] : x[1];
+      gfree[1] = both ? gc[1] : real(0);
+      xfree[1] = both ? x[1] : real(0);
+    } else {
 #pragma unroll
     for (int a = 0; a < M; a++) {
       real g = 0, xx = 0;
@@ -328,6 +367,7 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
       gfree[a] = g;
       xfree[a] = xx;
     }
+    }
 #pragma unroll
     for (int a = 0; a < M; a++) {
       real s = 0;
@@ -336,6 +376,11 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
         if (l < nfR) s += -Minv[a + M * l] * gfree[l];
       sfree[a] = s - xfree[a];
     }
+    if constexpr (M == 2) {
+      const bool f0 = res.v_free[0] != 0, f1 = res.v_free[1] != 0;
+      search[0] = f0 ? sfree[0] : real(0);
+      search[1] = f1 ? (f0 ? sfree[1] : sfree[0]) : real(0);
+    } else {
 #pragma unroll
     for (int i = 0; i < M; i++) {
       real s = 0;
@@ -343,6 +388,7 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
       for (int a = 0; a < M; a++)
         if (res.v_free[i] && rank[i] == a) s = sfree[a];
       search[i] = s;
+    }
     }
 
     real lx[M], lv = 0;

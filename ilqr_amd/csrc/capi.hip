@@ -702,6 +702,12 @@ void ilqr_destroy(ilqr_batch* h) {
         for (int q = 0; q < 8; q++) fprintf(stderr, "%s %.2f  ", nm[q], (double)d[t * 20 * 8 + q] / h->T);
         fprintf(stderr, "\n");
       }
+      {
+        long long bq[4];
+        if (hipMemcpyFromSymbol(bq, HIP_SYMBOL(g_bq_count), sizeof(bq)) == hipSuccess && bq[0] > 0)
+          fprintf(stderr, "[generic box-QP, trajectory 0 of tile 0, all passes] per QP: %.2f iterations, %.2f factorisations, %.2f Armijo trips beyond the first\n",
+                  (double)bq[1] / bq[0], (double)bq[2] / bq[0], (double)bq[3] / bq[0]);
+      }
       if (h->aos) {
         long long qc[8];
         if (hipMemcpyFromSymbol(qc, HIP_SYMBOL(g_qp_count), sizeof(qc)) == hipSuccess && qc[0] > 0)

@@ -62,3 +62,7 @@ extern "C" int devfn_box_qp_scalar_f32(float Q, float c, float x0, float lo, flo
 extern "C" int devfn_box_qp_scalar_fast_f32(float Q, float c, float x0, float lo, float hi, float* x, int* fr, float* minv) {
   return box_qp_scalar_fast(Q, c, x0, lo, hi, *x, *fr, *minv);
 }
+
+// sqrt(gn2) < minGrad without the square root (boxqp.hpp): the product's test next to the literal one
+extern "C" int devfn_grad_norm_below_min(double gn2) { return grad_norm_below_min(gn2) ? 1 : 0; }
+extern "C" int devfn_grad_norm_below_min_f32(float gn2) { return grad_norm_below_min(gn2) ? 1 : 0; }

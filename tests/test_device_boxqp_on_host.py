@@ -120,3 +120,33 @@ def test_float_instantiation_against_the_fp32_oracle(oracle, dev):
                     if fr.value != ro["v_free"][0] or abs(xs.value - ro["x_opt"][0]) > 2e-5 + 2e-4 * abs(xs.value):
                         n_tie += 1
     assert n_tie <= N // 100, n_tie
+
+
+def test_gradient_norm_test_without_the_square_root(dev):
+    """boxqp.cpp:93-97 tests sqrt(|g|^2) < 1e-8; the device code tests |g|^2 < y* (the smallest value whose correctly
+    rounded root is >= 1e-8).  Equivalent for every input: checked on the 4001 doubles / floats around the threshold,
+    on random magnitudes, and on 0 / denormals / inf / nan."""
+    dev.devfn_grad_norm_below_min.argtypes = [C.c_double]
+    dev.devfn_grad_norm_below_min_f32.argtypes = [C.c_float]
+    t = np.float64(1e-8)
+    y = t * t
+    cases = [0.0, 5e-324, 1e-300, 1e-20, 1e-12, 1.0, 1e300, np.inf, np.nan]
+    v = y
+    for _ in range(2000):
+        v = np.nextafter(v, 0)
+    for _ in range(4001):
+        cases.append(float(v))
+        v = np.nextafter(v, 1)
+    cases += list(10.0 ** np.random.default_rng(0).uniform(-40, 5, 2000))
+    for gn2 in cases:
+        assert bool(dev.devfn_grad_norm_below_min(gn2)) == bool(np.sqrt(np.float64(gn2)) < t), gn2
+    t32 = np.float32(1e-8)
+    v = np.float32(t32 * t32)
+    cases32 = [np.float32(0), np.float32(1e-45), np.float32(1e-30), np.float32(1.0), np.float32(np.inf), np.float32(np.nan)]
+    for _ in range(2000):
+        v = np.nextafter(v, np.float32(0))
+    for _ in range(4001):
+        cases32.append(v)
+        v = np.nextafter(v, np.float32(1))
+    for gn2 in cases32:
+        assert bool(dev.devfn_grad_norm_below_min_f32(float(gn2))) == bool(np.sqrt(np.float32(gn2)) < t32), gn2
