@@ -570,7 +570,10 @@ template <class V, class M, class MFD>
 static void launch_sweep_backward_t(ilqr_batch* h, const V& v, const M& m, const MFD& fdm, int variant, int mode, int force, const int* ci) {
   if (variant == 2)
     hipLaunchKernelGGL((k_sweep_backward<M, 1, kRingKbTwoBlocks, MFD>), dim3(h->ntiles), dim3(64 * 2), 0, h->stream, v, m, fdm, h->sp, mode, force, ci);
-  else
+  else if (M::NU == 1 && getenv("ILQR_AMD_HEX")) {  // experiment: four backward wavefronts per tile, 16 lanes per trajectory
+    if constexpr (M::NU == 1)
+      hipLaunchKernelGGL((k_sweep_backward_h<M, kProducers, ILQR_RING_KB, MFD>), dim3(h->ntiles), dim3(64 * (4 + kProducers)), 0, h->stream, v, m, fdm, h->sp, mode, force, ci);
+  } else
     hipLaunchKernelGGL((k_sweep_backward<M, kProducers, ILQR_RING_KB, MFD>), dim3(h->ntiles), dim3(64 * (1 + kProducers)), 0, h->stream, v, m, fdm, h->sp, mode, force, ci);
 }
 static int launch_sweep_backward(ilqr_batch* h, int mode, int force) {
@@ -700,6 +703,17 @@ void ilqr_destroy(ilqr_batch* h) {
       for (int t = 0; t < 3; t++) {
         fprintf(stderr, "[phase timing, tile %d, last backward pass] ", t * 20);
         for (int q = 0; q < 8; q++) fprintf(stderr, "%s %.2f  ", nm[q], (double)d[t * 20 * 8 + q] / h->T);
+        fprintf(stderr, "\n");
+      }
+      if (d[923] > 0)
+        fprintf(stderr, "[k_backward_q, block 0, last pass] %lld shader cycles in %lld wall ticks of 10 ns: %.3f GHz, %.0f cycles per step\n", d[922], d[923],
+                (double)d[922] / (10.0 * d[923]), (double)d[922] / h->T);
+      if (d[921] > 0)
+        fprintf(stderr, "[k_backward_h, block 0, last pass] %lld shader cycles in %lld wall ticks of 10 ns: %.3f GHz, %.0f cycles per step\n", d[920], d[921],
+                (double)d[920] / (10.0 * d[921]), (double)d[920] / h->T);
+      for (int t = 0; t < 2; t++) {
+        fprintf(stderr, "[hex fused, tile %d] HW_ID per wavefront (simd = bits 5:4, wave slot = bits 3:0, cu = bits 11:8):", t);
+        for (int w = 0; w < 8; w++) fprintf(stderr, " w%d: simd %lld slot %lld cu %lld |", w, (d[900 + t * 8 + w] >> 4) & 3, d[900 + t * 8 + w] & 15, (d[900 + t * 8 + w] >> 8) & 15);
         fprintf(stderr, "\n");
       }
       {

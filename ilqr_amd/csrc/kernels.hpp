@@ -450,11 +450,16 @@ __device__ __forceinline__ void fd_gradient(const real* x, F f, real* out) {
 #ifndef ILQR_RING_KB
 #define ILQR_RING_KB 150  // one block per CU; the two-blocks-per-CU variant of k_sweep_backward uses 60
 #endif
-template <int NX, int NU, class real, int RING_KB = ILQR_RING_KB>
+// PAD: extra `real`s per pair row.  0 = the HBM tile layout (row = 16 trajectories x 2 elements = a whole number of LDS
+// bank cycles: rows of the same trajectory share their banks, which is what the 4-lane backward wavefront wants -- its
+// lanes read one row for 16 trajectories).  The 16-lane backward wavefronts (backward_hex.hpp) read up to 8 ROWS for
+// one trajectory with one instruction: PAD = 2 (16 bytes) spreads the rows over the banks.
+template <int NX, int NU, class real, int RING_KB = ILQR_RING_KB, int PAD = 0>
 struct RingSlot {
   static constexpr int US = Rec<NX, NU>::SIZE;               // controls follow the record
   static constexpr int PAIRS = (Rec<NX, NU>::SIZE + NU + 1) / 2;
-  static constexpr int ELEMS = PAIRS * 2 * TW;               // per slot, in units of `real`
+  static constexpr int ROW = 2 * TW + PAD;                   // `real`s from one element pair to the next
+  static constexpr int ELEMS = PAIRS * ROW;                  // per slot, in units of `real`
   static constexpr int SLOTS = ((RING_KB * 1024 / (int)sizeof(real)) / ELEMS) / 4 * 4;  // ring size: what fits in RING_KB of LDS
 };
 
@@ -464,7 +469,7 @@ struct RingSlot {
 // the knot (float) is widened, the sweep below runs in double exactly as for an fp64 handle, and the record
 // is rounded to float when stored.  Rollouts, the commit and the analytic route stay in the handle's own
 // arithmetic (`model`).
-template <class M, bool RING = false, class MFD = M>
+template <class M, bool RING = false, class MFD = M, int RING_PAD = 0>
 __device__ __forceinline__ void derivatives_of_knot(const BatchViewT<typename M::real>& v, const M& model, const MFD& fdm, int force,
                                                     const int* __restrict__ commit_idx, int tile, int t, int l,
                                                     typename M::real* rs = nullptr, bool records = true) {
@@ -512,7 +517,7 @@ __device__ __forceinline__ void derivatives_of_knot(const BatchViewT<typename M:
   auto put = [&](int e, fdr val_) {
     const real val = (real)val_;
     if (RING)
-      rs[(e >> 1) * (2 * TW) + (e & 1)] = val;
+      rs[(e >> 1) * (2 * TW + RING_PAD) + (e & 1)] = val;
     else
       D[(size_t)(e >> 1) * (2 * TW) + (e & 1)] = val;
   };
@@ -521,13 +526,13 @@ __device__ __forceinline__ void derivatives_of_knot(const BatchViewT<typename M:
     w.x = (real)v0;
     w.y = (real)v1;
     if (RING)
-      *reinterpret_cast<real2_t*>(rs + (e >> 1) * (2 * TW)) = w;
+      *reinterpret_cast<real2_t*>(rs + (e >> 1) * (2 * TW + RING_PAD)) = w;
     else
       *reinterpret_cast<real2_t*>(D + (size_t)(e >> 1) * (2 * TW)) = w;
   };
   if (RING) {
 #pragma unroll
-    for (int j = 0; j < NU; j++) rs[((RSl::US + j) >> 1) * (2 * TW) + ((RSl::US + j) & 1)] = uk[j];
+    for (int j = 0; j < NU; j++) rs[((RSl::US + j) >> 1) * (2 * TW + RING_PAD) + ((RSl::US + j) & 1)] = uk[j];
   }
 
   if (v.analytic) {  // opt-in: the model's exact derivatives (wave-uniform branch)
@@ -1731,7 +1736,16 @@ __global__ __launch_bounds__(64) void k_backward_q(BatchViewT<typename M::real> 
   __shared__ real lds_steps[104];  // backtracking step sizes (per-lane indexed -> LDS, not constant cache)
   load_step_table(lds_steps);
   NoGate gate;
+#ifdef ILQR_PHASE_TIMING
+  const long long c0 = clock64(), w0 = wall_clock64();
+#endif
   backward_quad(v, model, sp, mode, (int)blockIdx.x, (int)threadIdx.x, lds_steps, gate);
+#ifdef ILQR_PHASE_TIMING
+  if (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) {  // shader cycles (s_memtime) and 100 MHz wall ticks of the pass: the clock the chip ran at
+    v.dbg[922] = clock64() - c0;
+    v.dbg[923] = wall_clock64() - w0;
+  }
+#endif
 }
 
 #ifndef ILQR_PRODUCERS
@@ -1742,9 +1756,9 @@ constexpr int kProducers = ILQR_PRODUCERS;
 #define ILQR_LEAD_ROUNDS 1
 #endif
 // LDS of one tile's sweep + backward pass
-template <class real, int NX, int NU, int kProd, int RING_KB>
+template <class real, int NX, int NU, int kProd, int RING_KB, int PAD = 0>
 struct SweepShared {
-  using RS = RingSlot<NX, NU, real, RING_KB>;
+  using RS = RingSlot<NX, NU, real, RING_KB, PAD>;
   real steps[104];                    // backtracking step sizes (per-lane indexed -> LDS, not constant cache)
   real ring[RS::SLOTS * RS::ELEMS];   // knot with running index G lives in slot G % SLOTS
   int rounds_done[kProd];             // rounds (counted across passes) whose records are in the ring

@@ -69,3 +69,44 @@ def test_hex_backward_fp32(oracle):
     den = np.maximum(np.abs(q["K"]).reshape(B, -1).max(axis=1), 1e-300)
     err = np.abs(h["K"] - q["K"]).reshape(B, -1).max(axis=1) / den
     assert np.median(err) < 1e-3, np.median(err)  # (float rounding through a 60-step recursion)
+
+
+def test_hex_fused_sweep_matches_the_default_route(oracle):
+    """ILQR_AMD_HEX=1 (experiment): the fused sweep + backward pass with FOUR 16-lane backward wavefronts per tile and the
+    tile-wide pass votes of RingGateH, per-stage launches.  One iteration from the same start agrees with the default
+    route to rounding (gains per trajectory, lambda schedule, accepted step); a solve to termination ends with the
+    same statuses for all but a few trajectories (last-bit differences meet ties over many iterations) and never
+    costs more than marginally."""
+    import os
+    from ilqr_amd import BatchILQR, capi
+    B, T = 100, 60  # (7 tiles, the last one partly filled)
+    rng = np.random.default_rng(5)
+    x0 = rng.uniform(-1, 1, (B, 4)) * np.array([np.pi, np.pi, 1, 1]) * 0.5
+    outs = {}
+    for label in ("quad", "hex"):
+        if label == "hex":
+            os.environ["ILQR_AMD_HEX"] = "1"
+        try:
+            g = BatchILQR("acrobot", B, T, DT, flags=capi.FLAG_STAGED, u_min=-1.5, u_max=1.5, params=dict(max_iter=40))
+            g.init_traj(x0, np.zeros((B, T, 1)))
+            g.iterate(1)
+            k, K = g.gains()
+            lam, _ = g.lambdas()
+            st, it, al = g.status()
+            first = dict(K=K.copy(), lam=lam.copy(), al=np.asarray(al).copy(), cost=g.cost().copy())
+            g.generate_trajectory()
+            st, it, al = g.status()
+            outs[label] = dict(first=first, cost=g.cost(), st=np.asarray(st), it=np.asarray(it))
+            g.close()
+        finally:
+            os.environ.pop("ILQR_AMD_HEX", None)
+    q, h = outs["quad"], outs["hex"]
+    den = np.maximum(np.abs(q["first"]["K"]).reshape(B, -1).max(axis=1), 1e-300)
+    err = np.abs(h["first"]["K"] - q["first"]["K"]).reshape(B, -1).max(axis=1) / den
+    assert np.median(err) < 1e-10 and (err < 1e-6).mean() >= 0.95, (np.median(err), (err < 1e-6).mean())
+    same = err < 1e-6
+    assert np.array_equal(h["first"]["al"][same], q["first"]["al"][same]) and np.array_equal(h["first"]["lam"][same], q["first"]["lam"][same])
+    assert np.allclose(h["first"]["cost"][same], q["first"]["cost"][same], rtol=1e-9)
+    assert np.all(np.isfinite(h["cost"])) and np.all(h["st"] != 0)
+    assert (h["st"] == q["st"]).mean() >= 0.9
+    assert np.median(h["cost"] / q["cost"]) < 1.001
