@@ -705,6 +705,9 @@ void ilqr_destroy(ilqr_batch* h) {
         for (int q = 0; q < 8; q++) fprintf(stderr, "%s %.2f  ", nm[q], (double)d[t * 20 * 8 + q] / h->T);
         fprintf(stderr, "\n");
       }
+      if (d[925] > 0 && d[927] > 0)
+        fprintf(stderr, "[k_solve_tile, tile 0, last launch] phase 1: %.3f GHz, phase 2: %.3f GHz (shader cycles / wall)\n", (double)d[924] / (10.0 * d[925]),
+                (double)d[926] / (10.0 * d[927]));
       if (d[923] > 0)
         fprintf(stderr, "[k_backward_q, block 0, last pass] %lld shader cycles in %lld wall ticks of 10 ns: %.3f GHz, %.0f cycles per step\n", d[922], d[923],
                 (double)d[922] / (10.0 * d[923]), (double)d[922] / h->T);

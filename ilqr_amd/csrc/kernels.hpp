@@ -1930,20 +1930,34 @@ __global__ __launch_bounds__(256) void k_solve_tile(BatchViewT<typename M::real>
   const int tile = blockIdx.x;
   long long t_sweep = 0, t_roll = 0, t0 = 0;
   const bool timing = (phase_ticks != nullptr) & (threadIdx.x == 0);
+#ifdef ILQR_PHASE_TIMING
+  long long c_sweep = 0, c_roll = 0, c0 = 0;  // the same in shader cycles (s_memtime): cycles / wall = the clock the chip ran at
+#endif
   int it = 0;
   for (; it < n_iters; it++) {
     if (timing) t0 = wall_clock64();
+#ifdef ILQR_PHASE_TIMING
+    if (timing) c0 = clock64();
+#endif
     sweep_backward_tile<M, kProducers, ILQR_RING_KB, MFD>(v, model, fdm, sp, 1, force, (it > 0 || commit_pending) ? commit_idx : nullptr, tile, sh);
     phase_barrier();  // the tile's gains, lambda, status are in memory for its rollout wavefronts
     if (timing) {
       const long long t1 = wall_clock64();
       t_sweep += t1 - t0;
       t0 = t1;
+#ifdef ILQR_PHASE_TIMING
+      const long long c1 = clock64();
+      c_sweep += c1 - c0;
+      c0 = c1;
+#endif
     }
     rollout_tile<M, true, true, kDeepPrefetch<M>, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, commit_idx, tile, lds_cost, /*count_running=*/it == n_iters - 1);
     if (threadIdx.x == 0) tile_running = 0;
     phase_barrier();  // candidates, costs, status, commit indices are in memory for the next sweep
     if (timing) t_roll += wall_clock64() - t0;
+#ifdef ILQR_PHASE_TIMING
+    if (timing) c_roll += clock64() - c0;
+#endif
     if (!sp.fixed_work) {  // has every trajectory of the tile left its loop?
       const int b = tile * TW + (int)threadIdx.x;
       if (threadIdx.x < TW && b < v.B && v.status[b] == 0) tile_running = 1;
@@ -1954,6 +1968,14 @@ __global__ __launch_bounds__(256) void k_solve_tile(BatchViewT<typename M::real>
       }
     }
   }
+#ifdef ILQR_PHASE_TIMING
+  if (timing && v.dbg && tile == 0) {
+    v.dbg[924] = c_sweep;
+    v.dbg[925] = t_sweep;
+    v.dbg[926] = c_roll;
+    v.dbg[927] = t_roll;
+  }
+#endif
   if (timing) {
     phase_ticks[3 * tile + 0] += t_sweep;
     phase_ticks[3 * tile + 1] += t_roll;
