@@ -1102,7 +1102,9 @@ struct NoGate {
   __device__ __forceinline__ void finish() {}
 };
 
-template <class M, class Gate, int RING_KB = ILQR_RING_KB>
+// FIXES: the opt-in deviations (sp.fixes) are compiled in; callers branch ONCE on sp.fixes != 0 and
+// run the copy without them otherwise -- inside the step their tests were 10 instructions of the common path.
+template <class M, class Gate, int RING_KB = ILQR_RING_KB, bool FIXES = true>
 __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>& v, const M& model, const SolverParams& sp, int mode,
                                               int tile, int lane, const typename M::real* __restrict__ lds_steps, Gate& gate,
                                               const typename M::real* ring = nullptr) {
@@ -1314,7 +1316,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       real Quxr[NU];
 #pragma unroll
       for (int a = 0; a < NU; a++) Quxr[a] = Quxc[a];
-      const bool reg_vxx = (sp.fixes & 4) != 0;
+      const bool reg_vxx = FIXES && (sp.fixes & 4) != 0;
       if (reg_vxx) {
 #pragma unroll
         for (int a = 0; a < NU; a++) {
@@ -1350,7 +1352,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         int free0;
         real minv;
         QP1StateT<real> q1;
-        qp1_begin<false>(QuuF[0], Qu[0], kprev[0], lo[0], hi[0], q1, (sp.fixes & 2) != 0);
+        qp1_begin<false>(QuuF[0], Qu[0], kprev[0], lo[0], hi[0], q1, FIXES && (sp.fixes & 2) != 0);
 #ifdef ILQR_PHASE_TIMING
         int why = 0;
         if (!qp1_search_quad(q1, s, lane, lds_steps, &why)) {  // fallback: rare
@@ -1411,7 +1413,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         k_minv = minv;
       } else {
         BoxQPResult<NU, real> r;
-        box_qp<NU>(QuuF, Qu, kprev, lo, hi, r, (sp.fixes & 2) != 0);
+        box_qp<NU>(QuuF, Qu, kprev, lo, hi, r, FIXES && (sp.fixes & 2) != 0);
         ok = r.result >= 1;
 #pragma unroll
         for (int a = 0; a < NU; a++) {
@@ -1739,7 +1741,10 @@ __global__ __launch_bounds__(64) void k_backward_q(BatchViewT<typename M::real> 
 #ifdef ILQR_PHASE_TIMING
   const long long c0 = clock64(), w0 = wall_clock64();
 #endif
-  backward_quad(v, model, sp, mode, (int)blockIdx.x, (int)threadIdx.x, lds_steps, gate);
+  if (sp.fixes)
+    backward_quad<M, NoGate, ILQR_RING_KB, true>(v, model, sp, mode, (int)blockIdx.x, (int)threadIdx.x, lds_steps, gate);
+  else
+    backward_quad<M, NoGate, ILQR_RING_KB, false>(v, model, sp, mode, (int)blockIdx.x, (int)threadIdx.x, lds_steps, gate);
 #ifdef ILQR_PHASE_TIMING
   if (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) {  // shader cycles (s_memtime) and 100 MHz wall ticks of the pass: the clock the chip ran at
     v.dbg[922] = clock64() - c0;
@@ -1836,7 +1841,10 @@ __device__ __forceinline__ void sweep_backward_tile(const BatchViewT<typename M:
   if (wave == 0) {
     __builtin_amdgcn_s_setprio(3);
     RingGate<SH, kProd> gate(sh, T);
-    backward_quad<M, decltype(gate), RING_KB>(v, model, sp, mode, tile, lane, sh.steps, gate, sh.ring);
+    if (sp.fixes)
+      backward_quad<M, decltype(gate), RING_KB, true>(v, model, sp, mode, tile, lane, sh.steps, gate, sh.ring);
+    else
+      backward_quad<M, decltype(gate), RING_KB, false>(v, model, sp, mode, tile, lane, sh.steps, gate, sh.ring);
 #ifdef ILQR_PHASE_TIMING
     if (v.dbg && lane == 0 && tile < 64) v.dbg[tile * 8 + 7] = gate.spins;
 #endif
