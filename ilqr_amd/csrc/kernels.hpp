@@ -1781,6 +1781,10 @@ struct RingGate {
   SH& sh;
   const int T, nrounds, N;
   int pass = -1, have = 0;
+  // wait(t) is called for t = T, T-1, T-2, ... within a pass (the backward pass prefetches in that order), so the
+  // running index of the knot and its ring slot are carried along instead of recomputed (a multiply-high modulo and
+  // half a dozen scalar instructions per step on the backward wavefront's chain)
+  int g_next = 0, slot_next = 0, slot_cur = 0;
 #ifdef ILQR_PHASE_TIMING
   long long spins = 0;
 #endif
@@ -1788,13 +1792,18 @@ struct RingGate {
   __device__ __forceinline__ void begin_pass() {  // wave-uniform among the lanes still in the pass loop
     pass++;
     have = pass * N;
+    g_next = pass * N;
+    slot_next = g_next % SH::RS::SLOTS;
     __hip_atomic_store(&sh.pass_lanes, __ballot(1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_store(&sh.passes_started, pass + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  __device__ __forceinline__ int slot(int t) const { return (pass * N + (T - t)) % SH::RS::SLOTS; }
-  __device__ __forceinline__ void wait(int t) {
-    const int j = T - t, G = pass * N + j;
+  __device__ __forceinline__ int slot(int) const { return slot_cur; }  // of the knot last waited for
+  __device__ __forceinline__ void wait(int) {
+    const int G = g_next++;
+    slot_cur = slot_next;
+    slot_next = (slot_next + 1 == SH::RS::SLOTS) ? 0 : slot_next + 1;
     if (G < have) return;
+    const int j = G - pass * N;
     const int round = pass * nrounds + j / kKnotsPerRound, w = (j % kKnotsPerRound) / 4;
     __hip_atomic_store(&sh.consumer_at, G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     while (__hip_atomic_load(&sh.rounds_done[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= round) {
