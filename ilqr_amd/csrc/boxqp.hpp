@@ -98,10 +98,18 @@ ILQR_HD void matvec(const real* Q, const real* x, real* y) {
 #if defined(ILQR_PHASE_TIMING) && defined(__HIPCC__) && !defined(ILQR_HOST_BUILD_OF_DEVICE_CODE)
 __device__ long long g_bq_count[4];  // (experiment builds) generic box-QP, thread 0 of block 0: QPs, iterations, factorisations, Armijo trips
 #endif
+#if defined(ILQR_PHASE_TIMING) && defined(__HIPCC__) && !defined(ILQR_HOST_BUILD_OF_DEVICE_CODE)
+__device__ long long g_bq_cycles[8];  // ... and shader cycles per section: setup, gradient + clamp set, factor + inverse, direction, line search, rest
+#endif
 #if defined(ILQR_PHASE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
 #define ILQR_BQ_COUNT(k) { if (threadIdx.x == 0 && blockIdx.x == 0) g_bq_count[k] += 1; }
+#define ILQR_BQ_T0 long long bq_t_ = clock64(), bq_acc_[6] = {0, 0, 0, 0, 0, 0};
+#define ILQR_BQ_MARK(k) { __builtin_amdgcn_sched_barrier(0); const long long n_ = clock64(); bq_acc_[k] += n_ - bq_t_; bq_t_ = n_; __builtin_amdgcn_sched_barrier(0); \
+    if (k == 5 && threadIdx.x == 0 && blockIdx.x == 0) { for (int q_ = 0; q_ < 6; q_++) g_bq_cycles[q_] += bq_acc_[q_]; } }
 #else
 #define ILQR_BQ_COUNT(k)
+#define ILQR_BQ_T0
+#define ILQR_BQ_MARK(k)
 #endif
 // src/boxqp.cpp:143-178.  Returns failed; x_opt/v_opt are written unless the direction is not
 // a descent direction (:151-154).
@@ -226,6 +234,7 @@ struct BoxQPResult {
 template <int M, class real>
 ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo,
                                        const real* hi, BoxQPResult<M, real>& res, bool detect_indefinite = false) {
+  ILQR_BQ_T0
   real x[M], grad[M], gc[M], search[M], tmp[M];
   real clamped[M], old_clamped[M];
   clamp_to_limits<M>(x0, lo, hi, x);  // :35
@@ -259,6 +268,7 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
   real Minv[M * M];  // (R^-1 R^-T) of the factor held in res.R: the reference inverts R in every iteration (:105-112); R only
 #pragma unroll       // changes when the free set does, so the product is formed there and kept -- same values
   for (int e = 0; e < M * M; e++) Minv[e] = 0;
+  ILQR_BQ_MARK(0)
 #pragma unroll 2  // (most QPs end in their second iteration: the loop-carried copies then sit on a back edge that is rarely taken)
   for (int iter = 0; iter <= kQpMaxIter; iter++) {  // :50
     ILQR_BQ_COUNT(1)
@@ -286,6 +296,7 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
       rank[i] = nf;
       nf += cl ? 0 : 1;
     }
+    ILQR_BQ_MARK(1)
     if (all_clamped) {  // :74-77
       result = 6;
       break;
@@ -329,6 +340,7 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
       nfR = nf;
       rinv_rinvT<M>(nfR, res.R, Minv);
     }
+    ILQR_BQ_MARK(2)
 
     real gn2 = 0;  // :93-97
 #pragma unroll
@@ -391,8 +403,10 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
     }
     }
 
+    ILQR_BQ_MARK(3)
     real lx[M], lv = 0;
     const bool failed = quadclamp_line_search<M>(x, search, Q, c, lo, hi, lx, lv);  // :121
+    ILQR_BQ_MARK(4)
     if (failed) {  // :122-125
       result = 2;
       break;
@@ -405,6 +419,7 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
   for (int i = 0; i < M; i++) res.x[i] = x[i];
   res.result = result;
   res.nfR = nfR;
+  ILQR_BQ_MARK(5)
 }
 
 

@@ -724,6 +724,10 @@ void ilqr_destroy(ilqr_batch* h) {
         if (hipMemcpyFromSymbol(bq, HIP_SYMBOL(g_bq_count), sizeof(bq)) == hipSuccess && bq[0] > 0)
           fprintf(stderr, "[generic box-QP, trajectory 0 of tile 0, all passes] per QP: %.2f iterations, %.2f factorisations, %.2f Armijo trips beyond the first\n",
                   (double)bq[1] / bq[0], (double)bq[2] / bq[0], (double)bq[3] / bq[0]);
+        long long bc[8];
+        if (bq[0] > 0 && hipMemcpyFromSymbol(bc, HIP_SYMBOL(g_bq_cycles), sizeof(bc)) == hipSuccess)
+          fprintf(stderr, "[generic box-QP] shader cycles per QP: setup %.0f  gradient + clamp set %.0f  factor + inverse %.0f  direction %.0f  line search %.0f  exits + copy-out %.0f\n",
+                  (double)bc[0] / bq[0], (double)bc[1] / bq[0], (double)bc[2] / bq[0], (double)bc[3] / bq[0], (double)bc[4] / bq[0], (double)bc[5] / bq[0]);
       }
       if (h->aos) {
         long long qc[8];
