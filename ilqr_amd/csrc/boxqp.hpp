@@ -628,13 +628,51 @@ ILQR_HD int qp1_finish(const QP1StateT<real>& q, real& x_out, int& free_out, rea
 // the bound: the Newton target stays outside, so they creep towards the bound over several
 // iterations.  Restarting the literal loop from iteration 0 for them (as the first version did)
 // made their wavefront the slowest of the launch once a solve had run ~20 iterations.
+#if defined(ILQR_PHASE_TIMING) && defined(__HIPCC__) && !defined(ILQR_HOST_BUILD_OF_DEVICE_CODE)
+__device__ unsigned long long g_qc_count[8];  // (experiment builds) qp1_continue, all lanes: entries, shortcut, loop iterations, results 4 / 6 / 5 / 2, line-search failures
+#endif
+#if defined(ILQR_PHASE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define ILQR_QC_COUNT(k) atomicAdd(&g_qc_count[k], 1ull);
+#else
+#define ILQR_QC_COUNT(k)
+#endif
 template <class real, class LineSearch>
 ILQR_HD int qp1_continue(QP1StateT<real>& q, LineSearch line_search, real& x_out, int& free_out) {
   real x = q.x1, val = q.v1, oldvalue = q.val0;
   int result = 0, free_ = 1;
+  ILQR_QC_COUNT(0)
+  if constexpr (sizeof(real) == 8) {  // (in float neither of the two exits below is reachable often enough: measured, the test only costs)
+    // The usual reason to be here late in a solve: x1 is the optimum to rounding, but with Quu ~ 1e10 its gradient
+    // Quu * (an ulp of error) is still above minGrad and the Newton step of iteration 1, a few 1e-17, still moves x.
+    // Iteration 1 then accepts the unit step and iteration 2 leaves through the improvement test (:54-57, result 4)
+    // Those two iterations written out (same expressions, same order; taken only if that IS what happens): the loop
+    // below with its line search cost ~6000 cycles of the wavefront for it, a quarter of the late-solve step.
+    const real g1 = q.Q * x + q.c;
+    const real s1 = -q.minv * q.c - x;
+    const real slope1 = s1 * g1;
+    const real x2 = min_of(max_of(x + real(1) * s1, q.lo), q.hi);  // qp1_trial at step 1
+    const real v2 = qp1_value(q, x2);
+    const bool unit_passes = !((v2 - val) > real(kArmijo) * (real(1) * slope1));  // qp1_armijo_fails, old_v = value(x1) = val
+    const bool moved = x2 != x;  // (x2 == x is exit H's business: the caller has excluded it, but stay exact)
+    const bool tiny = (val - v2) < real(kMinRelImprove) * abs_of(val);  // iteration 2's first test
+    // ... or, three times in four (counted), through the gradient test (:93-97, result 5): the step was a real one and
+    // x2 is the optimum to rounding.
+    const real g2 = q.Q * x2 + q.c;
+    const bool cl2 = ((abs_of(x2 - q.lo) < real(kClampTol)) & (g2 > 0)) | ((abs_of(x2 - q.hi) < real(kClampTol)) & (g2 < 0));
+    const bool flat2 = abs_of(g2) < real(kMinGrad);
+    const bool stepped = unit_passes & moved & (slope1 < real(0));
+    if (stepped & (tiny | (!cl2 & flat2))) {
+      ILQR_QC_COUNT(1)
+      x_out = x2;
+      free_out = 1;
+      return tiny ? 4 : 5;
+    }
+  }
   for (int iter = 1; iter <= kQpMaxIter; iter++) {
+    ILQR_QC_COUNT(2)
     if ((oldvalue - val) < real(kMinRelImprove) * abs_of(oldvalue)) {  // boxqp.cpp:54-57 (iter > 0 here)
       result = 4;
+      ILQR_QC_COUNT(3)
       break;
     }
     const real grad = q.Q * x + q.c;
@@ -643,11 +681,13 @@ ILQR_HD int qp1_continue(QP1StateT<real>& q, LineSearch line_search, real& x_out
     if (cl) {  // :74-77
       free_ = 0;
       result = 6;
+      ILQR_QC_COUNT(4)
       break;
     }
     free_ = 1;
     if (abs_of(grad) < real(kMinGrad)) {  // :93-97
       result = 5;
+      ILQR_QC_COUNT(5)
       break;
     }
     q.x = x;
@@ -656,6 +696,7 @@ ILQR_HD int qp1_continue(QP1StateT<real>& q, LineSearch line_search, real& x_out
     q.slope = q.search * grad;
     if (q.slope >= 0) {  // :150-153
       result = 2;
+      ILQR_QC_COUNT(6)
       break;
     }
     q.old_v = qp1_value(q, x);
@@ -665,6 +706,7 @@ ILQR_HD int qp1_continue(QP1StateT<real>& q, LineSearch line_search, real& x_out
     line_search(q);
     if (q.ls_failed) {  // :121-125
       result = 2;
+      ILQR_QC_COUNT(7)
       break;
     }
     x = q.x1;

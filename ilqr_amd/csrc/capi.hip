@@ -714,6 +714,12 @@ void ilqr_destroy(ilqr_batch* h) {
       if (d[921] > 0)
         fprintf(stderr, "[k_backward_h, block 0, last pass] %lld shader cycles in %lld wall ticks of 10 ns: %.3f GHz, %.0f cycles per step\n", d[920], d[921],
                 (double)d[920] / (10.0 * d[921]), (double)d[920] / h->T);
+      {
+        unsigned long long qc[8];
+        if (hipMemcpyFromSymbol(qc, HIP_SYMBOL(g_qc_count), sizeof(qc)) == hipSuccess && qc[0] > 0)
+          fprintf(stderr, "[qp1_continue, all lanes, whole run] entries %llu: two-iteration shortcut %.3f, loop iterations per entry %.2f; loop exits: improvement (4) %.3f, clamped (6) %.3f, gradient (5) %.3f, no descent (2) %.3f, line search failed (2) %.3f\n",
+                  qc[0], (double)qc[1] / qc[0], (double)qc[2] / qc[0], (double)qc[3] / qc[0], (double)qc[4] / qc[0], (double)qc[5] / qc[0], (double)qc[6] / qc[0], (double)qc[7] / qc[0]);
+      }
       for (int t = 0; t < 2; t++) {
         fprintf(stderr, "[hex fused, tile %d] HW_ID per wavefront (simd = bits 5:4, wave slot = bits 3:0, cu = bits 11:8):", t);
         for (int w = 0; w < 8; w++) fprintf(stderr, " w%d: simd %lld slot %lld cu %lld |", w, (d[900 + t * 8 + w] >> 4) & 3, d[900 + t * 8 + w] & 15, (d[900 + t * 8 + w] >> 8) & 15);
