@@ -641,7 +641,7 @@ ILQR_HD int qp1_continue(QP1StateT<real>& q, LineSearch line_search, real& x_out
   real x = q.x1, val = q.v1, oldvalue = q.val0;
   int result = 0, free_ = 1;
   ILQR_QC_COUNT(0)
-  if constexpr (sizeof(real) == 8) {  // (in float neither of the two exits below is reachable often enough: measured, the test only costs)
+  {
     // The usual reason to be here late in a solve: x1 is the optimum to rounding, but with Quu ~ 1e10 its gradient
     // Quu * (an ulp of error) is still above minGrad and the Newton step of iteration 1, a few 1e-17, still moves x.
     // Iteration 1 then accepts the unit step and iteration 2 leaves through the improvement test (:54-57, result 4)
@@ -660,12 +660,16 @@ ILQR_HD int qp1_continue(QP1StateT<real>& q, LineSearch line_search, real& x_out
     const real g2 = q.Q * x2 + q.c;
     const bool cl2 = ((abs_of(x2 - q.lo) < real(kClampTol)) & (g2 > 0)) | ((abs_of(x2 - q.hi) < real(kClampTol)) & (g2 < 0));
     const bool flat2 = abs_of(g2) < real(kMinGrad);
+    // ... or -- float's usual one, where |g| < 1e-8 is out of reach -- because iteration 2's own direction is no descent
+    // direction (:150-153, result 2, x2 kept).
+    const real s2 = -q.minv * q.c - x2;
+    const bool nodesc2 = (s2 * g2) >= real(0);
     const bool stepped = unit_passes & moved & (slope1 < real(0));
-    if (stepped & (tiny | (!cl2 & flat2))) {
+    if (stepped & (tiny | (!cl2 & (flat2 | nodesc2)))) {
       ILQR_QC_COUNT(1)
       x_out = x2;
       free_out = 1;
-      return tiny ? 4 : 5;
+      return tiny ? 4 : (flat2 ? 5 : 2);
     }
   }
   for (int iter = 1; iter <= kQpMaxIter; iter++) {
