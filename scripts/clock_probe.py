@@ -1,5 +1,10 @@
+"""Acrobot headline workload, 10 iterations in the persistent kernel; with an experiment build (-DILQR_PHASE_TIMING,
+ILQR_AMD_LIB) the chip clock of each phase (shader cycles over wall ticks) is printed when the handle closes.
+    python scripts/clock_probe.py [extra ilqr_flags]"""
+import os
 import sys
-sys.path.insert(0, "/root/repo")
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from ilqr_amd import BatchILQR, capi
 fl = int(sys.argv[1]) if len(sys.argv) > 1 else 0

@@ -1,5 +1,9 @@
-import sys, os
-sys.path.insert(0, "/root/repo")
+"""Double integrator, per-stage route, 10 iterations: stage times; with an experiment build (-DILQR_PHASE_TIMING, ILQR_AMD_LIB)
+the generic box-QP's counters are printed when the handle closes."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from ilqr_amd import BatchILQR, capi
 B, T = 4096, 100
