@@ -1600,6 +1600,18 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       // the freshly issued prefetch, which would expose one HBM round trip per step.
       QuadStep<NU, real> A, Bd;
       int i = T - 1;
+      if constexpr (RP && NU > 1) {
+        // m > 1 from the ring: ONE register set, loaded at the top of its own step.  The second set (86 registers for
+        // m = 2) pushed the step's live values into AGPR copies; an LDS read is ~150 cycles of a 6000-cycle step.
+        while (true) {
+          __builtin_amdgcn_sched_barrier(0);
+          load(i, A);
+          __builtin_amdgcn_s_waitcnt(kWaitLds);
+          __builtin_amdgcn_sched_barrier(0);
+          if (!step(i, A)) break;
+          if (--i < 0) break;
+        }
+      } else {
       load(i, A);
       __builtin_amdgcn_s_waitcnt(kWaitAll & kWaitLds);
       while (true) {
@@ -1613,6 +1625,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         __builtin_amdgcn_sched_barrier(0);
         if (!step(i, Bd)) break;
         if (--i < 0) break;
+      }
       }
     }
 
