@@ -396,7 +396,7 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
         lds_sync();
         v = w_quad_cost(m, Q, c, L.xc, lane);
         const double old_v = w_quad_cost(m, Q, c, L.x, lane);
-        while ((v - old_v) / (step * slope) < kArmijo) {
+        while ((v - old_v) > kArmijo * (step * slope)) {  // (the reference's quotient test without the division: step * slope < 0 here; boxqp.hpp)
 #ifdef ILQR_PHASE_TIMING
           qc[3]++;
 #endif
