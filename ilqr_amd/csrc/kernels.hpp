@@ -533,6 +533,10 @@ __device__ __forceinline__ void derivatives_of_knot(const BatchViewT<typename M:
   if (RING) {
 #pragma unroll
     for (int j = 0; j < NU; j++) rs[((RSl::US + j) >> 1) * (2 * TW + RING_PAD) + ((RSl::US + j) & 1)] = uk[j];
+    // m = 1: the slot's last pair has a free half next to u -- the weight 1 / (|u| + 1) of this knot's gradient-norm
+    // term (:405-412) goes there, computed here (the same recip() of the same value) instead of on the backward
+    // wavefront's chain
+    if constexpr (NU == 1) rs[((RSl::US + 1) >> 1) * (2 * TW + RING_PAD) + ((RSl::US + 1) & 1)] = recip(abs_of(uk[0]) + real(1));
   }
 
   if (v.analytic) {  // opt-in: the model's exact derivatives (wave-uniform branch)
@@ -1081,6 +1085,7 @@ struct QuadStep {  // what lane (l, s) needs of one derivative record, AS LOADED
   pair_t tail[(NU + NU * NU) / 2];     // cu, cuu
   pair_t cxx[2];                       // cxx[:, s]
   real us[NU];
+  real usw;                            // m = 1, from the ring: 1 / (|us| + 1), written there by the producers
   real cx;                             // cx[s]
   real cxu[NU];                        // cxu[s, :]
 };
@@ -1155,6 +1160,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       fill(pair, one, d);
 #pragma unroll
       for (int a = 0; a < NU; a++) d.us[a] = one(RS::US + a);
+      if constexpr (NU == 1) d.usw = one(RS::US + 1);
     } else {  // 16-byte / 8-byte global loads of the record in HBM
       const real* r = Dt + (unsigned)(t * ((R::SIZE / 2) * 2 * TW));  // in-tile offsets fit 32 bits
       auto pair = [&](int e) { return *reinterpret_cast<const real2_t*>(r + (unsigned)((e >> 1) * (2 * TW))); };
@@ -1556,7 +1562,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         real mx = 0;
 #pragma unroll
         for (int a = 0; a < NU; a++) {
-          const real val = abs_of(qp.x[a]) * recip(abs_of(d.us[a]) + 1);
+          const real val = abs_of(qp.x[a]) * ((RP && NU == 1) ? raw.usw : recip(abs_of(d.us[a]) + 1));
           mx = (a == 0 || val > mx) ? val : mx;
         }
         if (ok) gacc += (double)mx;
