@@ -6,8 +6,14 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib", "libilqr_amd.so")
 SOURCES = [os.path.join(CSRC, "capi.hip")]
-HEADERS = [os.path.join(CSRC, f) for f in ("common.hpp", "models.hpp", "boxqp.hpp", "kernels.hpp", "backward_wave.hpp", "generic.hpp")] + \
-          [os.path.join(os.path.dirname(PKG), "include", "ilqr_amd.h")]
+import glob
+
+
+def _headers():
+    """Everything the library is compiled from besides SOURCES: every file under csrc/ (globbed, so a header added
+    later is hashed without anyone remembering to list it) and the public C headers."""
+    inc = os.path.join(os.path.dirname(PKG), "include")
+    return sorted(set(glob.glob(os.path.join(CSRC, "*")) + glob.glob(os.path.join(inc, "*.h"))) - set(SOURCES))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: the SLP vectoriser turns the float dot products of the Riccati step into v_pk_mul_f32 +
 # scalar adds instead of FMA chains (fp32 backward kernel 0.64 -> 0.60 ms); there is no packed fp64 arithmetic
@@ -24,7 +30,7 @@ HASHFILE = LIB + ".srchash"
 def _source_hash():
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(SOURCES + HEADERS):
+    for f in sorted(SOURCES + _headers()):
         if os.path.exists(f):
             h.update(os.path.basename(f).encode())
             h.update(open(f, "rb").read())

@@ -6,7 +6,7 @@ from . import _build
 
 ABI_VERSION = 2
 MODEL_ACROBOT, MODEL_DOUBLE_INTEGRATOR, MODEL_LQ, MODEL_HOST = 0, 1, 2, 3
-FLAG_FIXED_WORK, FLAG_BACKWARD_THREAD_PER_TRAJ, FLAG_BACKWARD_LANE_GROUP, FLAG_UNFUSED, FLAG_ANALYTIC_DERIVATIVES, FLAG_STAGED, FLAG_REFERENCE_FIXES, FLAG_REGULARIZE_VXX = 1, 2, 4, 8, 16, 32, 64, 128
+FLAG_FIXED_WORK, FLAG_BACKWARD_THREAD_PER_TRAJ, _FLAG_RESERVED_4, FLAG_UNFUSED, FLAG_ANALYTIC_DERIVATIVES, FLAG_STAGED, FLAG_REFERENCE_FIXES, FLAG_REGULARIZE_VXX = 1, 2, 4, 8, 16, 32, 64, 128
 DTYPE_F64, DTYPE_F32 = 0, 1
 NUM_STAGES = 5
 STAGE_NAMES = ("derivatives", "backward", "rollout", "accept", "solve")

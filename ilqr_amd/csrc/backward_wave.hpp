@@ -188,18 +188,9 @@ __device__ __forceinline__ double w_quad_cost(int m, const double* Q, const doub
 
 // src/boxqp.cpp:26-139 for one trajectory per wavefront.  Inputs in LDS: QuuF (Q), Qu (c), kprev
 // (x0), lo, hi.  Outputs: L.x (solution), L.vfree, L.Minv (R^-1 R^-T of the last factor, ld LDM), nfR.
-#ifdef ILQR_PHASE_TIMING
-__device__ long long g_qp_count[8];  // [0] QPs, [1] iterations, [2] factorisations, [3] Armijo trips, [4..7] cycles: factor, inverse, search, rest
-#endif
 template <class LDS>
 __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
-#ifdef ILQR_PHASE_TIMING
-  long long qc[8] = {1, 0, 0, 0, 0, 0, 0, 0};
-  long long qmark = clock64();
-#define ILQR_QMARK(k) { const long long tn_ = clock64(); qc[k] += tn_ - qmark; qmark = tn_; }
-#else
 #define ILQR_QMARK(k)
-#endif
   const double* Q = L.QuuF();
   const double* c = L.Qu;
   // :35 clamp
@@ -224,9 +215,6 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
   double oldvalue = 0;
   int result = 0, nfR = 0;
   for (int iter = 0; iter <= kQpMaxIter; iter++) {
-#ifdef ILQR_PHASE_TIMING
-    qc[1]++;
-#endif
     if (iter > 0 && (oldvalue - val) < kMinRelImprove * fabs(oldvalue)) {  // :54-57
       result = 4;
       break;
@@ -258,9 +246,6 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
     lds_sync();
     ILQR_QMARK(7)
     if (iter == 0 || dsum != 0) {  // :80
-#ifdef ILQR_PHASE_TIMING
-      qc[2]++;
-#endif
       // Qfree = Q[free, free], row i on lane i, in registers: the factorisation and the inversion
       // below are chains of short dot products with a square root / division between them; through
       // LDS every link of the chain paid a write -> read round trip (~35 K cycles per QP at nf = 16),
@@ -397,9 +382,6 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
         v = w_quad_cost(m, Q, c, L.xc, lane);
         const double old_v = w_quad_cost(m, Q, c, L.x, lane);
         while ((v - old_v) > kArmijo * (step * slope)) {  // (the reference's quotient test without the division: step * slope < 0 here; boxqp.hpp)
-#ifdef ILQR_PHASE_TIMING
-          qc[3]++;
-#endif
           step *= kStepDec;
           lds_sync();
           if (lane < m) {
@@ -427,11 +409,6 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
     lds_sync();
   }
   lds_sync();
-#ifdef ILQR_PHASE_TIMING
-  ILQR_QMARK(7)
-  if (lane == 0 && blockIdx.x == 0)
-    for (int q = 0; q < 8; q++) g_qp_count[q] += qc[q];
-#endif
   nfR_out = nfR;
   return result;
 }
@@ -541,13 +518,7 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
     dV0 = dV1 = 0;
     diverge = 0;
     lds_sync();
-#ifdef ILQR_PHASE_TIMING
-    long long wph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long wmark = clock64();
-#define ILQR_WMARK(k) { __builtin_amdgcn_sched_barrier(0); const long long tn_ = clock64(); wph[k] += tn_ - wmark; wmark = tn_; __builtin_amdgcn_sched_barrier(0); }
-#else
 #define ILQR_WMARK(k)
-#endif
     RecA cur;
     load_rec_a(T - 1, cur);
     for (int i = T - 1; i >= 0; i--) {
@@ -851,10 +822,6 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
         if ((lane & 15) < m) Kb[(size_t)i * m * n + (lane & 15) + m * c] = L.K()[(lane & 15) + LDM * c];
       lds_sync();
     }
-#ifdef ILQR_PHASE_TIMING
-    if (v.dbg && lane == 0 && b == 0)
-      for (int q = 0; q < 8; q++) v.dbg[256 + q] = wph[q];
-#endif
     if (mode == 0) {
       done = (diverge == 0);
       break;

@@ -158,13 +158,7 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w2(BatchView v
     dV0 = dV1 = 0;
     diverge = 0;
     lds_sync();
-#ifdef ILQR_PHASE_TIMING
-    long long wph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long wmark = clock64();
-#define ILQR_W2MARK(k) { __builtin_amdgcn_sched_barrier(0); const long long tn_ = clock64(); wph[k] += tn_ - wmark; wmark = tn_; __builtin_amdgcn_sched_barrier(0); }
-#else
 #define ILQR_W2MARK(k)
-#endif
     for (int i = T - 1; i >= 0; i--) {
       ILQR_W2MARK(7)
       // No prefetch of the next record, unlike k_backward_w: its 54 registers, held through the box-QP (61 ms) or
@@ -438,10 +432,6 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w2(BatchView v
         }
       lds_sync();
     }
-#ifdef ILQR_PHASE_TIMING
-    if (v.dbg && lane == 0 && b == 0)
-      for (int q = 0; q < 8; q++) v.dbg[256 + q] = wph[q];
-#endif
     if (mode == 0) {
       done = (diverge == 0);
       break;

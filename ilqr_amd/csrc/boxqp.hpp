@@ -95,22 +95,6 @@ ILQR_HD void matvec(const real* Q, const real* x, real* y) {
   }
 }
 
-#if defined(ILQR_PHASE_TIMING) && defined(__HIPCC__) && !defined(ILQR_HOST_BUILD_OF_DEVICE_CODE)
-__device__ long long g_bq_count[4];  // (experiment builds) generic box-QP, thread 0 of block 0: QPs, iterations, factorisations, Armijo trips
-#endif
-#if defined(ILQR_PHASE_TIMING) && defined(__HIPCC__) && !defined(ILQR_HOST_BUILD_OF_DEVICE_CODE)
-__device__ long long g_bq_cycles[8];  // ... and shader cycles per section: setup, gradient + clamp set, factor + inverse, direction, line search, rest
-#endif
-#if defined(ILQR_PHASE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-#define ILQR_BQ_COUNT(k) { if (threadIdx.x == 0 && blockIdx.x == 0) g_bq_count[k] += 1; }
-#define ILQR_BQ_T0 long long bq_t_ = clock64(), bq_acc_[6] = {0, 0, 0, 0, 0, 0};
-#define ILQR_BQ_MARK(k) { __builtin_amdgcn_sched_barrier(0); const long long n_ = clock64(); bq_acc_[k] += n_ - bq_t_; bq_t_ = n_; __builtin_amdgcn_sched_barrier(0); \
-    if (k == 5 && threadIdx.x == 0 && blockIdx.x == 0) { for (int q_ = 0; q_ < 6; q_++) g_bq_cycles[q_] += bq_acc_[q_]; } }
-#else
-#define ILQR_BQ_COUNT(k)
-#define ILQR_BQ_T0
-#define ILQR_BQ_MARK(k)
-#endif
 // src/boxqp.cpp:143-178.  Returns failed; x_opt/v_opt are written unless the direction is not
 // a descent direction (:151-154).
 template <int M, class real>
@@ -133,7 +117,6 @@ ILQR_HD bool quadclamp_line_search(const real* x0, const real* dir, const real* 
   // (the reference's (v - old_v) / (step * slope) < armijo without the division: step * slope < 0 here, so the test is
   //  (v - old_v) > armijo * (step * slope) up to the rounding of the quotient -- the scalar fast path's form, see below)
   while ((v - old_v) > real(kArmijo) * (step * slope)) {
-    ILQR_BQ_COUNT(3)
     step *= real(kStepDec);
 #pragma unroll
     for (int i = 0; i < M; i++) xr[i] = x0[i] + step * dir[i];
@@ -234,7 +217,6 @@ struct BoxQPResult {
 template <int M, class real>
 ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo,
                                        const real* hi, BoxQPResult<M, real>& res, bool detect_indefinite = false) {
-  ILQR_BQ_T0
   real x[M], grad[M], gc[M], search[M], tmp[M];
   real clamped[M], old_clamped[M];
   clamp_to_limits<M>(x0, lo, hi, x);  // :35
@@ -264,14 +246,11 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
 #pragma unroll
   for (int e = 0; e < M * M; e++) res.R[e] = 0;
 
-  ILQR_BQ_COUNT(0)
   real Minv[M * M];  // (R^-1 R^-T) of the factor held in res.R: the reference inverts R in every iteration (:105-112); R only
 #pragma unroll       // changes when the free set does, so the product is formed there and kept -- same values
   for (int e = 0; e < M * M; e++) Minv[e] = 0;
-  ILQR_BQ_MARK(0)
 #pragma unroll 2  // (most QPs end in their second iteration: the loop-carried copies then sit on a back edge that is rarely taken)
   for (int iter = 0; iter <= kQpMaxIter; iter++) {  // :50
-    ILQR_BQ_COUNT(1)
     if (iter > 0 && (oldvalue - val) < real(kMinRelImprove) * abs_of(oldvalue)) {  // :54-57
       result = 4;
       break;
@@ -296,14 +275,12 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
       rank[i] = nf;
       nf += cl ? 0 : 1;
     }
-    ILQR_BQ_MARK(1)
     if (all_clamped) {  // :74-77
       result = 6;
       break;
     }
 
     if (iter == 0 || dsum != 0) {  // :80
-      ILQR_BQ_COUNT(2)
       real Qf[M * M];
 #pragma unroll
       for (int e = 0; e < M * M; e++) Qf[e] = 0;
@@ -340,7 +317,6 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
       nfR = nf;
       rinv_rinvT<M>(nfR, res.R, Minv);
     }
-    ILQR_BQ_MARK(2)
 
     real gn2 = 0;  // :93-97
 #pragma unroll
@@ -403,10 +379,8 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
     }
     }
 
-    ILQR_BQ_MARK(3)
     real lx[M], lv = 0;
     const bool failed = quadclamp_line_search<M>(x, search, Q, c, lo, hi, lx, lv);  // :121
-    ILQR_BQ_MARK(4)
     if (failed) {  // :122-125
       result = 2;
       break;
@@ -419,7 +393,6 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
   for (int i = 0; i < M; i++) res.x[i] = x[i];
   res.result = result;
   res.nfR = nfR;
-  ILQR_BQ_MARK(5)
 }
 
 
@@ -628,19 +601,10 @@ ILQR_HD int qp1_finish(const QP1StateT<real>& q, real& x_out, int& free_out, rea
 // the bound: the Newton target stays outside, so they creep towards the bound over several
 // iterations.  Restarting the literal loop from iteration 0 for them (as the first version did)
 // made their wavefront the slowest of the launch once a solve had run ~20 iterations.
-#if defined(ILQR_PHASE_TIMING) && defined(__HIPCC__) && !defined(ILQR_HOST_BUILD_OF_DEVICE_CODE)
-__device__ unsigned long long g_qc_count[8];  // (experiment builds) qp1_continue, all lanes: entries, shortcut, loop iterations, results 4 / 6 / 5 / 2, line-search failures
-#endif
-#if defined(ILQR_PHASE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-#define ILQR_QC_COUNT(k) atomicAdd(&g_qc_count[k], 1ull);
-#else
-#define ILQR_QC_COUNT(k)
-#endif
 template <class real, class LineSearch>
 ILQR_HD int qp1_continue(QP1StateT<real>& q, LineSearch line_search, real& x_out, int& free_out) {
   real x = q.x1, val = q.v1, oldvalue = q.val0;
   int result = 0, free_ = 1;
-  ILQR_QC_COUNT(0)
   {
     // The usual reason to be here late in a solve: x1 is the optimum to rounding, but with Quu ~ 1e10 its gradient
     // Quu * (an ulp of error) is still above minGrad and the Newton step of iteration 1, a few 1e-17, still moves x.
@@ -666,17 +630,14 @@ ILQR_HD int qp1_continue(QP1StateT<real>& q, LineSearch line_search, real& x_out
     const bool nodesc2 = (s2 * g2) >= real(0);
     const bool stepped = unit_passes & moved & (slope1 < real(0));
     if (stepped & (tiny | (!cl2 & (flat2 | nodesc2)))) {
-      ILQR_QC_COUNT(1)
       x_out = x2;
       free_out = 1;
       return tiny ? 4 : (flat2 ? 5 : 2);
     }
   }
   for (int iter = 1; iter <= kQpMaxIter; iter++) {
-    ILQR_QC_COUNT(2)
     if ((oldvalue - val) < real(kMinRelImprove) * abs_of(oldvalue)) {  // boxqp.cpp:54-57 (iter > 0 here)
       result = 4;
-      ILQR_QC_COUNT(3)
       break;
     }
     const real grad = q.Q * x + q.c;
@@ -685,13 +646,11 @@ ILQR_HD int qp1_continue(QP1StateT<real>& q, LineSearch line_search, real& x_out
     if (cl) {  // :74-77
       free_ = 0;
       result = 6;
-      ILQR_QC_COUNT(4)
       break;
     }
     free_ = 1;
     if (abs_of(grad) < real(kMinGrad)) {  // :93-97
       result = 5;
-      ILQR_QC_COUNT(5)
       break;
     }
     q.x = x;
@@ -700,7 +659,6 @@ ILQR_HD int qp1_continue(QP1StateT<real>& q, LineSearch line_search, real& x_out
     q.slope = q.search * grad;
     if (q.slope >= 0) {  // :150-153
       result = 2;
-      ILQR_QC_COUNT(6)
       break;
     }
     q.old_v = qp1_value(q, x);
@@ -710,7 +668,6 @@ ILQR_HD int qp1_continue(QP1StateT<real>& q, LineSearch line_search, real& x_out
     line_search(q);
     if (q.ls_failed) {  // :121-125
       result = 2;
-      ILQR_QC_COUNT(7)
       break;
     }
     x = q.x1;

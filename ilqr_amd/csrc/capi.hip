@@ -16,7 +16,6 @@
 
 #include "backward_wave.hpp"
 #include "backward_wave2.hpp"
-#include "backward_hex.hpp"
 #include "generic.hpp"
 #include "kernels.hpp"
 
@@ -95,6 +94,13 @@ struct ilqr_batch {
   double* d_umax = nullptr;
   bool profile = false;
   int num_cus = 256;
+  // Route switches for A/B runs and the bit-identity tests, read from the environment ONCE, in ilqr_create: a handle
+  // never changes kernels between calls.  (ILQR_AMD_STAGED / _UNFUSED / _FUSED=1|2 / _BACKWARD_W1 / _LQ_THREAD_ROLLOUT /
+  // _FULL_RECORDS / _NUM_CUS)
+  struct {
+    bool staged = false, unfused = false, backward_w1 = false, lq_thread_rollout = false, full_records = false;
+    int fused = 0;  // 0 = by batch size
+  } env;
   StageTimer timers[ILQR_NUM_STAGES];
   std::vector<hipEvent_t> event_pool;
   // inside ilqr_iterate nothing is enqueued between the end of one stage and the begin of the next: the
@@ -115,7 +121,7 @@ static void sync_float_view(ilqr_batch* h) {
   f.D = (float*)v.D; f.cand_u = (float*)v.cand_u; f.cand_x = (float*)v.cand_x; f.nch = v.nch;
   f.cost_c = v.cost_c; f.cost = v.cost; f.lambda = v.lambda; f.dlambda = v.dlambda; f.dV = v.dV; f.gnorm = v.gnorm;
   f.status = v.status; f.iters = v.iters; f.flg_change = v.flg_change; f.alpha_idx = v.alpha_idx; f.diverge = v.diverge;
-  f.backpass_done = v.backpass_done; f.n_running = v.n_running; f.dbg = v.dbg; f.analytic = v.analytic;
+  f.backpass_done = v.backpass_done; f.n_running = v.n_running; f.analytic = v.analytic;
 }
 // f(view, model, model the finite differences are taken in) for the handle's device model and arithmetic
 template <class F>
@@ -385,9 +391,8 @@ static int launch_rollout_t(ilqr_batch* h, const V& v, const M& m, bool gains, b
 // matrix cores (k_rollout_lq, one wavefront per trajectory); ILQR_AMD_LQ_THREAD_ROLLOUT=1 selects the
 // generic thread-per-rollout kernel (same results bit for bit; kept as the cross-check and as the
 // template for device models without matrix structure).
-static bool lq_thread_rollout() { return getenv("ILQR_AMD_LQ_THREAD_ROLLOUT") != nullptr; }
 static int launch_rollout_g(ilqr_batch* h, const LqModel& m, int what, const AlphaSet& al, double* cost_out, int mode, int write_cost) {
-  if (!lq_thread_rollout()) {
+  if (!h->env.lq_thread_rollout) {
     const dim3 grid(h->B), block(64);
     if (what == RG_SEARCH)
       hipLaunchKernelGGL((k_rollout_lq<RG_SEARCH>), grid, block, 0, h->stream, h->v, m, al, cost_out, nullptr, mode, 0);
@@ -478,7 +483,7 @@ static int launch_derivatives(ilqr_batch* h, int force) {
   const int* ci = h->commit_pending ? h->commit_idx : nullptr;
   if (h->model == ILQR_MODEL_LQ) {
     if (h->v.analytic) {
-      const int what = getenv("ILQR_AMD_FULL_RECORDS") ? 0 : 1;  // (the env switch: A/B runs and the bit-identity test)
+      const int what = h->env.full_records ? 0 : 1;  // (A/B runs and the bit-identity test)
       const int chunk = (what == 1) ? 4 * kAnalyticChunk : kAnalyticChunk;
       const int nchunk = (h->T + 1 + chunk - 1) / chunk;
       hipLaunchKernelGGL(k_analytic_lq, dim3(h->B * nchunk), dim3(64), 0, h->stream, h->v, h->lq, force, what, h->const_rec, chunk);
@@ -515,22 +520,13 @@ static int launch_backward(ilqr_batch* h, int mode) {
   if (h->aos) {
     // the register-resident kernel, two (nx > 16) or more (nx <= 16) wavefronts per SIMD; ILQR_AMD_BACKWARD_W1 forces round
     // 1's LDS kernel -- the two give bit-identical results (tests/test_gpu_generic_backward.py)
-    const size_t pad = getenv("ILQR_AMD_W2_PAD") ? (size_t)atoi(getenv("ILQR_AMD_W2_PAD")) : 0;  // (occupancy experiments)
     const double* crec = h->records_partial ? h->const_rec : nullptr;
-    if (getenv("ILQR_AMD_BACKWARD_W1"))
+    if (h->env.backward_w1)
       hipLaunchKernelGGL(k_backward_w, dim3(h->B), dim3(64), 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
     else if (h->nx > 16)
-      hipLaunchKernelGGL(k_backward_w2<2>, dim3(h->B), dim3(64), pad, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
+      hipLaunchKernelGGL(k_backward_w2<2>, dim3(h->B), dim3(64), 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
     else
-      hipLaunchKernelGGL(k_backward_w2<1>, dim3(h->B), dim3(64), pad, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
-  } else if ((h->flags & ILQR_FLAG_BACKWARD_LANE_GROUP) && h->nx == 4 && h->nu == 1 && !(h->sp.fixes & 4)) {
-    dim3 grid(h->ntiles * 4), block(64);  // experiment: 16 lanes per trajectory, one wavefront = 4 trajectories (backward_hex.hpp)
-    if (int rc = with_model(h, [&](auto& v, auto& m, auto&) {
-          using MM = std::decay_t<decltype(m)>;
-          if constexpr (MM::NU == 1) hipLaunchKernelGGL((k_backward_h<MM>), grid, block, 0, h->stream, v, m, h->sp, mode);
-          return 0;
-        }))
-      return rc;
+      hipLaunchKernelGGL(k_backward_w2<1>, dim3(h->B), dim3(64), 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
   } else if (use_quad_backward(h)) {
     dim3 grid(h->ntiles), block(64);  // one wavefront = one tile of 16 trajectories x 4 lanes
     if (int rc = with_model(h, [&](auto& v, auto& m, auto&) {
@@ -559,9 +555,11 @@ static int launch_backward(ilqr_batch* h, int mode) {
 // 16 x #CU < B <= 32 x #CU: the variant with one producer and a 60 KB ring, two blocks per CU (kernels.hpp;
 // B = 8192: 1.26 vs 1.42 ms per iteration).  ILQR_AMD_FUSED=1 / =2 force a variant for A/B runs and tests.
 static int fused_variant(const ilqr_batch* h) {  // 0: two kernels, 1: one block per CU, 2: two blocks per CU
-  if (!use_quad_backward(h) || h->aos || (h->flags & ILQR_FLAG_UNFUSED) || getenv("ILQR_AMD_UNFUSED")) return 0;
-  if (const char* f = getenv("ILQR_AMD_FUSED")) return (f[0] == '2') ? 2 : 1;
+  if (!use_quad_backward(h) || h->aos || (h->flags & ILQR_FLAG_UNFUSED) || h->env.unfused) return 0;
+  if (h->env.fused) return h->env.fused;
   if (h->ntiles <= h->num_cus) return 1;
+  const bool staged = (h->flags & ILQR_FLAG_STAGED) || h->env.staged;
+  if (!staged) return 2;  // persistent tiles, two per CU, for ANY larger batch: the dispatcher hands a CU its next tile when one is through
   return (h->ntiles <= 2 * h->num_cus) ? 2 : 0;
 }
 static bool use_fused_sweep(const ilqr_batch* h) { return fused_variant(h) != 0; }
@@ -570,10 +568,7 @@ template <class V, class M, class MFD>
 static void launch_sweep_backward_t(ilqr_batch* h, const V& v, const M& m, const MFD& fdm, int variant, int mode, int force, const int* ci) {
   if (variant == 2)
     hipLaunchKernelGGL((k_sweep_backward<M, 1, kRingKbTwoBlocks, MFD>), dim3(h->ntiles), dim3(64 * 2), 0, h->stream, v, m, fdm, h->sp, mode, force, ci);
-  else if (M::NU == 1 && getenv("ILQR_AMD_HEX")) {  // experiment: four backward wavefronts per tile, 16 lanes per trajectory
-    if constexpr (M::NU == 1)
-      hipLaunchKernelGGL((k_sweep_backward_h<M, kProducers, ILQR_RING_KB, MFD>), dim3(h->ntiles), dim3(64 * (4 + kProducers)), 0, h->stream, v, m, fdm, h->sp, mode, force, ci);
-  } else
+  else
     hipLaunchKernelGGL((k_sweep_backward<M, kProducers, ILQR_RING_KB, MFD>), dim3(h->ntiles), dim3(64 * (1 + kProducers)), 0, h->stream, v, m, fdm, h->sp, mode, force, ci);
 }
 static int launch_sweep_backward(ilqr_batch* h, int mode, int force) {
@@ -606,8 +601,8 @@ static int launch_accept(ilqr_batch* h) {
 // Whole iterations per tile in one persistent kernel (k_solve_tile): the one-block-per-CU regime of the fused
 // kernel.  ILQR_FLAG_STAGED / ILQR_AMD_STAGED=1: per-stage launches instead (A/B runs, the bit-identity tests).
 static bool use_persistent(const ilqr_batch* h) {
-  if (h->aos || (h->flags & ILQR_FLAG_STAGED) || getenv("ILQR_AMD_STAGED")) return false;
-  return fused_variant(h) == 1;
+  if (h->aos || (h->flags & ILQR_FLAG_STAGED) || h->env.staged) return false;
+  return fused_variant(h) != 0;
 }
 static AlphaSet line_search_alphas();
 static int launch_solve_tiles(ilqr_batch* h, int n_iters) {
@@ -617,9 +612,14 @@ static int launch_solve_tiles(ilqr_batch* h, int n_iters) {
   const AlphaSet al = line_search_alphas();
   const int pending = h->commit_pending ? 1 : 0;
   long long* ticks = h->profile ? h->phase_ticks : nullptr;
+  const int occ = fused_variant(h);
   if (int rc = with_model(h, [&](auto& v, auto& m, auto& fdm) {
-        hipLaunchKernelGGL((k_solve_tile<std::decay_t<decltype(m)>, std::decay_t<decltype(fdm)>>), dim3(h->ntiles), dim3(256), 0, h->stream, v, m, fdm,
-                           al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
+        using MM = std::decay_t<decltype(m)>;
+        using MF = std::decay_t<decltype(fdm)>;
+        if (occ == 1)
+          hipLaunchKernelGGL((k_solve_tile<MM, MF, 1>), dim3(h->ntiles), dim3(256), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
+        else
+          hipLaunchKernelGGL((k_solve_tile<MM, MF, 2>), dim3(h->ntiles), dim3(256), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
         return 0;
       }))
     return rc;
@@ -663,99 +663,6 @@ void ilqr_destroy(ilqr_batch* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-#ifdef ILQR_PHASE_TIMING
-  if (h->v.dbg) {
-    long long d[1024];
-    if (hipMemcpy(d, h->v.dbg, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess) {
-      static const char* nm[8] = {"load-issue", "Q-products", "slowQP+K", "V-update+dpp", "vmcnt-wait", "stores", "fastQP", "slow-path steps/T"};
-      {  // spread over the first 64 tiles: the kernel lasts as long as its slowest tile
-        double tot[64];
-        int worst = 0;
-        for (int t = 0; t < 64; t++) {
-          tot[t] = 0;
-          for (int q = 0; q < 7; q++) tot[t] += (double)d[t * 8 + q];
-          if (tot[t] > tot[worst]) worst = t;
-        }
-        double mn = tot[0], sum = 0;
-        for (int t = 0; t < 64; t++) {
-          mn = tot[t] < mn ? tot[t] : mn;
-          sum += tot[t];
-        }
-        fprintf(stderr, "[phase timing, tiles 0..63] cycles/step min %.0f mean %.0f max %.0f (tile %d, slow-path %.3f/step)\n", mn / h->T,
-                sum / 64 / h->T, tot[worst] / h->T, worst, (double)d[worst * 8 + 7] / h->T);
-        {
-          const double* dd = reinterpret_cast<const double*>(d + 768);
-          fprintf(stderr, "[a sequential-fallback sample] search %.6g bound-x %.6g v_b-old_v %.6g slope %.6g Q %.6g x %.17g bound %.17g\n", dd[0], dd[1], dd[2], dd[3], dd[4], dd[5], dd[6]);
-        }
-        fprintf(stderr, "[worst tile] per step: QP-continues %.3f, continue iterations %.3f, sequential-search fallbacks %.3f, sequential trips %.2f\n",
-                (double)d[512 + worst * 4 + 0] / h->T, (double)d[512 + worst * 4 + 1] / h->T, (double)d[512 + worst * 4 + 2] / h->T,
-                (double)d[512 + worst * 4 + 3] / h->T);
-      }
-      {
-        long long y[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int t = 0; t < 16; t++)
-          for (int q = 0; q < 8; q++) y[q] += d[800 + t * 8 + q];
-        const double per = 16.0 * 16 * h->T;
-        fprintf(stderr, "[search fallbacks to the sequential loop, tiles 0..15, per QP] first search: estimate unusable %.4f (Q <= 0: %.4f) window all fail %.4f "
-                        "first window lane passes %.4f | searches of later QP iterations: %.4f (Q <= 0: %.4f) %.4f %.4f\n",
-                y[1] / per, y[0] / per, y[2] / per, y[3] / per, y[5] / per, y[4] / per, y[6] / per, y[7] / per);
-      }
-      for (int t = 0; t < 3; t++) {
-        fprintf(stderr, "[phase timing, tile %d, last backward pass] ", t * 20);
-        for (int q = 0; q < 8; q++) fprintf(stderr, "%s %.2f  ", nm[q], (double)d[t * 20 * 8 + q] / h->T);
-        fprintf(stderr, "\n");
-      }
-      if (d[925] > 0 && d[927] > 0)
-        fprintf(stderr, "[k_solve_tile, tile 0, last launch] phase 1: %.3f GHz, phase 2: %.3f GHz (shader cycles / wall)\n", (double)d[924] / (10.0 * d[925]),
-                (double)d[926] / (10.0 * d[927]));
-      if (d[923] > 0)
-        fprintf(stderr, "[k_backward_q, block 0, last pass] %lld shader cycles in %lld wall ticks of 10 ns: %.3f GHz, %.0f cycles per step\n", d[922], d[923],
-                (double)d[922] / (10.0 * d[923]), (double)d[922] / h->T);
-      if (d[921] > 0)
-        fprintf(stderr, "[k_backward_h, block 0, last pass] %lld shader cycles in %lld wall ticks of 10 ns: %.3f GHz, %.0f cycles per step\n", d[920], d[921],
-                (double)d[920] / (10.0 * d[921]), (double)d[920] / h->T);
-      {
-        unsigned long long qc[8];
-        if (hipMemcpyFromSymbol(qc, HIP_SYMBOL(g_qc_count), sizeof(qc)) == hipSuccess && qc[0] > 0)
-          fprintf(stderr, "[qp1_continue, all lanes, whole run] entries %llu: two-iteration shortcut %.3f, loop iterations per entry %.2f; loop exits: improvement (4) %.3f, clamped (6) %.3f, gradient (5) %.3f, no descent (2) %.3f, line search failed (2) %.3f\n",
-                  qc[0], (double)qc[1] / qc[0], (double)qc[2] / qc[0], (double)qc[3] / qc[0], (double)qc[4] / qc[0], (double)qc[5] / qc[0], (double)qc[6] / qc[0], (double)qc[7] / qc[0]);
-      }
-      for (int t = 0; t < 2; t++) {
-        fprintf(stderr, "[hex fused, tile %d] HW_ID per wavefront (simd = bits 5:4, wave slot = bits 3:0, cu = bits 11:8):", t);
-        for (int w = 0; w < 8; w++) fprintf(stderr, " w%d: simd %lld slot %lld cu %lld |", w, (d[900 + t * 8 + w] >> 4) & 3, d[900 + t * 8 + w] & 15, (d[900 + t * 8 + w] >> 8) & 15);
-        fprintf(stderr, "\n");
-      }
-      {
-        long long bq[4];
-        if (hipMemcpyFromSymbol(bq, HIP_SYMBOL(g_bq_count), sizeof(bq)) == hipSuccess && bq[0] > 0)
-          fprintf(stderr, "[generic box-QP, trajectory 0 of tile 0, all passes] per QP: %.2f iterations, %.2f factorisations, %.2f Armijo trips beyond the first\n",
-                  (double)bq[1] / bq[0], (double)bq[2] / bq[0], (double)bq[3] / bq[0]);
-        long long bc[8];
-        if (bq[0] > 0 && hipMemcpyFromSymbol(bc, HIP_SYMBOL(g_bq_cycles), sizeof(bc)) == hipSuccess)
-          fprintf(stderr, "[generic box-QP] shader cycles per QP: setup %.0f  gradient + clamp set %.0f  factor + inverse %.0f  direction %.0f  line search %.0f  exits + copy-out %.0f\n",
-                  (double)bc[0] / bq[0], (double)bc[1] / bq[0], (double)bc[2] / bq[0], (double)bc[3] / bq[0], (double)bc[4] / bq[0], (double)bc[5] / bq[0]);
-      }
-      if (h->aos) {
-        long long qc[8];
-        if (hipMemcpyFromSymbol(qc, HIP_SYMBOL(g_qp_count), sizeof(qc)) == hipSuccess && qc[0] > 0)
-          fprintf(stderr, "[wave box-QP, trajectory 0, all passes] per QP: %.2f iterations, %.2f factorisations, %.2f Armijo trips; cycles: factor %.0f  inverse+Minv %.0f  line search %.0f  rest %.0f\n",
-                  (double)qc[1] / qc[0], (double)qc[2] / qc[0], (double)qc[3] / qc[0], (double)qc[4] / qc[0], (double)qc[5] / qc[0],
-                  (double)qc[6] / qc[0], (double)qc[7] / qc[0]);
-      }
-      if (h->aos)
-        fprintf(stderr, "[wave backward phase timing, cyc/step] lds-fill+prefetch %.0f  Qx,A1,A2 %.0f  Qxx,Qux,Quu %.0f  boxQP %.0f  K %.0f  dV,T1,Vx,Vn %.0f  sym+stores(+loop) %.0f\n",
-                (double)d[256 + 0] / h->T, (double)d[256 + 1] / h->T, (double)d[256 + 2] / h->T, (double)d[256 + 3] / h->T,
-                (double)d[256 + 4] / h->T, (double)d[256 + 5] / h->T, (double)d[256 + 7] / h->T);
-      if (h->aos)
-        fprintf(stderr, "[generic FD sweep, knot (0,0), cycles] knot+fx,fu %lld  cost singles %lld  cx,cu,cxu %lld  cxx %lld  cuu %lld\n", d[272], d[273],
-                d[274], d[275], d[276]);
-      for (int t = 0; t < 3; t++)
-        fprintf(stderr, "[rollout phase timing, tile %d] loop+prefetch %.1f  wait+feedback+ustore %.1f  cost+dynamics %.1f  xstores %.1f cyc/step\n", t,
-                (double)d[512 - 16 + t * 4 + 0] / h->T, (double)d[512 - 16 + t * 4 + 1] / h->T, (double)d[512 - 16 + t * 4 + 2] / h->T,
-                (double)d[512 - 16 + t * 4 + 3] / h->T);
-    }
-  }
-#endif
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->staging) (void)hipFree(h->staging);
   (void)timers_drain(h);  // (every event back into the pool, each once)
@@ -775,6 +682,12 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, d->device) == hipSuccess && khz > 0) h->wall_clock_khz = khz;
   }
+  h->env.staged = getenv("ILQR_AMD_STAGED") != nullptr;
+  h->env.unfused = getenv("ILQR_AMD_UNFUSED") != nullptr;
+  h->env.backward_w1 = getenv("ILQR_AMD_BACKWARD_W1") != nullptr;
+  h->env.lq_thread_rollout = getenv("ILQR_AMD_LQ_THREAD_ROLLOUT") != nullptr;
+  h->env.full_records = getenv("ILQR_AMD_FULL_RECORDS") != nullptr;
+  if (const char* f = getenv("ILQR_AMD_FUSED")) h->env.fused = (f[0] == '2') ? 2 : 1;
   if (const char* e = getenv("ILQR_AMD_NUM_CUS"))  // tests: exercise the batch-size thresholds of the route selection on small batches
     if (atoi(e) > 0) h->num_cus = atoi(e);
   h->device = d->device;
@@ -933,7 +846,6 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   rc |= dev_alloc(h, &h->commit_idx, Bp);
   rc |= dev_alloc(h, &h->phase_ticks, 3 * (size_t)h->ntiles);
   if (!rc && hipMemsetAsync(h->commit_idx, 0xFF, Bp * sizeof(int), h->stream) != hipSuccess) rc = 1;
-  rc |= dev_alloc(h, &v.dbg, 1024);
   if (rc) return ILQR_ERR_HIP;
   sync_float_view(h);
 
@@ -1399,12 +1311,12 @@ const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
   switch (stage) {
     case ILQR_STAGE_DERIVATIVES: return (h && h->aos) ? ((h->v.analytic) ? "k_analytic_lq" : "k_derivatives_g") : "k_derivatives";
     case ILQR_STAGE_BACKWARD:
-      if (h && h->aos) return getenv("ILQR_AMD_BACKWARD_W1") ? "k_backward_w" : "k_backward_w2";
+      if (h && h->aos) return h->env.backward_w1 ? "k_backward_w" : "k_backward_w2";
       if (h && use_fused_sweep(h)) return "k_sweep_backward";  // what ilqr_iterate launches
       return (h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t";
-    case ILQR_STAGE_ROLLOUT: return (h && h->aos) ? (lq_thread_rollout() ? "k_rollout_g" : "k_rollout_lq") : "k_rollout";
+    case ILQR_STAGE_ROLLOUT: return (h && h->aos) ? (h->env.lq_thread_rollout ? "k_rollout_g" : "k_rollout_lq") : "k_rollout";
     case ILQR_STAGE_ACCEPT: return "k_accept";
-    case ILQR_STAGE_SOLVE: return (h && use_persistent(h)) ? "k_solve_tile" : "";
+    case ILQR_STAGE_SOLVE: return (h && use_persistent(h)) ? (fused_variant(h) == 1 ? "k_solve_tile" : "k_solve_tile<2>") : "";
     default: return "";
   }
 }

@@ -125,7 +125,6 @@ struct BatchViewT {
   int* diverge;       // return value of the last backward_pass()
   int* backpass_done; // ilqr_core.cpp:136
   int* n_running;     // [1] device counter
-  long long* dbg;     // phase-timing scratch (only used by -DILQR_PHASE_TIMING experiment builds)
   int analytic;       // ILQR_FLAG_ANALYTIC_DERIVATIVES: the models' exact derivatives instead of finite differences
 };
 using BatchView = BatchViewT<double>;  // (the generic nx <= 32 path, generic.hpp / backward_wave.hpp, is fp64 only)

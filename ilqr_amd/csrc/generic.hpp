@@ -671,12 +671,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   double* D = v.D + ((size_t)b * (T + 1) + t) * REC;
   const bool last = (t == T);
 
-#ifdef ILQR_PHASE_TIMING
-  long long dmark = clock64();
-#define ILQR_DMARK(k) { __builtin_amdgcn_sched_barrier(0); const long long tn_ = clock64(); if (v.dbg && blockIdx.x == 0 && lane == 0) v.dbg[272 + k] = tn_ - dmark; dmark = tn_; __builtin_amdgcn_sched_barrier(0); }
-#else
 #define ILQR_DMARK(k)
-#endif
   double x[NX], u[NU];  // the knot (same in every lane): one coalesced load per vector, handed round with
                         // v_readlane (NX + NU same-address loads cost ~10 us per knot, see k_analytic_lq)
   {

@@ -196,10 +196,10 @@ constexpr int kDeepPrefetch = (M::NU * M::NX + M::NX + 2 * M::NU <= 10) ? 8 : 4;
 template <class M, bool GAINS, bool CAND, int PD, bool ACCEPT>
 __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>& v, const M& model, const AlphaSet& alphas, int n_alpha,
                                              double* __restrict__ cost_out, int mode, const SolverParams& sp,
-                                             int* __restrict__ commit_idx, int tile, double* lds_cost, bool count_running = true) {
+                                             int* __restrict__ commit_idx, int tile, double* lds_cost, bool count_running = true, int rwave = -1) {
   using real = typename M::real;
   constexpr int NX = M::NX, NU = M::NU;
-  const int wave = threadIdx.x >> 6;
+  const int wave = (rwave >= 0) ? rwave : (int)(threadIdx.x >> 6);  // which four alphas this wavefront rolls out (>= 3: none)
   const int lane = threadIdx.x & 63;
   const int l = lane & (TW - 1);
   const int a_sub = lane >> 4;
@@ -242,13 +242,6 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
       for (int i = 0; i < NX; i++) d.xnom[i] = v.xs[tidx(tile, t, i, l, T + 1, NX)];
     }
   };
-#ifdef ILQR_PHASE_TIMING
-  long long rph[4] = {0, 0, 0, 0};
-  long long rmark = clock64();
-#define ILQR_RMARK(k) { __builtin_amdgcn_sched_barrier(0); const long long tn_ = clock64(); rph[k] += tn_ - rmark; rmark = tn_; __builtin_amdgcn_sched_barrier(0); }
-#else
-#define ILQR_RMARK(k)
-#endif
   auto emit_knot = [&](int t, const real* xx, const real* uu) __attribute__((always_inline)) {  // knot t = (x_t, u_t)
     if (CAND) {
       const int ta = a * v.ntiles + tile;
@@ -270,7 +263,6 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
     }
   };
   auto do_step = [&](int t, const StepIn& d) __attribute__((always_inline)) {
-    ILQR_RMARK(0)  // loop control + prefetch issue
     real u[NU];
 #pragma unroll
     for (int j = 0; j < NU; j++) u[j] = d.u[j];
@@ -289,14 +281,11 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
       for (int j = 0; j < NU; j++) u[j] = min_of(max_of(u[j], model.u_min[j]), model.u_max[j]);
     }
     emit_knot(t, x, u);
-    ILQR_RMARK(1)  // wait for inputs + feedback + knot store
     total += (double)model.cost(x, u);  // :324
     real x1[NX];
     integrate_dynamics(model, x, u, dt, x1);  // :325
-    ILQR_RMARK(2)  // cost + dynamics
 #pragma unroll
     for (int i = 0; i < NX; i++) x[i] = x1[i];
-    ILQR_RMARK(3)
   };
   StepIn ring[PD];
 #pragma unroll
@@ -321,10 +310,6 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
     for (int q = 0; q < NU; q++) uz[q] = 0;
     emit_knot(T, x, uz);
   }
-#ifdef ILQR_PHASE_TIMING
-  if (v.dbg && threadIdx.x == 0 && tile < 3 && GAINS)
-    for (int q = 0; q < 4; q++) v.dbg[512 - 16 + tile * 4 + q] = rph[q];
-#endif
   total += (double)model.final_cost(x);  // :335
   cost_out[(size_t)a * v.Bp + b] = total;
   if (ACCEPT) lds_cost[a * TW + l] = total;
@@ -1021,7 +1006,7 @@ __device__ __forceinline__ const float* step_table(float) { return kStepTableF.s
 // else (estimate off, Q <= 0, k near the minStep cut-off) returns false and the caller runs the
 // sequential loop: the result is the reference's either way.
 template <class real>
-__device__ __forceinline__ bool qp1_search_quad(QP1StateT<real>& q, int s, int lane, const real* __restrict__ lds_steps, int* why = nullptr) {
+__device__ __forceinline__ bool qp1_search_quad(QP1StateT<real>& q, int s, int lane, const real* __restrict__ lds_steps) {
   const real bound = (q.search > 0) ? q.hi : q.lo;
   const real v_b = qp1_value(q, bound);
   // fp32 estimates: f = fraction of the step inside the box, r = Armijo threshold on the bound
@@ -1067,9 +1052,6 @@ __device__ __forceinline__ bool qp1_search_quad(QP1StateT<real>& q, int s, int l
   const unsigned int s4 = (unsigned int)(__ballot(my_x1 == q.x) >> (lane & ~3)) & 0xFu;
   const bool dead = (k1 == 1) & (m4 == 0u) & ((s4 & 8u) != 0u) & !q.early;
   q.ls_failed = q.ls_failed | stuck | dead;
-  // (experiment builds: why a search is handed to the sequential loop -- 1 estimate unusable and k = 0..3 all fail,
-  //  2 every window lane fails, 3 the first window lane already passes)
-  if (why) *why = (ok | q.early | stuck | dead) ? 0 : (!sane ? 1 : (w == 0u ? 2 : 3));
   return ok | q.early | stuck | dead;
 }
 
@@ -1109,7 +1091,10 @@ struct NoGate {
 
 // FIXES: the opt-in deviations (sp.fixes) are compiled in; callers branch ONCE on sp.fixes != 0 and
 // run the copy without them otherwise -- inside the step their tests were 10 instructions of the common path.
-template <class M, class Gate, int RING_KB = ILQR_RING_KB, bool FIXES = true>
+// ONESET: one register set for the records instead of two (ring only): the load of a step is issued at the top of that step
+// and waited for -- ~150 exposed cycles per step, 72 registers less: what lets two tiles share a CU (k_solve_tile<.., 2>),
+// where the other tile's wavefronts fill the gap.
+template <class M, class Gate, int RING_KB = ILQR_RING_KB, bool FIXES = true, bool ONESET = false>
 __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>& v, const M& model, const SolverParams& sp, int mode,
                                               int tile, int lane, const typename M::real* __restrict__ lds_steps, Gate& gate,
                                               const typename M::real* ring = nullptr) {
@@ -1204,19 +1189,8 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
     diverge = 0;
     gacc = 0;
 
-#ifdef ILQR_PHASE_TIMING
-    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long xc[4] = {0, 0, 0, 0};  // (per lane: counts of lane 0's own quad)
-    long long yc[4] = {0, 0, 0, 0};  // first-level fallbacks by reason (see qp1_search_quad), [0] = of reason 1 with Q <= 0
-    long long zc[4] = {0, 0, 0, 0};  // the same for the searches of qp1_continue
-    long long tmark = clock64();
-#define ILQR_MARK(k) { __builtin_amdgcn_sched_barrier(0); const long long tn_ = clock64(); ph[k] += tn_ - tmark; tmark = tn_; __builtin_amdgcn_sched_barrier(0); }
-#else
-#define ILQR_MARK(k)
-#endif
     // one Riccati step; returns false if the box-QP reports failure (ilqr_core.cpp:371)
     auto step = [&](int i, const QuadStep<NU, real>& raw) -> bool {
-      ILQR_MARK(0)  // load issue + loop overhead
       struct {  // the record, unpacked (register renames: the loads have landed, see QuadStep)
         real fx[16], fxc[4], fu[4 * NU], cu[NU], cuu[NU * NU], us[NU], cx, cxx[4], cxu[NU];
       } d;
@@ -1339,7 +1313,6 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
           Quxr[a] = Quxc[a] + lam_r * acc;
         }
       }
-      ILQR_MARK(1)  // Q-function products
       // :369  box-QP (replicated in the quad)
       real lo[NU], hi[NU];
 #pragma unroll
@@ -1359,57 +1332,19 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         real minv;
         QP1StateT<real> q1;
         qp1_begin<false>(QuuF[0], Qu[0], kprev[0], lo[0], hi[0], q1, FIXES && (sp.fixes & 2) != 0);
-#ifdef ILQR_PHASE_TIMING
-        int why = 0;
-        if (!qp1_search_quad(q1, s, lane, lds_steps, &why)) {  // fallback: rare
-          xc[2] += 1;
-          yc[why & 3] += 1;
-          if (why == 1) {
-            yc[0] += (q1.Q > real(0)) ? 0 : 1;  // of which: Q <= 0
-          }
-#else
         if (__builtin_expect(!qp1_search_quad(q1, s, lane, lds_steps), 0)) {  // fallback: rare, out of line
-#endif
           q1.step = 1;
           q1.x1 = qp1_trial(q1, real(1));
           q1.v1 = qp1_value(q1, q1.x1);
           qp1_backtrack_seq(q1);
         }
         int result = qp1_finish(q1, qp.x[0], free0, minv);
-        ILQR_MARK(6)  // fast QP
-#ifdef ILQR_PHASE_TIMING
-        if (__any(result == kQpGoesOn)) ph[7] += 1;
-#endif
-#ifdef ILQR_PHASE_TIMING
-        if (__any(result == kQpGoesOn)) xc[0] += 1;
-#endif
         if (result == kQpGoesOn)  // the QP goes on (rare early in a solve, a quarter of the steps of some tiles later)
           result = qp1_continue(
               q1,
               [&](QP1StateT<real>& qs) __attribute__((always_inline)) {
-#ifdef ILQR_PHASE_TIMING
-                xc[1] += 1;
-#endif
-#ifdef ILQR_PHASE_TIMING
-                int why2 = 0;
-                if (!qp1_search_quad(qs, s, lane, lds_steps, &why2)) {
-                  zc[why2 & 3] += 1;
-                  if (why2 == 1) zc[0] += (qs.Q > real(0)) ? 0 : 1;
-#else
                 if (__builtin_expect(!qp1_search_quad(qs, s, lane, lds_steps), 0)) {
-#endif
-#ifdef ILQR_PHASE_TIMING
-                  xc[2] += 1;
-                  if (v.dbg && s == 0) {
-                    const real bnd = (qs.search > 0) ? qs.hi : qs.lo;
-                    real* dd = reinterpret_cast<real*>(v.dbg + 768);
-                    dd[0] = qs.search; dd[1] = bnd - qs.x; dd[2] = qp1_value(qs, bnd) - qs.old_v; dd[3] = qs.slope; dd[4] = qs.Q; dd[5] = qs.x; dd[6] = bnd;
-                  }
-#endif
                   qp1_line_search_seq(qs);
-#ifdef ILQR_PHASE_TIMING
-                  xc[3] += (long long)(log(qs.step) / log(0.6) + 0.5);
-#endif
                 }
               },
               qp.x[0], free0);
@@ -1463,7 +1398,6 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         }
       }
       if (!ok) diverge = i;
-      ILQR_MARK(2)  // box-QP + K
       // :388-389
       {
         real d0 = 0;
@@ -1567,7 +1501,6 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         }
         if (ok) gacc += (double)mx;
       }
-      ILQR_MARK(3)  // value-function update + quad exchanges
       // the prefetch issued at the top of this step has had the whole step to land.  From HBM:
       // vmcnt(0) (this also drains the previous step's stores).  From the ring: only the LDS
       // reads are waited for -- they must have landed before the next gate() frees the slot --
@@ -1578,7 +1511,6 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       else
         __builtin_amdgcn_s_waitcnt(kWaitAll);
       __builtin_amdgcn_sched_barrier(0);
-      ILQR_MARK(4)  // wait for the prefetch
       // :396-397
       if (ok) {
 #pragma unroll
@@ -1591,7 +1523,6 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
           for (int a = 0; a < NU; a++) kt[(unsigned)((i * NU + a) * TW)] = qp.x[a];
         }
       }
-      ILQR_MARK(5)  // stores
       return ok;
     };
 
@@ -1606,7 +1537,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       // the freshly issued prefetch, which would expose one HBM round trip per step.
       QuadStep<NU, real> A, Bd;
       int i = T - 1;
-      if constexpr (RP && NU > 1) {
+      if constexpr (RP && (NU > 1 || ONESET)) {
         // m > 1 from the ring: ONE register set, loaded at the top of its own step.  The second set (86 registers for
         // m = 2) pushed the step's live values into AGPR copies; an LDS read is ~150 cycles of a 6000-cycle step.
         while (true) {
@@ -1635,48 +1566,6 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       }
     }
 
-#ifdef ILQR_PHASE_TIMING
-    if (v.dbg && lane == 0 && tile < 64)
-      for (int q = 0; q < 8; q++) v.dbg[tile * 8 + q] = ph[q];
-    {  // worst quad of the tile
-      long long m0 = xc[0], m1 = xc[1], m2 = xc[2], m3 = xc[3];
-      for (int off = 4; off < 64; off <<= 1) {
-        const long long o1 = __shfl_xor(m1, off, 64), o2 = __shfl_xor(m2, off, 64), o3 = __shfl_xor(m3, off, 64);
-        m1 = o1 > m1 ? o1 : m1;
-        m2 = o2 > m2 ? o2 : m2;
-        m3 = o3 > m3 ? o3 : m3;
-      }
-      {  // tile totals of the fallback reasons (sum over quads / 4 lanes)
-        long long y0 = yc[0], y1 = yc[1], y2 = yc[2], y3 = yc[3], z0 = zc[0], z1 = zc[1], z2 = zc[2], z3 = zc[3];
-        for (int off = 1; off < 64; off <<= 1) {
-          y0 += __shfl_xor(y0, off, 64);
-          y1 += __shfl_xor(y1, off, 64);
-          y2 += __shfl_xor(y2, off, 64);
-          y3 += __shfl_xor(y3, off, 64);
-          z0 += __shfl_xor(z0, off, 64);
-          z1 += __shfl_xor(z1, off, 64);
-          z2 += __shfl_xor(z2, off, 64);
-          z3 += __shfl_xor(z3, off, 64);
-        }
-        if (v.dbg && lane == 0 && tile < 16) {
-          v.dbg[800 + tile * 8 + 0] = y0 / 4;
-          v.dbg[800 + tile * 8 + 1] = y1 / 4;
-          v.dbg[800 + tile * 8 + 2] = y2 / 4;
-          v.dbg[800 + tile * 8 + 3] = y3 / 4;
-          v.dbg[800 + tile * 8 + 4] = z0 / 4;
-          v.dbg[800 + tile * 8 + 5] = z1 / 4;
-          v.dbg[800 + tile * 8 + 6] = z2 / 4;
-          v.dbg[800 + tile * 8 + 7] = z3 / 4;
-        }
-      }
-      if (v.dbg && lane == 0 && tile < 64) {
-        v.dbg[512 + tile * 4 + 0] = m0;
-        v.dbg[512 + tile * 4 + 1] = m1;
-        v.dbg[512 + tile * 4 + 2] = m2;
-        v.dbg[512 + tile * 4 + 3] = m3;
-      }
-    }
-#endif
   };
 
   while (true) {
@@ -1757,19 +1646,10 @@ __global__ __launch_bounds__(64) void k_backward_q(BatchViewT<typename M::real> 
   __shared__ real lds_steps[104];  // backtracking step sizes (per-lane indexed -> LDS, not constant cache)
   load_step_table(lds_steps);
   NoGate gate;
-#ifdef ILQR_PHASE_TIMING
-  const long long c0 = clock64(), w0 = wall_clock64();
-#endif
   if (sp.fixes)
     backward_quad<M, NoGate, ILQR_RING_KB, true>(v, model, sp, mode, (int)blockIdx.x, (int)threadIdx.x, lds_steps, gate);
   else
     backward_quad<M, NoGate, ILQR_RING_KB, false>(v, model, sp, mode, (int)blockIdx.x, (int)threadIdx.x, lds_steps, gate);
-#ifdef ILQR_PHASE_TIMING
-  if (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) {  // shader cycles (s_memtime) and 100 MHz wall ticks of the pass: the clock the chip ran at
-    v.dbg[922] = clock64() - c0;
-    v.dbg[923] = wall_clock64() - w0;
-  }
-#endif
 }
 
 #ifndef ILQR_PRODUCERS
@@ -1804,9 +1684,6 @@ struct RingGate {
   // running index of the knot and its ring slot are carried along instead of recomputed (a multiply-high modulo and
   // half a dozen scalar instructions per step on the backward wavefront's chain)
   int g_next = 0, slot_next = 0, slot_cur = 0;
-#ifdef ILQR_PHASE_TIMING
-  long long spins = 0;
-#endif
   __device__ __forceinline__ RingGate(SH& s, int T_) : sh(s), T(T_), nrounds((T_ + 1 + kKnotsPerRound - 1) / kKnotsPerRound), N(nrounds * kKnotsPerRound) {}
   __device__ __forceinline__ void begin_pass() {  // wave-uniform among the lanes still in the pass loop
     pass++;
@@ -1827,9 +1704,6 @@ struct RingGate {
     __hip_atomic_store(&sh.consumer_at, G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     while (__hip_atomic_load(&sh.rounds_done[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= round) {
       __builtin_amdgcn_s_sleep(2);
-#ifdef ILQR_PHASE_TIMING
-      spins++;
-#endif
     }
     have = pass * N + (j / kKnotsPerRound) * kKnotsPerRound + (w + 1) * 4;
   }
@@ -1850,9 +1724,10 @@ struct RingGate {
 // vmcnt wait in its loop.  The records never reach HBM: a lambda-retry pass (ilqr_core.cpp:136-150) makes the
 // producers sweep again, for the trajectories that retry; whoever else wants records (getters, stage calls)
 // has k_derivatives compute them.  Workgroup-scope release/acquire is all the ordering needed.
-template <class M, int kProd, int RING_KB, class MFD, class SH>
+// role: what this wavefront does -- 0 the backward pass, 1..kProd producer role-1, anything else nothing (default: by wavefront index)
+template <class M, int kProd, int RING_KB, class MFD, class SH, bool ONESET = false>
 __device__ __forceinline__ void sweep_backward_tile(const BatchViewT<typename M::real>& v, const M& model, const MFD& fdm, const SolverParams& sp,
-                                                    int mode, int force, const int* __restrict__ commit_idx, int tile, SH& sh) {
+                                                    int mode, int force, const int* __restrict__ commit_idx, int tile, SH& sh, int role = -1) {
   using real = typename M::real;
   constexpr int kKnotsPerRound = 4 * kProd;                      // 4 knots per producer wavefront
   constexpr int kLeadKnots = ILQR_LEAD_ROUNDS * kKnotsPerRound;  // producers stay at most this far ahead of the consumer
@@ -1864,18 +1739,15 @@ __device__ __forceinline__ void sweep_backward_tile(const BatchViewT<typename M:
     sh.passes_started = 0;
   }
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = (role >= 0) ? role : (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int T = v.T;
   if (wave == 0) {
     __builtin_amdgcn_s_setprio(3);
     RingGate<SH, kProd> gate(sh, T);
     if (sp.fixes)
-      backward_quad<M, decltype(gate), RING_KB, true>(v, model, sp, mode, tile, lane, sh.steps, gate, sh.ring);
+      backward_quad<M, decltype(gate), RING_KB, true, ONESET>(v, model, sp, mode, tile, lane, sh.steps, gate, sh.ring);
     else
-      backward_quad<M, decltype(gate), RING_KB, false>(v, model, sp, mode, tile, lane, sh.steps, gate, sh.ring);
-#ifdef ILQR_PHASE_TIMING
-    if (v.dbg && lane == 0 && tile < 64) v.dbg[tile * 8 + 7] = gate.spins;
-#endif
+      backward_quad<M, decltype(gate), RING_KB, false, ONESET>(v, model, sp, mode, tile, lane, sh.steps, gate, sh.ring);
     gate.finish();
     __builtin_amdgcn_s_setprio(0);
   } else {
@@ -1955,45 +1827,79 @@ __device__ __forceinline__ void phase_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
-template <class M, class MFD>
-__global__ __launch_bounds__(256) void k_solve_tile(BatchViewT<typename M::real> v, M model, MFD fdm, AlphaSet alphas, SolverParams sp, int n_iters,
+// Resources of one persistent tile, by how many tiles share a CU (OCC):
+//   1: three producers, a 150 KB ring, rollout inputs prefetched 8 steps ahead, two register sets of records in the
+//      backward wavefront: ~400 registers per wavefront, one block per CU -- the shortest iteration for a tile that has a
+//      CU to itself (B <= 16 x #CU)
+//   2: <= 256 registers and <= 78 KB of LDS, two blocks per CU: two producers (one for m = 2, whose slots are larger) on a
+//      72 KB ring, prefetch depth 4, one register set.  Every tile is slower by itself, two side by side are faster:
+//      the chip's issue slots, not a tile's latency, are what a big batch is short of.
+template <class M, int OCC>
+struct SolveCfg {
+  using real = typename M::real;
+  static constexpr int kRingKb = (OCC == 1) ? ILQR_RING_KB : 72;
+  static constexpr int kSlotsAvail = RingSlot<M::NX, M::NU, real, kRingKb>::SLOTS;
+  static constexpr int kProd = (OCC == 1) ? kProducers : (kSlotsAvail >= 12 ? 2 : 1);
+  static constexpr int kPrefetch = (OCC == 1) ? kDeepPrefetch<M> : 4;
+  static constexpr bool kOneSet = (OCC != 1);
+};
+
+// Which SIMD of its CU a wavefront runs on, and where its workgroup's LDS allocation starts (in the allocation granule):
+// the second of two co-resident workgroups starts above zero.
+__device__ __forceinline__ int hw_simd_id() { return (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)); }       // HW_ID[5:4]
+__device__ __forceinline__ int hw_lds_base() { return (int)__builtin_amdgcn_s_getreg(6 | (0 << 6) | (11 << 11)); }     // LDS_ALLOC[11:0]
+
+template <class M, class MFD, int OCC = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_solve_tile(BatchViewT<typename M::real> v, M model, MFD fdm, AlphaSet alphas, SolverParams sp, int n_iters,
                                                     int force, int* __restrict__ commit_idx, int commit_pending, long long* __restrict__ phase_ticks) {
   using real = typename M::real;
-  __shared__ SweepShared<real, M::NX, M::NU, kProducers, ILQR_RING_KB> sh;
+  using Cfg = SolveCfg<M, OCC>;
+  __shared__ SweepShared<real, M::NX, M::NU, Cfg::kProd, Cfg::kRingKb> sh;
   __shared__ double lds_cost[NALPHA * TW];
   __shared__ int tile_running;
+  __shared__ int simd_mask, chain_wave;
+  if (threadIdx.x == 0) {
+    simd_mask = 0;
+    chain_wave = -1;
+  }
   load_step_table(sh.steps);  // (barrier)
+  // Roles.  One tile per CU: wavefront 0 runs the backward pass, 1..3 produce; 0..2 roll out.  Two tiles per CU: the
+  // dispatcher puts the four wavefronts of a workgroup on the four SIMDs (measured: always, in varying order --
+  // scripts/ubench/placement.hip), and a backward chain issues at 0.8 of what a SIMD can issue at all: two chains on one
+  // SIMD would halve each other.  So roles go by SIMD: the workgroup whose LDS starts at 0 runs its chain on SIMD 0, the
+  // other one on SIMD 2; SIMDs 1 and 3 host both tiles' producers and two of each tile's three rollout wavefronts, the
+  // third one (alphas 8..10) runs where the tile's own chain -- idle in that phase -- sits.  A chain never shares its SIMD
+  // with a wavefront that is busy at the same time, and the four SIMDs carry about the same number of instructions.
+  int role = (int)(threadIdx.x >> 6), rwave = role;
+  if constexpr (OCC != 1) {
+    const int simd = hw_simd_id();
+    if ((threadIdx.x & 63) == 0) atomicOr(&simd_mask, 1 << simd);
+    const int chain_simd = (hw_lds_base() != 0) ? 2 : 0;
+    if ((threadIdx.x & 63) == 0 && simd == chain_simd) chain_wave = (int)(threadIdx.x >> 6);
+    __syncthreads();
+    if (simd_mask == 0xF && chain_wave >= 0) {
+      const int rel = (simd - chain_simd) & 3;  // 0: chain; 1, 3: the helper SIMDs; 2: the other tile's chain SIMD (this wavefront stays idle)
+      role = (rel == 0) ? 0 : (rel == 1) ? 1 : (rel == 3) ? 2 : 3;
+      rwave = (rel == 0) ? 2 : (rel == 1) ? 0 : (rel == 3) ? 1 : 3;
+    }  // (else: not one wavefront per SIMD -- roles by wavefront index, as with one tile per CU)
+  }
   const int tile = blockIdx.x;
   long long t_sweep = 0, t_roll = 0, t0 = 0;
   const bool timing = (phase_ticks != nullptr) & (threadIdx.x == 0);
-#ifdef ILQR_PHASE_TIMING
-  long long c_sweep = 0, c_roll = 0, c0 = 0;  // the same in shader cycles (s_memtime): cycles / wall = the clock the chip ran at
-#endif
   int it = 0;
   for (; it < n_iters; it++) {
     if (timing) t0 = wall_clock64();
-#ifdef ILQR_PHASE_TIMING
-    if (timing) c0 = clock64();
-#endif
-    sweep_backward_tile<M, kProducers, ILQR_RING_KB, MFD>(v, model, fdm, sp, 1, force, (it > 0 || commit_pending) ? commit_idx : nullptr, tile, sh);
+    sweep_backward_tile<M, Cfg::kProd, Cfg::kRingKb, MFD, decltype(sh), Cfg::kOneSet>(v, model, fdm, sp, 1, force, (it > 0 || commit_pending) ? commit_idx : nullptr, tile, sh, role);
     phase_barrier();  // the tile's gains, lambda, status are in memory for its rollout wavefronts
     if (timing) {
       const long long t1 = wall_clock64();
       t_sweep += t1 - t0;
       t0 = t1;
-#ifdef ILQR_PHASE_TIMING
-      const long long c1 = clock64();
-      c_sweep += c1 - c0;
-      c0 = c1;
-#endif
     }
-    rollout_tile<M, true, true, kDeepPrefetch<M>, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, commit_idx, tile, lds_cost, /*count_running=*/it == n_iters - 1);
+    rollout_tile<M, true, true, Cfg::kPrefetch, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, commit_idx, tile, lds_cost, /*count_running=*/it == n_iters - 1, rwave);
     if (threadIdx.x == 0) tile_running = 0;
     phase_barrier();  // candidates, costs, status, commit indices are in memory for the next sweep
     if (timing) t_roll += wall_clock64() - t0;
-#ifdef ILQR_PHASE_TIMING
-    if (timing) c_roll += clock64() - c0;
-#endif
     if (!sp.fixed_work) {  // has every trajectory of the tile left its loop?
       const int b = tile * TW + (int)threadIdx.x;
       if (threadIdx.x < TW && b < v.B && v.status[b] == 0) tile_running = 1;
@@ -2004,14 +1910,6 @@ __global__ __launch_bounds__(256) void k_solve_tile(BatchViewT<typename M::real>
       }
     }
   }
-#ifdef ILQR_PHASE_TIMING
-  if (timing && v.dbg && tile == 0) {
-    v.dbg[924] = c_sweep;
-    v.dbg[925] = t_sweep;
-    v.dbg[926] = c_roll;
-    v.dbg[927] = t_roll;
-  }
-#endif
   if (timing) {
     phase_ticks[3 * tile + 0] += t_sweep;
     phase_ticks[3 * tile + 1] += t_roll;

@@ -88,10 +88,9 @@ enum ilqr_flags {
    * work done.  Accept/reject and the lambda schedule stay as in the reference. */
   ILQR_FLAG_FIXED_WORK = 1,
   /* Backward-pass kernel of the stage call ilqr_backward_pass and of the two-kernel route (nx = 4 models; see
-   * DESIGN.md): the default is four lanes per trajectory; one thread per trajectory (the cross-check); sixteen
-   * lanes per trajectory (experiment, nu = 1: same results to rounding, not bit for bit). */
+   * DESIGN.md): the default is four lanes per trajectory; this flag selects one thread per trajectory (the cross-check).
+   * (4 was an experiment kernel of round 2 and is ignored.) */
   ILQR_FLAG_BACKWARD_THREAD_PER_TRAJ = 2,
-  ILQR_FLAG_BACKWARD_LANE_GROUP = 4,
   /* ilqr_iterate / ilqr_solve normally run the derivative sweep and the backward pass of an
    * iteration in one kernel (nx = 4 models: the sweep uses the SIMDs the backward pass leaves
    * idle).  This flag launches them as two kernels, as the stage calls do.  Same results. */

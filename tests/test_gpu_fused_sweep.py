@@ -100,11 +100,13 @@ def test_short_horizons_fused_equals_unfused(T):
         assert np.all(np.isfinite(out[0]["cost"]))
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("name", ["acrobot", "integrator"])
-def test_two_blocks_per_cu_variant_equals_unfused(name, monkeypatch):
-    """The second instantiation of k_sweep_backward (one producer wavefront, 60 KB ring, two blocks per
-    CU: what ilqr_iterate picks for 16 x #CU < B <= 32 x #CU), forced here on small batches, normal mode
-    until every trajectory has left its loop (lambda retries re-read records from HBM)."""
+def test_two_tiles_per_cu_variants_equal_unfused(name, dtype, monkeypatch):
+    """The two-tiles-per-CU instantiations -- k_solve_tile<.., 2> (persistent: <= 256 registers, 72 KB ring, one register
+    set of records, roles assigned by SIMD; what ilqr_iterate picks for every B > 16 x #CU) and, with ILQR_FLAG_STAGED,
+    k_sweep_backward<1 producer, 60 KB> -- forced here on a small batch, normal mode until every trajectory has left its
+    loop (lambda retries make the producers sweep again), against the two-kernel route: bit-identical."""
     from ilqr_amd import BatchILQR, capi
     B, T = 37, 61
     if name == "acrobot":
@@ -113,38 +115,50 @@ def test_two_blocks_per_cu_variant_equals_unfused(name, monkeypatch):
         x0, nu, kw = integrator_x0(B), 2, dict(goal=[1.0, 0.5, 0.0, 0.0])
     u0 = np.zeros((B, T, nu))
     out = []
-    for fl, env in ((0, "2"), (capi.FLAG_UNFUSED, None)):
+    for fl, env in ((0, "2"), (capi.FLAG_STAGED, "2"), (capi.FLAG_UNFUSED, None)):
         if env:
             monkeypatch.setenv("ILQR_AMD_FUSED", env)
         else:
             monkeypatch.delenv("ILQR_AMD_FUSED", raising=False)
-        g = BatchILQR(name, B, T, DT, flags=fl, **kw)
+        g = BatchILQR(name, B, T, DT, flags=fl, dtype=dtype, **kw)
         g.generate_trajectory(x0, u0)
         out.append(_state(g))
         g.close()
     _same(out[0], out[1])
+    _same(out[0], out[2])
 
 
-def test_batch_between_one_and_two_tiles_per_cu_takes_the_fused_route(monkeypatch):
-    """Route selection by batch size (ILQR_AMD_NUM_CUS scales the thresholds down to test sizes): up to one
-    tile per CU the three-producer kernel, up to two tiles per CU the one-producer kernel, then two kernels."""
+def test_route_selection_by_batch_size(monkeypatch):
+    """Route selection by batch size (ILQR_AMD_NUM_CUS scales the thresholds down to test sizes): up to one tile per CU
+    the persistent kernel with a CU per tile, beyond that -- at ANY batch size -- the persistent kernel with two tiles per
+    CU (the records never reach HBM); with ILQR_FLAG_STAGED the per-stage kernels, and two kernels beyond two tiles per CU.
+    Every route leaves the same bits."""
     from ilqr_amd import BatchILQR, capi
     cus = 6
     monkeypatch.setenv("ILQR_AMD_NUM_CUS", str(cus))
-    B, T = 16 * cus + 16, 20  # one tile more than one block per CU
-    x0 = acrobot_x0(B, scale=0.3, seed=4)
-    u0 = np.zeros((B, T, 1))
-    out = []
-    for fl in (0, capi.FLAG_UNFUSED):
-        g = BatchILQR("acrobot", B, T, DT, u_min=-1.5, u_max=1.5, flags=fl)
-        assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("backward")) == (b"k_backward_q" if fl else b"k_sweep_backward")
-        g.init_traj(x0, u0)
-        g.iterate(3)
-        out.append(_state(g))
-        g.close()
-    _same(out[0], out[1])
-    g = BatchILQR("acrobot", 32 * cus + 16, 4, DT)  # more than two tiles per CU: two kernels
-    assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("backward")) == b"k_backward_q"
+    T = 20
+    bw, sv = capi.STAGE_NAMES.index("backward"), capi.STAGE_NAMES.index("solve")
+    for B in (16 * cus + 16, 80 * cus + 3):  # one tile more than one per CU; five tiles per CU and a ragged last tile
+        x0 = acrobot_x0(B, scale=0.3, seed=4)
+        u0 = np.zeros((B, T, 1))
+        out = []
+        for fl in (0, capi.FLAG_STAGED, capi.FLAG_UNFUSED):
+            g = BatchILQR("acrobot", B, T, DT, u_min=-1.5, u_max=1.5, flags=fl)
+            name = lambda st: g.lib.ilqr_stage_kernel_name(g.h, st)
+            if fl == 0:
+                assert name(sv) == b"k_solve_tile<2>"
+            elif fl == capi.FLAG_STAGED:
+                assert name(sv) == b"" and name(bw) == (b"k_sweep_backward" if B <= 32 * cus else b"k_backward_q")
+            else:
+                assert name(bw) == b"k_backward_q"
+            g.init_traj(x0, u0)
+            g.iterate(3)
+            out.append(_state(g))
+            g.close()
+        _same(out[0], out[1])
+        _same(out[0], out[2])
+    g = BatchILQR("acrobot", 64, 4, DT)  # four tiles on "six CUs"
+    assert g.lib.ilqr_stage_kernel_name(g.h, sv) == b"k_solve_tile"
     g.close()
 
 

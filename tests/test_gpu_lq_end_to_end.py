@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from tests.util import TOL, mat, relerr, relerr_abs
-from tests.parity import check_backward, walk_iterations
+from tests.parity import check_backward, sampled_walk, walk_iterations
 
 pytestmark = pytest.mark.gpu
 DT = 0.02
@@ -182,7 +182,7 @@ def test_lq_matrix_core_rollout_equals_thread_per_rollout(n, m, B, T, monkeypatc
 
 
 @pytest.mark.parametrize("lim", [1.0, 0.3])
-def test_lq_full_size_properties(lim):
+def test_lq_full_size_properties(oracle, lim):
     """BASELINE.json configs[4] at full size (n = 32, m = 16, T = 200, B = 8192; limits +-1 as SURVEY.md 8d
     cfg 5 has them, and +-0.3 where far more box-QPs end clamped): size-independent properties of two
     finite-difference iterations."""
@@ -194,6 +194,10 @@ def test_lq_full_size_properties(lim):
     x0[1] = x0[0]
     x0[B - 1] = x0[0]  # duplicates in other wavefronts / CUs
     g = BatchILQR("lq", B, T, DT, u_min=-lim, u_max=lim, lq=mats)
+    # 24 trajectories of the full batch walked against the oracle, iteration by iteration (tests/parity.py: Sampled)
+    r = sampled_walk(oracle, oracle.Model("lq", lq=mats, u_lim=lim), g, x0, np.zeros((B, T, m)), DT, 2, n_sample=24, verbose=True)
+    print("configs[4] lim", lim, "sampled walk:", {kk: v for kk, v in r.items() if kk != "sel"})
+    assert r["checked"] == 2 * len(r["sel"]) and len(r["tied"]) <= 3, r
     c0 = g.init_traj(x0, np.zeros((B, T, m)))
     g.iterate(2)
     cost = g.cost()
