@@ -122,7 +122,14 @@ ILQR_HD bool quadclamp_line_search(const real* x0, const real* dir, const real* 
     for (int i = 0; i < M; i++) xr[i] = x0[i] + step * dir[i];
     clamp_to_limits<M>(xr, lo, hi, xc);
     v = quad_cost<M>(Q, c, xc);
-    if (step < real(kMinStep)) {
+    // A trial that lands on x0 itself (the direction is rounding noise, or points out of the box from a bound) has
+    // v == old_v, and so has every shorter step: the reference's loop keeps failing the test down to minStep (:167-171)
+    // -- unless step * slope underflows first, which ends it "accepting" the same point; either way x and the free set
+    // stay as they are (result 2 or, one iteration later, 4).  Same outcome, up to 100 trips earlier.
+    bool stuck = true;
+#pragma unroll
+    for (int i = 0; i < M; i++) stuck = stuck & (xc[i] == x0[i]);
+    if (step < real(kMinStep) || stuck) {
       failed = true;
       break;
     }
@@ -395,6 +402,134 @@ ILQR_HD void box_qp(const real* Q, const real* c, const real* x0, const real* lo
   res.nfR = nfR;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// M = 2 (the double integrator, include/double_integrator.h:16-17): box_qp<2> written out for two scalars.
+// The generic solver spends most of a 2 x 2 QP in Eigen's recipe for (R^-1 R^-T) -- Cholesky, two triangular
+// inverses, a product: two square roots and five IEEE divisions, formed in the loop and once more by the caller for
+// K (:373-385) -- and in rank-matched selects that emulate the mask helpers.  Here the free set is one of three cases
+// (both, only 0, only 1), the compaction is a pair of selects, and (R^-1 R^-T) of a positive definite free block is its
+// inverse by the adjugate: 1 / Q_ff for one free dimension, adj(Q_ff) / det for two (one rcp + Newton; rounding-level
+// difference from the Cholesky route, as for M = 1 below).  What leaks into results is kept:
+//   - initial value without 1/2, inclusive loop bound, stall / all-clamped / gradient / line-search exits in the
+//     reference's order (boxqp.cpp:50-125);
+//   - refactor only when the NUMBER of clamped dimensions changed (:80): with one free dimension the factor may belong
+//     to the OTHER index -- Minv is kept compact (rank-indexed) exactly like R_free;
+//   - Eigen's unchecked partial Cholesky (LLT.h:318-319) when the free block is not positive definite: that rare case
+//     runs the generic llt_lower<2> / rinv_rinvT<2> on the compacted block, so its partial factor is the reference's.
+// Outputs: x, the free mask, and Minv (what the caller needs for K) instead of R.
+// ------------------------------------------------------------------------------------------
+template <class real>
+struct BoxQP2Result {
+  int result;
+  real x[2];
+  bool free0, free1;
+  real m00, m01, m11;  // compact (R^-1 R^-T) of the factor held at exit: leading nfR x nfR block
+  int nfR;
+};
+
+template <class real>
+ILQR_HD void box_qp2(const real* Q, const real* c, const real* x0, const real* lo, const real* hi, BoxQP2Result<real>& res,
+                     bool detect_indefinite = false) {
+  const real q00 = Q[0], q10 = Q[1], q01 = Q[2], q11 = Q[3];
+  real x[2];
+  clamp_to_limits<2>(x0, lo, hi, x);  // :35
+  real val = ((x[0] * q00 + x[1] * q10) * x[0] + (x[0] * q01 + x[1] * q11) * x[1]) + (x[0] * c[0] + x[1] * c[1]);  // :36 (no 1/2)
+  real oldvalue = 0;
+  int result = 0, nfR = 0;
+  bool cl0 = false, cl1 = false;
+  real m00 = 0, m01 = 0, m11 = 0;
+#pragma unroll 2  // (most QPs end in their second iteration)
+  for (int iter = 0; iter <= kQpMaxIter; iter++) {  // :50
+    if (iter > 0 && (oldvalue - val) < real(kMinRelImprove) * abs_of(oldvalue)) {  // :54-57
+      result = 4;
+      break;
+    }
+    const real g0 = (q00 * x[0] + q01 * x[1]) + c[0], g1 = (q10 * x[0] + q11 * x[1]) + c[1];
+    oldvalue = val;
+    const int n_old = (int)cl0 + (int)cl1;
+    cl0 = ((abs_of(x[0] - lo[0]) < real(kClampTol)) & (g0 > 0)) | ((abs_of(x[0] - hi[0]) < real(kClampTol)) & (g0 < 0));  // :62-71
+    cl1 = ((abs_of(x[1] - lo[1]) < real(kClampTol)) & (g1 > 0)) | ((abs_of(x[1] - hi[1]) < real(kClampTol)) & (g1 < 0));
+    if (cl0 & cl1) {  // :74-77
+      result = 6;
+      break;
+    }
+    const bool f0 = !cl0, both = f0 & !cl1;
+    if (iter == 0 || n_old != (int)cl0 + (int)cl1) {  // :80
+      // the free block, compacted (eigen_helpers.h:46-61)
+      const real a00 = f0 ? q00 : q11, a10 = both ? q10 : real(0), a11 = both ? q11 : real(0);
+      const real det = a00 * a11 - a10 * a10;
+      const bool pd = both ? ((a00 > real(0)) & (det > real(0))) : (a00 > real(0));
+      if (detect_indefinite && !pd) {  // opt-in fix: a failed factorisation ends the QP
+        result = -1;
+        break;
+      }
+      nfR = both ? 2 : 1;
+      if (__builtin_expect(pd, 1)) {
+        if (both) {
+          const real rd = recip(det);
+          m00 = a11 * rd;
+          m01 = -a10 * rd;
+          m11 = a00 * rd;
+        } else {
+          m00 = recip(a00);
+          m01 = m11 = 0;
+        }
+      } else {  // Eigen's partial factor, literally
+        real Qf[4] = {a00, a10, both ? q01 : real(0), a11}, R[4], Mi[4];
+        llt_lower<2>(nfR, Qf);
+        R[0] = Qf[0];
+        R[1] = 0;
+        R[2] = both ? Qf[1] : real(0);
+        R[3] = both ? Qf[3] : real(0);
+        rinv_rinvT<2>(nfR, R, Mi);
+        m00 = Mi[0];
+        m01 = Mi[1];
+        m11 = Mi[3];
+      }
+    }
+    real gn2 = 0;  // :93-97
+    if (!cl0) gn2 += g0 * g0;
+    if (!cl1) gn2 += g1 * g1;
+    if (grad_norm_below_min(gn2)) {
+      result = 5;
+      break;
+    }
+    // :100  grad_clamped = Q (x .* clamped) + c
+    const real t0 = cl0 ? x[0] : real(0), t1 = cl1 ? x[1] : real(0);
+    const real gc0 = (q00 * t0 + q01 * t1) + c[0], gc1 = (q10 * t0 + q11 * t1) + c[1];
+    // :103-119  search(free) = -(R^-1 R^-T) gc(free) - x(free), by rank
+    const real gf0 = f0 ? gc0 : gc1, xf0 = f0 ? x[0] : x[1];
+    real sf0, sf1 = 0;
+    if (nfR == 2) {
+      const real gf1 = both ? gc1 : real(0), xf1 = both ? x[1] : real(0);
+      sf0 = (-m00 * gf0 + -m01 * gf1) - xf0;
+      sf1 = (-m01 * gf0 + -m11 * gf1) - xf1;
+    } else {
+      sf0 = -m00 * gf0 - xf0;
+    }
+    real search[2];
+    search[0] = f0 ? sf0 : real(0);
+    search[1] = cl1 ? real(0) : (f0 ? sf1 : sf0);
+    real lx[2], lv = 0;
+    if (quadclamp_line_search<2>(x, search, Q, c, lo, hi, lx, lv)) {  // :121-125
+      result = 2;
+      break;
+    }
+    x[0] = lx[0];  // :133-134
+    x[1] = lx[1];
+    val = lv;
+  }
+  res.result = result;
+  res.x[0] = x[0];
+  res.x[1] = x[1];
+  res.free0 = !cl0;
+  res.free1 = !cl1;
+  res.m00 = m00;
+  res.m01 = m01;
+  res.m11 = m11;
+  res.nfR = nfR;
+}
 
 // ------------------------------------------------------------------------------------------
 // M = 1 fast path (acrobot, the headline configuration): the same projected-Newton iteration as

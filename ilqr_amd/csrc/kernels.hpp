@@ -1352,6 +1352,19 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         Kc[0] = free0 ? -minv * Quxr[0] : real(0);  // :373-385
         k_free = free0;
         k_minv = minv;
+      } else if constexpr (NU == 2) {
+        // m = 2: the scalarised solver (boxqp.hpp: box_qp2); K[:, s] = -(R^-1 R^-T) Qux[free, s] scattered to the free rows (:373-385)
+        BoxQP2Result<real> r;
+        box_qp2(QuuF, Qu, kprev, lo, hi, r, FIXES && (sp.fixes & 2) != 0);
+        ok = r.result >= 1;
+        qp.x[0] = r.x[0];
+        qp.x[1] = r.x[1];
+        const bool both = r.free0 & r.free1;
+        const real q0 = r.free0 ? Quxr[0] : Quxr[1];  // rows_w_ind(Qux_reg, v_free)(:, s), by rank
+        const real kA = (r.nfR == 2) ? (-r.m00 * q0 + -r.m01 * Quxr[1]) : -r.m00 * q0;  // rank 0 (the second term only if both are free)
+        const real kB = -r.m01 * Quxr[0] + -r.m11 * Quxr[1];                              // rank 1
+        Kc[0] = r.free0 ? kA : real(0);
+        Kc[1] = r.free1 ? (both ? kB : kA) : real(0);
       } else {
         BoxQPResult<NU, real> r;
         box_qp<NU>(QuuF, Qu, kprev, lo, hi, r, FIXES && (sp.fixes & 2) != 0);

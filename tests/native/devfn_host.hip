@@ -66,3 +66,22 @@ extern "C" int devfn_box_qp_scalar_fast_f32(float Q, float c, float x0, float lo
 // sqrt(gn2) < minGrad without the square root (boxqp.hpp): the product's test next to the literal one
 extern "C" int devfn_grad_norm_below_min(double gn2) { return grad_norm_below_min(gn2) ? 1 : 0; }
 extern "C" int devfn_grad_norm_below_min_f32(float gn2) { return grad_norm_below_min(gn2) ? 1 : 0; }
+
+// m = 2 scalarised solver (boxqp.hpp: box_qp2), double and float
+extern "C" int devfn_box_qp2(const double* Q, const double* c, const double* x0, const double* lo, const double* hi, double* x, int* vfree,
+                             double* minv3, int* nfR, int detect_indefinite) {
+  BoxQP2Result<double> r;
+  box_qp2(Q, c, x0, lo, hi, r, detect_indefinite != 0);
+  x[0] = r.x[0]; x[1] = r.x[1];
+  vfree[0] = r.free0; vfree[1] = r.free1;
+  minv3[0] = r.m00; minv3[1] = r.m01; minv3[2] = r.m11;
+  *nfR = r.nfR;
+  return r.result;
+}
+extern "C" int devfn_box_qp2_f32(const float* Q, const float* c, const float* x0, const float* lo, const float* hi, float* x, int* vfree) {
+  BoxQP2Result<float> r;
+  box_qp2(Q, c, x0, lo, hi, r);
+  x[0] = r.x[0]; x[1] = r.x[1];
+  vfree[0] = r.free0; vfree[1] = r.free1;
+  return r.result;
+}
