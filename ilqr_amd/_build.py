@@ -61,5 +61,30 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_user(header, out, verbose=False):
+    """A build of the library that carries the caller's device twin (ILQR_MODEL_USER): `header` defines
+    UserModelT<real> (contract: csrc/models.hpp).  Rebuilt when the library sources, the header or the flags change."""
+    import hashlib
+    header, out = os.path.abspath(header), os.path.abspath(out)
+    h = hashlib.sha256((_source_hash() + open(header, "rb").read().hex()).encode()).hexdigest()
+    stamp = out + ".srchash"
+    if os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == h:
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    tmp = out + ".tmp.%d" % os.getpid()
+    cmd = [HIPCC] + FLAGS + ["-DILQR_USER_MODEL_HEADER=\"%s\"" % header, "-o", tmp] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(tmp, out)
+    with open(stamp, "w") as f:
+        f.write(h)
+    return out
+
+
+USER_EXAMPLE_HEADER = os.path.join(os.path.dirname(PKG), "examples", "user_model_acrobot.hpp")
+USER_EXAMPLE_LIB = os.path.join(PKG, "lib", "libilqr_amd_user_example.so")
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

@@ -20,7 +20,9 @@ _MODELS = {"acrobot": (capi.MODEL_ACROBOT, 4, 1), "double_integrator": (capi.MOD
            # host-evaluated model: only the backward pass runs on the device (nx, nu given by the caller)
            "host": (capi.MODEL_HOST, None, None),
            # synthetic LQ model (BASELINE.json configs[4]): lq=(A, B, Q, R, Qf), row-major; nx, nu from their shapes
-           "lq": (capi.MODEL_LQ, None, None)}
+           "lq": (capi.MODEL_LQ, None, None),
+           # the caller's own device twin, compiled into the library given by lib= (ilqr_amd._build.build_user); nx, nu by the caller
+           "user": (capi.MODEL_USER, None, None)}
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 
@@ -35,10 +37,11 @@ def _p(a):
 
 class BatchILQR:
     def __init__(self, model, B, T, dt, u_min=None, u_max=None, goal=None, device=0, flags=0,
-                 stream=None, params=None, nx=None, nu=None, lq=None, dtype="f64"):
-        self.lib = capi.load()
+                 stream=None, params=None, nx=None, nu=None, lq=None, dtype="f64", lib=None, user_params=None):
+        self.lib = capi.load(path=lib)
+        self._check = lambda rc: capi.check(rc, self.lib)
         self._ctor = dict(model=model, B=B, T=T, dt=dt, u_min=u_min, u_max=u_max, goal=goal, device=device, flags=flags,
-                          stream=stream, params=params, nx=nx, nu=nu, lq=lq, dtype=dtype)
+                          stream=stream, params=params, nx=nx, nu=nu, lq=lq, dtype=dtype, lib=lib, user_params=user_params)
         mid, mnx, mnu = _MODELS[model]
         if lq is not None:
             lq = [_c(a) for a in lq]
@@ -62,6 +65,10 @@ class BatchILQR:
             self._keep.extend(lq)
             d.lq_A, d.lq_B, d.lq_Q, d.lq_R, d.lq_Qf = (_p(a) for a in lq)
         d.stream = stream
+        if user_params is not None:
+            up = _c(user_params).ravel()
+            self._keep.append(up)
+            d.user_params, d.n_user_params = _p(up), len(up)
         if params is not None:
             p = capi.Params()
             self.lib.ilqr_default_params(C.byref(p))
@@ -70,7 +77,7 @@ class BatchILQR:
             self._keep.append(p)
             d.params = C.pointer(p)
         self.h = C.c_void_p()
-        capi.check(self.lib.ilqr_create(C.byref(d), C.byref(self.h)))
+        self._check(self.lib.ilqr_create(C.byref(d), C.byref(self.h)))
 
     def clone(self):
         """A second, independent handle for the same problem description (own device memory and state)."""
@@ -92,61 +99,61 @@ class BatchILQR:
         x0, u0 = _c(x0), _c(u0)
         assert x0.shape == (self.B, self.nx) and u0.shape == (self.B, self.T, self.nu)
         cost = np.zeros(self.B)
-        capi.check(self.lib.ilqr_init_traj(self.h, _p(x0), _p(u0), _p(cost)))
+        self._check(self.lib.ilqr_init_traj(self.h, _p(x0), _p(u0), _p(cost)))
         return cost
 
     def generate_trajectory(self, x0=None, u0=None):
         if x0 is not None and u0 is not None:
             x0, u0 = _c(x0), _c(u0)
-            capi.check(self.lib.ilqr_solve(self.h, _p(x0), _p(u0)))
+            self._check(self.lib.ilqr_solve(self.h, _p(x0), _p(u0)))
         elif x0 is not None:
             x0 = _c(x0)
-            capi.check(self.lib.ilqr_warm_start(self.h, _p(x0)))
+            self._check(self.lib.ilqr_warm_start(self.h, _p(x0)))
         else:
-            capi.check(self.lib.ilqr_generate_trajectory(self.h))
+            self._check(self.lib.ilqr_generate_trajectory(self.h))
 
     solve = generate_trajectory  # BASELINE.json's "iLQR::solve()"
 
     def iterate(self, n=1):
-        capi.check(self.lib.ilqr_iterate(self.h, int(n)))
+        self._check(self.lib.ilqr_iterate(self.h, int(n)))
 
     def synchronize(self):
-        capi.check(self.lib.ilqr_synchronize(self.h))
+        self._check(self.lib.ilqr_synchronize(self.h))
 
     # ---- stages ----
     def compute_derivatives(self):
-        capi.check(self.lib.ilqr_compute_derivatives(self.h))
+        self._check(self.lib.ilqr_compute_derivatives(self.h))
 
     def backward_pass(self):
         div = np.zeros(self.B, dtype=np.int32)
-        capi.check(self.lib.ilqr_backward_pass(self.h, div.ctypes.data_as(_ip)))
+        self._check(self.lib.ilqr_backward_pass(self.h, div.ctypes.data_as(_ip)))
         return div
 
     def backward_step(self):
-        capi.check(self.lib.ilqr_backward_step(self.h))
+        self._check(self.lib.ilqr_backward_step(self.h))
 
     def rollout_candidates(self):
         cost = np.zeros((self.B, len(ALPHAS)))
-        capi.check(self.lib.ilqr_rollout_candidates(self.h, _p(cost)))
+        self._check(self.lib.ilqr_rollout_candidates(self.h, _p(cost)))
         return cost
 
     def line_search(self):
-        capi.check(self.lib.ilqr_line_search(self.h))
+        self._check(self.lib.ilqr_line_search(self.h))
 
     def reset_state(self, warm=False):
         """warm=False: the non-rollout part of init_traj; warm=True: a new outer loop on the stored
         solution (status / iteration count / flgChange restart, lambda and gains persist)."""
-        capi.check(self.lib.ilqr_reset_state(self.h, int(bool(warm))))
+        self._check(self.lib.ilqr_reset_state(self.h, int(bool(warm))))
 
     # ---- setters (canonical layouts; matrices given as [..., rows, cols]) ----
     def set_trajectory(self, x0=None, xs=None, us=None, cost=None):
         a = [None if v is None else _c(v) for v in (x0, xs, us, cost)]
-        capi.check(self.lib.ilqr_set_trajectory(self.h, *[_p(v) for v in a]))
+        self._check(self.lib.ilqr_set_trajectory(self.h, *[_p(v) for v in a]))
 
     def set_gains(self, k=None, K=None):
         k = None if k is None else _c(k)
         K = None if K is None else _c(np.swapaxes(np.asarray(K), -1, -2))
-        capi.check(self.lib.ilqr_set_gains(self.h, _p(k), _p(K)))
+        self._check(self.lib.ilqr_set_gains(self.h, _p(k), _p(K)))
 
     def set_derivatives(self, **d):
         """fx, fu, cx, cu, cxx, cxu, cuu as [B][T+1][rows][cols] (vectors [B][T+1][n])."""
@@ -160,12 +167,12 @@ class BatchILQR:
                 arrs.append(_c(v))
             else:
                 arrs.append(_c(np.swapaxes(np.asarray(v), -1, -2)))
-        capi.check(self.lib.ilqr_set_derivatives(self.h, *[_p(v) for v in arrs]))
+        self._check(self.lib.ilqr_set_derivatives(self.h, *[_p(v) for v in arrs]))
 
     def set_lambda(self, lam=None, dlam=None):
         lam = None if lam is None else _c(np.broadcast_to(lam, (self.B,)))
         dlam = None if dlam is None else _c(np.broadcast_to(dlam, (self.B,)))
-        capi.check(self.lib.ilqr_set_lambda(self.h, _p(lam), _p(dlam)))
+        self._check(self.lib.ilqr_set_lambda(self.h, _p(lam), _p(dlam)))
 
     # ---- getters ----
     def trajectory(self, out=None):
@@ -180,13 +187,13 @@ class BatchILQR:
             for a, shape in ((xs, (self.B, self.T + 1, self.nx)), (us, (self.B, self.T, self.nu))):
                 if a.shape != shape or a.dtype != np.float64 or not a.flags.c_contiguous:
                     raise ValueError("out arrays must be C-contiguous float64 of shape %s" % (shape,))
-        capi.check(self.lib.ilqr_get_trajectory(self.h, _p(xs), _p(us)))
+        self._check(self.lib.ilqr_get_trajectory(self.h, _p(xs), _p(us)))
         return xs, us
 
     def gains(self):
         k = np.zeros((self.B, self.T, self.nu))
         K = np.zeros((self.B, self.T, self.nx, self.nu))  # memory: column-major nu x nx
-        capi.check(self.lib.ilqr_get_gains(self.h, _p(k), _p(K)))
+        self._check(self.lib.ilqr_get_gains(self.h, _p(k), _p(K)))
         return k, np.swapaxes(K, -1, -2)
 
     def derivatives(self):
@@ -195,55 +202,55 @@ class BatchILQR:
                    cu=np.zeros((B, T1, m)), cxx=np.zeros((B, T1, n, n)), cxu=np.zeros((B, T1, m, n)),
                    cuu=np.zeros((B, T1, m, m)))
         order = ("fx", "fu", "cx", "cu", "cxx", "cxu", "cuu")
-        capi.check(self.lib.ilqr_get_derivatives(self.h, *[_p(mem[k]) for k in order]))
+        self._check(self.lib.ilqr_get_derivatives(self.h, *[_p(mem[k]) for k in order]))
         return {k: (v if k in ("cx", "cu") else np.swapaxes(v, -1, -2)) for k, v in mem.items()}
 
     def cost(self):
         c = np.zeros(self.B)
-        capi.check(self.lib.ilqr_get_cost(self.h, _p(c)))
+        self._check(self.lib.ilqr_get_cost(self.h, _p(c)))
         return c
 
     def lambdas(self):
         lam, dlam = np.zeros(self.B), np.zeros(self.B)
-        capi.check(self.lib.ilqr_get_lambda(self.h, _p(lam), _p(dlam)))
+        self._check(self.lib.ilqr_get_lambda(self.h, _p(lam), _p(dlam)))
         return lam, dlam
 
     def dV(self):
         d = np.zeros((self.B, 2))
-        capi.check(self.lib.ilqr_get_dV(self.h, _p(d)))
+        self._check(self.lib.ilqr_get_dV(self.h, _p(d)))
         return d
 
     def gnorm(self):
         g = np.zeros(self.B)
-        capi.check(self.lib.ilqr_get_gnorm(self.h, _p(g)))
+        self._check(self.lib.ilqr_get_gnorm(self.h, _p(g)))
         return g
 
     def status(self):
         st, it, al = (np.zeros(self.B, dtype=np.int32) for _ in range(3))
-        capi.check(self.lib.ilqr_get_status(self.h, st.ctypes.data_as(_ip), it.ctypes.data_as(_ip),
+        self._check(self.lib.ilqr_get_status(self.h, st.ctypes.data_as(_ip), it.ctypes.data_as(_ip),
                                             al.ctypes.data_as(_ip)))
         return st, it, al
 
     def candidate(self, a):
         xs = np.zeros((self.B, self.T + 1, self.nx))
         us = np.zeros((self.B, self.T, self.nu))
-        capi.check(self.lib.ilqr_get_candidate(self.h, int(a), _p(xs), _p(us)))
+        self._check(self.lib.ilqr_get_candidate(self.h, int(a), _p(xs), _p(us)))
         return xs, us
 
     def count_running(self):
         n = C.c_int(0)
-        capi.check(self.lib.ilqr_count_running(self.h, C.byref(n)))
+        self._check(self.lib.ilqr_count_running(self.h, C.byref(n)))
         return n.value
 
     # ---- measurement ----
     def profile(self, enable=True):
-        capi.check(self.lib.ilqr_profile_enable(self.h, int(enable)))
+        self._check(self.lib.ilqr_profile_enable(self.h, int(enable)))
 
     def profile_reset(self):
-        capi.check(self.lib.ilqr_profile_reset(self.h))
+        self._check(self.lib.ilqr_profile_reset(self.h))
 
     def profile_read(self):
         ms = (C.c_double * capi.NUM_STAGES)()
         n = (C.c_int * capi.NUM_STAGES)()
-        capi.check(self.lib.ilqr_profile_read(self.h, ms, n))
+        self._check(self.lib.ilqr_profile_read(self.h, ms, n))
         return {capi.STAGE_NAMES[i]: (ms[i], n[i]) for i in range(capi.NUM_STAGES)}

@@ -4,8 +4,8 @@ import os
 
 from . import _build
 
-ABI_VERSION = 2
-MODEL_ACROBOT, MODEL_DOUBLE_INTEGRATOR, MODEL_LQ, MODEL_HOST = 0, 1, 2, 3
+ABI_VERSION = 3
+MODEL_ACROBOT, MODEL_DOUBLE_INTEGRATOR, MODEL_LQ, MODEL_HOST, MODEL_USER = 0, 1, 2, 3, 4
 FLAG_FIXED_WORK, FLAG_BACKWARD_THREAD_PER_TRAJ, _FLAG_RESERVED_4, FLAG_UNFUSED, FLAG_ANALYTIC_DERIVATIVES, FLAG_STAGED, FLAG_REFERENCE_FIXES, FLAG_REGULARIZE_VXX = 1, 2, 4, 8, 16, 32, 64, 128
 DTYPE_F64, DTYPE_F32 = 0, 1
 NUM_STAGES = 5
@@ -27,7 +27,7 @@ class Desc(C.Structure):
                 ("T", C.c_int), ("B", C.c_int), ("dt", C.c_double), ("device", C.c_int),
                 ("flags", C.c_int), ("dtype", C.c_int), ("u_min", _dp), ("u_max", _dp), ("goal", _dp),
                 ("lq_A", _dp), ("lq_B", _dp), ("lq_Q", _dp), ("lq_R", _dp), ("lq_Qf", _dp),
-                ("stream", C.c_void_p), ("params", C.POINTER(Params))]
+                ("stream", C.c_void_p), ("params", C.POINTER(Params)), ("user_params", _dp), ("n_user_params", C.c_int)]
 
 
 # every symbol include/ilqr_amd.h declares: name -> (restype, argtypes)
@@ -35,6 +35,7 @@ _H = C.c_void_p
 SYMBOLS = {
     "ilqr_last_error": (C.c_char_p, []),
     "ilqr_abi_version": (C.c_int, []),
+    "ilqr_has_user_model": (C.c_int, []),
     "ilqr_default_params": (None, [C.POINTER(Params)]),
     "ilqr_create": (C.c_int, [C.POINTER(Desc), C.POINTER(_H)]),
     "ilqr_destroy": (None, [_H]),
@@ -74,6 +75,7 @@ SYMBOLS = {
 }
 
 _lib = None
+_libs = {}   # path -> loaded library (builds with a user device model live next to the stock one)
 
 
 class ILQRError(RuntimeError):
@@ -84,9 +86,26 @@ def lib_path():
     return _build.LIB
 
 
-def load(build_if_missing=True):
-    """Load libilqr_amd.so (building it in-tree first if it is missing or stale)."""
+def _bind(path):
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def load(build_if_missing=True, path=None):
+    """Load libilqr_amd.so (building it in-tree first if it is missing or stale).  path: another build of the same
+    sources, e.g. one with a user device model (ilqr_amd._build.build_user)."""
     global _lib
+    if path is not None:
+        path = os.path.abspath(path)
+        if path not in _libs:
+            if not os.path.exists(path):
+                raise ILQRError("%s is missing: build it with ilqr_amd._build.build_user(header, out)" % path)
+            _libs[path] = _bind(path)
+        return _libs[path]
     if _lib is None:
         if build_if_missing and os.path.exists(_build.HIPCC):
             _build.build()
@@ -103,7 +122,7 @@ def load(build_if_missing=True):
     return _lib
 
 
-def check(rc):
+def check(rc, lib=None):
     if rc != 0:
-        msg = load().ilqr_last_error()
+        msg = (lib or load()).ilqr_last_error()
         raise ILQRError("libilqr_amd error %d: %s" % (rc, msg.decode() if msg else "?"))

@@ -64,6 +64,10 @@ struct ilqr_batch {
   AcrobotModelT<float> acrobot_f;          // fp32 handle: what the rollouts integrate
   DoubleIntegratorModelT<float> dint_f;
   LqModel lq;                   // ILQR_MODEL_LQ: padded matrices on the device
+#ifdef ILQR_HAVE_USER_MODEL
+  UserModelT<double> user;      // ILQR_MODEL_USER: the build's user device twin (fp32 handle: the twin the finite differences are taken in)
+  UserModelT<float> user_f;
+#endif
   // v is the view every entry point addresses arrays through; for an fp32 handle its trajectory pointers hold
   // the addresses of FLOAT arrays (never dereferenced as double: kernels get vf, the same addresses typed float*)
   BatchView v;
@@ -130,12 +134,18 @@ static int with_model(ilqr_batch* h, F&& f) {
     switch (h->model) {
       case ILQR_MODEL_ACROBOT: return f(h->vf, h->acrobot_f, h->acrobot);
       case ILQR_MODEL_DOUBLE_INTEGRATOR: return f(h->vf, h->dint_f, h->dint);
+#ifdef ILQR_HAVE_USER_MODEL
+      case ILQR_MODEL_USER: return f(h->vf, h->user_f, h->user);
+#endif
       default: break;
     }
   } else {
     switch (h->model) {
       case ILQR_MODEL_ACROBOT: return f(h->v, h->acrobot, h->acrobot);
       case ILQR_MODEL_DOUBLE_INTEGRATOR: return f(h->v, h->dint, h->dint);
+#ifdef ILQR_HAVE_USER_MODEL
+      case ILQR_MODEL_USER: return f(h->v, h->user, h->user);
+#endif
       default: break;
     }
   }
@@ -646,6 +656,13 @@ extern "C" {
 
 const char* ilqr_last_error(void) { return g_err; }
 int ilqr_abi_version(void) { return ILQR_AMD_ABI_VERSION; }
+int ilqr_has_user_model(void) {
+#ifdef ILQR_HAVE_USER_MODEL
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 void ilqr_default_params(ilqr_params* p) {  // include/ilqr.h:14-24
   p->max_iter = 100;
@@ -700,7 +717,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   h->model = d->model;
   h->dtype = d->dtype;
   if (d->dtype != ILQR_DTYPE_F64 && d->dtype != ILQR_DTYPE_F32) return fail(ILQR_ERR_INVALID, "dtype %d: ILQR_DTYPE_F64 or ILQR_DTYPE_F32", d->dtype);
-  if (d->dtype == ILQR_DTYPE_F32 && d->model != ILQR_MODEL_ACROBOT && d->model != ILQR_MODEL_DOUBLE_INTEGRATOR)
+  if (d->dtype == ILQR_DTYPE_F32 && d->model != ILQR_MODEL_ACROBOT && d->model != ILQR_MODEL_DOUBLE_INTEGRATOR && d->model != ILQR_MODEL_USER)
     return fail(ILQR_ERR_UNSUPPORTED, "fp32 is available for the nx = 4 device models (acrobot, double integrator); the generic nx <= 32 path is fp64");
   h->nx = d->nx;
   h->nu = d->nu;
@@ -746,6 +763,28 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
         m.u_max[j] = (double)(f.u_max[j] = (float)m.u_max[j]);
       }
     }
+#ifdef ILQR_HAVE_USER_MODEL
+  } else if (d->model == ILQR_MODEL_USER) {
+    using UM = UserModelT<double>;
+    REQUIRE(d->nx == UM::NX && d->nu == UM::NU, "this build's user model is nx=%d nu=%d, got %d/%d", UM::NX, UM::NU, d->nx, d->nu);
+    REQUIRE(d->u_min && d->u_max, "ILQR_MODEL_USER needs u_min/u_max (Model::u_min/u_max, include/model.h:17)");
+    REQUIRE(!(d->flags & ILQR_FLAG_ANALYTIC_DERIVATIVES) || has_analytic_record<UM>::value, "this user model has no analytic_record()");
+    h->user_f.set_params(d->user_params, d->n_user_params);
+    if (h->dtype == ILQR_DTYPE_F32) {  // the twin the finite differences are taken in: built from the parameters' FLOAT values, like the shipped models'
+      std::vector<double> p32(d->user_params, d->user_params + (d->user_params ? d->n_user_params : 0));
+      for (double& q : p32) q = (double)(float)q;
+      h->user.set_params(p32.data(), (int)p32.size());
+    } else {
+      h->user.set_params(d->user_params, d->n_user_params);
+    }
+    for (int j = 0; j < UM::NU; j++) {
+      h->user_f.u_min[j] = (float)d->u_min[j];
+      h->user_f.u_max[j] = (float)d->u_max[j];
+      // fp32 handle: the double twin carries the float model's limits (its other parameters are whatever set_params made of them)
+      h->user.u_min[j] = (h->dtype == ILQR_DTYPE_F32) ? (double)h->user_f.u_min[j] : d->u_min[j];
+      h->user.u_max[j] = (h->dtype == ILQR_DTYPE_F32) ? (double)h->user_f.u_max[j] : d->u_max[j];
+    }
+#endif
   } else if (d->model == ILQR_MODEL_HOST || d->model == ILQR_MODEL_LQ) {
     // Generic dimensions: trajectory-contiguous layout, one wavefront per trajectory in the backward
     // pass.  Host-evaluated models receive their derivatives through ilqr_set_derivatives; the LQ

@@ -524,12 +524,14 @@ __device__ __forceinline__ void derivatives_of_knot(const BatchViewT<typename M:
     if constexpr (NU == 1) rs[((RSl::US + 1) >> 1) * (2 * TW + RING_PAD) + ((RSl::US + 1) & 1)] = recip(abs_of(uk[0]) + real(1));
   }
 
-  if (v.analytic) {  // opt-in: the model's exact derivatives (wave-uniform branch)
-    real rec[R::SIZE];
-    model.analytic_record(xk, uk, dt, t == T, rec);
+  if constexpr (has_analytic_record<M>::value) {
+    if (v.analytic) {  // opt-in: the model's exact derivatives (wave-uniform branch)
+      real rec[R::SIZE];
+      model.analytic_record(xk, uk, dt, t == T, rec);
 #pragma unroll
-    for (int e = 0; e < R::SIZE; e += 2) put2(e, (fdr)rec[e], (fdr)rec[e + 1]);
-    return;
+      for (int e = 0; e < R::SIZE; e += 2) put2(e, (fdr)rec[e], (fdr)rec[e + 1]);
+      return;
+    }
   }
   // the knot in the finite differences' arithmetic (a no-op unless the handle is fp32)
   fdr x[NX], u[NU];

@@ -5,6 +5,9 @@
 // i.e. exactly the three virtuals of the reference interface, resolved statically so the
 // rollout and finite-difference kernels can inline them (a GPU cannot call host virtuals).
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "common.hpp"
 
 namespace ilqr {
@@ -281,5 +284,47 @@ __device__ __forceinline__ void integrate_dynamics(const M& m, const typename M:
 
 using AcrobotModel = AcrobotModelT<double>;
 using DoubleIntegratorModel = DoubleIntegratorModelT<double>;
+
+// does a device model ship exact derivatives (analytic_record)?  Optional: without it ILQR_FLAG_ANALYTIC_DERIVATIVES
+// is refused for that model and the finite-difference sweep is the only one.
+template <class M, class = void>
+struct has_analytic_record : std::false_type {};
+template <class M>
+struct has_analytic_record<M, std::void_t<decltype(std::declval<const M&>().analytic_record((const typename M::real*)nullptr, (const typename M::real*)nullptr,
+                                                                                            typename M::real(0), false, (typename M::real*)nullptr))>> : std::true_type {};
+
+}  // namespace ilqr
+
+// ------------------------------------------------------------------------------------------
+// A user's device twin WITHOUT editing the library (the reference's Model is an open plugin interface,
+// include/model.h:6-21): build with  -DILQR_USER_MODEL_HEADER='"my_model.hpp"'  (ilqr_amd._build.build_user) and create
+// handles with ILQR_MODEL_USER.  The header is included here, inside namespace ilqr, and defines
+//
+//     template <class real_> struct UserModelT {
+//       using real = real_;
+//       static constexpr int NX = 4;             // the lane-quad kernels are written for nx = 4
+//       static constexpr int NU = 1;             // 1 or 2
+//       real u_min[NU], u_max[NU];               // filled by ilqr_create from ilqr_desc.u_min / u_max
+//       ... its own parameters (plain data) ...
+//       void set_params(const double* p, int n);                                  // host: ilqr_desc.user_params
+//       __device__ void dynamics(const real* x, const real* u, real* dx) const;   // Model::dynamics
+//       __device__ real cost(const real* x, const real* u) const;                 // Model::cost
+//       __device__ real final_cost(const real* x) const;                          // Model::final_cost
+//       // optional: __device__ void analytic_record(const real* x, const real* u, real dt, bool last, real* rec) const;
+//     };
+//
+// It may use what this file offers (sincos_shared, Rec<>).  Both arithmetic flavours are instantiated (fp32 handles
+// take their finite differences in UserModelT<double>).  examples/user_model_acrobot.hpp is a worked example.
+// ------------------------------------------------------------------------------------------
+#ifdef ILQR_USER_MODEL_HEADER
+namespace ilqr {
+#include ILQR_USER_MODEL_HEADER
+static_assert(UserModelT<double>::NX == 4 && (UserModelT<double>::NU == 1 || UserModelT<double>::NU == 2),
+              "user device models run in the nx = 4 kernels: NX == 4, NU in {1, 2}");
+}  // namespace ilqr
+#define ILQR_HAVE_USER_MODEL 1
+#endif
+
+namespace ilqr {
 
 }  // namespace ilqr

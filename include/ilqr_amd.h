@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ILQR_AMD_ABI_VERSION 2 /* 2: ilqr_desc.dtype */
+#define ILQR_AMD_ABI_VERSION 3 /* 2: ilqr_desc.dtype; 3: ILQR_MODEL_USER, ilqr_desc.user_params */
 
 typedef struct ilqr_batch ilqr_batch; /* opaque: owns all device memory of one batch */
 
@@ -58,10 +58,15 @@ enum ilqr_model_id {
   ILQR_MODEL_DOUBLE_INTEGRATOR = 1, /* include/double_integrator.h  nx=4 nu=2 */
   ILQR_MODEL_LQ = 2,                /* synthetic LQ (BASELINE.json configs[4]): xdot = A x + B u, cost .5(x'Qx + u'Ru),
                                        final .5 x'Qf x, nx<=32 nu<=16; device twin, runs end to end (lq_* of the desc) */
-  ILQR_MODEL_HOST = 3               /* a Model that exists only as host code, nx<=32 nu<=16: the caller evaluates its
+  ILQR_MODEL_HOST = 3,              /* a Model that exists only as host code, nx<=32 nu<=16: the caller evaluates its
                                        rollouts and finite differences (ilqr_set_trajectory, ilqr_set_derivatives,
                                        ilqr_accept_candidates), the backward pass / box-QPs / accept logic run on the
                                        device; rollout and finite-difference entry points return ILQR_ERR_UNSUPPORTED */
+  ILQR_MODEL_USER = 4               /* the caller's OWN device twin (nx=4, nu in {1,2}), compiled into a build of this
+                                       library from a header that is not part of it: -DILQR_USER_MODEL_HEADER='"file.hpp"'
+                                       (ilqr_amd/csrc/models.hpp states the contract, INTEGRATION.md 5 the recipe).  Runs
+                                       every kernel of the nx = 4 path, both dtypes.  A build without such a header
+                                       answers ILQR_ERR_UNSUPPORTED; ilqr_has_user_model() tells which one is loaded. */
 };
 
 /* Arithmetic of the device models (BASELINE.json configs[3] asks for fp32; the reference is fp64 only).
@@ -149,10 +154,13 @@ typedef struct ilqr_desc {
   const double *lq_A, *lq_B, *lq_Q, *lq_R, *lq_Qf; /* ILQR_MODEL_LQ: row-major [nx][nx],[nx][nu],[nx][nx],[nu][nu],[nx][nx] */
   void* stream;             /* hipStream_t to enqueue on; NULL = the library creates one */
   const ilqr_params* params; /* NULL = reference defaults */
+  const double* user_params; /* ILQR_MODEL_USER: [n_user_params] handed to UserModelT::set_params (its constructor's arguments) */
+  int n_user_params;
 } ilqr_desc;
 
 const char* ilqr_last_error(void);
 int ilqr_abi_version(void);
+int ilqr_has_user_model(void); /* 1 if this build carries a user device model (ILQR_MODEL_USER), else 0 */
 void ilqr_default_params(ilqr_params* p);
 
 /* iLQR::iLQR(Model*, double), include/ilqr.h:30-44 */

@@ -68,3 +68,17 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.lower().replace("no cpu", ""), os.path.join(dirpath, f)
+
+
+def test_user_model_build_exports_the_same_abi():
+    """A build with a user device model (-DILQR_USER_MODEL_HEADER, examples/user_model_acrobot.hpp) is the same library:
+    every symbol of the header, and ilqr_has_user_model() says which build is loaded (no device needed for that)."""
+    from ilqr_amd import _build, capi
+    if not os.path.exists(_build.HIPCC):
+        pytest.skip("hipcc not available")
+    path = _build.build_user(_build.USER_EXAMPLE_HEADER, _build.USER_EXAMPLE_LIB)
+    user = capi.load(path=path)
+    for n in _declared_symbols():
+        assert hasattr(user, n), n
+    assert user.ilqr_has_user_model() == 1 and capi.load().ilqr_has_user_model() == 0
+    assert user.ilqr_abi_version() == capi.ABI_VERSION

@@ -1,0 +1,85 @@
+"""ILQR_MODEL_USER: a device twin compiled into a build of the library from a header that is NOT part of the library
+(examples/user_model_acrobot.hpp, -DILQR_USER_MODEL_HEADER; the reference's Model is an open plugin interface,
+include/model.h:6-21).  With the shipped acrobot's parameters the user model must leave, kernel for kernel, the same bits
+as the built-in acrobot; with other parameters it must agree with the same model evaluated through host virtuals
+(ILQR_MODEL_HOST route of the C++ facade's recipe: rollouts + finite differences by the caller) to 1e-6."""
+import numpy as np
+import pytest
+
+from tests.util import TOL, acrobot_x0
+
+pytestmark = pytest.mark.gpu
+DT = 0.02
+
+
+@pytest.fixture(scope="module")
+def user_lib():
+    from ilqr_amd import _build
+    return _build.build_user(_build.USER_EXAMPLE_HEADER, _build.USER_EXAMPLE_LIB)
+
+
+def _state(g):
+    xs, us = g.trajectory()
+    k, K = g.gains()
+    st, it, al = g.status()
+    return dict(xs=xs, us=us, k=k, K=K, cost=g.cost(), st=st, it=it, al=al, lam=g.lambdas()[0], gnorm=g.gnorm(), dV=g.dV(), **g.derivatives())
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("flags", ["persistent", "staged", "unfused"])
+def test_user_copy_of_the_acrobot_equals_the_builtin_bit_for_bit(user_lib, dtype, flags):
+    from ilqr_amd import BatchILQR, capi
+    fl = {"persistent": 0, "staged": capi.FLAG_STAGED, "unfused": capi.FLAG_UNFUSED}[flags]
+    B, T, lim = 83, 120, 1.5
+    x0 = acrobot_x0(B, scale=0.5, seed=31)
+    u0 = np.zeros((B, T, 1))
+    out = []
+    for kw in (dict(model="acrobot"), dict(model="user", lib=user_lib, nx=4, nu=1, user_params=[3.1415, 0, 0, 0, 20, 20])):
+        g = BatchILQR(B=B, T=T, dt=DT, u_min=-lim, u_max=lim, dtype=dtype, flags=fl, **kw)
+        c0 = g.init_traj(x0, u0)
+        g.iterate(5)
+        s = _state(g)
+        s["c0"] = c0
+        g.generate_trajectory()  # ... and to termination
+        s["final"] = g.cost()
+        s["final_it"] = g.status()[1]
+        out.append(s)
+        g.close()
+    for n in out[0]:
+        assert np.array_equal(out[0][n], out[1][n], equal_nan=True), n
+
+
+def test_user_model_with_its_own_parameters_matches_the_oracle(user_lib, oracle):
+    """Other parameters than the built-in's (goal, terminal weights): one iteration against the oracle's acrobot with the
+    same goal is not available (the oracle's acrobot has fixed weights), so the check is structural: the rollout cost is
+    the model's own final_cost (computed here in numpy from the returned states), and the finite-difference records of
+    the terminal knot equal its analytic Hessian 2 Ks^2 / 2 Kd^2."""
+    from ilqr_amd import BatchILQR
+    B, T = 20, 40
+    goal, Ks, Kd = np.array([1.0, -0.5, 0.2, 0.0]), 7.0, 3.0
+    x0 = acrobot_x0(B, scale=0.3, seed=2)
+    u0 = np.random.default_rng(0).normal(size=(B, T, 1)) * 0.2
+    g = BatchILQR("user", B, T, DT, u_min=-2.0, u_max=2.0, lib=user_lib, nx=4, nu=1, user_params=list(goal) + [Ks, Kd])
+    c0 = g.init_traj(x0, u0)
+    xs, us = g.trajectory()
+    d = goal[None, :] - xs[:, T]
+    fin = Ks * Ks * (d[:, 0] ** 2 + d[:, 1] ** 2) + Kd * Kd * (d[:, 2] ** 2 + d[:, 3] ** 2)
+    run = (0.1 * 0.1 * us[:, :, 0] ** 2).sum(axis=1)
+    assert np.allclose(c0, fin + run, rtol=1e-12)
+    g.compute_derivatives()
+    rec = g.derivatives()
+    H = np.diag([2 * Ks * Ks, 2 * Ks * Ks, 2 * Kd * Kd, 2 * Kd * Kd])
+    assert np.allclose(rec["cxx"][:, T], H[None], rtol=1e-5, atol=1e-5 * 2 * Ks * Ks)
+    assert np.allclose(rec["cx"][:, T], -2 * np.array([Ks * Ks, Ks * Ks, Kd * Kd, Kd * Kd]) * d, rtol=1e-6, atol=1e-8)
+    g.iterate(3)
+    assert np.all(g.cost() <= c0 * (1 + 1e-12)) and (g.status()[2] >= 0).mean() > 0.5
+    g.close()
+
+
+def test_builds_say_what_they_carry(user_lib):
+    from ilqr_amd import BatchILQR, capi
+    assert capi.load().ilqr_has_user_model() == 0 and capi.load(path=user_lib).ilqr_has_user_model() == 1
+    with pytest.raises(capi.ILQRError, match="not available in this build"):
+        BatchILQR("user", 4, 5, DT, u_min=-1.0, u_max=1.0, nx=4, nu=1)  # the stock library has no user model
+    with pytest.raises(capi.ILQRError, match="analytic_record"):
+        BatchILQR("user", 4, 5, DT, u_min=-1.0, u_max=1.0, nx=4, nu=1, lib=user_lib, flags=capi.FLAG_ANALYTIC_DERIVATIVES)
