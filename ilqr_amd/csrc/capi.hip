@@ -98,11 +98,17 @@ struct ilqr_batch {
   double* d_umax = nullptr;
   bool profile = false;
   int num_cus = 256;
+  // full solves of batches with more tiles than CUs: running trajectories are re-packed into the leading tiles between
+  // chunks of iterations (ilqr_generate_trajectory); active_tiles = how many tiles the persistent kernel is launched for
+  int active_tiles = 0;
+  int* d_perm = nullptr;       // [Bp]
+  void* perm_scratch = nullptr;  // as large as the largest per-knot array
+  size_t perm_scratch_bytes = 0;
   // Route switches for A/B runs and the bit-identity tests, read from the environment ONCE, in ilqr_create: a handle
   // never changes kernels between calls.  (ILQR_AMD_STAGED / _UNFUSED / _FUSED=1|2 / _BACKWARD_W1 / _LQ_THREAD_ROLLOUT /
   // _FULL_RECORDS / _NUM_CUS)
   struct {
-    bool staged = false, unfused = false, backward_w1 = false, lq_thread_rollout = false, full_records = false;
+    bool staged = false, unfused = false, backward_w1 = false, lq_thread_rollout = false, full_records = false, no_compaction = false;
     int fused = 0;  // 0 = by batch size
   } env;
   StageTimer timers[ILQR_NUM_STAGES];
@@ -623,13 +629,14 @@ static int launch_solve_tiles(ilqr_batch* h, int n_iters) {
   const int pending = h->commit_pending ? 1 : 0;
   long long* ticks = h->profile ? h->phase_ticks : nullptr;
   const int occ = fused_variant(h);
+  const int grid_tiles = (h->active_tiles > 0 && h->active_tiles < h->ntiles) ? h->active_tiles : h->ntiles;  // (the rest hold finished trajectories only)
   if (int rc = with_model(h, [&](auto& v, auto& m, auto& fdm) {
         using MM = std::decay_t<decltype(m)>;
         using MF = std::decay_t<decltype(fdm)>;
         if (occ == 1)
-          hipLaunchKernelGGL((k_solve_tile<MM, MF, 1>), dim3(h->ntiles), dim3(256), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
+          hipLaunchKernelGGL((k_solve_tile<MM, MF, 1>), dim3(grid_tiles), dim3(256), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
         else
-          hipLaunchKernelGGL((k_solve_tile<MM, MF, 2>), dim3(h->ntiles), dim3(256), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
+          hipLaunchKernelGGL((k_solve_tile<MM, MF, 2>), dim3(grid_tiles), dim3(256), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
         return 0;
       }))
     return rc;
@@ -682,6 +689,8 @@ void ilqr_destroy(ilqr_batch* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->staging) (void)hipFree(h->staging);
+  if (h->d_perm) (void)hipFree(h->d_perm);
+  if (h->perm_scratch) (void)hipFree(h->perm_scratch);
   (void)timers_drain(h);  // (every event back into the pool, each once)
   for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -704,6 +713,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   h->env.backward_w1 = getenv("ILQR_AMD_BACKWARD_W1") != nullptr;
   h->env.lq_thread_rollout = getenv("ILQR_AMD_LQ_THREAD_ROLLOUT") != nullptr;
   h->env.full_records = getenv("ILQR_AMD_FULL_RECORDS") != nullptr;
+  h->env.no_compaction = getenv("ILQR_AMD_NO_COMPACTION") != nullptr;
   if (const char* f = getenv("ILQR_AMD_FUSED")) h->env.fused = (f[0] == '2') ? 2 : 1;
   if (const char* e = getenv("ILQR_AMD_NUM_CUS"))  // tests: exercise the batch-size thresholds of the route selection on small batches
     if (atoi(e) > 0) h->num_cus = atoi(e);
@@ -1019,21 +1029,116 @@ int ilqr_count_running(ilqr_batch* h, int* n) {
   return 0;
 }
 
+// Slot j <- slot perm[j] for every per-trajectory array a running solve carries (tiled: x0, xs, us, k, K; scalars: cost,
+// lambda, dlambda, dV, gnorm, status, iters, flgChange, alpha index, diverge, backpass_done).  Candidates and derivative
+// records are not moved: no accept is pending between ilqr_iterate calls, and the records are recomputed when asked for.
+static int apply_permutation(ilqr_batch* h, const std::vector<int>& perm) {
+  const size_t es = elem_size(h), Bp = (size_t)h->Bp;
+  const size_t biggest = std::max<size_t>((size_t)h->ntiles * (h->T + 1) * h->nx * TW, (size_t)h->ntiles * h->T * h->nu * h->nx * TW) * es;
+  const size_t need = std::max<size_t>(biggest, 2 * Bp * sizeof(double));
+  if (h->perm_scratch_bytes < need) {
+    if (h->perm_scratch) HIPCHK(hipFree(h->perm_scratch));
+    h->perm_scratch = nullptr;
+    HIPCHK(hipMalloc(&h->perm_scratch, need));
+    h->perm_scratch_bytes = need;
+  }
+  if (!h->d_perm) HIPCHK(hipMalloc((void**)&h->d_perm, Bp * sizeof(int)));
+  HIPCHK(hipMemcpyAsync(h->d_perm, perm.data(), Bp * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  auto tiled = [&](void* arr, int S, int E) -> int {
+    const size_t n = (size_t)h->ntiles * S * E * TW;
+    if (h->dtype == ILQR_DTYPE_F32)
+      hipLaunchKernelGGL(k_permute_tiled<float>, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, (const float*)arr, (float*)h->perm_scratch, h->d_perm, h->ntiles, S, E);
+    else
+      hipLaunchKernelGGL(k_permute_tiled<double>, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, (const double*)arr, (double*)h->perm_scratch, h->d_perm, h->ntiles, S, E);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(arr, h->perm_scratch, n * es, hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+  };
+  auto scalar = [&](auto* arr, size_t n) -> int {
+    using T = std::remove_pointer_t<decltype(arr)>;
+    hipLaunchKernelGGL(k_permute_scalar<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const T*)arr, (T*)h->perm_scratch, h->d_perm, (int)n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(arr, h->perm_scratch, n * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+  };
+  BatchView& v = h->v;
+  int rc = 0;
+  rc |= tiled(v.x0, 1, h->nx);
+  rc |= tiled(v.xs, h->T + 1, h->nx);
+  rc |= tiled(v.us, h->T, h->nu);
+  rc |= tiled(v.kff, h->T, h->nu);
+  rc |= tiled(v.Kfb, h->T, h->nu * h->nx);
+  rc |= scalar(v.cost, Bp);
+  rc |= scalar(v.lambda, Bp);
+  rc |= scalar(v.dlambda, Bp);
+  rc |= scalar(v.dV, Bp);
+  rc |= scalar(v.dV + Bp, Bp);
+  rc |= scalar(v.gnorm, Bp);
+  rc |= scalar(v.status, Bp);
+  rc |= scalar(v.iters, Bp);
+  rc |= scalar(v.flg_change, Bp);
+  rc |= scalar(v.alpha_idx, Bp);
+  rc |= scalar(v.diverge, Bp);
+  rc |= scalar(v.backpass_done, Bp);
+  if (rc) return rc;
+  h->recs = ilqr_batch::REC_STALE;
+  return 0;
+}
+
 int ilqr_generate_trajectory(ilqr_batch* h) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
   if (!h->initialised) return fail(ILQR_ERR_STATE, "generate_trajectory needs x0/xs/us (asserts of ilqr_core.cpp:80-82)");
+  // Intra-tile compaction (the reference's own TODO, notes.md:16): a tile costs what its slowest trajectory costs, and with
+  // more tiles than the device holds at once (ntiles > #CU) every tile that still has ONE running trajectory takes a slot.
+  // So a big batch is solved in chunks of iterations; after a chunk, if the running trajectories would fit into at most
+  // half of the tiles that are still launched, they are re-packed into the leading tiles (one permutation pass over
+  // the per-trajectory arrays, ~0.1 ms per 4096 trajectories), and only those tiles are launched from then on.  The
+  // original order is restored before returning.  Trajectories never interact and no kernel's arithmetic depends on a
+  // trajectory's slot: statuses, iteration counts and costs are bit-identical (tests/test_gpu_full_solves.py).
+  const bool persistent = use_persistent(h);
+  const bool compacting = persistent && h->ntiles > h->num_cus && !(h->sp.fixed_work) && !h->env.no_compaction;
   int done_iters = 0;
-  const int chunk = use_persistent(h) ? std::max(1, h->params.max_iter) : 10;  // (a persistent tile stops by itself)
+  const int chunk = persistent ? (compacting ? std::min(std::max(1, h->params.max_iter), 8) : std::max(1, h->params.max_iter)) : 10;  // (a persistent tile stops by itself)
+  std::vector<int> slot_orig;  // slot j currently holds original trajectory slot_orig[j] (empty: identity)
+  h->active_tiles = h->ntiles;
+  int rc_out = 0;
   while (done_iters < h->params.max_iter) {
     const int n = std::min(chunk, h->params.max_iter - done_iters);
-    if (int rc = ilqr_iterate(h, n)) return rc;
+    if (int rc = ilqr_iterate(h, n)) { rc_out = rc; break; }
     done_iters += n;
     int running = 0;
     HIPCHK(hipMemcpyAsync(&running, h->v.n_running, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (running == 0) break;
+    if (compacting && done_iters < h->params.max_iter && 2 * ((running + TW - 1) / TW) <= h->active_tiles && h->active_tiles > 1) {
+      std::vector<int> st(h->Bp);
+      HIPCHK(hipMemcpyAsync(st.data(), h->v.status, (size_t)h->Bp * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      if (slot_orig.empty()) {
+        slot_orig.resize(h->Bp);
+        for (int j = 0; j < h->Bp; j++) slot_orig[j] = j;
+      }
+      std::vector<int> perm;
+      perm.reserve(h->Bp);
+      for (int j = 0; j < h->Bp; j++)
+        if (st[j] == 0) perm.push_back(j);
+      const int n_run = (int)perm.size();
+      for (int j = 0; j < h->Bp; j++)
+        if (st[j] != 0) perm.push_back(j);
+      if (int rc = apply_permutation(h, perm)) { rc_out = rc; break; }
+      std::vector<int> so(h->Bp);
+      for (int j = 0; j < h->Bp; j++) so[j] = slot_orig[perm[j]];
+      slot_orig.swap(so);
+      h->active_tiles = std::max(1, (n_run + TW - 1) / TW);
+    }
   }
-  return 0;
+  h->active_tiles = h->ntiles;
+  if (!slot_orig.empty()) {  // back to the caller's order: slot o <- the slot that holds original trajectory o
+    std::vector<int> back(h->Bp);
+    for (int j = 0; j < h->Bp; j++) back[slot_orig[j]] = j;
+    if (int rc = apply_permutation(h, back)) return rc;
+  }
+  return rc_out;
 }
 
 int ilqr_solve(ilqr_batch* h, const double* x0, const double* u0) {

@@ -79,6 +79,28 @@ __global__ void k_unpack_rec(const real* __restrict__ src, double* __restrict__ 
   }
 }
 
+// dst slot j <- src slot perm[j], for every slot of the padded batch (compaction of running trajectories between chunks
+// of a full solve, capi.hip): tiled arrays [tile][S][E][16] and per-trajectory scalars
+template <class real>
+__global__ void k_permute_tiled(const real* __restrict__ src, real* __restrict__ dst, const int* __restrict__ perm, int ntiles, int S, int E) {
+  const size_t n = (size_t)ntiles * S * E * TW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i % TW);
+    size_t r = i / TW;
+    const int e = (int)(r % E);
+    r /= E;
+    const int s = (int)(r % S);
+    const int tile = (int)(r / S);
+    const int p = perm[tile * TW + l];
+    dst[i] = src[tidx(p / TW, s, e, p % TW, S, E)];
+  }
+}
+template <class T>
+__global__ void k_permute_scalar(const T* __restrict__ src, T* __restrict__ dst, const int* __restrict__ perm, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) dst[j] = src[perm[j]];
+}
+
 // ------------------------------------------------------------------------------------------
 // per-trajectory state reset (init_traj, ilqr_core.cpp:11-56; statics of ilqr.h:17-18)
 // ------------------------------------------------------------------------------------------

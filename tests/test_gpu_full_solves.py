@@ -61,3 +61,52 @@ def test_acrobot_batch_full_solve_statistics(oracle):
     # and the trajectories that DID follow the same path agree tightly
     same = np.isclose(cost, ro["cost"], rtol=1e-6)
     assert same.mean() > 0.02
+
+
+def _everything(g):
+    xs, us = g.trajectory()
+    k, K = g.gains()
+    st, it, al = g.status()
+    lam, dlam = g.lambdas()
+    return dict(xs=xs, us=us, k=k, K=K, cost=g.cost(), st=st, it=it, al=al, lam=lam, dlam=dlam, gnorm=g.gnorm(), dV=g.dV())
+
+
+@pytest.mark.parametrize("name,dtype", [("integrator", "f64"), ("acrobot", "f64"), ("acrobot", "f32")])
+def test_compaction_of_running_trajectories_changes_nothing(name, dtype, monkeypatch):
+    """ilqr_generate_trajectory on a batch with more tiles than CUs (ILQR_AMD_NUM_CUS = 2 scales that down to test size)
+    re-packs the trajectories that still run into the leading tiles between chunks of iterations and launches only those
+    (notes.md:16, src/ilqr_core.cpp:180-183: the reference's own TODO).  Against the same solve with compaction switched
+    off (ILQR_AMD_NO_COMPACTION=1): every array and scalar bit-identical, in the caller's order -- and the compacting
+    solve must actually have compacted (trajectories leave their loops at different iterations here)."""
+    from ilqr_amd import BatchILQR
+    monkeypatch.setenv("ILQR_AMD_NUM_CUS", "2")
+    if name == "integrator":
+        B, T, nu = 203, 99, 2
+        x0, kw = integrator_x0(B), dict(goal=[1.0, 0.5, 0.0, 0.0])
+        x0[::3] *= 0.05  # a third of the problems are nearly solved at the start: they stop after a few iterations
+    else:
+        B, T, nu = 150, 80, 1
+        x0, kw = acrobot_x0(B, scale=0.2, seed=3), dict(u_min=-1.5, u_max=1.5, params=dict(max_iter=40))
+        x0[::2] *= 0.01
+        if dtype == "f32":
+            x0 = x0.astype(np.float32).astype(np.float64)
+    u0 = np.zeros((B, T, nu))
+    out = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("ILQR_AMD_NO_COMPACTION", "1")
+        else:
+            monkeypatch.delenv("ILQR_AMD_NO_COMPACTION", raising=False)
+        g = BatchILQR(name, B, T, DT, dtype=dtype, **kw)
+        g.generate_trajectory(x0, u0)
+        assert g.count_running() == 0
+        out.append(_everything(g))
+        # a second solve on the same handle (warm start from perturbed states) goes through the same machinery
+        g.generate_trajectory(x0 * 1.001)
+        s2 = _everything(g)
+        out[-1].update({"w_" + n: a for n, a in s2.items()})
+        g.close()
+    for n in out[0]:
+        assert np.array_equal(out[0][n], out[1][n], equal_nan=True), n
+    it = out[0]["it"]
+    assert it.min() < it.max() - 8, (it.min(), it.max())  # (else nothing would have been compacted)
