@@ -260,7 +260,12 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
         for (int j = 0; j < WM; j++) row[j] = (lane < nf && j < nf) ? Q[gi + LDM * L.idx[(j < nf) ? j : 0]] : 0.0;
       }
       // Eigen llt_inplace<Lower>::unblocked (Cholesky/LLT.h:302-325); stops at a non-positive pivot
-      // and leaves the rest of the lower triangle as it was
+      // and leaves the rest of the lower triangle as it was.
+      // No IEEE square root / division in the chain: a pivot's root comes with its reciprocal (rsqrt_and_sqrt, boxqp.hpp:
+      // v_rsq_f64 + Newton, <= 1 ulp each), the column is scaled by that reciprocal, and the triangular inverse below reuses
+      // it for its diagonal -- 16 roots + 48 divisions of ~12-20 instructions each were a third of the step's VALU work.
+      double my_inv = 0;   // lane k: 1 / L(k, k) of a factored pivot
+      int n_fact = 0;      // pivots factored before the stop (wave-uniform)
       {
         bool stopped = false;
 #pragma unroll
@@ -278,14 +283,17 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
             if (xk <= 0.0) {
               stopped = true;
             } else {
-              xk = sqrt(xk);
+              double rs;
+              rsqrt_and_sqrt(xk, rs, xk);
               double s = 0;
 #pragma unroll
               for (int j = 0; j < k; j++) s = __builtin_fma(row[j], rk[j], s);
               double v = row[k];
               if (k > 0) v -= s;
-              v = v / xk;
+              v = v * rs;
               row[k] = (lane == k) ? xk : ((lane > k && lane < nf) ? v : row[k]);
+              my_inv = (lane == k) ? rs : my_inv;
+              n_fact = k + 1;
             }
           }
         }
@@ -303,12 +311,14 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
 #pragma unroll
         for (int i = WM - 1; i >= 0; i--) {
           if (i < nfR) {
-            const double rii = bcast(row[i], i);
+            // 1 / R(i, i): kept from the factorisation; a pivot the factorisation stopped before (Eigen's partial factor: its
+            // "root" is the unmodified entry) gets a reciprocal of its own
+            const double inv_rii = (i < n_fact) ? bcast(my_inv, i) : recip(bcast(row[i], i));
             double s = 0;
 #pragma unroll
             for (int l2 = i + 1; l2 < WM; l2++) s = __builtin_fma(bcast(row[i], l2), ri[l2], s);
-            const double off = -s / rii;
-            ri[i] = (lane >= nfR) ? 0.0 : ((lane == i) ? 1.0 / rii : ((lane > i) ? off : 0.0));
+            const double off = -s * inv_rii;
+            ri[i] = (lane >= nfR) ? 0.0 : ((lane == i) ? inv_rii : ((lane > i) ? off : 0.0));
           }
         }
         if (lane < WM) {
