@@ -91,41 +91,59 @@ def cpu_baseline(B_total, T, dt, lim, target_wall_s=4.0):
                       "threads" % (nb2, iters, t2, t2 * cores)}
 
 
-def pmc_traffic(kernel, iterations_per_launch=1):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/): the bench cannot run
-    rocprofv3 on itself, so it quotes the last collected figures when present (the persistent kernel's are kept per
-    iteration and scaled to the launch timed here)."""
+def counters():
+    """profiles/traffic.json: what the rocprofv3 PMC passes of scripts/collect_profiles.sh counted per kernel (HBM bytes,
+    VALU instructions).  The bench cannot run rocprofv3 on itself; it may only quote counters that describe THE CODE IT
+    IS TIMING: the file carries the content hash of the library sources it was collected on, and a file collected on other
+    sources is not used (the fields it would have filled say "stale")."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
-        return None, None
+        return None, "no profiles/traffic.json"
     try:
+        from ilqr_amd import _build
         d = json.load(open(path))
-        e = d["kernels"].get(kernel)
-        if not e:
-            return None, None
-        if "hbm_bytes_per_iteration" in e:
-            return e["hbm_bytes_per_iteration"] * iterations_per_launch, d.get("source")
-        return e["hbm_bytes_per_launch"], d.get("source")
-    except Exception:
-        return None, None
+        if d.get("source_hash") != _build._source_hash():
+            return None, "stale: profiles/traffic.json was collected on other library sources (hash %s..., now %s...)" % (
+                str(d.get("source_hash"))[:12], _build._source_hash()[:12])
+        return d, d.get("source")
+    except Exception as e:  # noqa: BLE001
+        return None, "unreadable profiles/traffic.json: %s" % e
+
+
+def pmc_traffic(kernel, iterations_per_launch=1):
+    """HBM bytes per launch of `kernel` from the counter passes (the persistent kernel's are kept per iteration and scaled
+    to the launch timed here); None + the reason when there are no counters for this code."""
+    d, note = counters()
+    if d is None:
+        return None, note
+    e = d["kernels"].get(kernel)
+    if not e:
+        return None, "no counters for %s in profiles/traffic.json" % kernel
+    if "hbm_bytes_per_iteration" in e:
+        return e["hbm_bytes_per_iteration"] * iterations_per_launch, note
+    return e["hbm_bytes_per_launch"], note
 
 
 # VALU issue: one wave64 instruction occupies a SIMD's 16 lanes for 4 cycles, so a SIMD issues at most 0.25
 # VALU instructions per cycle (MI355X_MICROARCH.md).  The dominant kernel is one dependent chain per tile and is
 # bound by that, not by bytes: the figure quoted is from the committed SQ-counter pass (profiles/), which the
 # bench cannot collect on itself.
-def issue_roofline(kernel):
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        d = json.load(open(path))
-        e = d["kernels"][kernel]
-        ipc = e["valu_insts_per_iteration"] / (e["busy_simds"] * e["avg_iteration_us"] * 1e-6 * e["sclk_hz"])
-        return {"bound": "valu_issue", "kernel": kernel, "achieved": ipc, "peak": 0.25, "unit": "VALU instructions / cycle / SIMD",
-                "frac": ipc / 0.25, "valu_insts_per_timestep": e["valu_insts_per_iteration"] / e["timesteps_per_iteration"],
-                "wait_fraction_of_wave_cycles": e.get("wait_fraction_of_wave_cycles"),
-                "lds_bank_conflict_fraction": e.get("lds_bank_conflict_fraction"), "source": d.get("source")}
-    except Exception:
-        return None
+def issue_roofline(kernel, iteration_ms, sclk_mhz, timesteps, n_simds=1024):
+    """VALU issue of `kernel` in THIS run: instructions per trajectory-timestep (a property of the code: SQ_INSTS_VALU of
+    the counter pass, valid only for the sources it was collected on) x the timesteps of an iteration, over the SIMD
+    cycles the iteration took HERE -- duration from the HIP events of this run, clock from the kernel's own
+    s_memtime / wall-clock ratio in this run (the chip lowers its clock with the number of busy SIMDs)."""
+    d, note = counters()
+    e = d["kernels"].get(kernel) if d else None
+    if not e or "valu_insts_per_iteration" not in e or not sclk_mhz:
+        return {"bound": "valu_issue", "kernel": kernel, "achieved": None, "peak": 0.25, "unit": "VALU instructions / cycle / SIMD",
+                "frac": None, "sclk_mhz_measured": sclk_mhz, "note": note}
+    per_ts = e["valu_insts_per_iteration"] / e["timesteps_per_iteration"]
+    ipc = per_ts * timesteps / (n_simds * iteration_ms * 1e-3 * sclk_mhz * 1e6)
+    return {"bound": "valu_issue", "kernel": kernel, "achieved": ipc, "peak": 0.25, "unit": "VALU instructions / cycle / SIMD",
+            "frac": ipc / 0.25, "valu_insts_per_timestep": per_ts, "sclk_mhz_measured": sclk_mhz, "iteration_ms_measured": iteration_ms,
+            "wait_fraction_of_wave_cycles": e.get("wait_fraction_of_wave_cycles"),
+            "lds_bank_conflict_fraction": e.get("lds_bank_conflict_fraction"), "source": note}
 
 
 def lq_mats(n, m, seed=7):
@@ -223,6 +241,7 @@ def main():
         barrier()
         elapsed = D.max_over_ranks(time.perf_counter() - t0, device="cuda")
         prof = g.profile_read()
+        g.sclk_mhz = g.shader_clock_mhz() if prof.get("solve", (0, 0))[1] else None
         g.profile(False)
         assert g.count_running() == B, "fixed-work run lost trajectories: the throughput figure would be inflated"
         return g, elapsed, prof, gathered
@@ -243,7 +262,7 @@ def main():
                                 "algorithmic_bytes_per_timestep": bytes_ts[name],
                                 "algorithmic_GBps": bytes_ts[name] * B * T / (ms / launches * 1e-3) / 1e9}
                 if persistent and name in ("backward", "rollout"):
-                    stages[name]["kernel"] = "k_solve_tile"
+                    stages[name]["kernel"] = name_of[capi.STAGE_NAMES.index("solve")]
                     stages[name]["clock"] = "the kernel's own per-phase clock, mean over tiles and per iteration (not a launch)"
         if fused:
             stages["backward"]["includes"] = "derivative sweep (fused)"
@@ -282,10 +301,24 @@ def main():
     bw_ms = g.profile_read()["backward"][0] / R
     g.profile(False)
     stages, bytes_ts = stage_table(g, prof, B, s_bytes, steps)
+    headline_sclk = g.sclk_mhz
     g.close()
 
     # ---------------- the other configurations (each a fixed-work run of its own) ----------------
     extra = {}
+    if not args.no_extra_configs and world == 1:
+        # the saturated regime: the largest batch of the sweep (two persistent tiles per CU, the dispatcher hands a CU its
+        # next tile as one finishes): what one MI355X sustains when the batch is not the limit
+        Bs = 32768
+        gs, els, profs, _ = acrobot_run(args.dtype, Bs, lim, steps, args.warmup, args.flags, gather=False)
+        sts, bts = stage_table(gs, profs, Bs, s_bytes, steps)
+        sclk = gs.sclk_mhz
+        gs.close()
+        roofs = roofline_of(sts, bts, Bs)
+        extra["saturated"] = {
+            "workload": "the headline workload at B=%d per GPU (persistent tiles, two per CU; records never reach HBM)" % Bs,
+            "value": Bs * T * steps / els, "unit": "trajectory-timesteps/s", "ms_per_step": els / steps * 1e3, "batch_per_gpu": Bs,
+            "stages": sts, "roofline": roofs, "roofline_issue": issue_roofline(roofs["kernel"], els / steps * 1e3, sclk, Bs * T)}
     if not args.no_extra_configs:
         # late in a solve: iterations 4..103 of the same workload -- box-QPs leave the fast path
         # once lambda has reached 0, the launch lasts as long as its slowest tile
@@ -390,7 +423,7 @@ def main():
                        "batch_per_gpu": B, "T": T, "parallelism": "batch-sharded x%d, no data-path collective; "
                        "one all_gather of per-trajectory costs at the end" % world},
             "roofline": roof,
-            "roofline_issue": issue_roofline(roof["kernel"]),
+            "roofline_issue": issue_roofline(roof["kernel"], elapsed / steps * 1e3, headline_sclk, B * T),
             "stages": stages,
             # north star "backward-pass throughput": k_backward_q alone on fixed derivative records
             "backward_only": {"kernel": "k_backward_q", "ms_per_launch": bw_ms,

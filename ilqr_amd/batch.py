@@ -254,3 +254,9 @@ class BatchILQR:
         n = (C.c_int * capi.NUM_STAGES)()
         self._check(self.lib.ilqr_profile_read(self.h, ms, n))
         return {capi.STAGE_NAMES[i]: (ms[i], n[i]) for i in range(capi.NUM_STAGES)}
+
+    def shader_clock_mhz(self):
+        """clock of the CUs during the persistent kernel's launches since the last profile_reset (ilqr_profile_shader_clock)"""
+        mhz = C.c_double(0)
+        self._check(self.lib.ilqr_profile_shader_clock(self.h, C.byref(mhz)))
+        return mhz.value

@@ -71,6 +71,7 @@ SYMBOLS = {
     "ilqr_profile_enable": (C.c_int, [_H, C.c_int]),
     "ilqr_profile_reset": (C.c_int, [_H]),
     "ilqr_profile_read": (C.c_int, [_H, _dp, _ip]),
+    "ilqr_profile_shader_clock": (C.c_int, [_H, _dp]),
     "ilqr_stage_kernel_name": (C.c_char_p, [_H, C.c_int]),
 }
 

@@ -76,7 +76,7 @@ struct ilqr_batch {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int* commit_idx = nullptr;
-  long long* phase_ticks = nullptr;  // [ntiles][3] per-tile clocks of k_solve_tile: sweep+backward, rollouts+accept, iterations
+  long long* phase_ticks = nullptr;  // [ntiles][5] per-tile clocks of k_solve_tile: sweep+backward, rollouts+accept, iterations, shader cycles, wall ticks
   double wall_clock_khz = 100000.0;
   double* staging = nullptr;  // device scratch for canonical <-> tiled conversion
   // LQ model with exact derivatives: the sweep writes one copy of the constant matrices (const_rec) and
@@ -893,7 +893,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   rc |= dev_alloc(h, &v.backpass_done, Bp);
   rc |= dev_alloc(h, &v.n_running, 1);
   rc |= dev_alloc(h, &h->commit_idx, Bp);
-  rc |= dev_alloc(h, &h->phase_ticks, 3 * (size_t)h->ntiles);
+  rc |= dev_alloc(h, &h->phase_ticks, 5 * (size_t)h->ntiles);
   if (!rc && hipMemsetAsync(h->commit_idx, 0xFF, Bp * sizeof(int), h->stream) != hipSuccess) rc = 1;
   if (rc) return ILQR_ERR_HIP;
   sync_float_view(h);
@@ -1417,7 +1417,7 @@ int ilqr_profile_reset(ilqr_batch* h) {
     t.ms = 0;
     t.launches = 0;
   }
-  HIPCHK(hipMemsetAsync(h->phase_ticks, 0, 3 * (size_t)h->ntiles * sizeof(long long), h->stream));
+  HIPCHK(hipMemsetAsync(h->phase_ticks, 0, 5 * (size_t)h->ntiles * sizeof(long long), h->stream));
   return 0;
 }
 int ilqr_profile_read(ilqr_batch* h, double ms_out[ILQR_NUM_STAGES], int launches_out[ILQR_NUM_STAGES]) {
@@ -1430,14 +1430,14 @@ int ilqr_profile_read(ilqr_batch* h, double ms_out[ILQR_NUM_STAGES], int launche
     ln[s] = h->timers[s].launches;
   }
   if (h->timers[ILQR_STAGE_SOLVE].launches > 0) {  // the persistent kernel's own phase clocks: mean over tiles
-    std::vector<long long> tk(3 * (size_t)h->ntiles);
+    std::vector<long long> tk(5 * (size_t)h->ntiles);
     HIPCHK(hipMemcpyAsync(tk.data(), h->phase_ticks, tk.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     double sweep = 0, roll = 0, its = 0;
     for (int t = 0; t < h->ntiles; t++) {
-      sweep += (double)tk[3 * t];
-      roll += (double)tk[3 * t + 1];
-      its += (double)tk[3 * t + 2];
+      sweep += (double)tk[5 * t];
+      roll += (double)tk[5 * t + 1];
+      its += (double)tk[5 * t + 2];
     }
     const double to_ms = 1.0 / h->wall_clock_khz / h->ntiles;  // ticks -> ms, mean over tiles
     ms[ILQR_STAGE_BACKWARD] += sweep * to_ms;
@@ -1449,6 +1449,19 @@ int ilqr_profile_read(ilqr_batch* h, double ms_out[ILQR_NUM_STAGES], int launche
     if (ms_out) ms_out[s] = ms[s];
     if (launches_out) launches_out[s] = ln[s];
   }
+  return 0;
+}
+int ilqr_profile_shader_clock(ilqr_batch* h, double* mhz_out) {
+  if (!h || !mhz_out) return fail(ILQR_ERR_INVALID, "null argument");
+  std::vector<long long> tk(5 * (size_t)h->ntiles);
+  HIPCHK(hipMemcpyAsync(tk.data(), h->phase_ticks, tk.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double cyc = 0, wall = 0;
+  for (int t = 0; t < h->ntiles; t++) {
+    cyc += (double)tk[5 * t + 3];
+    wall += (double)tk[5 * t + 4];
+  }
+  *mhz_out = (wall > 0) ? cyc / wall * h->wall_clock_khz * 1e-3 : 0.0;  // cycles per tick x ticks per ms / 1000
   return 0;
 }
 const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {

@@ -1923,6 +1923,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   const int tile = blockIdx.x;
   long long t_sweep = 0, t_roll = 0, t0 = 0;
   const bool timing = (phase_ticks != nullptr) & (threadIdx.x == 0);
+  const long long c_begin = timing ? clock64() : 0, w_begin = timing ? wall_clock64() : 0;  // shader cycles (s_memtime) / constant-rate ticks
   int it = 0;
   for (; it < n_iters; it++) {
     if (timing) t0 = wall_clock64();
@@ -1948,9 +1949,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     }
   }
   if (timing) {
-    phase_ticks[3 * tile + 0] += t_sweep;
-    phase_ticks[3 * tile + 1] += t_roll;
-    phase_ticks[3 * tile + 2] += it;
+    phase_ticks[5 * tile + 0] += t_sweep;
+    phase_ticks[5 * tile + 1] += t_roll;
+    phase_ticks[5 * tile + 2] += it;
+    phase_ticks[5 * tile + 3] += clock64() - c_begin;       // shader cycles over the tile's whole run ...
+    phase_ticks[5 * tile + 4] += wall_clock64() - w_begin;  // ... and the wall ticks they took: the clock the CU ran at
   }
 }
 

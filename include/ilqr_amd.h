@@ -250,6 +250,10 @@ int ilqr_profile_enable(ilqr_batch* h, int enable);
 int ilqr_profile_reset(ilqr_batch* h);
 /* total milliseconds and launch count per stage since the last reset (synchronises) */
 int ilqr_profile_read(ilqr_batch* h, double ms_out[ILQR_NUM_STAGES], int launches_out[ILQR_NUM_STAGES]);
+/* The clock the CUs ran at during the persistent kernel's launches since the last reset, in MHz: shader cycles (s_memtime)
+ * over constant-rate ticks, summed over tiles.  MI355X lowers its clock with the number of busy SIMDs, so issue-rate
+ * figures derived from a launch duration need the clock of THAT launch (bench.py: roofline_issue). */
+int ilqr_profile_shader_clock(ilqr_batch* h, double* mhz_out);
 /* name of the kernel a stage launches (as rocprofv3 reports it), for bench.py's roofline line */
 const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage);
 
