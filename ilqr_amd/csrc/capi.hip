@@ -17,6 +17,7 @@
 #include "backward_wave.hpp"
 #include "backward_wave2.hpp"
 #include "generic.hpp"
+#include "kernels_wide.hpp"
 #include "kernels.hpp"
 
 using namespace ilqr;
@@ -110,6 +111,7 @@ struct ilqr_batch {
   struct {
     bool staged = false, unfused = false, backward_w1 = false, lq_thread_rollout = false, full_records = false, no_compaction = false;
     int fused = 0;  // 0 = by batch size
+    int wide_occ = 0;  // wide tiles per CU: 0 = by batch size
   } env;
   StageTimer timers[ILQR_NUM_STAGES];
   std::vector<hipEvent_t> event_pool;
@@ -570,11 +572,13 @@ static int launch_backward(ilqr_batch* h, int mode) {
 // (measured at B = 16384: 2.2 ms vs 3.2 ms per iteration).
 // 16 x #CU < B <= 32 x #CU: the variant with one producer and a 60 KB ring, two blocks per CU (kernels.hpp;
 // B = 8192: 1.26 vs 1.42 ms per iteration).  ILQR_AMD_FUSED=1 / =2 force a variant for A/B runs and tests.
-static int fused_variant(const ilqr_batch* h) {  // 0: two kernels, 1: one block per CU, 2: two blocks per CU
+static int fused_variant(const ilqr_batch* h) {  // 0: two kernels, 1: one tile per CU, 2: two tiles per CU, 3: wide tiles (64 trajectories, one per CU)
   if (!use_quad_backward(h) || h->aos || (h->flags & ILQR_FLAG_UNFUSED) || h->env.unfused) return 0;
-  if (h->env.fused) return h->env.fused;
-  if (h->ntiles <= h->num_cus) return 1;
   const bool staged = (h->flags & ILQR_FLAG_STAGED) || h->env.staged;
+  const bool wide_ok = !staged && h->nu == 1 && h->sp.fixes == 0;  // wide tiles (kernels_wide.hpp): persistent route, m = 1, no opt-in fixes
+  if (h->env.fused) return (h->env.fused == 3 && !wide_ok) ? 2 : h->env.fused;
+  if (h->ntiles <= h->num_cus) return 1;
+  if (wide_ok && h->ntiles >= 4 * h->num_cus) return 3;  // a 64-trajectory wide tile for every CU: the thread-per-trajectory chain
   if (!staged) return 2;  // persistent tiles, two per CU, for ANY larger batch: the dispatcher hands a CU its next tile when one is through
   return (h->ntiles <= 2 * h->num_cus) ? 2 : 0;
 }
@@ -633,7 +637,15 @@ static int launch_solve_tiles(ilqr_batch* h, int n_iters) {
   if (int rc = with_model(h, [&](auto& v, auto& m, auto& fdm) {
         using MM = std::decay_t<decltype(m)>;
         using MF = std::decay_t<decltype(fdm)>;
-        if (occ == 1)
+        if (occ == 3) {
+          if constexpr (MM::NU == 1)
+          {
+            if (h->env.wide_occ == 1 || (h->env.wide_occ == 0 && (grid_tiles + 3) / 4 <= h->num_cus))
+              hipLaunchKernelGGL((k_solve_wide<MM, MF, 1>), dim3((grid_tiles + 3) / 4), dim3(512), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
+            else
+              hipLaunchKernelGGL((k_solve_wide<MM, MF, 2>), dim3((grid_tiles + 3) / 4), dim3(256), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
+          }
+        } else if (occ == 1)
           hipLaunchKernelGGL((k_solve_tile<MM, MF, 1>), dim3(grid_tiles), dim3(256), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
         else
           hipLaunchKernelGGL((k_solve_tile<MM, MF, 2>), dim3(grid_tiles), dim3(256), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
@@ -714,7 +726,8 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   h->env.lq_thread_rollout = getenv("ILQR_AMD_LQ_THREAD_ROLLOUT") != nullptr;
   h->env.full_records = getenv("ILQR_AMD_FULL_RECORDS") != nullptr;
   h->env.no_compaction = getenv("ILQR_AMD_NO_COMPACTION") != nullptr;
-  if (const char* f = getenv("ILQR_AMD_FUSED")) h->env.fused = (f[0] == '2') ? 2 : 1;
+  if (const char* f = getenv("ILQR_AMD_FUSED")) h->env.fused = (f[0] == '3') ? 3 : (f[0] == '2') ? 2 : 1;
+  if (const char* w = getenv("ILQR_AMD_WIDE_OCC")) h->env.wide_occ = (w[0] == '2') ? 2 : 1;
   if (const char* e = getenv("ILQR_AMD_NUM_CUS"))  // tests: exercise the batch-size thresholds of the route selection on small batches
     if (atoi(e) > 0) h->num_cus = atoi(e);
   h->device = d->device;
@@ -1473,7 +1486,7 @@ const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
       return (h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t";
     case ILQR_STAGE_ROLLOUT: return (h && h->aos) ? (h->env.lq_thread_rollout ? "k_rollout_g" : "k_rollout_lq") : "k_rollout";
     case ILQR_STAGE_ACCEPT: return "k_accept";
-    case ILQR_STAGE_SOLVE: return (h && use_persistent(h)) ? (fused_variant(h) == 1 ? "k_solve_tile" : "k_solve_tile<2>") : "";
+    case ILQR_STAGE_SOLVE: return (h && use_persistent(h)) ? (fused_variant(h) == 1 ? "k_solve_tile" : fused_variant(h) == 3 ? "k_solve_wide" : "k_solve_tile<2>") : "";
     default: return "";
   }
 }

@@ -1710,10 +1710,11 @@ struct SweepShared {
 
 // The consumer side of the ring (see NoGate).  Knots are numbered by a RUNNING index G = pass * N + (T - t),
 // N = knots per pass rounded up to whole producer rounds: passes follow each other seamlessly in the ring.
-template <class SH, int kProd>
+// KPP: knots per producer wavefront and round (4 x 16 trajectories for a tile; 1 x 64 for a wide tile, kernels_wide.hpp)
+template <class SH, int kProd, int KPP = 4>
 struct RingGate {
   static constexpr bool kRing = true;
-  static constexpr int kKnotsPerRound = 4 * kProd;
+  static constexpr int kKnotsPerRound = KPP * kProd;
   SH& sh;
   const int T, nrounds, N;
   int pass = -1, have = 0;
@@ -1737,12 +1738,12 @@ struct RingGate {
     slot_next = (slot_next + 1 == SH::RS::SLOTS) ? 0 : slot_next + 1;
     if (G < have) return;
     const int j = G - pass * N;
-    const int round = pass * nrounds + j / kKnotsPerRound, w = (j % kKnotsPerRound) / 4;
+    const int round = pass * nrounds + j / kKnotsPerRound, w = (j % kKnotsPerRound) / KPP;
     __hip_atomic_store(&sh.consumer_at, G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     while (__hip_atomic_load(&sh.rounds_done[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= round) {
       __builtin_amdgcn_s_sleep(2);
     }
-    have = pass * N + (j / kKnotsPerRound) * kKnotsPerRound + (w + 1) * 4;
+    have = pass * N + (j / kKnotsPerRound) * kKnotsPerRound + (w + 1) * KPP;
   }
   __device__ __forceinline__ void finish() {  // releases the producers (also from a pass abandoned half way)
     __hip_atomic_store(&sh.consumer_at, 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -128,6 +128,39 @@ def test_two_tiles_per_cu_variants_equal_unfused(name, dtype, monkeypatch):
     _same(out[0], out[2])
 
 
+@pytest.mark.parametrize("occ", ["1", "2"])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("B,T", [(37, 61), (64, 5), (130, 13), (300, 120), (5, 1)])
+def test_wide_tiles_equal_unfused(B, T, dtype, occ, monkeypatch):
+    """k_solve_wide (kernels_wide.hpp: 64-trajectory tiles, thread-per-trajectory backward chain, what ilqr_iterate picks
+    once every CU gets a wide tile) forced on small batches -- ragged wide tiles, partial producer rounds, horizons shorter
+    than the ring -- in normal mode until every trajectory has left its loop (lambda retries, abandoned passes), against
+    the two-kernel route: every array and scalar bit-identical.  occ: one wide tile per CU (8 wavefronts, 148 KB ring) or two
+    (4 wavefronts each, 74 KB ring = three slots in fp64, roles by SIMD)."""
+    from ilqr_amd import BatchILQR, capi
+    monkeypatch.setenv("ILQR_AMD_WIDE_OCC", occ)
+    x0 = acrobot_x0(B, scale=0.3, seed=B + T)
+    u0 = np.zeros((B, T, 1))
+    kw = dict(u_min=-1.5, u_max=1.5, params=dict(max_iter=14), dtype=dtype)
+    sv = capi.STAGE_NAMES.index("solve")
+    out = []
+    for fl, env in ((0, "3"), (capi.FLAG_UNFUSED, None)):
+        if env:
+            monkeypatch.setenv("ILQR_AMD_FUSED", env)
+        else:
+            monkeypatch.delenv("ILQR_AMD_FUSED", raising=False)
+        g = BatchILQR("acrobot", B, T, DT, flags=fl, **kw)
+        if env:
+            assert g.lib.ilqr_stage_kernel_name(g.h, sv) == b"k_solve_wide"
+        g.init_traj(x0, u0)
+        g.iterate(3)
+        s3 = _state(g)
+        g.generate_trajectory()
+        out.append(dict(_state(g), **{"i3_" + n: a for n, a in s3.items()}))
+        g.close()
+    _same(out[0], out[1])
+
+
 def test_route_selection_by_batch_size(monkeypatch):
     """Route selection by batch size (ILQR_AMD_NUM_CUS scales the thresholds down to test sizes): up to one tile per CU
     the persistent kernel with a CU per tile, beyond that -- at ANY batch size -- the persistent kernel with two tiles per
@@ -138,15 +171,15 @@ def test_route_selection_by_batch_size(monkeypatch):
     monkeypatch.setenv("ILQR_AMD_NUM_CUS", str(cus))
     T = 20
     bw, sv = capi.STAGE_NAMES.index("backward"), capi.STAGE_NAMES.index("solve")
-    for B in (16 * cus + 16, 80 * cus + 3):  # one tile more than one per CU; five tiles per CU and a ragged last tile
+    for B in (16 * cus + 16, 48 * cus + 3, 80 * cus + 3):  # one tile more than one per CU; three per CU; five per CU and a ragged last tile
         x0 = acrobot_x0(B, scale=0.3, seed=4)
         u0 = np.zeros((B, T, 1))
         out = []
         for fl in (0, capi.FLAG_STAGED, capi.FLAG_UNFUSED):
             g = BatchILQR("acrobot", B, T, DT, u_min=-1.5, u_max=1.5, flags=fl)
             name = lambda st: g.lib.ilqr_stage_kernel_name(g.h, st)
-            if fl == 0:
-                assert name(sv) == b"k_solve_tile<2>"
+            if fl == 0:  # two tiles per CU, and wide (64-trajectory) tiles once every CU gets one
+                assert name(sv) == (b"k_solve_tile<2>" if B < 64 * cus else b"k_solve_wide")
             elif fl == capi.FLAG_STAGED:
                 assert name(sv) == b"" and name(bw) == (b"k_sweep_backward" if B <= 32 * cus else b"k_backward_q")
             else:
