@@ -316,7 +316,8 @@ def main():
         gs.close()
         roofs = roofline_of(sts, bts, Bs)
         extra["saturated"] = {
-            "workload": "the headline workload at B=%d per GPU (persistent tiles, two per CU; records never reach HBM)" % Bs,
+            "workload": "the headline workload at B=%d per GPU (persistent wide tiles of 64 trajectories, two per CU, thread-per-trajectory "
+                        "backward chain; records never reach HBM)" % Bs,
             "value": Bs * T * steps / els, "unit": "trajectory-timesteps/s", "ms_per_step": els / steps * 1e3, "batch_per_gpu": Bs,
             "stages": sts, "roofline": roofs, "roofline_issue": issue_roofline(roofs["kernel"], els / steps * 1e3, sclk, Bs * T)}
     if not args.no_extra_configs:

@@ -50,7 +50,7 @@ struct UserModelT {
     const real G1 = 1 * g * half * s12;
     const real r0 = (real(0.0) - (C00 * qd0 + C01 * qd1)) - G0;
     const real r1 = (u[0] - (C10 * qd0)) - G1;
-    const real invdet = real(1.0) / (H00 * H11 - H01 * H01);
+    const real invdet = recip(H00 * H11 - H01 * H01);  // (1 / det by v_rcp + Newton, boxqp.hpp -- as the shipped acrobot does)
     dx[0] = qd0;
     dx[1] = qd1;
     dx[2] = (H11 * invdet) * r0 + (-H01 * invdet) * r1;

@@ -316,9 +316,8 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
   for (; t + PD <= T; t += PD) {
 #pragma unroll
     for (int d = 0; d < PD; d++) {
-      const StepIn cur = ring[d];
-      load_step(t + d + PD, ring[d]);
-      do_step(t + d, cur);
+      do_step(t + d, ring[d]);          // (the set is consumed in place and refilled right after: copying it out first so
+      load_step(t + d + PD, ring[d]);   //  that the refill could be issued a step earlier cost ten register moves per step)
     }
   }
   for (; t < T; t++) {  // remainder (< PD steps)

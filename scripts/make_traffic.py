@@ -23,6 +23,8 @@ def read(path, counter):
                 name = "k_rollout_init"
             if name == "k_solve_tile" and targs.rstrip().endswith(", 2>"):
                 name = "k_solve_tile<2>"
+            if name == "k_solve_wide":
+                name = "k_solve_wide"
             if "float" in targs:
                 name += "_f32"
             out[name] = (avg, n)
@@ -93,11 +95,13 @@ def main(d, tag):
         kernels[k] = e
     if os.path.exists("%s/sat_pmc_FETCH_SIZE.txt" % d):  # the saturated batch (B = 32768: k_solve_tile<2>)
         fs, ws = read("%s/sat_pmc_FETCH_SIZE.txt" % d, "FETCH_SIZE"), read("%s/sat_pmc_WRITE_SIZE.txt" % d, "WRITE_SIZE")
-        kernels["k_solve_tile<2>"] = solve_entry(d, "sat_", "k_solve_tile<2>", 32768, T, fs, ws)
+        for key in ("k_solve_wide", "k_solve_tile<2>"):  # what the saturated batch runs: wide tiles (nu = 1), else two tiles per CU
+            if key in fs or key in ws:
+                kernels[key] = solve_entry(d, "sat_", key, 32768, T, fs, ws)
     json.dump({"source": "rocprofv3 passes of `bench.py --no-cpu-baseline --no-extra-configs --steps 5 --warmup 3` on MI355X, one counter "
                          "set per run with --kernel-trace only (scripts/collect_profiles.sh; summaries profiles/%s_*.txt): FETCH_SIZE doubled per "
                          "MI355X_MICROARCH.md (gfx950 reports half of a coalesced stream), WRITE_SIZE as is, KB = 1024 B; k_sweep_backward / "
-                         "k_rollout rows from the same workload launched per stage (--flags 32); k_solve_tile<2> from the same command with "
+                         "k_rollout rows from the same workload launched per stage (--flags 32); k_solve_wide (the saturated batch) from the same command with "
                          "--batch 32768" % tag,
                "source_hash": _build._source_hash(),
                "workload": "acrobot T=499 B=4096 fp64 limits +-1.5", "kernels": kernels}, sys.stdout, indent=1)

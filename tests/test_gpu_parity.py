@@ -312,3 +312,28 @@ def test_config1_full_size(oracle):
     cost = g.cost()
     assert np.all(np.isfinite(cost)) and np.all(cost <= c0 * (1 + 1e-12))
     assert (g.status()[2] >= 0).mean() > 0.5
+
+
+def test_saturated_batch_wide_route_against_the_oracle(oracle):
+    """The route a saturating batch takes (B = 16384: one 64-trajectory wide tile per CU, thread-per-trajectory backward
+    chain, kernels_wide.hpp) at the headline horizon and limits: 64 trajectories of the free-running batch walked against the
+    oracle for two iterations, and the first 4096 trajectories of the big batch equal, bit for bit, a 4096-trajectory batch
+    of the same problems (which takes the one-tile-per-CU route)."""
+    from ilqr_amd import BatchILQR, capi
+    B, T, lim = 16384, 499, 1.5
+    g = BatchILQR("acrobot", B, T, DT, u_min=-lim, u_max=lim)
+    assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("solve")) == b"k_solve_wide"
+    x0 = acrobot_x0(B)
+    u0 = np.zeros((B, T, 1))
+    r = sampled_walk(oracle, oracle.Model("acrobot", u_lim=lim), g, x0, u0, DT, 2)
+    print("saturated (wide tiles) sampled walk:", {kk: v for kk, v in r.items() if kk != "sel"})
+    assert r["checked"] == 2 * len(r["sel"]) and len(r["tied"]) <= len(r["sel"]) // 16 and r["cond_over10"] <= max(2, r["checked"] // 24), r
+    cost_big = g.cost()  # (two free-running iterations, left by the walk)
+    st_big, it_big, al_big = g.status()
+    g.close()
+    g = BatchILQR("acrobot", 4096, T, DT, u_min=-lim, u_max=lim)
+    g.init_traj(x0[:4096], u0[:4096])
+    g.iterate(1)
+    g.iterate(1)
+    assert np.array_equal(g.cost(), cost_big[:4096]) and np.array_equal(g.status()[2], al_big[:4096])
+    g.close()
