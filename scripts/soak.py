@@ -2,8 +2,9 @@
 
 Every case draws a model, batch size, horizon, control limit, initial conditions and an iteration
 count, then checks
-  * the persistent tile kernel (k_solve_tile), the per-stage launches (k_sweep_backward + k_rollout) and the two-kernel
-    route (records in HBM) leave bit-identical state,
+  * the persistent tile kernel (k_solve_tile, one and two tiles per CU), the wide-tile kernel (k_solve_wide, one and two per
+    CU), the per-stage launches (k_sweep_backward + k_rollout), the two-kernel route (records in HBM) and a solve with
+    compaction of running trajectories leave bit-identical state,
   * the thread-per-trajectory backward kernel agrees with the quad kernel (1e-6 on >= 90 % of the
     trajectories: the two differ in rounding, and a few acrobot iterations amplify that),
   * after `iters` iterations (normal mode, per-trajectory exits) iteration counts and statuses match
@@ -62,14 +63,22 @@ def main():
         u0 = rng.normal(size=(B, T, nu)) * float(rng.choice([0.0, 0.1, 0.6]))
         desc = "%s B=%d T=%d lim=%g iters=%d" % (name, B, T, lim, iters)
         outs = {}
-        for label, fl in (("fused", 0), ("staged", capi.FLAG_STAGED), ("unfused", capi.FLAG_UNFUSED),
-                          ("thread", capi.FLAG_UNFUSED | capi.FLAG_BACKWARD_THREAD_PER_TRAJ)):
+        for label, fl, env in (("fused", 0, {}), ("staged", capi.FLAG_STAGED, {}), ("unfused", capi.FLAG_UNFUSED, {}),
+                               ("thread", capi.FLAG_UNFUSED | capi.FLAG_BACKWARD_THREAD_PER_TRAJ, {}),
+                               # the routes big batches take, forced on these small ones: two tiles per CU, wide tiles (one / two per
+                               # CU; m = 2 falls back to two tiles per CU), and compaction of running trajectories between chunks
+                               ("occ2", 0, {"ILQR_AMD_FUSED": "2"}), ("wide1", 0, {"ILQR_AMD_FUSED": "3", "ILQR_AMD_WIDE_OCC": "1"}),
+                               ("wide2", 0, {"ILQR_AMD_FUSED": "3", "ILQR_AMD_WIDE_OCC": "2"}),
+                               ("compact", 0, {"ILQR_AMD_NUM_CUS": "2"})):
+            for kk in ("ILQR_AMD_FUSED", "ILQR_AMD_WIDE_OCC", "ILQR_AMD_NUM_CUS"):
+                os.environ.pop(kk, None)
+            os.environ.update(env)
             g = BatchILQR(name, B, T, DT, flags=fl, params=dict(max_iter=iters), **kw)
             g.init_traj(x0, u0)
             g.generate_trajectory()
             outs[label] = state(g)
             g.close()
-        for other in ("staged", "unfused"):  # persistent tile kernel == per-stage launches == two kernels with records in HBM
+        for other in ("staged", "unfused", "occ2", "wide1", "wide2", "compact"):  # every route leaves the same bits
             for key in outs["fused"]:
                 if not np.array_equal(outs["fused"][key], outs[other][key], equal_nan=True):
                     print("FAIL persistent != %s:" % other, key, desc, "seed", seed)
