@@ -54,20 +54,21 @@ __device__ __forceinline__ void sincos_shared(double x, double& s_out, double& c
   c_out = ((q + 1) & 2) ? -ca : ca;
 }
 
-// fp32 flavour of the above: j = rint(x 2/pi), r = x - j pi/2 in three FMAs (pi/2 split in three floats),
-// minimax polynomials on [-pi/4, pi/4] (the classic single-precision kernels): ~1 ulp for |x| <= 1e4.
+// fp32 flavour of the above.  The range reduction runs in DOUBLE (conversion, product, rint, one FMA against a 53-bit pi/2:
+// the same six instructions as a three-term float Cody-Waite reduction, whose exactness ends at |x| ~ 3.2e3): r = x - j pi/2
+// is good to 1e-16 |j|, i.e. float-exact for every |x| a float rollout can reach before the line search rejects it on cost.
+// Then the classic single-precision minimax kernels on [-pi/4, pi/4]: ~1 ulp.
 __device__ __forceinline__ void sincos_shared(float x, float& s_out, float& c_out) {
   // contraction by the source, not by the optimiser: every inlined copy of this function (rollout kernels, the
   // persistent kernel, the commit / getter re-integration, the finite differences) must round identically
 #pragma clang fp contract(on)
-  const float j = __builtin_rintf(x * 6.36619772e-01f);
-  float r = __builtin_fmaf(-j, 1.57079601e+00f, x);   // pi/2, leading bits (exact product with |j| < 2^11)
-  r = __builtin_fmaf(-j, 3.13916473e-07f, r);         // next
-  r = __builtin_fmaf(-j, 5.39030253e-15f, r);         // rest
+  const double xd = (double)x;
+  const double j = __builtin_rint(xd * 6.36619772367581382433e-01);  // 2/pi
+  const float r = (float)__builtin_fma(-j, 1.57079632679489655800e+00, xd);
   const float z = r * r;
   const float sr = r + (z * r) * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
   const float cr = (1.0f - 0.5f * z) + (z * z) * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
-  const int q = (int)j & 3;
+  const int q = (int)j & 3;  // (|j| >= 2^31 saturates: see the double version)
   const float sa = (q & 1) ? cr : sr;
   const float ca = (q & 1) ? sr : cr;
   s_out = (q & 2) ? -sa : sa;

@@ -1,0 +1,288 @@
+// rollout.hpp -- forward_pass (src/ilqr_core.cpp:305-337) for all line-search alphas concurrently, the accept logic
+// (STEP 3/4, :185-282), candidate checkpoints and their re-integration.
+#pragma once
+#include "layout.hpp"
+
+namespace ilqr {
+
+// ------------------------------------------------------------------------------------------
+// line-search selection + lambda schedule + termination (ilqr_core.cpp:185-282)
+// ------------------------------------------------------------------------------------------
+// STEP 3/4 for trajectory b; cost_of(a) = cost of its candidate a
+template <class View, class CostOf>
+__device__ __forceinline__ void accept_one(const View& v, const SolverParams& sp, int b, CostOf cost_of,
+                                           int* __restrict__ commit_idx, bool count_running = true) {
+  if (b >= v.Bp) return;
+  int commit = -1;
+  if (b < v.B && v.status[b] == 0) {
+    double lambda = v.lambda[b], dlambda = v.dlambda[b];
+    const double cost_s = v.cost[b];
+    bool fwd = false;
+    double new_cost = 0, dcost = 0;
+    int acc = -1;
+    if (v.backpass_done[b]) {  // :184
+      const double dV0 = v.dV[b], dV1 = v.dV[v.Bp + b];
+      for (int a = 0; a < NALPHA; a++) {  // the serial order of :185-220, first z > zMin wins
+        const double alpha = kAlpha[a];
+        new_cost = cost_of(a);
+        dcost = cost_s - new_cost;                          // :199
+        const double expected = -alpha * (dV0 + alpha * dV1);  // :200
+        double z;
+        if (expected > 0)
+          z = dcost / expected;
+        else
+          z = (double)((0.0 < dcost) - (dcost < 0.0));  // sgn, common.h:52
+        if (z > sp.z_min) {
+          fwd = true;
+          acc = a;
+          break;
+        }
+      }
+    }
+    int status = 0;
+    if (fwd) {  // :242-263
+      dlambda = fmin(dlambda / sp.lambda_factor, 1 / sp.lambda_factor);
+      lambda = lambda * dlambda * (lambda > sp.lambda_min ? 1.0 : 0.0);
+      v.cost[b] = new_cost;
+      v.flg_change[b] = 1;
+      commit = acc;
+      if (!sp.fixed_work && dcost < sp.tol_fun) status = 2;
+    } else {  // :264-282
+      dlambda = fmax(dlambda * sp.lambda_factor, sp.lambda_factor);
+      lambda = fmax(lambda * dlambda, sp.lambda_min);
+      v.flg_change[b] = 0;
+      if (!sp.fixed_work && lambda > sp.lambda_max) status = 3;
+    }
+    v.lambda[b] = lambda;
+    v.dlambda[b] = dlambda;
+    v.alpha_idx[b] = acc;
+    const int it = v.iters[b] + 1;
+    v.iters[b] = it;
+    // :103.  Not in bench mode: ILQR_FLAG_FIXED_WORK promises that B*T*iters is exactly the work done,
+    // whatever max_iter says.
+    if (status == 0 && !sp.fixed_work && it >= sp.max_iter) status = 4;
+    v.status[b] = status;
+    if (status == 0 && count_running) atomicAdd(v.n_running, 1);
+  }
+  commit_idx[b] = commit;
+}
+template <class real>
+__global__ void k_accept(BatchViewT<real> v, SolverParams sp, int* __restrict__ commit_idx) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  accept_one(v, sp, b, [&](int a) { return v.cost_c[(size_t)a * v.Bp + b]; }, commit_idx);
+}
+
+struct AlphaSet {
+  double a[NALPHA];  // include/ilqr.h:24 as written; a kernel rounds it to its arithmetic once
+};
+
+// One thread per (trajectory, alpha).  A wavefront = one tile of 16 trajectories x 4 alphas
+// (lane = 16*alpha_sub + l): the nominal controls, gains and states of the tile are fetched once
+// per wavefront and shared by its four alphas (one 128-byte line per load instruction).  AW
+// wavefronts of the same tile (alphas 4w..4w+3) form one block, i.e. sit on one CU and share its
+// L1.  grid = ntiles, block = 64*AW.
+//   GAINS=false : u_t = us[t]                                   (init_traj: K empty, :316)
+//   GAINS=true  : u_t = us[t] + alpha k[t] + K[t] (x_t - xs[t]) (:188-190, :315-316)
+//   CAND=false  : knots (x_t, u_t) go straight into the nominal tiled xs/us (init_traj)
+//   CAND=true   : candidate `a` keeps every u_t and the state at every CT-th knot (common.hpp)
+// The cost goes to cost_out[a][b].  mode: 0 = all trajectories, 1 = only running ones whose
+// backward pass succeeded.
+// ACCEPT: the block also performs STEP 3/4 for its 16 trajectories once its three wavefronts have
+// their costs (k_accept's work without a launch of its own; sp, commit_idx are only used then).
+// Prefetch depth of the rollout when a tile has a CU to itself: 8 steps for the acrobot (10 doubles per step: 160
+// registers of ring), 4 for the double integrator (16 per step: at depth 8 the ring alone is 256 registers, the
+// kernel spills -- and inside k_solve_tile the spilled build produced wrong rollouts from knot 59 on).
+template <class M>
+constexpr int kDeepPrefetch = (M::NU * M::NX + M::NX + 2 * M::NU <= 10) ? 8 : 4;
+
+// (the body of k_rollout for one tile: the persistent kernel k_solve_tile runs it too, with a fourth, idle wavefront)
+template <class M, bool GAINS, bool CAND, int PD, bool ACCEPT>
+__device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>& v, const M& model, const AlphaSet& alphas, int n_alpha,
+                                             double* __restrict__ cost_out, int mode, const SolverParams& sp,
+                                             int* __restrict__ commit_idx, int tile, double* lds_cost, bool count_running = true, int rwave = -1) {
+  using real = typename M::real;
+  constexpr int NX = M::NX, NU = M::NU;
+  const int wave = (rwave >= 0) ? rwave : (int)(threadIdx.x >> 6);  // which four alphas this wavefront rolls out (>= 3: none)
+  const int lane = threadIdx.x & 63;
+  const int l = lane & (TW - 1);
+  const int a_sub = lane >> 4;
+  const int a = wave * 4 + a_sub;
+  const int b = tile * TW + l;
+  bool active = (b < v.B) && (a < n_alpha);
+  if (active && mode == 1) active = (v.status[b] == 0 && v.backpass_done[b]);
+  if (!ACCEPT && !active) return;
+  if (active) {
+  const int T = v.T;
+  const real alpha = (real)alphas.a[a < NALPHA ? a : NALPHA - 1];
+  const real dt = (real)v.dt;
+
+  real x[NX];
+#pragma unroll
+  for (int i = 0; i < NX; i++) x[i] = v.x0[tidx(tile, 0, i, l, 1, NX)];
+  double total = 0;  // (the sum over the horizon is a per-trajectory accumulator: double in both modes, common.hpp)
+
+  // The nominal controls / gains / states of step t do not depend on the rollout's own state,
+  // and one step of arithmetic (~600 cycles) is far shorter than an HBM round trip under load
+  // (~2000+ cycles), so they are prefetched PD steps ahead into a ring of register sets; the
+  // main loop is unrolled by PD so that every set is statically indexed.
+  // Measured on the bench workload (10 loads per step, one block per CU): PD 2 -> 0.298 ms,
+  // 4 -> 0.259, 8 -> 0.237, 12 -> 0.236 (more than vmcnt's 63 outstanding), 16 -> 0.76 (register
+  // spills).  Depth 8 costs 266 registers, i.e. one block per CU; when the tiles outnumber the CUs
+  // the launcher picks depth 4 (136 registers, several blocks per CU hide the latency instead).
+  struct StepIn {
+    real u[NU], k[GAINS ? NU : 1], K[GAINS ? NU * NX : 1], xnom[GAINS ? NX : 1];
+  };
+  auto load_step = [&](int t, StepIn& d) __attribute__((always_inline)) {
+    t = (t < T) ? t : T - 1;  // tail: harmless re-load instead of a branch
+#pragma unroll
+    for (int j = 0; j < NU; j++) d.u[j] = v.us[tidx(tile, t, j, l, T, NU)];
+    if (GAINS) {
+#pragma unroll
+      for (int j = 0; j < NU; j++) d.k[j] = v.kff[tidx(tile, t, j, l, T, NU)];
+#pragma unroll
+      for (int e = 0; e < NU * NX; e++) d.K[e] = v.Kfb[tidx(tile, t, e, l, T, NU * NX)];
+#pragma unroll
+      for (int i = 0; i < NX; i++) d.xnom[i] = v.xs[tidx(tile, t, i, l, T + 1, NX)];
+    }
+  };
+  auto emit_knot = [&](int t, const real* xx, const real* uu) __attribute__((always_inline)) {  // knot t = (x_t, u_t)
+    if (CAND) {
+      const int ta = a * v.ntiles + tile;
+      if (t < T) {
+#pragma unroll
+        for (int q = 0; q < NU; q++) v.cand_u[tidx(ta, t, q, l, T, NU)] = uu[q];
+      }
+      if ((t & (CT - 1)) == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; i++) v.cand_x[tidx(ta, t / CT, i, l, v.nch, NX)] = xx[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NX; i++) v.xs[tidx(tile, t, i, l, T + 1, NX)] = xx[i];
+      if (t < T) {
+#pragma unroll
+        for (int q = 0; q < NU; q++) v.us[tidx(tile, t, q, l, T, NU)] = uu[q];  // :323 (no clamping)
+      }
+    }
+  };
+  auto do_step = [&](int t, const StepIn& d) __attribute__((always_inline)) {
+    real u[NU];
+#pragma unroll
+    for (int j = 0; j < NU; j++) u[j] = d.u[j];
+    if (GAINS) {
+#pragma unroll
+      for (int j = 0; j < NU; j++) {
+        u[j] += d.k[j] * alpha;  // :190
+        real acc = 0;
+#pragma unroll
+        for (int i = 0; i < NX; i++) acc += d.K[j + NU * i] * (x[i] - d.xnom[i]);
+        u[j] += acc;  // :316
+      }
+    }
+    if (sp.fixes & 1) {  // opt-in fix: "the right way" of ilqr_core.cpp:327-329 -- the clamped control is stored and integrated
+#pragma unroll
+      for (int j = 0; j < NU; j++) u[j] = min_of(max_of(u[j], model.u_min[j]), model.u_max[j]);
+    }
+    emit_knot(t, x, u);
+    total += (double)model.cost(x, u);  // :324
+    real x1[NX];
+    integrate_dynamics(model, x, u, dt, x1);  // :325
+#pragma unroll
+    for (int i = 0; i < NX; i++) x[i] = x1[i];
+  };
+  StepIn ring[PD];
+#pragma unroll
+  for (int d = 0; d < PD; d++) load_step(d, ring[d]);
+  int t = 0;
+  for (; t + PD <= T; t += PD) {
+#pragma unroll
+    for (int d = 0; d < PD; d++) {
+      do_step(t + d, ring[d]);          // (the set is consumed in place and refilled right after: copying it out first so
+      load_step(t + d + PD, ring[d]);   //  that the refill could be issued a step earlier cost ten register moves per step)
+    }
+  }
+  for (; t < T; t++) {  // remainder (< PD steps)
+    StepIn cur;
+    load_step(t, cur);
+    do_step(t, cur);
+  }
+  {  // knot T: the final state (no control)
+    real uz[NU];
+#pragma unroll
+    for (int q = 0; q < NU; q++) uz[q] = 0;
+    emit_knot(T, x, uz);
+  }
+  total += (double)model.final_cost(x);  // :335
+  cost_out[(size_t)a * v.Bp + b] = total;
+  if (ACCEPT) lds_cost[a * TW + l] = total;
+  }  // if (active)
+  if constexpr (ACCEPT) {
+    __syncthreads();
+    if (threadIdx.x < TW)
+      accept_one(v, sp, tile * TW + (int)threadIdx.x, [&](int aa) { return lds_cost[aa * TW + threadIdx.x]; }, commit_idx, count_running);
+  }
+}
+
+template <class M, bool GAINS, bool CAND, int PD = 4, bool ACCEPT = false>
+__global__ __launch_bounds__(192) void k_rollout(BatchViewT<typename M::real> v, M model, AlphaSet alphas, int n_alpha,
+                                                 double* __restrict__ cost_out, int mode, SolverParams sp,
+                                                 int* __restrict__ commit_idx) {
+  __shared__ double lds_cost[ACCEPT ? NALPHA * TW : 1];
+  rollout_tile<M, GAINS, CAND, PD, ACCEPT>(v, model, alphas, n_alpha, cost_out, mode, sp, commit_idx, (int)blockIdx.x, lds_cost);
+}
+
+// Knot t of candidate `a` of trajectory (tile, l): the control as stored, the state re-integrated
+// from the checkpoint at knot (t/CT)*CT with the rollout's own step (include/model.h:12-15).  The
+// CT-1 controls of the chunk are fetched up front (one memory round trip), the steps run predicated.
+template <class M>
+__device__ __forceinline__ void candidate_knot(const BatchViewT<typename M::real>& v, const M& model, int a, int tile, int t, int l,
+                                               typename M::real* x, typename M::real* u) {
+  using real = typename M::real;
+  constexpr int NX = M::NX, NU = M::NU;
+  const int T = v.T, ta = a * v.ntiles + tile, c = t / CT, off = t - c * CT;
+#pragma unroll
+  for (int i = 0; i < NX; i++) x[i] = v.cand_x[tidx(ta, c, i, l, v.nch, NX)];
+  real uq[CT][NU];
+#pragma unroll
+  for (int q = 0; q < CT; q++) {
+    const int tq = (c * CT + q < T) ? c * CT + q : T - 1;
+#pragma unroll
+    for (int j = 0; j < NU; j++) uq[q][j] = v.cand_u[tidx(ta, tq, j, l, T, NU)];
+  }
+#pragma unroll
+  for (int j = 0; j < NU; j++) u[j] = 0.0;  // knot T has no control
+#pragma unroll
+  for (int q = 0; q < CT; q++) {
+    if (q < off) {
+      real x1[NX];
+      integrate_dynamics(model, x, uq[q], (real)v.dt, x1);
+#pragma unroll
+      for (int i = 0; i < NX; i++) x[i] = x1[i];
+    }
+    if (q == off && t < T) {
+#pragma unroll
+      for (int j = 0; j < NU; j++) u[j] = uq[q][j];
+    }
+  }
+}
+
+// candidate `a` -> canonical xs [B][T+1][nx], us [B][T][nu]   (getter only)
+template <class M>
+__global__ void k_unpack_cand(BatchViewT<typename M::real> v, M model, int a, double* __restrict__ xs, double* __restrict__ us) {
+  using real = typename M::real;
+  constexpr int NX = M::NX, NU = M::NU;
+  const int T = v.T;
+  const size_t n = (size_t)v.B * (T + 1);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i % (T + 1));
+    const int b = (int)(i / (T + 1));
+    real x[NX], u[NU];
+    candidate_knot(v, model, a, b / TW, t, b % TW, x, u);
+    if (xs)
+      for (int e = 0; e < NX; e++) xs[((size_t)b * (T + 1) + t) * NX + e] = (double)x[e];
+    if (us && t < T)
+      for (int e = 0; e < NU; e++) us[((size_t)b * T + t) * NU + e] = (double)u[e];
+  }
+}
+
+}  // namespace ilqr

@@ -147,3 +147,19 @@ def test_host_model_evaluated_by_several_threads(tmp_path):
     assert r.returncode == 0, r.stderr
     row = [l.split() for l in r.stdout.splitlines() if l.startswith("host_threads")][0]
     assert int(row[1]) == 4 and float(row[3]) == 0.0
+
+
+@pytest.mark.gpu
+def test_user_device_twin_through_the_facade(tmp_path):
+    """examples/user_model.cpp: a Model subclass whose device twin lives in a header OUTSIDE the library
+    (examples/user_model_acrobot.hpp, compiled in by ilqr_amd._build.build_user) solved through ilqr_amd::iLQR, linked
+    against that build: identical, to the last bit, to the shipped acrobot on the same problem."""
+    from ilqr_amd import _build
+    lib = _build.build_user(_build.USER_EXAMPLE_HEADER, _build.USER_EXAMPLE_LIB)
+    exe = str(tmp_path / "user_model")
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "user_model.cpp"), "-o", exe, lib, "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bit_identical 1" in r.stdout

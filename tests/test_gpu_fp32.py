@@ -218,3 +218,26 @@ def test_config3_full_size_eight_shards_equal_one_batch():
     assert np.all(np.isfinite(cost)) and np.all(cost <= c0 * (1 + 1e-6)) and (al >= 0).mean() > 0.5
     for a, b, name in zip(gathered, (cost, st, it, al), ("cost", "status", "iters", "alpha")):
         assert np.array_equal(a, b), name
+
+
+def test_fp32_rollout_at_large_angles(oracle):
+    """Acrobot angles are not wrapped (the reference does not wrap them either), so a float rollout can carry |q| in the
+    thousands of radians.  The device's float sincos reduces its argument in double (models.hpp): a rollout from such states
+    agrees with the float oracle (libm sinf / cosf on the same floats) like one from small angles does -- the three-term
+    float Cody-Waite reduction this replaced was exact only for |x| < 3.2e3."""
+    from ilqr_amd import BatchILQR
+    B, T = 48, 25
+    rng = np.random.default_rng(3)
+    x0 = f32(rng.uniform(-1, 1, (B, 4)) * np.array([9000.0, 20000.0, 1.0, 1.0]))
+    u0 = f32(rng.normal(size=(B, T, 1)) * 0.5)
+    g = BatchILQR("acrobot", B, T, DT, u_min=-5.0, u_max=5.0, dtype="f32")
+    cost = g.init_traj(x0, u0)
+    xs, us = g.trajectory()
+    om = oracle.Model("acrobot", u_lim=5.0)
+    with oracle.flavour("f32"):
+        xs32, us32, c32 = oracle.batch_rollout(om.twin("f32"), x0, u0, DT)
+    # velocities are O(1..10), angles O(1e4) with a float ulp of 1e-3: compare the velocities, and the angles in ulps of themselves
+    assert np.max(np.abs(xs[:, :, 2:] - xs32[:, :, 2:])) < 2e-3 * max(1.0, np.abs(xs32[:, :, 2:]).max())
+    assert np.max(np.abs(xs[:, :, :2] - xs32[:, :, :2]) / np.maximum(np.abs(xs32[:, :, :2]), 1.0)) < 1e-6
+    assert np.max(np.abs(cost - c32) / np.abs(c32)) < 1e-4
+    g.close()
