@@ -320,6 +320,16 @@ def main():
                         "backward chain; records never reach HBM)" % Bs,
             "value": Bs * T * steps / els, "unit": "trajectory-timesteps/s", "ms_per_step": els / steps * 1e3, "batch_per_gpu": Bs,
             "stages": sts, "roofline": roofs, "roofline_issue": issue_roofline(roofs["kernel"], els / steps * 1e3, sclk, Bs * T)}
+        # BASELINE configs[3] at its stated size, all 32768 trajectories on ONE GPU (fp32, limits +-5): the batch the 8-GPU partition shards
+        other = "f32" if args.dtype == "f64" else "f64"
+        g5, el5, prof5, _ = acrobot_run(other, 32768, 5.0, steps, args.warmup, gather=False)
+        st5, bt5 = stage_table(g5, prof5, 32768, 4 if other == "f32" else 8, steps)
+        g5.close()
+        extra["acrobot_T500_B32768_lim5_%s_one_gpu" % other] = {
+            "workload": "acrobot T=499 B=32768 on one GPU, u in [-5,5], %s (BASELINE configs[3] at its stated size, unsharded); the 8 x 4096 partition of "
+                        "the same batch gives the same bits (tests/test_gpu_fp32.py)" % other,
+            "dtype": other, "value": 32768 * T * steps / el5, "unit": "trajectory-timesteps/s", "ms_per_step": el5 / steps * 1e3,
+            "stages": st5, "roofline": roofline_of(st5, bt5, 32768)}
     if not args.no_extra_configs:
         # late in a solve: iterations 4..103 of the same workload -- box-QPs leave the fast path
         # once lambda has reached 0, the launch lasts as long as its slowest tile
