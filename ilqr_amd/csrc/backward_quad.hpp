@@ -100,12 +100,13 @@ __device__ __forceinline__ bool qp1_search_quad(QP1StateT<real>& q, int s, int l
   // Armijo ratio is 0 at every k, and the reference's loop runs its ~100 trips down to minStep and
   // reports failure (boxqp.cpp:167-171).  Same outcome, without the trips -- late in a solve this
   // was a quarter of the steps of the slowest tiles.
-  const bool stuck = (qp1_trial(q, real(1)) == q.x) & !q.early;
+  // (the unit-step trial is lane 0's candidate: bit 0 of s4)
   // The same once the search direction is rounding noise (late in a solve Quu reaches 1e12+ and x
   // sits on the optimum to an ulp: search ~ 1e-19): steps 1 and 0.6 still move x by an ulp, from
   // 0.36 on the trial IS x.  With the window at k = 1, 2, 3 every k <= 3 has been tested exactly;
   // if none passes and the k = 3 trial equals x, no later k can pass either.
   const unsigned int s4 = (unsigned int)(__ballot(my_x1 == q.x) >> (lane & ~3)) & 0xFu;
+  const bool stuck = ((s4 & 1u) != 0u) & !q.early;
   const bool dead = (k1 == 1) & (m4 == 0u) & ((s4 & 8u) != 0u) & !q.early;
   q.ls_failed = q.ls_failed | stuck | dead;
   return ok | q.early | stuck | dead;
@@ -381,8 +382,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       struct { real x[NU]; } qp;
       real Kc[NU];
       bool ok;
-      int k_free = 0;      // (NU == 1: what K is scaled from, see the exchange below)
-      real k_minv = 0;
+      real k_scale = 0;    // (NU == 1: what K is scaled from, see the exchange below)
       if constexpr (NU == 1) {
         int free0;
         real minv;
@@ -394,20 +394,20 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
           q1.v1 = qp1_value(q1, q1.x1);
           qp1_backtrack_seq(q1);
         }
-        int result = qp1_finish(q1, qp.x[0], free0, minv);
-        if (result == kQpGoesOn)  // the QP goes on (rare early in a solve, a quarter of the steps of some tiles later)
-          result = qp1_continue(
-              q1,
-              [&](QP1StateT<real>& qs) __attribute__((always_inline)) {
-                if (__builtin_expect(!qp1_search_quad(qs, s, lane, lds_steps), 0)) {
-                  qp1_line_search_seq(qs);
-                }
-              },
-              qp.x[0], free0);
-        ok = result >= 1;
-        Kc[0] = free0 ? -minv * Quxr[0] : real(0);  // :373-385
-        k_free = free0;
-        k_minv = minv;
+        bool goes_on;
+        ok = qp1_finish_ok(q1, qp.x[0], free0, minv, goes_on);
+        if (goes_on)  // the QP goes on (rare early in a solve, a quarter of the steps of some tiles later)
+          ok = qp1_continue(
+                   q1,
+                   [&](QP1StateT<real>& qs) __attribute__((always_inline)) {
+                     if (__builtin_expect(!qp1_search_quad(qs, s, lane, lds_steps), 0)) {
+                       qp1_line_search_seq(qs);
+                     }
+                   },
+                   qp.x[0], free0) >= 1;
+        // :373-385  K = -(R^-1 R^-T) Qux on a free control, 0 on a clamped one: one scale for the row (0 x Qux = +-0)
+        k_scale = free0 ? -minv : real(0);
+        Kc[0] = k_scale * Quxr[0];
       } else if constexpr (NU == 2) {
         // m = 2: the scalarised solver (boxqp.hpp: box_qp2); K[:, s] = -(R^-1 R^-T) Qux[free, s] scattered to the free rows (:373-385)
         BoxQP2Result<real> r;
@@ -511,7 +511,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       if (NU == 1 && !reg_vxx) {
         // K[0, r] = -minv Qux[0, r] in lane r; the same product of the same operands here: no second exchange
 #pragma unroll
-        for (int r = 0; r < 4; r++) Kall[0][r] = k_free ? -k_minv * Qall[0][r] : real(0);
+        for (int r = 0; r < 4; r++) Kall[0][r] = k_scale * Qall[0][r];
       } else {
 #pragma unroll
         for (int a = 0; a < NU; a++) quad_gather(Kc[a], Kall[a]);

@@ -129,7 +129,7 @@ __device__ __forceinline__ bool qp1_search_lane(QP1StateT<real>& q, const real* 
   q.x1 = (src == 1) ? cx[1] : (src == 2) ? cx[2] : (src == 3) ? cx[3] : cx[0];
   q.v1 = (src == 1) ? cv[1] : (src == 2) ? cv[2] : (src == 3) ? cv[3] : cv[0];
   q.step = (src == 1) ? cs[1] : (src == 2) ? cs[2] : (src == 3) ? cs[3] : cs[0];
-  const bool stuck = (qp1_trial(q, real(1)) == q.x) & !q.early;
+  const bool stuck = ((s4 & 1u) != 0u) & !q.early;  // (the unit-step trial is candidate 0)
   const bool dead = (k1 == 1) & (m4 == 0u) & ((s4 & 8u) != 0u) & !q.early;
   q.ls_failed = q.ls_failed | stuck | dead;
   return ok | q.early | stuck | dead;
@@ -293,19 +293,20 @@ __device__ __forceinline__ void backward_wide(const BatchViewT<typename M::real>
         q1.v1 = qp1_value(q1, q1.x1);
         qp1_backtrack_seq(q1);
       }
-      int result = qp1_finish(q1, x, free0, minv);
-      if (result == kQpGoesOn)
-        result = qp1_continue(
-            q1,
-            [&](QP1StateT<real>& qs) __attribute__((always_inline)) {
-              if (__builtin_expect(!qp1_search_lane(qs, lds_steps), 0)) qp1_line_search_seq(qs);
-            },
-            x, free0);
-      const bool ok = result >= 1;
+      bool goes_on;
+      bool ok = qp1_finish_ok(q1, x, free0, minv, goes_on);
+      if (goes_on)
+        ok = qp1_continue(
+                 q1,
+                 [&](QP1StateT<real>& qs) __attribute__((always_inline)) {
+                   if (__builtin_expect(!qp1_search_lane(qs, lds_steps), 0)) qp1_line_search_seq(qs);
+                 },
+                 x, free0) >= 1;
       if (!ok) diverge = i;
       real K[4];  // :373-385
+      const real k_scale = free0 ? -minv : real(0);
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++) K[rr] = free0 ? -minv * Qux[rr] : real(0);
+      for (int rr = 0; rr < 4; rr++) K[rr] = k_scale * Qux[rr];
       // :388-389
       {
         real d0 = 0;
