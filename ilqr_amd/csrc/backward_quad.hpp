@@ -74,8 +74,8 @@ __device__ __forceinline__ bool qp1_search_quad(QP1StateT<real>& q, int s, int l
   //  for a few trajectories late in a solve: along a descent direction the value change of a trial on the bound is a
   //  negative constant N, the test passes iff step <= N / (0.1 slope), and an interior trial has ratio
   //  1 + Q step search^2 / (2 slope) > 1: the passing set is upward closed for either sign of Q)
-  const bool sane = (q.Q != real(0)) & (thr > 0.f) & (thr < 1.f) & (kg >= 1) & (kg <= 96);
-  const int k1 = (sane & (kg > 2)) ? kg - 1 : 1;
+  const bool sane = p_and(p_and(q.Q != real(0), p_and(thr > 0.f, thr < 1.f)), p_and(kg >= 1, kg <= 96));
+  const int k1 = p_and(sane, kg > 2) ? kg - 1 : 1;
   const int my_k = (s == 0) ? 0 : k1 + s - 1;
   const real my_step = lds_steps[my_k];
   const real my_x1 = qp1_trial(q, my_step);
@@ -88,8 +88,8 @@ __device__ __forceinline__ bool qp1_search_quad(QP1StateT<real>& q, int s, int l
   const bool unit = (m4 & 1u) != 0u;
   const unsigned int w = m4 >> 1;
   const int wwin = __ffs(w);  // 1..3, 0 if none
-  const bool wok = (w != 0u) & ((wwin > 1) | (k1 == 1)) & (sane | (k1 == 1));
-  const bool ok = unit | wok;
+  const bool wok = p_and(p_and(w != 0u, p_or(wwin > 1, k1 == 1)), p_or(sane, k1 == 1));
+  const bool ok = p_or(unit, wok);
   const int win = unit ? 0 : wwin;
   const int src = (lane & ~3) + (ok ? win : 0);
   q.x1 = __shfl(my_x1, src, 64);
@@ -106,10 +106,10 @@ __device__ __forceinline__ bool qp1_search_quad(QP1StateT<real>& q, int s, int l
   // 0.36 on the trial IS x.  With the window at k = 1, 2, 3 every k <= 3 has been tested exactly;
   // if none passes and the k = 3 trial equals x, no later k can pass either.
   const unsigned int s4 = (unsigned int)(__ballot(my_x1 == q.x) >> (lane & ~3)) & 0xFu;
-  const bool stuck = ((s4 & 1u) != 0u) & !q.early;
-  const bool dead = (k1 == 1) & (m4 == 0u) & ((s4 & 8u) != 0u) & !q.early;
-  q.ls_failed = q.ls_failed | stuck | dead;
-  return ok | q.early | stuck | dead;
+  const bool stuck = p_and((s4 & 1u) != 0u, !q.early);
+  const bool dead = p_and(p_and(k1 == 1, m4 == 0u), p_and((s4 & 8u) != 0u, !q.early));
+  q.ls_failed = p_or(q.ls_failed, p_or(stuck, dead));
+  return p_or(p_or(ok, q.early), p_or(stuck, dead));
 }
 
 template <int NU, class real>

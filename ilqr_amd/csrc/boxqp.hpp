@@ -62,6 +62,11 @@ ILQR_HD void rsqrt_and_sqrt(double a, double& rs, double& s) {
   rs = 1.0 / s;
 #endif
 }
+// and / or of predicates as SELECTS on i1: `a | b` on bool is integer arithmetic on the promoted operands, which the GPU back
+// end tends to carry out in vector registers (0 / 1 materialised per predicate, 16-bit logic, a compare to get a lane mask
+// back); `||` would be a branch.  These stay lane masks (s_or_b64 / s_and_b64).
+ILQR_HD bool p_or(bool a, bool b) { return a ? true : b; }
+ILQR_HD bool p_and(bool a, bool b) { return a ? b : false; }
 // type-directed math (an unqualified fabs / fmin / fmax / sqrt on a float silently picks the double
 // function in a host pass and wherever only the C declarations are visible)
 ILQR_HD double sqrt_of(double a) { return __builtin_sqrt(a); }
@@ -679,13 +684,13 @@ ILQR_HD void qp1_begin(real Q, real c, real x0, real lo, real hi, QP1StateT<real
   const real den = (Q > real(0)) ? Q : Q * Q;
   q.minv = recip(den);
   // (bitwise & | on purpose: no short-circuit branches in the wavefront's instruction stream)
-  q.clA = ((abs_of(q.x - lo) < real(kClampTol)) & (q.g0 > 0)) | ((abs_of(q.x - hi) < real(kClampTol)) & (q.g0 < 0));
+  q.clA = p_or(p_and(abs_of(q.x - lo) < real(kClampTol), q.g0 > 0), p_and(abs_of(q.x - hi) < real(kClampTol), q.g0 < 0));
   q.exB = abs_of(q.g0) < real(kMinGrad);
   q.search = -q.minv * c - q.x;
   q.slope = q.search * q.g0;
   q.exC = q.slope >= 0;
-  q.indef = detect_indefinite & !(Q > real(0));
-  q.early = q.clA | q.indef | q.exB | q.exC;
+  q.indef = p_and(detect_indefinite, !(Q > real(0)));
+  q.early = p_or(p_or(q.clA, q.indef), p_or(q.exB, q.exC));
   q.step = 1;
   if (EVAL_UNIT) {
     q.x1 = qp1_trial(q, real(1));
@@ -751,7 +756,7 @@ template <class real>
 ILQR_HD bool qp1_finish_ok(const QP1StateT<real>& q, real& x_out, int& free_out, real& minv_out, bool& goes_on) {
   const bool exD = (q.val0 - q.v1) < real(kMinRelImprove) * abs_of(q.val0);
   const real g1 = q.Q * q.x1 + q.c;
-  const bool clE = ((abs_of(q.x1 - q.lo) < real(kClampTol)) & (g1 > 0)) | ((abs_of(q.x1 - q.hi) < real(kClampTol)) & (g1 < 0));
+  const bool clE = p_or(p_and(abs_of(q.x1 - q.lo) < real(kClampTol), g1 > 0), p_and(abs_of(q.x1 - q.hi) < real(kClampTol), g1 < 0));
   const bool exF = abs_of(g1) < real(kMinGrad);
   // G: iteration 1's own search direction is not a descent direction (boxqp.cpp:150-153 -> result 2, x kept).
   // After an interior Newton step x1 IS the optimum to rounding, so search = -minv c - x1 is 0 or an ulp of
@@ -770,13 +775,13 @@ ILQR_HD bool qp1_finish_ok(const QP1StateT<real>& q, real& x_out, int& free_out,
   const bool exH = min_of(max_of(q.x1 + search1, q.lo), q.hi) == q.x1;
   minv_out = q.minv;
   // the reference's order of tests, as selects (no branches)
-  const bool stay = q.clA | q.indef | q.exB | q.exC | q.ls_failed;  // x is not updated
+  const bool stay = p_or(p_or(p_or(q.clA, q.indef), p_or(q.exB, q.exC)), q.ls_failed);  // x is not updated
   // what the kernels need of the result code: does the QP go on, and (if not) did it succeed (result >= 1)?  Every exit
   // code of the ladder in qp1_finish is >= 1 except -1 (indefinite free block with the opt-in fix, tested after "all clamped")
   x_out = stay ? q.x : q.x1;
-  free_out = (q.clA | (!stay & !exD & clE)) ? 0 : 1;
-  goes_on = !stay & !(exD | clE | exF | exG | exH);
-  return !stay | q.clA | !q.indef;
+  free_out = p_or(q.clA, p_and(p_and(!stay, !exD), clE)) ? 0 : 1;
+  goes_on = p_and(!stay, !p_or(p_or(exD, clE), p_or(exF, p_or(exG, exH))));
+  return p_or(!stay, p_or(q.clA, !q.indef));
 }
 
 // Iterations >= 1 of the loop of box_qp_scalar, continued from the state the two-iteration fast

@@ -107,8 +107,8 @@ __device__ __forceinline__ bool qp1_search_lane(QP1StateT<real>& q, const real* 
   const float r = (float)(v_b - q.old_v) * __builtin_amdgcn_rcpf((float)(real(kArmijo) * q.slope));
   const float thr = fmaxf(f, r);
   const int kg = (int)ceilf(__log2f(thr) * -1.35691545f);
-  const bool sane = (q.Q != real(0)) & (thr > 0.f) & (thr < 1.f) & (kg >= 1) & (kg <= 96);
-  const int k1 = (sane & (kg > 2)) ? kg - 1 : 1;
+  const bool sane = p_and(p_and(q.Q != real(0), p_and(thr > 0.f, thr < 1.f)), p_and(kg >= 1, kg <= 96));
+  const int k1 = p_and(sane, kg > 2) ? kg - 1 : 1;
   real cx[4], cv[4], cs[4];
   unsigned int m4 = 0u, s4 = 0u;
 #pragma unroll
@@ -123,16 +123,16 @@ __device__ __forceinline__ bool qp1_search_lane(QP1StateT<real>& q, const real* 
   const bool unit = (m4 & 1u) != 0u;
   const unsigned int w = m4 >> 1;
   const int wwin = __ffs(w);
-  const bool wok = (w != 0u) & ((wwin > 1) | (k1 == 1)) & (sane | (k1 == 1));
-  const bool ok = unit | wok;
+  const bool wok = p_and(p_and(w != 0u, p_or(wwin > 1, k1 == 1)), p_or(sane, k1 == 1));
+  const bool ok = p_or(unit, wok);
   const int src = ok ? (unit ? 0 : wwin) : 0;
   q.x1 = (src == 1) ? cx[1] : (src == 2) ? cx[2] : (src == 3) ? cx[3] : cx[0];
   q.v1 = (src == 1) ? cv[1] : (src == 2) ? cv[2] : (src == 3) ? cv[3] : cv[0];
   q.step = (src == 1) ? cs[1] : (src == 2) ? cs[2] : (src == 3) ? cs[3] : cs[0];
-  const bool stuck = ((s4 & 1u) != 0u) & !q.early;  // (the unit-step trial is candidate 0)
-  const bool dead = (k1 == 1) & (m4 == 0u) & ((s4 & 8u) != 0u) & !q.early;
-  q.ls_failed = q.ls_failed | stuck | dead;
-  return ok | q.early | stuck | dead;
+  const bool stuck = p_and((s4 & 1u) != 0u, !q.early);  // (the unit-step trial is candidate 0)
+  const bool dead = p_and(p_and(k1 == 1, m4 == 0u), p_and((s4 & 8u) != 0u, !q.early));
+  q.ls_failed = p_or(q.ls_failed, p_or(stuck, dead));
+  return p_or(p_or(ok, q.early), p_or(stuck, dead));
 }
 
 // The backward pass of one wide tile, one thread per trajectory (lane = trajectory of the wide tile), records from the ring.
