@@ -152,7 +152,7 @@ ILQR_HD bool quadclamp_line_search(const real* x0, const real* dir, const real* 
     // stay as they are (result 2 or, one iteration later, 4).  Same outcome, up to 100 trips earlier.
     bool stuck = true;
 #pragma unroll
-    for (int i = 0; i < M; i++) stuck = stuck & (xc[i] == x0[i]);
+    for (int i = 0; i < M; i++) stuck = p_and(stuck, xc[i] == x0[i]);
     if (step < real(kMinStep) || stuck) {
       failed = true;
       break;
@@ -472,18 +472,18 @@ ILQR_HD void box_qp2(const real* Q, const real* c, const real* x0, const real* l
     const real g0 = (q00 * x[0] + q01 * x[1]) + c[0], g1 = (q10 * x[0] + q11 * x[1]) + c[1];
     oldvalue = val;
     const int n_old = (int)cl0 + (int)cl1;
-    cl0 = ((abs_of(x[0] - lo[0]) < real(kClampTol)) & (g0 > 0)) | ((abs_of(x[0] - hi[0]) < real(kClampTol)) & (g0 < 0));  // :62-71
-    cl1 = ((abs_of(x[1] - lo[1]) < real(kClampTol)) & (g1 > 0)) | ((abs_of(x[1] - hi[1]) < real(kClampTol)) & (g1 < 0));
-    if (cl0 & cl1) {  // :74-77
+    cl0 = p_or(p_and(abs_of(x[0] - lo[0]) < real(kClampTol), g0 > 0), p_and(abs_of(x[0] - hi[0]) < real(kClampTol), g0 < 0));  // :62-71
+    cl1 = p_or(p_and(abs_of(x[1] - lo[1]) < real(kClampTol), g1 > 0), p_and(abs_of(x[1] - hi[1]) < real(kClampTol), g1 < 0));
+    if (p_and(cl0, cl1)) {  // :74-77
       result = 6;
       break;
     }
-    const bool f0 = !cl0, both = f0 & !cl1;
+    const bool f0 = !cl0, both = p_and(f0, !cl1);
     if (iter == 0 || n_old != (int)cl0 + (int)cl1) {  // :80
       // the free block, compacted (eigen_helpers.h:46-61)
       const real a00 = f0 ? q00 : q11, a10 = both ? q10 : real(0), a11 = both ? q11 : real(0);
       const real det = a00 * a11 - a10 * a10;
-      const bool pd = both ? ((a00 > real(0)) & (det > real(0))) : (a00 > real(0));
+      const bool pd = p_and(a00 > real(0), p_or(!both, det > real(0)));
       if (detect_indefinite && !pd) {  // opt-in fix: a failed factorisation ends the QP
         result = -1;
         break;
@@ -683,7 +683,7 @@ ILQR_HD void qp1_begin(real Q, real c, real x0, real lo, real hi, QP1StateT<real
   q.g0 = Q * q.x + c;
   const real den = (Q > real(0)) ? Q : Q * Q;
   q.minv = recip(den);
-  // (bitwise & | on purpose: no short-circuit branches in the wavefront's instruction stream)
+  // (p_and / p_or: no short-circuit branches in the wavefront's instruction stream, no integer arithmetic on promoted bools)
   q.clA = p_or(p_and(abs_of(q.x - lo) < real(kClampTol), q.g0 > 0), p_and(abs_of(q.x - hi) < real(kClampTol), q.g0 < 0));
   q.exB = abs_of(q.g0) < real(kMinGrad);
   q.search = -q.minv * c - q.x;
@@ -815,14 +815,14 @@ ILQR_HD int qp1_continue(QP1StateT<real>& q, LineSearch line_search, real& x_out
     // ... or, three times in four (counted), through the gradient test (:93-97, result 5): the step was a real one and
     // x2 is the optimum to rounding.
     const real g2 = q.Q * x2 + q.c;
-    const bool cl2 = ((abs_of(x2 - q.lo) < real(kClampTol)) & (g2 > 0)) | ((abs_of(x2 - q.hi) < real(kClampTol)) & (g2 < 0));
+    const bool cl2 = p_or(p_and(abs_of(x2 - q.lo) < real(kClampTol), g2 > 0), p_and(abs_of(x2 - q.hi) < real(kClampTol), g2 < 0));
     const bool flat2 = abs_of(g2) < real(kMinGrad);
     // ... or -- float's usual one, where |g| < 1e-8 is out of reach -- because iteration 2's own direction is no descent
     // direction (:150-153, result 2, x2 kept).
     const real s2 = -q.minv * q.c - x2;
     const bool nodesc2 = (s2 * g2) >= real(0);
-    const bool stepped = unit_passes & moved & (slope1 < real(0));
-    if (stepped & (tiny | (!cl2 & (flat2 | nodesc2)))) {
+    const bool stepped = p_and(p_and(unit_passes, moved), slope1 < real(0));
+    if (p_and(stepped, p_or(tiny, p_and(!cl2, p_or(flat2, nodesc2))))) {
       x_out = x2;
       free_out = 1;
       return tiny ? 4 : (flat2 ? 5 : 2);
@@ -835,7 +835,7 @@ ILQR_HD int qp1_continue(QP1StateT<real>& q, LineSearch line_search, real& x_out
     }
     const real grad = q.Q * x + q.c;
     oldvalue = val;
-    const bool cl = ((abs_of(x - q.lo) < real(kClampTol)) & (grad > 0)) | ((abs_of(x - q.hi) < real(kClampTol)) & (grad < 0));
+    const bool cl = p_or(p_and(abs_of(x - q.lo) < real(kClampTol), grad > 0), p_and(abs_of(x - q.hi) < real(kClampTol), grad < 0));
     if (cl) {  // :74-77
       free_ = 0;
       result = 6;
