@@ -85,3 +85,19 @@ extern "C" int devfn_box_qp2_f32(const float* Q, const float* c, const float* x0
   vfree[0] = r.free0; vfree[1] = r.free1;
   return r.result;
 }
+
+// qp1_finish (the reference's result code) against qp1_finish_ok (what the kernels use: the two predicates): returns 0 when they agree
+extern "C" int devfn_qp1_finish_flavours_agree(double Q, double c, double x0, double lo, double hi, int detect_indefinite) {
+  QP1StateT<double> q;
+  qp1_begin(Q, c, x0, lo, hi, q, detect_indefinite != 0);
+  qp1_backtrack_seq(q);
+  double xa, xb, ma, mb;
+  int fa, fb;
+  bool goes_on;
+  const int code = qp1_finish(q, xa, fa, ma);
+  const bool ok = qp1_finish_ok(q, xb, fb, mb, goes_on);
+  if (xa != xb || fa != fb || ma != mb) return 1;
+  if (goes_on != (code == kQpGoesOn)) return 2;
+  if (!goes_on && ok != (code >= 1)) return 3;
+  return 0;
+}

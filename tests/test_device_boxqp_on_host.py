@@ -219,3 +219,20 @@ def test_gradient_norm_test_without_the_square_root(dev):
         v = np.nextafter(v, np.float32(1))
     for gn2 in cases32:
         assert bool(dev.devfn_grad_norm_below_min_f32(float(gn2))) == bool(np.sqrt(np.float32(gn2)) < t32), gn2
+
+
+def test_finish_predicates_equal_the_result_code(dev):
+    """qp1_finish_ok (boxqp.hpp: what the kernels call -- success and "goes on" as predicates) against qp1_finish (the
+    reference's result code 4 / 5 / 6 / 2 / -1): same x, free flag, minv; goes_on <=> code == "goes on"; ok <=> code >= 1.
+    Positive definite, indefinite (with and without the opt-in detection), warm starts on the bounds."""
+    dev.devfn_qp1_finish_flavours_agree.argtypes = [C.c_double] * 5 + [C.c_int]
+    rng = np.random.default_rng(17)
+    n_goes_on = 0
+    for t in range(40000):
+        Q = rng.uniform(0.01, 5) if t % 7 else rng.uniform(-2, 0.01)
+        c = rng.normal() * 2
+        lo, hi = -rng.uniform(0.01, 2), rng.uniform(0.01, 2)
+        x0 = (rng.normal(), lo, hi)[t % 3]
+        for det in (0, 1):
+            r = dev.devfn_qp1_finish_flavours_agree(Q, c, x0, lo, hi, det)
+            assert r == 0, (r, Q, c, x0, lo, hi, det)
