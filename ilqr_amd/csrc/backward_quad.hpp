@@ -247,6 +247,8 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
     gacc = 0;
 
     // one Riccati step; returns false if the box-QP reports failure (ilqr_core.cpp:371)
+    real* __restrict__ Kt_i = Kt + (unsigned)(((T - 1) * NU * NX + NU * s) * TW);  // this lane's K(:, s) and k of step i
+    real* __restrict__ kt_i = kt + (unsigned)((T - 1) * NU * TW);
     auto step = [&](int i, const QuadStep<NU, real>& raw) -> bool {
       struct {  // the record, unpacked (register renames: the loads have landed, see QuadStep)
         real fx[16], fxc[4], fu[4 * NU], cu[NU], cuu[NU * NU], us[NU], cx, cxx[4], cxu[NU];
@@ -585,13 +587,17 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
 #pragma unroll
         for (int a = 0; a < NU; a++) {
           kprev[a] = qp.x[a];
-          Kt[(unsigned)((i * NU * NX + a + NU * s) * TW)] = Kc[a];
+          Kt_i[a * TW] = Kc[a];
         }
         if (s == 0) {
 #pragma unroll
-          for (int a = 0; a < NU; a++) kt[(unsigned)((i * NU + a) * TW)] = qp.x[a];
+          for (int a = 0; a < NU; a++) kt_i[a * TW] = qp.x[a];
         }
       }
+      // (running per-lane pointers, not base + i * stride: the scalar index cost two SGPRs whose zero high word the
+      //  register allocator kept reloading from its spill lanes inside this block)
+      Kt_i -= NU * NX * TW;
+      kt_i -= NU * TW;
       return ok;
     };
 
