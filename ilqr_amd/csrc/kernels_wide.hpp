@@ -41,6 +41,7 @@ struct WideShared {
   int rounds_done[kProd];
   int consumer_at;
   int passes_started;
+  int committed_to;               // knots >= this one hold the accepted candidate (commit_chunks_wide)
   unsigned long long pass_lanes;  // bit l = trajectory l of the wide tile takes part in the current pass
 };
 
@@ -421,8 +422,81 @@ __device__ __forceinline__ void backward_wide(const BatchViewT<typename M::real>
   }
 }
 
+// The pending commit of the accepted candidates (ilqr_core.cpp:210-213) for the 64 trajectories of a wide tile, by ONE
+// wavefront that runs ahead of the producers.  A candidate is stored as its controls and every CT-th state
+// (candidate_knot): knot t costs t mod CT integration steps, 3.5 on average -- as much as the knot's finite differences --
+// when every knot is re-derived by itself, which is what a producer that meets a pending commit does in the 16-trajectory
+// kernel (its producers have the time).  Here the producers share their SIMDs and were what the chain waited for (two
+// tiles per CU: 6200 cycles per knot against the chain's 3500).  Integrating a chunk of CT knots forward ONCE gives the
+// same states by the same sequence of steps (bit-identical) for 7 steps per 8 knots; they go to xs / us, committed_to
+// tells the producers how far down the nominal trajectory is valid, and the producers read it as if nothing were pending.
+template <class M>
+__device__ __forceinline__ void commit_chunks_wide(const BatchViewT<typename M::real>& v, const M& model, const int* __restrict__ commit_idx,
+                                                   int tile, int l, int* committed_to) {
+  using real = typename M::real;
+  constexpr int NX = M::NX, NU = M::NU;
+  const int T = v.T, b = tile * TW + l;
+  const int ci = (b < v.B) ? commit_idx[b] : -1;
+  const int ta = (ci >= 0 ? ci : 0) * v.ntiles + tile;
+  const real dt = (real)v.dt;
+  struct Chunk {
+    real x[NX], u[CT][NU];
+  };
+  auto fetch = [&](int c, Chunk& d) __attribute__((always_inline)) {
+    if (ci < 0 || c < 0) return;
+#pragma unroll
+    for (int i = 0; i < NX; i++) d.x[i] = v.cand_x[tidx(ta, c, i, l, v.nch, NX)];
+#pragma unroll
+    for (int q = 0; q < CT; q++) {
+      const int tq = (c * CT + q < T) ? c * CT + q : T - 1;
+#pragma unroll
+      for (int j = 0; j < NU; j++) d.u[q][j] = v.cand_u[tidx(ta, tq, j, l, T, NU)];
+    }
+  };
+  auto run = [&](int c, Chunk& d) __attribute__((always_inline)) {
+    if (ci >= 0) {
+      real x[NX];
+#pragma unroll
+      for (int i = 0; i < NX; i++) x[i] = d.x[i];
+#pragma unroll
+      for (int q = 0; q < CT; q++) {
+        const int t = c * CT + q;
+        if (t <= T) {  // (wave-uniform)
+#pragma unroll
+          for (int i = 0; i < NX; i++) v.xs[tidx(tile, t, i, l, T + 1, NX)] = x[i];
+          if (t < T) {
+#pragma unroll
+            for (int j = 0; j < NU; j++) v.us[tidx(tile, t, j, l, T, NU)] = d.u[q][j];
+            if (q + 1 < CT) {
+              real x1[NX];
+              integrate_dynamics(model, x, d.u[q], dt, x1);
+#pragma unroll
+              for (int i = 0; i < NX; i++) x[i] = x1[i];
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);  // the chunk's stores are out
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(committed_to, c * CT, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  Chunk A, Bc;  // two register sets: the next chunk's loads fly while this one integrates
+  int c = T / CT;
+  fetch(c, A);
+  while (true) {
+    fetch(c - 1, Bc);
+    run(c, A);
+    if (--c < 0) break;
+    fetch(c - 1, A);
+    run(c, Bc);
+    if (--c < 0) break;
+  }
+}
+
 // STEP 1 + STEP 2 of one iteration for one wide tile (see sweep_backward_tile): wavefront 0 the chain, 1..kProd producers
-// (one knot x 64 trajectories per producer and round), the rest of the block idle in this phase.
+// (one knot x 64 trajectories per producer and round), wavefront kProd + 1 the pending commit, the rest of the block idle
+// in this phase.
 template <class M, int kProd, class MFD, class SH>
 __device__ __forceinline__ void sweep_backward_wide(const BatchViewT<typename M::real>& v, const M& model, const MFD& fdm, const SolverParams& sp,
                                                     int mode, int force, const int* __restrict__ commit_idx, int wtile, SH& sh, int role = -1) {
@@ -433,6 +507,7 @@ __device__ __forceinline__ void sweep_backward_wide(const BatchViewT<typename M:
   if (threadIdx.x == kProd) {
     sh.consumer_at = 0;
     sh.passes_started = 0;
+    sh.committed_to = (commit_idx != nullptr) ? v.T + 1 : 0;
   }
   __syncthreads();
   const int wave = (role >= 0) ? role : (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;  // 0 the chain, 1..kProd producers, else idle
@@ -462,16 +537,21 @@ __device__ __forceinline__ void sweep_backward_wide(const BatchViewT<typename M:
         const int j = r * kProd + w, G = pass * N + j;
         while (G > __hip_atomic_load(&sh.consumer_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + kLeadKnots) __builtin_amdgcn_s_sleep(4);
         const int started = __hip_atomic_load(&sh.passes_started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const bool moved_on = (started < 0) | (started > pass + 1);
-        if (moved_on && (pass > 0 || commit_idx == nullptr)) break;
+        if ((started < 0) | (started > pass + 1)) break;  // the chain has left this pass behind
         const int t = T - j;
+        if (t >= 0 && pass == 0 && commit_idx != nullptr)  // (the nominal knot t is the accepted candidate's from here on)
+          while (__hip_atomic_load(&sh.committed_to, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) > t) __builtin_amdgcn_s_sleep(2);
         if (t >= 0 && (pass == 0 || mine))
-          derivatives_of_knot<M, true, MFD, RS::PAD>(v, model, fdm, force, pass == 0 ? commit_idx : nullptr, tile, t, l,
-                                                     sh.ring + (G % RS::SLOTS) * RS::ELEMS + lane * 2, !moved_on);
+          derivatives_of_knot<M, true, MFD, RS::PAD>(v, model, fdm, force, nullptr, tile, t, l,
+                                                     sh.ring + (G % RS::SLOTS) * RS::ELEMS + lane * 2, true);
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the round's LDS writes are done
         if (lane == 0) __hip_atomic_store(&sh.rounds_done[w], pass * nrounds + r + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
+  } else if (wave == kProd + 1 && commit_idx != nullptr) {
+    __builtin_amdgcn_s_setprio(1);
+    commit_chunks_wide<M>(v, model, commit_idx, wtile * (WT / TW) + (lane >> 4), lane & (TW - 1), &sh.committed_to);
     __builtin_amdgcn_s_setprio(0);
   }
 }
@@ -516,6 +596,10 @@ __global__ __launch_bounds__(64 * WideCfg<OCC>::kWaves) __attribute__((amdgpu_wa
       rwave = (rel == 1) ? 0 : (rel == 3) ? 1 : (rel == 0) ? 2 : 3;  // (keeping the wavefront on the OTHER tile's chain SIMD out of the rollouts: 6 % slower)
     }
   }
+  // (the ring is idle while the tile rolls out: each wavefront's share of it passes the nominal rows between its alpha groups)
+  constexpr int kShareReals = 4 * ((2 * M::NU + M::NU * M::NX + M::NX + 3) / 4) * TW;
+  static_assert(kWaves * kShareReals <= (int)(sizeof(sh.ring) / sizeof(real)), "the ring holds every wavefront's rollout rows");
+  real* const roll_share = sh.ring + wave * kShareReals;
   long long t_sweep = 0, t_roll = 0, t0 = 0;
   const bool timing = (phase_ticks != nullptr) & (threadIdx.x == 0);
   const long long c_begin = timing ? clock64() : 0, w_begin = timing ? wall_clock64() : 0;
@@ -532,7 +616,7 @@ __global__ __launch_bounds__(64 * WideCfg<OCC>::kWaves) __attribute__((amdgpu_wa
     // 12 rollout units (tile of the wide tile, alpha group) over the wavefronts that roll out.  (Handing units out
     // dynamically, as wavefronts become free, measured 3 % slower than this fixed assignment.)
     for (int u = rwave; u < (WT / TW) * 3; u += roll_waves)
-      rollout_tile<M, true, true, 4, false>(v, model, alphas, NALPHA, v.cost_c, 1, sp, nullptr, wtile * (WT / TW) + u / 3, nullptr, false, u % 3);
+      rollout_tile<M, true, true, 4, false, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, nullptr, wtile * (WT / TW) + u / 3, nullptr, false, u % 3, roll_share);
     phase_barrier();  // the candidates' costs are in memory
     if (threadIdx.x < WT)
       accept_one(v, sp, wtile * WT + (int)threadIdx.x, [&](int a) { return v.cost_c[(size_t)a * v.Bp + wtile * WT + threadIdx.x]; }, commit_idx,

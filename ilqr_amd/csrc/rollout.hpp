@@ -96,10 +96,21 @@ template <class M>
 constexpr int kDeepPrefetch = (M::NU * M::NX + M::NX + 2 * M::NU <= 10) ? 8 : 4;
 
 // (the body of k_rollout for one tile: the persistent kernel k_solve_tile runs it too, with a fourth, idle wavefront)
-template <class M, bool GAINS, bool CAND, int PD, bool ACCEPT>
+//
+// SHARE (with `share` = 4 * ceil(rows / 4) * TW reals of LDS owned by this wavefront): the four alpha groups of a wavefront
+// need the SAME nominal rows (u, k, K, xs of 16 trajectories at step t) and each fetched all of them -- ten vector memory
+// instructions per step, every one ~10.6 cycles of the CU's address path whatever its lane mask or footprint
+// (scripts/ubench/vmem.hip), which with eight wavefronts rolling out is two thirds of a step's issue time: the wide
+// kernels' rollouts ran 1.5 x their instruction count.  Shared, group s fetches rows s, s + 4, s + 8 (three instructions
+// for ten rows), the wavefront passes them through LDS one step ahead (in-order LDS: no barrier) and every lane reads its
+// ten values back with broadcast reads.  Same values: bit-identical.  It pays even with one rollout wavefront per SIMD
+// (the 16-trajectory kernel at B <= 16 x #CU: 0.205 -> 0.191 ms per rollout phase); the stage kernel k_rollout, which has
+// no LDS to spare a priori, keeps the per-lane loads.
+template <class M, bool GAINS, bool CAND, int PD, bool ACCEPT, bool SHARE = false>
 __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>& v, const M& model, const AlphaSet& alphas, int n_alpha,
                                              double* __restrict__ cost_out, int mode, const SolverParams& sp,
-                                             int* __restrict__ commit_idx, int tile, double* lds_cost, bool count_running = true, int rwave = -1) {
+                                             int* __restrict__ commit_idx, int tile, double* lds_cost, bool count_running = true, int rwave = -1,
+                                             typename M::real* share = nullptr) {
   using real = typename M::real;
   constexpr int NX = M::NX, NU = M::NU;
   const int wave = (rwave >= 0) ? rwave : (int)(threadIdx.x >> 6);  // which four alphas this wavefront rolls out (>= 3: none)
@@ -110,8 +121,11 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
   const int b = tile * TW + l;
   bool active = (b < v.B) && (a < n_alpha);
   if (active && mode == 1) active = (v.status[b] == 0 && v.backpass_done[b]);
-  if (!ACCEPT && !active) return;
-  if (active) {
+  // SHARE: every lane of a wavefront with work fetches its rows and runs the steps (an alpha group without an alpha, the
+  // lanes of a finished trajectory: their arithmetic is discarded); `active` only decides who stores
+  const bool run = (SHARE && GAINS) ? (__ballot(active) != 0ull) : active;
+  if (!ACCEPT && !run) return;
+  if (run) {
   const int T = v.T;
   const real alpha = (real)alphas.a[a < NALPHA ? a : NALPHA - 1];
   const real dt = (real)v.dt;
@@ -146,6 +160,7 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
     }
   };
   auto emit_knot = [&](int t, const real* xx, const real* uu) __attribute__((always_inline)) {  // knot t = (x_t, u_t)
+    if (SHARE && !active) return;
     if (CAND) {
       const int ta = a * v.ntiles + tile;
       if (t < T) {
@@ -190,6 +205,79 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
 #pragma unroll
     for (int i = 0; i < NX; i++) x[i] = x1[i];
   };
+  if constexpr (SHARE && GAINS) {
+    static_assert(PD % 2 == 0 || PD == 1, "static ring indices");
+    constexpr int NROWS = 2 * NU + NU * NX + NX;  // u, k, K, xs
+    constexpr int NLD = (NROWS + 3) / 4;          // rows per alpha group
+    struct Raw {
+      real r[NLD];
+    };
+    // this lane's rows: a_sub, a_sub + 4, ... (past the end: the last row again, parked in a dummy LDS row)
+    const real* rbase[NLD];
+    unsigned rstride[NLD];  // elements from step t to step t + 1
+#pragma unroll
+    for (int j = 0; j < NLD; j++) {
+      const int row = (a_sub + 4 * j < NROWS) ? a_sub + 4 * j : NROWS - 1;
+      if (row < NU) {
+        rbase[j] = v.us + tidx(tile, 0, row, l, T, NU);
+        rstride[j] = NU * TW;
+      } else if (row < 2 * NU) {
+        rbase[j] = v.kff + tidx(tile, 0, row - NU, l, T, NU);
+        rstride[j] = NU * TW;
+      } else if (row < 2 * NU + NU * NX) {
+        rbase[j] = v.Kfb + tidx(tile, 0, row - 2 * NU, l, T, NU * NX);
+        rstride[j] = NU * NX * TW;
+      } else {
+        rbase[j] = v.xs + tidx(tile, 0, row - 2 * NU - NU * NX, l, T + 1, NX);
+        rstride[j] = NX * TW;
+      }
+    }
+    auto fetch = [&](int tt, Raw& d) __attribute__((always_inline)) {
+      tt = (tt < T) ? tt : T - 1;  // tail: harmless re-load instead of a branch
+#pragma unroll
+      for (int j = 0; j < NLD; j++) d.r[j] = rbase[j][(size_t)tt * rstride[j]];
+    };
+    real* const mine = share + (a_sub * TW + l);
+    auto put = [&](const Raw& d) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < NLD; j++) mine[4 * j * TW] = d.r[j];
+    };
+    const real* const row0 = share + l;
+    auto get = [&](StepIn& d) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < NU; j++) d.u[j] = row0[j * TW];
+#pragma unroll
+      for (int j = 0; j < NU; j++) d.k[j] = row0[(NU + j) * TW];
+#pragma unroll
+      for (int e = 0; e < NU * NX; e++) d.K[e] = row0[(2 * NU + e) * TW];
+#pragma unroll
+      for (int i = 0; i < NX; i++) d.xnom[i] = row0[(2 * NU + NU * NX + i) * TW];
+    };
+    Raw ring[PD];
+#pragma unroll
+    for (int d = 0; d < PD; d++) fetch(d, ring[d]);
+    StepIn cur, nxt;
+    put(ring[0]);
+    get(cur);
+    // step s: pass step s + 1 through LDS (its rows are in ring[(s + 1) % PD]), refill ring[s % PD] -- free since step
+    // s - 1 -- with step s + PD, compute step s from `cur`.  LDS executes a wavefront's operations in order: the reads
+    // of step s + 1 follow its writes, and the next writes follow those reads.
+    auto one = [&](int s_, Raw& free_set, const Raw& next_set) __attribute__((always_inline)) {
+      put(next_set);
+      get(nxt);
+      fetch(s_ + PD, free_set);
+      do_step(s_, cur);
+      cur = nxt;
+    };
+    int t = 0;
+    for (; t + PD <= T; t += PD) {
+#pragma unroll
+      for (int d = 0; d < PD; d++) one(t + d, ring[d], ring[(d + 1) % PD]);
+    }
+#pragma unroll
+    for (int d = 0; d < PD; d++)  // remainder (< PD steps; t is a multiple of PD)
+      if (t + d < T) one(t + d, ring[d], ring[(d + 1) % PD]);
+  } else {
   StepIn ring[PD];
 #pragma unroll
   for (int d = 0; d < PD; d++) load_step(d, ring[d]);
@@ -206,6 +294,7 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
     load_step(t, cur);
     do_step(t, cur);
   }
+  }
   {  // knot T: the final state (no control)
     real uz[NU];
 #pragma unroll
@@ -213,9 +302,11 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
     emit_knot(T, x, uz);
   }
   total += (double)model.final_cost(x);  // :335
-  cost_out[(size_t)a * v.Bp + b] = total;
-  if (ACCEPT) lds_cost[a * TW + l] = total;
-  }  // if (active)
+  if (active) {
+    cost_out[(size_t)a * v.Bp + b] = total;
+    if (ACCEPT) lds_cost[a * TW + l] = total;
+  }
+  }  // if (run)
   if constexpr (ACCEPT) {
     __syncthreads();
     if (threadIdx.x < TW)

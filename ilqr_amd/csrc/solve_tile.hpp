@@ -252,7 +252,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
       t_sweep += t1 - t0;
       t0 = t1;
     }
-    rollout_tile<M, true, true, Cfg::kPrefetch, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, commit_idx, tile, lds_cost, /*count_running=*/it == n_iters - 1, rwave);
+    static_assert(4 * (4 * ((2 * M::NU + M::NU * M::NX + M::NX + 3) / 4) * TW) * sizeof(real) <= sizeof(sh.ring), "the ring holds the four wavefronts' rollout rows");
+    // (the ring is idle in this phase: each wavefront's corner of it passes the nominal rows between its alpha groups --
+    //  rollout.hpp, SHARE: phase 2 0.205 -> 0.191 ms with one tile per CU, 0.319 -> 0.289 with two)
+    rollout_tile<M, true, true, Cfg::kPrefetch, true, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, commit_idx, tile, lds_cost, /*count_running=*/it == n_iters - 1, rwave,
+                                                            sh.ring + (threadIdx.x >> 6) * (4 * ((2 * M::NU + M::NU * M::NX + M::NX + 3) / 4) * TW));
     if (threadIdx.x == 0) tile_running = 0;
     phase_barrier();  // candidates, costs, status, commit indices are in memory for the next sweep
     if (timing) t_roll += wall_clock64() - t0;
