@@ -12,34 +12,34 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --no-cpu-baseline"
 SHORT="$BENCH --no-extra-configs --steps 5 --warmup 3"
 # the whole default record (headline + configs) under the tracer
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o $R -- $BENCH --steps 20 --warmup 3 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o $R -- $BENCH --steps 20 --warmup 3 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 # the headline alone, 5 iterations per launch: durations in the units of the counter passes below
-rocprofv3 --kernel-trace --stats -d $OUT/stats5 -o $R -- $SHORT > /dev/null 2> $OUT/stats5.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats5 -o $R -- $SHORT > /dev/null 2> $OUT/stats5.err
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o $R -- $SHORT > /dev/null 2> $OUT/pmc_$C.err
+  timeout 300 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o $R -- $SHORT > /dev/null 2> $OUT/pmc_$C.err
 done
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace -d $OUT/pmc_sq1 -o $R -- $SHORT > /dev/null 2> $OUT/pmc_sq1.err
-rocprofv3 --pmc SQ_INSTS_VMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $OUT/pmc_sq2 -o $R -- $SHORT > /dev/null 2> $OUT/pmc_sq2.err
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/pmc_sq3 -o $R -- $SHORT > /dev/null 2> $OUT/pmc_sq3.err
-# the saturated batch (B = 32768: two persistent tiles per CU, k_solve_tile<.., 2>)
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace -d $OUT/pmc_sq1 -o $R -- $SHORT > /dev/null 2> $OUT/pmc_sq1.err
+timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $OUT/pmc_sq2 -o $R -- $SHORT > /dev/null 2> $OUT/pmc_sq2.err
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/pmc_sq3 -o $R -- $SHORT > /dev/null 2> $OUT/pmc_sq3.err
+# the saturated batch (B = 32768: two 64-trajectory wide tiles per CU, k_solve_wide<.., 2>)
 SAT="$SHORT --batch 32768"
-rocprofv3 --kernel-trace --stats -d $OUT/sat_stats5 -o $R -- $SAT > /dev/null 2> $OUT/sat_stats5.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/sat_stats5 -o $R -- $SAT > /dev/null 2> $OUT/sat_stats5.err
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace -d $OUT/sat_pmc_$C -o $R -- $SAT > /dev/null 2> $OUT/sat_pmc_$C.err
+  timeout 300 rocprofv3 --pmc $C --kernel-trace -d $OUT/sat_pmc_$C -o $R -- $SAT > /dev/null 2> $OUT/sat_pmc_$C.err
 done
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace -d $OUT/sat_pmc_sq1 -o $R -- $SAT > /dev/null 2> $OUT/sat_pmc_sq1.err
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/sat_pmc_sq3 -o $R -- $SAT > /dev/null 2> $OUT/sat_pmc_sq3.err
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace -d $OUT/sat_pmc_sq1 -o $R -- $SAT > /dev/null 2> $OUT/sat_pmc_sq1.err
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/sat_pmc_sq3 -o $R -- $SAT > /dev/null 2> $OUT/sat_pmc_sq3.err
 # the per-stage route of the same workload (ILQR_FLAG_STAGED = 32): one launch per phase, for the per-phase traffic
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace -d $OUT/staged_pmc_$C -o $R -- $SHORT --flags 32 > /dev/null 2> $OUT/staged_pmc_$C.err
+  timeout 300 rocprofv3 --pmc $C --kernel-trace -d $OUT/staged_pmc_$C -o $R -- $SHORT --flags 32 > /dev/null 2> $OUT/staged_pmc_$C.err
 done
-rocprofv3 --kernel-trace --stats -d $OUT/staged_stats -o $R -- $SHORT --flags 32 > /dev/null 2> $OUT/staged_stats.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/staged_stats -o $R -- $SHORT --flags 32 > /dev/null 2> $OUT/staged_stats.err
 # the generic path (configs[4]: LQ n=32, m=16, T=200, B=8192, exact derivatives): k_backward_w2 and, forced, k_backward_w
 LQ="python $ROOT/scripts/bench_lq.py 8192 2 16"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $OUT/lq_pmc_sq -o $R -- $LQ > /dev/null 2> $OUT/lq_pmc_sq.err
-rocprofv3 --pmc MeanOccupancyPerCU MeanOccupancyPerActiveCU --kernel-trace -d $OUT/lq_pmc_occ -o $R -- $LQ > /dev/null 2> $OUT/lq_pmc_occ.err
-ILQR_AMD_BACKWARD_W1=1 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $OUT/lq_w1_pmc_sq -o $R -- $LQ > /dev/null 2> $OUT/lq_w1_pmc_sq.err
-ILQR_AMD_BACKWARD_W1=1 rocprofv3 --pmc MeanOccupancyPerCU MeanOccupancyPerActiveCU --kernel-trace -d $OUT/lq_w1_pmc_occ -o $R -- $LQ > /dev/null 2> $OUT/lq_w1_pmc_occ.err
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $OUT/lq_pmc_sq -o $R -- $LQ > /dev/null 2> $OUT/lq_pmc_sq.err
+timeout 300 rocprofv3 --pmc MeanOccupancyPerCU MeanOccupancyPerActiveCU --kernel-trace -d $OUT/lq_pmc_occ -o $R -- $LQ > /dev/null 2> $OUT/lq_pmc_occ.err
+ILQR_AMD_BACKWARD_W1=1 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $OUT/lq_w1_pmc_sq -o $R -- $LQ > /dev/null 2> $OUT/lq_w1_pmc_sq.err
+ILQR_AMD_BACKWARD_W1=1 timeout 300 rocprofv3 --pmc MeanOccupancyPerCU MeanOccupancyPerActiveCU --kernel-trace -d $OUT/lq_w1_pmc_occ -o $R -- $LQ > /dev/null 2> $OUT/lq_w1_pmc_occ.err
 cd $ROOT
 scripts/ubench/lat > $OUT/ubench_lat.txt 2>/dev/null
 for d in stats stats5 pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq1 pmc_sq2 pmc_sq3 sat_stats5 sat_pmc_FETCH_SIZE sat_pmc_WRITE_SIZE sat_pmc_sq1 sat_pmc_sq3 staged_pmc_FETCH_SIZE staged_pmc_WRITE_SIZE staged_stats lq_pmc_sq lq_pmc_occ lq_w1_pmc_sq lq_w1_pmc_occ; do
