@@ -9,8 +9,10 @@
 // costs ~260 more -- about 9 instead of 33 wave-instructions per trajectory-timestep for the backward pass.
 //
 //   block = 8 wavefronts, one block per CU (one 64-trajectory ring slot is 24 KB in fp64: six slots fill the LDS)
-//   phase 1: wavefront 0 = the chain (backward_wide), wavefronts 1..3 = producers, one knot x 64 trajectories each per round
-//   phase 2: 12 rollout units (4 tiles x 3 alpha groups of rollout_tile) over the 8 wavefronts, then accept_one x 64
+//   phase 1: wavefront 0 = the chain (backward_wide), wavefronts 1..3 = producers, one knot x 64 trajectories each per round,
+//            wavefront 4 = the pending commit of the accepted candidates, one chunk of CT knots at a time (commit_chunks_wide)
+//   phase 2: 12 rollout units (4 tiles x 3 alpha groups of rollout_tile, nominal rows shared through the idle ring) over
+//            the 8 wavefronts, then accept_one x 64
 //
 // Every element is computed by the expression, in the order, that backward_quad uses for it (that kernel is a column split
 // of the same arithmetic), and the single-lane Armijo search evaluates the quad search's four candidates with the same
