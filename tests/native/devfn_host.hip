@@ -78,6 +78,17 @@ extern "C" int devfn_box_qp2(const double* Q, const double* c, const double* x0,
   *nfR = r.nfR;
   return r.result;
 }
+// the loop box_qp2 falls back to (and whose exits its straight-line part reproduces)
+extern "C" int devfn_box_qp2_loop(const double* Q, const double* c, const double* x0, const double* lo, const double* hi, double* x, int* vfree,
+                                  double* minv3, int* nfR, int detect_indefinite) {
+  BoxQP2Result<double> r;
+  box_qp2_loop(Q, c, x0, lo, hi, r, detect_indefinite != 0);
+  x[0] = r.x[0]; x[1] = r.x[1];
+  vfree[0] = r.free0; vfree[1] = r.free1;
+  minv3[0] = r.m00; minv3[1] = r.m01; minv3[2] = r.m11;
+  *nfR = r.nfR;
+  return r.result;
+}
 extern "C" int devfn_box_qp2_f32(const float* Q, const float* c, const float* x0, const float* lo, const float* hi, float* x, int* vfree) {
   BoxQP2Result<float> r;
   box_qp2(Q, c, x0, lo, hi, r);

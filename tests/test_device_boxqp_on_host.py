@@ -108,6 +108,38 @@ def test_scalarised_m2_solver(oracle, dev):
     assert r == -1
 
 
+def test_m2_straight_line_part_equals_the_loop(dev):
+    """box_qp2 = iteration 0 with the unit step + iteration 1 up to its gradient test, written straight-line, and
+    box_qp2_loop for everything else.  Whatever the straight-line part answers must be what the loop leaves: result code,
+    x, free set, the compact inverse and its size -- to the last bit on x and Minv up to fused-multiply-add placement
+    (1e-15), over positive definite, indefinite, clamped-start and (opt-in) failed-factorisation cases."""
+    rng = np.random.default_rng(2024)
+    N = 30000
+    n_fast_exit = {}
+    for t in range(N):
+        A = rng.normal(size=(2, 2))
+        Q = A @ A.T + (0.05 if t % 5 else -0.4) * np.eye(2)
+        if t % 7 == 0:
+            Q = Q * 10.0 ** rng.uniform(-3, 6)
+        c = rng.normal(size=2) * 2 * (np.abs(Q).max() if t % 7 == 0 else 1.0)
+        lo = -rng.uniform(0.05, 1.5, size=2)
+        hi = rng.uniform(0.05, 1.5, size=2)
+        x0 = rng.normal(size=2)
+        if t % 3 == 1:
+            x0 = np.where(rng.uniform(size=2) < 0.5, lo, hi)
+        detect = int(t % 13 == 0)
+        a = _qp2(dev, Q, c, x0, lo, hi, detect)
+        q = np.ascontiguousarray(np.asarray(Q, float).T).ravel()
+        x, vf, mi, nf = np.zeros(2), np.zeros(2, dtype=np.int32), np.zeros(3), C.c_int(0)
+        r = dev.devfn_box_qp2_loop(q.ctypes.data_as(dp), c.ctypes.data_as(dp), x0.ctypes.data_as(dp), lo.ctypes.data_as(dp), hi.ctypes.data_as(dp),
+                                   x.ctypes.data_as(dp), vf.ctypes.data_as(ip), mi.ctypes.data_as(dp), C.byref(nf), detect)
+        assert a[0] == r, (t, a[0], r)
+        assert np.array_equal(a[2], vf) and a[4] == nf.value, t
+        assert np.allclose(a[1], x, rtol=1e-15, atol=0) and np.allclose(a[3], mi, rtol=1e-14, atol=0), (t, a[1], x, a[3], mi)
+        n_fast_exit[r] = n_fast_exit.get(r, 0) + 1
+    assert {2, 4, 5, 6} <= set(n_fast_exit) and -1 in n_fast_exit, n_fast_exit
+
+
 @pytest.mark.parametrize("m", [2])
 def test_scalarised_m2_solver_reproduces_the_reference_vectors(dev, m):
     """tests/golden/ref_pieces.npz qp2_*: inputs and outputs of the REAL src/boxqp.cpp (scripts/make_golden.py)."""
