@@ -555,7 +555,7 @@ ILQR_HD void box_qp2_loop(const real* Q, const real* c, const real* x0, const re
   res.nfR = nfR;
 }
 
-// What the double integrator's QPs actually do (counted over the bench workload with the oracle: 286 652 QPs): 13.5 %
+// What the double integrator's QPs actually do (counted over the bench workload on the CPU: 286 652 QPs): 13.5 %
 // find both controls clamped in iteration 0 (result 6); 86 % take ONE projected-Newton step whose unit step passes the
 // Armijo test (99.87 % of all line searches do) and leave iteration 1 through the gradient test (result 5); a few per
 // mille do anything else.  box_qp2 therefore runs iteration 0 with the unit step only, and iteration 1 as far as its
