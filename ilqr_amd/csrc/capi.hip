@@ -94,6 +94,9 @@ struct ilqr_batch {
   std::vector<void*> allocs;
   bool initialised = false;  // init_traj / set_trajectory has run
   bool commit_pending = false;  // an accepted candidate is not yet copied into xs/us
+  // cand_u / cand_x / cost_c hold, slot for slot, the last rollouts of the trajectories now in those slots.  Compaction
+  // (ilqr_generate_trajectory) moves trajectories without moving their candidates: after it they belong to nobody.
+  bool cands_valid = false;
   bool aos = false;             // host-model / generic handles: trajectory-contiguous layout, wave-per-trajectory backward
   double* d_umin = nullptr;     // [nu] device copies of the limits (generic kernel)
   double* d_umax = nullptr;
@@ -564,14 +567,16 @@ static int launch_backward(ilqr_batch* h, int mode) {
   return timer_end(h, ILQR_STAGE_BACKWARD, ev);
 }
 
-// STEP 1 + STEP 2 in one launch (k_sweep_backward): the tile's derivative sweep runs on the three
-// SIMDs the quad backward pass leaves idle.  Timed as ILQR_STAGE_BACKWARD.
-// One block of the fused kernel owns a whole CU (four wavefronts of ~290 registers, ~150 KB of LDS),
-// so it pays while the tiles fit on the device in one wave of blocks; beyond two tiles per CU
-// (B > 32 x #CUs) the two-kernel path keeps four tiles' backward wavefronts per CU busy and wins
-// (measured at B = 16384: 2.2 ms vs 3.2 ms per iteration).
-// 16 x #CU < B <= 32 x #CU: the variant with one producer and a 60 KB ring, two blocks per CU (kernels.hpp;
-// B = 8192: 1.26 vs 1.42 ms per iteration).  ILQR_AMD_FUSED=1 / =2 force a variant for A/B runs and tests.
+// Which route ilqr_iterate takes.  All of them leave the same bits (tests/test_gpu_fused_sweep.py):
+//   ntiles <= #CU                      one persistent 16-trajectory tile per CU            k_solve_tile<.., 1>
+//   m = 1, no opt-in fixes, >= 4 tiles per CU   64-trajectory wide tiles, one or two per CU   k_solve_wide
+//   anything larger otherwise          persistent 16-trajectory tiles, two per CU (the dispatcher hands a CU its next
+//                                      tile when one is through)                           k_solve_tile<.., 2>
+//   ILQR_FLAG_STAGED                   one launch per stage: k_sweep_backward (records in the LDS ring, one block per CU
+//                                      or the one-producer variant, two per CU) up to two tiles per CU, beyond that
+//                                      k_derivatives + k_backward_q with the records in HBM
+//   ILQR_FLAG_UNFUSED, AoS (generic) models   always the two-kernel route
+// ILQR_AMD_FUSED=1 / 2 / 3 force a variant for A/B runs and the bit-identity tests.
 static int fused_variant(const ilqr_batch* h) {  // 0: two kernels, 1: one tile per CU, 2: two tiles per CU, 3: wide tiles (64 trajectories, one per CU)
   if (!use_quad_backward(h) || h->aos || (h->flags & ILQR_FLAG_UNFUSED) || h->env.unfused) return 0;
   const bool staged = (h->flags & ILQR_FLAG_STAGED) || h->env.staged;
@@ -665,7 +670,9 @@ static AlphaSet line_search_alphas() {
 }
 
 static int do_rollout_candidates(ilqr_batch* h, int mode) {
-  return launch_rollout(h, true, true, line_search_alphas(), NALPHA, h->v.cost_c, mode);
+  if (int rc = launch_rollout(h, true, true, line_search_alphas(), NALPHA, h->v.cost_c, mode)) return rc;
+  h->cands_valid = true;
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -792,6 +799,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     REQUIRE(d->nx == UM::NX && d->nu == UM::NU, "this build's user model is nx=%d nu=%d, got %d/%d", UM::NX, UM::NU, d->nx, d->nu);
     REQUIRE(d->u_min && d->u_max, "ILQR_MODEL_USER needs u_min/u_max (Model::u_min/u_max, include/model.h:17)");
     REQUIRE(!(d->flags & ILQR_FLAG_ANALYTIC_DERIVATIVES) || has_analytic_record<UM>::value, "this user model has no analytic_record()");
+    REQUIRE(d->n_user_params >= 0 && (d->n_user_params == 0 || d->user_params), "ILQR_MODEL_USER: n_user_params = %d with user_params = %p", d->n_user_params, (const void*)d->user_params);
     h->user_f.set_params(d->user_params, d->n_user_params);
     if (h->dtype == ILQR_DTYPE_F32) {  // the twin the finite differences are taken in: built from the parameters' FLOAT values, like the shipped models'
       std::vector<double> p32(d->user_params, d->user_params + (d->user_params ? d->n_user_params : 0));
@@ -1008,6 +1016,7 @@ int ilqr_iterate(ilqr_batch* h, int n_iters) {
     explicit Chain(ilqr_batch* hh) : h(hh) { h->chain_timers = true; h->chain_event = nullptr; }
     ~Chain() { h->chain_timers = false; h->chain_event = nullptr; }
   } chain(h);
+  if (n_iters > 0) h->cands_valid = !(h->active_tiles > 0 && h->active_tiles < h->ntiles);  // (a compacted chunk rolls out the leading tiles only)
   if (use_persistent(h) && n_iters > 0) {
     if (int rc = launch_solve_tiles(h, n_iters)) return rc;
     return flush_commit(h);
@@ -1044,7 +1053,8 @@ int ilqr_count_running(ilqr_batch* h, int* n) {
 
 // Slot j <- slot perm[j] for every per-trajectory array a running solve carries (tiled: x0, xs, us, k, K; scalars: cost,
 // lambda, dlambda, dV, gnorm, status, iters, flgChange, alpha index, diverge, backpass_done).  Candidates and derivative
-// records are not moved: no accept is pending between ilqr_iterate calls, and the records are recomputed when asked for.
+// records are not moved: no accept is pending between ilqr_iterate calls, the records are recomputed when asked for, and
+// the candidates are marked as nobody's (ilqr_get_candidate then fails with ILQR_ERR_STATE until the next rollout).
 static int apply_permutation(ilqr_batch* h, const std::vector<int>& perm) {
   const size_t es = elem_size(h), Bp = (size_t)h->Bp;
   const size_t biggest = std::max<size_t>((size_t)h->ntiles * (h->T + 1) * h->nx * TW, (size_t)h->ntiles * h->T * h->nu * h->nx * TW) * es;
@@ -1095,6 +1105,7 @@ static int apply_permutation(ilqr_batch* h, const std::vector<int>& perm) {
   rc |= scalar(v.backpass_done, Bp);
   if (rc) return rc;
   h->recs = ilqr_batch::REC_STALE;
+  h->cands_valid = false;  // the candidates stayed where they were
   return 0;
 }
 
@@ -1114,10 +1125,12 @@ int ilqr_generate_trajectory(ilqr_batch* h) {
   const int chunk = persistent ? (compacting ? std::min(std::max(1, h->params.max_iter), 8) : std::max(1, h->params.max_iter)) : 10;  // (a persistent tile stops by itself)
   std::vector<int> slot_orig;  // slot j currently holds original trajectory slot_orig[j] (empty: identity)
   h->active_tiles = h->ntiles;
-  int rc_out = 0;
+  // Every exit of the chunk loop -- also a failing HIP call -- goes through the restore below: the handle is never left
+  // with permuted slots or a subset of tiles behind the caller's back.
+  auto chunks = [&]() -> int {
   while (done_iters < h->params.max_iter) {
     const int n = std::min(chunk, h->params.max_iter - done_iters);
-    if (int rc = ilqr_iterate(h, n)) { rc_out = rc; break; }
+    if (int rc = ilqr_iterate(h, n)) return rc;
     done_iters += n;
     int running = 0;
     HIPCHK(hipMemcpyAsync(&running, h->v.n_running, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1138,18 +1151,27 @@ int ilqr_generate_trajectory(ilqr_batch* h) {
       const int n_run = (int)perm.size();
       for (int j = 0; j < h->Bp; j++)
         if (st[j] != 0) perm.push_back(j);
-      if (int rc = apply_permutation(h, perm)) { rc_out = rc; break; }
+      if (int rc = apply_permutation(h, perm)) {
+        h->initialised = false;  // a half-applied permutation: the arrays no longer describe one batch
+        return rc;
+      }
       std::vector<int> so(h->Bp);
       for (int j = 0; j < h->Bp; j++) so[j] = slot_orig[perm[j]];
       slot_orig.swap(so);
       h->active_tiles = std::max(1, (n_run + TW - 1) / TW);
     }
   }
+  return 0;
+  };
+  const int rc_out = chunks();
   h->active_tiles = h->ntiles;
-  if (!slot_orig.empty()) {  // back to the caller's order: slot o <- the slot that holds original trajectory o
+  if (!slot_orig.empty() && h->initialised) {  // back to the caller's order: slot o <- the slot that holds original trajectory o
     std::vector<int> back(h->Bp);
     for (int j = 0; j < h->Bp; j++) back[slot_orig[j]] = j;
-    if (int rc = apply_permutation(h, back)) return rc;
+    if (int rc = apply_permutation(h, back)) {
+      h->initialised = false;  // (stage calls and getters of trajectories then fail with ILQR_ERR_STATE instead of reporting the wrong order)
+      return rc_out ? rc_out : rc;
+    }
   }
   return rc_out;
 }
@@ -1393,6 +1415,9 @@ int ilqr_get_candidate(ilqr_batch* h, int a, double* xs, double* us) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
   if (host_model(h)) return no_device_model();
   REQUIRE(a >= 0 && a < NALPHA, "alpha index %d out of range", a);
+  if (!h->cands_valid)
+    return fail(ILQR_ERR_STATE, "no candidates: none rolled out yet, or the solve re-packed running trajectories (compaction) and left the "
+                                "candidate buffers behind -- call ilqr_rollout_candidates / ilqr_iterate first");
   HIPCHK(hipSetDevice(h->device));
   const size_t nx_el = (size_t)h->B * (h->T + 1) * h->nx, nu_el = (size_t)h->B * h->T * h->nu;
   if (int rc = ensure_staging(h, nx_el + nu_el)) return rc;

@@ -232,7 +232,11 @@ int ilqr_get_lambda(ilqr_batch* h, double* lambda, double* dlambda); /* [B] */
 int ilqr_get_dV(ilqr_batch* h, double* dV);                         /* [B][2] */
 int ilqr_get_gnorm(ilqr_batch* h, double* gnorm);                   /* [B] */
 int ilqr_get_status(ilqr_batch* h, int* status, int* iters, int* alpha_idx); /* [B] each, any NULL */
-int ilqr_get_candidate(ilqr_batch* h, int alpha_idx, double* xs, double* us); /* one alpha's rollout */
+/* one alpha's rollout of the LAST line search (ilqr_rollout_candidates / ilqr_line_search / ilqr_iterate).  The candidate
+ * buffers are scratch of the line search (the reference keeps x_new/u_new as locals of its loop, src/ilqr_core.cpp:184-186):
+ * ILQR_ERR_STATE when none has been rolled out yet or when ilqr_generate_trajectory re-packed running trajectories
+ * (compaction), which leaves the buffers behind. */
+int ilqr_get_candidate(ilqr_batch* h, int alpha_idx, double* xs, double* us);
 int ilqr_count_running(ilqr_batch* h, int* n_running);
 /* device-to-device copy of the per-trajectory costs [B] into caller-owned device memory
  * (the payload of the multi-GPU gather).  Enqueued on the handle's stream:

@@ -136,7 +136,7 @@ def twin_iterate(oracle, om, prec, x0, st, dt, fixed_work):
     return {kk: (_f64(v) if v.dtype.kind == "f" else v) for kk, v in r.items()}
 
 
-def check_backward(oracle, om, us, derivs, k_prev, lam, k, K, dV, div, ro, max_ties, precision="f64", max_over10=None):
+def check_backward(oracle, om, us, derivs, k_prev, lam, k, K, dV, div, ro, max_ties, max_over10, precision="f64"):
     """One teacher-forced backward pass: device outputs (k, K [B][T][nu][nx], dV, div) against the oracle's
     `ro` (batch_backward) for every trajectory the oracle completes: per-knot gains and dV within tol and
     the same diverge flag -- or fp64 rounding shown to be the limit (conditioning_verdict) -- or a proven
@@ -172,7 +172,7 @@ def check_backward(oracle, om, us, derivs, k_prev, lam, k, K, dV, div, ro, max_t
             good[b] = True
     assert ties <= max_ties, (ties, max_ties)
     assert np.array_equal(div[good | ~conv], ro["diverge"][good | ~conv])
-    assert over10 <= (max(1, B // 50) if max_over10 is None else max_over10), over10
+    assert over10 <= max_over10, (over10, max_over10)  # every caller states its own bound
     return dict(good=conv & good, ties=ties, conditioned=conditioned, cond_over10=over10)
 
 
@@ -221,9 +221,14 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
         st = gpu_state(g)
     running = np.ones(B, dtype=bool)
     out = dict(checked=0, ties_backward=0, ties_search=0, ties_stop=0, conditioned=0, cond_over10=0, conditioned_branch=0, unresolved=0, worst_cond_ratio=0.0, tied=set(), worst_cost=0.0, worst_gain=0.0)
+    out["per_iter"] = []
     for it in range(n_iters):
         if not running.any():
             break
+        # what happened to this iteration's trajectories (profiles/parity_r04.json): every checked one lands in exactly one bin
+        pit = dict(iteration=it, n=0, plain=0, knife_edge=0, cond_le10=0, cond_le100=0, amplified=0, explained_by_records=0,
+                   search_tie=0, stop_tie=0, unresolved=0)
+        out["per_iter"].append(pit)
         nx = twin_iterate(oracle, om, prec, x0, st, dt, fixed_work)
         if drive == "oracle":
             load_state(g, x0, st)
@@ -237,6 +242,7 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
         cond_ok = None  # extended-precision verdicts for this iteration's deviating trajectories, computed on demand
         for b in np.flatnonzero(running):
             out["checked"] += 1
+            pit["n"] += 1
             same_disc = gs["alpha"][b] == nx["alpha"][b] and g_status[b] == nx["status"][b]
             lam_ok = np.isclose(gs["lam"][b], nx["lam"][b], rtol=1e-12, atol=0) and np.isclose(gs["dlam"][b], nx["dlam"][b], rtol=1e-12)  # (double on both sides in both modes)
             if same_disc and lam_ok and eg[b] < tol and ec[b] < tol:
@@ -245,6 +251,7 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
                 assert np.allclose(gs["dV"][b], nx["dV"][b], rtol=tol, atol=tol * abs(st["cost"][b])), (gs["dV"][b], nx["dV"][b])
                 out["worst_cost"] = max(out["worst_cost"], float(ec[b]))
                 out["worst_gain"] = max(out["worst_gain"], float(eg[b]))
+                pit["plain"] += 1
                 continue
             where = "iteration %d trajectory %d: alpha %d/%d status %d/%d lambda %.6g/%.6g cost err %.2e gain err %.2e" % (
                 it, b, gs["alpha"][b], nx["alpha"][b], g_status[b], nx["status"][b], gs["lam"][b], nx["lam"][b], ec[b], eg[b])
@@ -255,6 +262,7 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
                 if first_gain_mismatch_is_knife_edge(gs["k"][b], gs["K"][b], nx["k"][b], nx["K"][b], st["us"][b], lo[b], hi[b], tol):
                     out["ties_backward"] += 1
                     out["tied"].add(int(b))
+                    pit["knife_edge"] += 1
                     continue
                 # ... or fp64 rounding, not the implementation, limits the per-knot agreement
                 if cond_ok is None:
@@ -269,6 +277,7 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
                     # the fp64 answer (long horizon, lambda -> 0: Quu = cuu + fu'Vxx fu cancels to a few float ulps)
                     out["unresolved"] += 1
                     out["tied"].add(int(b))
+                    pit["unresolved"] += 1
                     continue
                 if not okb:
                     # Last resort before failing: is it the INPUT of the backward pass, not the pass?  The device's finite
@@ -281,10 +290,12 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
                     if _explained_by_records(oracle, om, prec, aux, x0, st, int(b), gs, tol):
                         out["explained_by_records"] = out.get("explained_by_records", 0) + 1
                         out["tied"].add(int(b))
+                        pit["explained_by_records"] += 1
                         continue
                 assert okb, "backward passes differ away from a clamp tie and beyond conditioning -- " + where
                 out["conditioned"] += 1
                 out["cond_over10"] += int(e_d > max(tol, COND_FACTOR * e_o))
+                pit["cond_le100" if e_d > max(tol, COND_FACTOR * e_o) else "cond_le10"] += 1
                 out["worst_cond_ratio"] = max(out["worst_cond_ratio"], e_d / max(e_o, 1e-300))
                 if same_disc and lam_ok and ec[b] < max(tol, COND_HARD * e_o):
                     continue
@@ -304,6 +315,7 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
                 assert np.any(np.abs(cand) <= prec["tie_rel"] * abs(st["cost"][b])), "line searches differ away from a tie (dcost %s) -- %s" % (dcost, where)
                 out["ties_search"] += 1
                 out["tied"].add(int(b))
+                pit["search_tie"] += 1
                 continue
             if g_status[b] != nx["status"][b]:
                 dcost = st["cost"][b] - nx["cost"][b]
@@ -313,6 +325,7 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
                 assert near_tolfun or near_lmax or near_grad, "terminations differ away from a tie -- " + where
                 out["ties_stop"] += 1
                 out["tied"].add(int(b))
+                pit["stop_tie"] += 1
                 continue
             # Same gains (within tol), alpha, status and lambda, but the new cost differs by more than tol: at the
             # BASELINE horizon (T = 499, swing-up scale) the closed-loop rollout amplifies a 1e-7 difference in the gains
@@ -328,6 +341,7 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
                 assert abs(gs["cost"][b] - float(c_r[0])) <= tol * abs(float(c_r[0])), "rollout of the device's own gains differs -- " + where
                 out["amplified"] = out.get("amplified", 0) + 1
                 out["worst_gain"] = max(out["worst_gain"], float(eg[b]))
+                pit["amplified"] += 1
                 continue
             raise AssertionError("same gains, alpha and status but cost / lambda differ -- " + where)
         if drive == "oracle":
@@ -392,6 +406,37 @@ def _candidate_costs(g, x0, st, b):
     g.compute_derivatives()
     g.backward_step()
     return g.rollout_candidates()[b]
+
+
+def publish(name, r, **meta):
+    """Adds the per-iteration bins of a walk to the tracked statistics file (copied to profiles/parity_r04.json from the GPU
+    run): which share of the checked trajectory-iterations met the plain 1e-6 criterion and which went through which proof."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.environ.get("ILQR_PARITY_JSON", os.path.join(root, "gpurun_out", "parity_r04.json"))
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    tot = {kk: sum(p[kk] for p in r["per_iter"]) for kk in r["per_iter"][0] if kk != "iteration"} if r["per_iter"] else {}
+    doc[name] = dict(meta, tolerance=PRECISIONS[meta.get("precision", "f64")]["tol"], checked=r["checked"], totals=tot,
+                     plain_fraction=(tot["plain"] / max(tot["n"], 1)) if tot else None,
+                     worst_cond_ratio=r["worst_cond_ratio"], worst_gain_err_plain=r["worst_gain"], worst_cost_err_plain=r["worst_cost"],
+                     per_iteration=r["per_iter"])
+    with open(path, "w") as f:
+        json.dump(doc, f, indent=1, sort_keys=True)
+    return doc[name]
+
+
+def assert_walk(r, n_iters, min_plain_it0=0.95, tied_div=16, over10_div=24):
+    """The bounds every full-size walk is held to: every sampled trajectory checked in every iteration it ran, at least
+    95 % of them plainly within tolerance at iteration 0 (lambda = 1: where the oracle and the real reference agree to 1e-9),
+    proven ties and > 10 x conditioning cases counted and bounded."""
+    p0 = r["per_iter"][0]
+    assert p0["n"] == len(r["sel"]) and p0["plain"] >= min_plain_it0 * p0["n"], p0
+    assert sum(p["n"] for p in r["per_iter"]) == r["checked"] and r["checked"] >= len(r["sel"]) * min(n_iters, 3), r["checked"]
+    assert r["cond_over10"] <= max(2, r["checked"] // over10_div), r["cond_over10"]
+    ties = sum(p["knife_edge"] + p["search_tie"] + p["stop_tie"] for p in r["per_iter"])
+    assert ties <= max(2, r["checked"] // tied_div), ties
 
 
 class Sampled:

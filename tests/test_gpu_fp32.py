@@ -10,7 +10,7 @@ through the C ABI.  The reference has no fp32 build, so parity is stated two way
 import numpy as np
 import pytest
 
-from tests.parity import TOL32, assert_free_run, check_backward, sampled_walk, walk_both, walk_iterations
+from tests.parity import TOL32, assert_free_run, assert_walk, check_backward, publish, sampled_walk, walk_both, walk_iterations
 from tests.util import acrobot_x0, integrator_x0, mat, relerr, relerr_abs
 
 pytestmark = pytest.mark.gpu
@@ -82,7 +82,7 @@ def test_backward_teacher_forced(oracle, name, B, T, lim, lam):
     div = g.backward_pass()
     k, K = g.gains()
     r = check_backward(oracle, om, us, {kk: np.asarray(v, dtype=np.float64) for kk, v in do.items()}, k_prev, lam, k, K, g.dV(), div, ro,
-                       max_ties=max(2, B // 8), precision="f32")
+                       max_ties=max(2, B // 8), max_over10=max(1, B // 50), precision="f32")
     print("fp32 backward", name, lim, lam, {kk: v for kk, v in r.items() if kk != "good"})
     assert r["good"].sum() > 0
 
@@ -163,12 +163,14 @@ def test_full_size_properties(oracle):
     B, T, lim = 4096, 499, 5.0
     g = BatchILQR("acrobot", B, T, DT, u_min=-lim, u_max=lim, dtype="f32")
     x0 = f32(acrobot_x0(B))
-    r = sampled_walk(oracle, oracle.Model("acrobot", u_lim=lim), g, x0, np.zeros((B, T, 1)), DT, 2, precision="f32", verbose=True)
-    print("configs[3] shard, sampled walk:", {kk: v for kk, v in r.items() if kk != "sel"})
+    NIT = 10
+    r = sampled_walk(oracle, oracle.Model("acrobot", u_lim=lim), g, x0, np.zeros((B, T, 1)), DT, NIT, precision="f32")
+    print("configs[3] shard, sampled walk:", publish("configs[3] shard acrobot T=499 B=4096 +-5 fp32", r, B=B, T=T, u_lim=lim, n_sample=len(r["sel"]), precision="f32"))
     # (x0 at full scale, T = 499: from the second iteration on float conditioning, not the implementation, limits most
     #  trajectories' per-knot agreement -- every one of them is judged against the fp64 yardstick by the walk; "tied" are
     #  the ones whose line search then also branched differently, or whose gains float cannot resolve at all)
-    assert r["checked"] == 2 * len(r["sel"]) and len(r["tied"]) <= len(r["sel"]) // 4 and r["unresolved"] <= len(r["sel"]) // 8, r
+    assert_walk(r, NIT, min_plain_it0=0.9, tied_div=8)
+    assert r["unresolved"] <= r["checked"] // 8, r["unresolved"]
     x0[1] = x0[0]
     x0[B - 1] = x0[0]
     c0 = g.init_traj(x0, np.zeros((B, T, 1)))

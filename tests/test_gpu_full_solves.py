@@ -101,6 +101,15 @@ def test_compaction_of_running_trajectories_changes_nothing(name, dtype, monkeyp
         g.generate_trajectory(x0, u0)
         assert g.count_running() == 0
         out.append(_everything(g))
+        # the line search's scratch: a solve that compacted has left it behind and says so; one that did not still holds
+        # every trajectory's last rollouts.  After a fresh set of rollouts the two handles agree again.
+        if off:
+            g.candidate(0)
+        else:
+            with pytest.raises(RuntimeError, match="candidates"):
+                g.candidate(0)
+        out[-1]["cand_cost"] = g.rollout_candidates()
+        out[-1]["cand_x"], out[-1]["cand_u"] = g.candidate(3)
         # a second solve on the same handle (warm start from perturbed states) goes through the same machinery
         g.generate_trajectory(x0 * 1.001)
         s2 = _everything(g)

@@ -45,7 +45,7 @@ def run_case(oracle, om, B, T, lam, x_scale=1.0, u_scale=0.5, cuu_shift=None):
     dV = g.dV()
     Ko = mat(ro["K"])
     lo, hi = om.u_min[None, None, :] - us, om.u_max[None, None, :] - us
-    r = check_backward(oracle, om, us, dv, k_prev, lam, k, K, dV, div, ro, max_ties=max(1, B // 8))  # gains: per knot
+    r = check_backward(oracle, om, us, dv, k_prev, lam, k, K, dV, div, ro, max_ties=max(1, B // 8), max_over10=max(1, B // 50))  # gains: per knot
     ok, ties = r["good"], r["ties"]
     clamped = (np.abs(k - lo) < 1e-9) | (np.abs(k - hi) < 1e-9)
     g.last = dict(div=div, ro=ro, ok=ok, ties=ties)

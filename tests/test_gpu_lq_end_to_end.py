@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from tests.util import TOL, mat, relerr, relerr_abs
-from tests.parity import check_backward, sampled_walk, walk_iterations
+from tests.parity import assert_walk, check_backward, publish, sampled_walk, walk_iterations
 
 pytestmark = pytest.mark.gpu
 DT = 0.02
@@ -80,7 +80,7 @@ def test_lq_stages_match_oracle(oracle, n, m, B, T, dense):
     ro = oracle.batch_backward(om, us_o, do, k_prev=k_prev, lam=1.0)
     k, K = g.gains()
     Ko = mat(ro["K"])
-    check_backward(oracle, om, us_o, do, k_prev, 1.0, k, K, g.dV(), div, ro, max_ties=max(1, B // 8))  # gains: per knot
+    check_backward(oracle, om, us_o, do, k_prev, 1.0, k, K, g.dV(), div, ro, max_ties=max(1, B // 8), max_over10=max(1, B // 50))  # gains: per knot
     # the 11 closed-loop rollouts of the line search, with the oracle's gains
     g.set_gains(k=ro["k"], K=Ko)
     costs = g.rollout_candidates()
@@ -195,9 +195,10 @@ def test_lq_full_size_properties(oracle, lim):
     x0[B - 1] = x0[0]  # duplicates in other wavefronts / CUs
     g = BatchILQR("lq", B, T, DT, u_min=-lim, u_max=lim, lq=mats)
     # 24 trajectories of the full batch walked against the oracle, iteration by iteration (tests/parity.py: Sampled)
-    r = sampled_walk(oracle, oracle.Model("lq", lq=mats, u_lim=lim), g, x0, np.zeros((B, T, m)), DT, 2, n_sample=24, verbose=True)
-    print("configs[4] lim", lim, "sampled walk:", {kk: v for kk, v in r.items() if kk != "sel"})
-    assert r["checked"] == 2 * len(r["sel"]) and len(r["tied"]) <= 3, r
+    NIT = 10
+    r = sampled_walk(oracle, oracle.Model("lq", lq=mats, u_lim=lim), g, x0, np.zeros((B, T, m)), DT, NIT, n_sample=24)
+    print("configs[4] lim", lim, "sampled walk:", publish("configs[4] LQ n=32 m=16 T=200 B=8192 +-%g fp64 (finite differences)" % lim, r, B=B, T=T, u_lim=lim, n_sample=len(r["sel"])))
+    assert_walk(r, NIT)
     c0 = g.init_traj(x0, np.zeros((B, T, m)))
     g.iterate(2)
     cost = g.cost()
