@@ -67,7 +67,7 @@ def main():
                                ("thread", capi.FLAG_UNFUSED | capi.FLAG_BACKWARD_THREAD_PER_TRAJ, {}),
                                # the routes big batches take, forced on these small ones: two tiles per CU, wide tiles (one / two per
                                # CU; m = 2 falls back to two tiles per CU), and compaction of running trajectories between chunks
-                               ("occ2", 0, {"ILQR_AMD_FUSED": "2"}), ("wide1", 0, {"ILQR_AMD_FUSED": "3", "ILQR_AMD_WIDE_OCC": "1"}),
+                               ("quad1", 0, {"ILQR_AMD_FUSED": "1"}), ("occ2", 0, {"ILQR_AMD_FUSED": "2"}), ("wide1", 0, {"ILQR_AMD_FUSED": "3", "ILQR_AMD_WIDE_OCC": "1"}),
                                ("wide2", 0, {"ILQR_AMD_FUSED": "3", "ILQR_AMD_WIDE_OCC": "2"}),
                                ("compact", 0, {"ILQR_AMD_NUM_CUS": "2"})):
             for kk in ("ILQR_AMD_FUSED", "ILQR_AMD_WIDE_OCC", "ILQR_AMD_NUM_CUS"):
