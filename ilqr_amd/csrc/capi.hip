@@ -568,8 +568,7 @@ static int launch_backward(ilqr_batch* h, int mode) {
 }
 
 // Which route ilqr_iterate takes.  All of them leave the same bits (tests/test_gpu_fused_sweep.py):
-//   ntiles <= #CU, m = 1, no fixes     one persistent tile per CU, its backward pass as four 16-lane chains  k_solve_hex
-//   ntiles <= #CU otherwise            one persistent 16-trajectory tile per CU            k_solve_tile<.., 1>
+//   ntiles <= #CU                      one persistent 16-trajectory tile per CU            k_solve_tile<.., 1>
 //   m = 1, no opt-in fixes, >= 4 tiles per CU   64-trajectory wide tiles, one or two per CU   k_solve_wide
 //   anything larger otherwise          persistent 16-trajectory tiles, two per CU (the dispatcher hands a CU its next
 //                                      tile when one is through)                           k_solve_tile<.., 2>
@@ -577,13 +576,13 @@ static int launch_backward(ilqr_batch* h, int mode) {
 //                                      or the one-producer variant, two per CU) up to two tiles per CU, beyond that
 //                                      k_derivatives + k_backward_q with the records in HBM
 //   ILQR_FLAG_UNFUSED, AoS (generic) models   always the two-kernel route
-// ILQR_AMD_FUSED=1 / 2 / 3 / 4 force a variant for A/B runs and the bit-identity tests.
-static int fused_variant(const ilqr_batch* h) {  // 0: two kernels, 1: one tile per CU, 2: two tiles per CU, 3: wide tiles (64 trajectories, one per CU), 4: one tile per CU as four hex chains
+// ILQR_AMD_FUSED=1 / 2 / 3 force a variant for A/B runs and the bit-identity tests.
+static int fused_variant(const ilqr_batch* h) {  // 0: two kernels, 1: one tile per CU, 2: two tiles per CU, 3: wide tiles (64 trajectories, one per CU)
   if (!use_quad_backward(h) || h->aos || (h->flags & ILQR_FLAG_UNFUSED) || h->env.unfused) return 0;
   const bool staged = (h->flags & ILQR_FLAG_STAGED) || h->env.staged;
-  const bool wide_ok = !staged && h->nu == 1 && h->sp.fixes == 0;  // wide tiles (kernels_wide.hpp) and hex chains (backward_hex.hpp): persistent route, m = 1, no opt-in fixes
-  if (h->env.fused) return (h->env.fused >= 3 && !wide_ok) ? (h->env.fused == 3 ? 2 : 1) : h->env.fused;
-  if (h->ntiles <= h->num_cus) return 1;  // (4 = k_solve_hex only on request: measured 0.66 ms against 0.48 ms per backward phase at B = 4096)
+  const bool wide_ok = !staged && h->nu == 1 && h->sp.fixes == 0;  // wide tiles (kernels_wide.hpp): persistent route, m = 1, no opt-in fixes
+  if (h->env.fused) return (h->env.fused == 3 && !wide_ok) ? 2 : h->env.fused;
+  if (h->ntiles <= h->num_cus) return 1;
   if (wide_ok && h->ntiles >= 4 * h->num_cus) return 3;  // a 64-trajectory wide tile for every CU: the thread-per-trajectory chain
   if (!staged) return 2;  // persistent tiles, two per CU, for ANY larger batch: the dispatcher hands a CU its next tile when one is through
   return (h->ntiles <= 2 * h->num_cus) ? 2 : 0;
@@ -651,9 +650,6 @@ static int launch_solve_tiles(ilqr_batch* h, int n_iters) {
             else
               hipLaunchKernelGGL((k_solve_wide<MM, MF, 2>), dim3((grid_tiles + 3) / 4), dim3(256), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
           }
-        } else if (occ == 4) {
-          if constexpr (MM::NU == 1)
-            hipLaunchKernelGGL((k_solve_hex<MM, MF>), dim3(grid_tiles), dim3(512), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
         } else if (occ == 1)
           hipLaunchKernelGGL((k_solve_tile<MM, MF, 1>), dim3(grid_tiles), dim3(256), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
         else
@@ -662,7 +658,7 @@ static int launch_solve_tiles(ilqr_batch* h, int n_iters) {
       }))
     return rc;
   HIPCHK(hipGetLastError());
-  h->commit_pending = (occ != 4);   // the last iteration's accepts (flushed by the caller); k_solve_hex commits every iteration's itself
+  h->commit_pending = true;   // the last iteration's accepts (flushed by the caller)
   h->recs = ilqr_batch::REC_STALE;
   return timer_end(h, ILQR_STAGE_SOLVE, ev);
 }
@@ -737,7 +733,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   h->env.lq_thread_rollout = getenv("ILQR_AMD_LQ_THREAD_ROLLOUT") != nullptr;
   h->env.full_records = getenv("ILQR_AMD_FULL_RECORDS") != nullptr;
   h->env.no_compaction = getenv("ILQR_AMD_NO_COMPACTION") != nullptr;
-  if (const char* f = getenv("ILQR_AMD_FUSED")) h->env.fused = (f[0] == '4') ? 4 : (f[0] == '3') ? 3 : (f[0] == '2') ? 2 : 1;
+  if (const char* f = getenv("ILQR_AMD_FUSED")) h->env.fused = (f[0] == '3') ? 3 : (f[0] == '2') ? 2 : 1;
   if (const char* w = getenv("ILQR_AMD_WIDE_OCC")) h->env.wide_occ = (w[0] == '2') ? 2 : 1;
   if (const char* e = getenv("ILQR_AMD_NUM_CUS"))  // tests: exercise the batch-size thresholds of the route selection on small batches
     if (atoi(e) > 0) h->num_cus = atoi(e);
@@ -1446,14 +1442,6 @@ int ilqr_copy_cost_to_device(ilqr_batch* h, void* dst) {
   return 0;
 }
 
-#ifdef ILQR_HEX_DEBUG
-int ilqr_debug_read(long long* out, int reset) {
-  long long z[16] = {0};
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ilqr::g_hex_dbg), sizeof(z)) != hipSuccess) return -1;
-  if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(ilqr::g_hex_dbg), z, sizeof(z));
-  return 0;
-}
-#endif
 // ---- measurement -----------------------------------------------------------------------------
 int ilqr_profile_enable(ilqr_batch* h, int enable) {
   if (!h) return fail(ILQR_ERR_INVALID, "null handle");
@@ -1523,7 +1511,7 @@ const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
       return (h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t";
     case ILQR_STAGE_ROLLOUT: return (h && h->aos) ? (h->env.lq_thread_rollout ? "k_rollout_g" : "k_rollout_lq") : "k_rollout";
     case ILQR_STAGE_ACCEPT: return "k_accept";
-    case ILQR_STAGE_SOLVE: return (h && use_persistent(h)) ? (fused_variant(h) == 1 ? "k_solve_tile" : fused_variant(h) == 3 ? "k_solve_wide" : fused_variant(h) == 4 ? "k_solve_hex" : "k_solve_tile<2>") : "";
+    case ILQR_STAGE_SOLVE: return (h && use_persistent(h)) ? (fused_variant(h) == 1 ? "k_solve_tile" : fused_variant(h) == 3 ? "k_solve_wide" : "k_solve_tile<2>") : "";
     default: return "";
   }
 }

@@ -59,7 +59,7 @@ __device__ __forceinline__ void fd_gradient(const real* x, F f, real* out) {
 #endif
 // PAD: extra `real`s per pair row.  0 = the HBM tile layout (row = 16 trajectories x 2 elements = a whole number of LDS
 // bank cycles: rows of the same trajectory share their banks, which is what the 4-lane backward wavefront wants -- its
-// lanes read one row for 16 trajectories).  The 16-lane backward wavefronts (backward_hex.hpp) read up to 8 ROWS for
+// lanes read one row for 16 trajectories).  A 16-lane-per-trajectory chain (tried in rounds 2 and 4, profiles/r04_hex_experiment.txt) reads up to 8 ROWS for
 // one trajectory with one instruction: PAD = 2 (16 bytes) spreads the rows over the banks.
 template <int NX, int NU, class real, int RING_KB = ILQR_RING_KB, int PAD = 0>
 struct RingSlot {

@@ -195,38 +195,6 @@ def test_route_selection_by_batch_size(monkeypatch):
     g.close()
 
 
-@pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("B,T,lim", [(64, 60, 1.5), (37, 123, 0.4), (200, 499, 1.5)])
-def test_hex_chains_equal_the_quad_chain(B, T, lim, dtype, monkeypatch):
-    """One tile per CU, m = 1: k_solve_hex (four 16-lane chains per tile, 16 step sizes per Armijo pass, the commit right
-    after the line search) against k_solve_tile<1> (one 4-lane chain, the quad search, the commit on the producers' way)
-    and the two-kernel route: every array and scalar bit-identical, through late iterations (lambda retries, slow QP exits)."""
-    from ilqr_amd import BatchILQR, capi
-    x0 = acrobot_x0(B, scale=0.6, seed=11)
-    if dtype == "f32":
-        x0 = x0.astype(np.float32).astype(np.float64)
-    u0 = np.zeros((B, T, 1))
-    out = []
-    for fl, env in ((0, "4"), (0, "1"), (capi.FLAG_UNFUSED, None)):
-        if env:
-            monkeypatch.setenv("ILQR_AMD_FUSED", env)
-        else:
-            monkeypatch.delenv("ILQR_AMD_FUSED", raising=False)
-        g = BatchILQR("acrobot", B, T, DT, u_min=-lim, u_max=lim, flags=fl, dtype=dtype, params=dict(max_iter=40))
-        if env:
-            assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("solve")) == (b"k_solve_hex" if env == "4" else b"k_solve_tile")
-        g.init_traj(x0, u0)
-        g.iterate(3)
-        s = _state(g)
-        g.iterate(1)
-        g.generate_trajectory()
-        s.update({"end_" + n: a for n, a in _state(g).items()})
-        out.append(s)
-        g.close()
-    _same(out[0], out[1])
-    _same(out[0], out[2])
-
-
 @pytest.mark.parametrize("name", ["acrobot", "integrator"])
 def test_committed_trajectory_is_the_rollout_that_was_scored(name):
     """Candidate states are not stored: the commit (k_commit, the sweep's fused commit) and the getter
