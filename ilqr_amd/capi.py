@@ -68,6 +68,10 @@ SYMBOLS = {
     "ilqr_get_candidate": (C.c_int, [_H, C.c_int, _dp, _dp]),
     "ilqr_count_running": (C.c_int, [_H, _ip]),
     "ilqr_copy_cost_to_device": (C.c_int, [_H, C.c_void_p]),
+    "ilqr_group_create": (C.c_int, [C.POINTER(_H), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ilqr_group_destroy": (None, [C.c_void_p]),
+    "ilqr_group_gather_costs": (C.c_int, [C.c_void_p, _dp]),
+    "ilqr_group_uses_rccl": (C.c_int, [C.c_void_p, _ip]),
     "ilqr_profile_enable": (C.c_int, [_H, C.c_int]),
     "ilqr_profile_reset": (C.c_int, [_H]),
     "ilqr_profile_read": (C.c_int, [_H, _dp, _ip]),

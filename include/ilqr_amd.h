@@ -243,6 +243,25 @@ int ilqr_count_running(ilqr_batch* h, int* n_running);
  * ilqr_synchronize before handing the buffer to work on another stream (a collective). */
 int ilqr_copy_cost_to_device(ilqr_batch* h, void* dst_device);
 
+/* ---- several shards of one batch, one process ----------------------------------
+ * The path partitions by trajectory: shard i = a handle of its own (any device, ilqr_desc.device) holding the contiguous block
+ * [offset_i, offset_i + B_i) of the global batch; there is no data-path collective.  A group names the shards of one job and
+ * performs its ONE exchange, the gather of the per-trajectory costs in global order:
+ *   - shards on n > 1 DISTINCT devices: one RCCL communicator per device (ncclCommInitAll, one process) and one
+ *     ncclAllGather of the padded shards over xGMI -- every device ends up with the whole vector (librccl.so is loaded when the
+ *     first such group is created, not by ilqr_create);
+ *   - shards that share a device (N logical shards on one GPU): device-to-host copies, shard by shard.
+ * The reference has no counterpart (one trajectory per process, src/run_ilqr.cpp:27-59); a caller of it who solves many
+ * problems loops over them -- this is that loop's gather. */
+typedef struct ilqr_group ilqr_group;
+/* flags: 1 = use RCCL even for a single device / a single shard (tests) */
+int ilqr_group_create(ilqr_batch* const* shards, int n_shards, int flags, ilqr_group** out);
+void ilqr_group_destroy(ilqr_group* g);
+/* cost_out: host [sum of the shards' B], global order.  Synchronises every shard. */
+int ilqr_group_gather_costs(ilqr_group* g, double* cost_out);
+/* 1 if the group's gather runs over RCCL, 0 if it copies; *n_ranks = communicators in use (0 without RCCL) */
+int ilqr_group_uses_rccl(ilqr_group* g, int* n_ranks);
+
 /* ---- measurement --------------------------------------------------------------------------- */
 enum ilqr_stage { ILQR_STAGE_DERIVATIVES = 0, ILQR_STAGE_BACKWARD = 1, ILQR_STAGE_ROLLOUT = 2,
                   ILQR_STAGE_ACCEPT = 3, ILQR_STAGE_SOLVE = 4, ILQR_NUM_STAGES = 5 };

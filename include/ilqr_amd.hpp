@@ -26,6 +26,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ilqr_amd.h"
@@ -601,6 +602,112 @@ class BatchILQR {
   int host_threads_ = 1;
   std::vector<double> hx0_, hxs_, hus_, d_fx_, d_fu_, d_cx_, d_cu_, d_cxx_, d_cxu_, d_cuu_;
   std::vector<char> need_derivs_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// One batch over several devices of a node, ONE process: shard i of the batch is a BatchILQR of its own on
+// devices[i], holding the contiguous block [i ceil(B/n), ...) of the problems.  Trajectories never interact, so there is
+// no data-path exchange; the one collective of the path is the gather of the per-trajectory costs (ilqr_group_*: RCCL
+// ncclAllGather over xGMI between distinct devices, plain copies between shards that share one).  `devices` may name
+// a device several times: N logical shards on one GPU give, bit for bit, what N GPUs give (and what one handle of B does).
+// A caller of the reference who solves many problems loops over src/run_ilqr.cpp:27-59; this is that loop, sharded.
+// ---------------------------------------------------------------------------------------------
+class ShardedBatchILQR {
+ public:
+  ShardedBatchILQR(std::shared_ptr<Model> model, int B, int T, double dt, const std::vector<int>& devices, int flags = 0)
+      : B_(B), T_(T), n_(model->x_dims), m_(model->u_dims), group_(nullptr) {
+    if (devices.empty() || B < 1) throw std::invalid_argument("ShardedBatchILQR: at least one device and one trajectory");
+    const int n = (int)devices.size(), per = (B + n - 1) / n;
+    for (int i = 0; i < n && i * per < B; i++) {
+      offset_.push_back(i * per);
+      shards_.emplace_back(new BatchILQR(model, std::min(per, B - i * per), T, dt, devices[i], flags));
+    }
+    offset_.push_back(B);
+    std::vector<ilqr_batch*> hs;
+    for (auto& sh : shards_) hs.push_back(sh->handle());
+    check(ilqr_group_create(hs.data(), (int)hs.size(), 0, &group_), "ilqr_group_create");
+  }
+  ~ShardedBatchILQR() { ilqr_group_destroy(group_); }
+  ShardedBatchILQR(const ShardedBatchILQR&) = delete;
+  ShardedBatchILQR& operator=(const ShardedBatchILQR&) = delete;
+
+  int shards() const { return (int)shards_.size(); }
+  int batch() const { return B_; }
+  BatchILQR& shard(int i) { return *shards_[i]; }
+  // how the gather travels: ranks of the RCCL communicator (0: the shards share a device and are copied)
+  int rccl_ranks() const {
+    int r = 0;
+    return ilqr_group_uses_rccl(group_, &r) ? r : 0;
+  }
+
+  std::vector<double> init_traj(const std::vector<double>& x0, const std::vector<double>& u0) {
+    if (x0.size() != (size_t)B_ * n_ || u0.size() != (size_t)B_ * T_ * m_) throw std::invalid_argument("init_traj: x0 [B][nx], u0 [B][T][nu]");
+    std::vector<double> cost;
+    for (int i = 0; i < shards(); i++) {
+      const size_t lo = offset_[i], hi = offset_[i + 1];
+      const std::vector<double> c = shards_[i]->init_traj(std::vector<double>(x0.begin() + lo * n_, x0.begin() + hi * n_),
+                                                          std::vector<double>(u0.begin() + lo * T_ * m_, u0.begin() + hi * T_ * m_));
+      cost.insert(cost.end(), c.begin(), c.end());
+    }
+    return cost;
+  }
+  // ilqr_iterate only enqueues on the shard's own stream: the shards' kernels run side by side, the first getter waits
+  void iterate(int n_iters) {
+    for (auto& sh : shards_) sh->iterate(n_iters);
+  }
+  // whole solves decide on the host when to stop (and re-pack running trajectories between chunks): one host thread per shard
+  void generate_trajectory() {
+    each_in_its_own_thread([](BatchILQR& sh) { sh.generate_trajectory(); });
+  }
+  void generate_trajectory(const std::vector<double>& x0, const std::vector<double>& u0) {
+    init_traj(x0, u0);
+    generate_trajectory();
+  }
+  void solve(const std::vector<double>& x0, const std::vector<double>& u0) { generate_trajectory(x0, u0); }
+
+  // the path's one exchange: [B] costs in global order
+  std::vector<double> cost() {
+    std::vector<double> c(B_);
+    check(ilqr_group_gather_costs(group_, c.data()), "ilqr_group_gather_costs");
+    return c;
+  }
+  std::vector<double> states() { return concat<double>([](BatchILQR& sh) { return sh.states(); }); }
+  std::vector<double> controls() { return concat<double>([](BatchILQR& sh) { return sh.controls(); }); }
+  std::vector<double> gains_k() { return concat<double>([](BatchILQR& sh) { return sh.gains_k(); }); }
+  std::vector<double> gains_K() { return concat<double>([](BatchILQR& sh) { return sh.gains_K(); }); }
+  std::vector<int> status() { return concat<int>([](BatchILQR& sh) { return sh.status(); }); }
+  std::vector<int> iterations() { return concat<int>([](BatchILQR& sh) { return sh.iterations(); }); }
+
+ private:
+  template <class V, class F>
+  std::vector<V> concat(F get) {
+    std::vector<V> all;
+    for (auto& sh : shards_) {
+      const std::vector<V> part = get(*sh);
+      all.insert(all.end(), part.begin(), part.end());
+    }
+    return all;
+  }
+  template <class F>
+  void each_in_its_own_thread(F f) {
+    std::vector<std::thread> th;
+    std::vector<std::string> err(shards_.size());
+    for (size_t i = 0; i < shards_.size(); i++)
+      th.emplace_back([&, i] {
+        try {
+          f(*shards_[i]);
+        } catch (const std::exception& e) {
+          err[i] = e.what();
+        }
+      });
+    for (auto& t : th) t.join();
+    for (auto& e : err)
+      if (!e.empty()) throw std::runtime_error(e);
+  }
+  int B_, T_, n_, m_;
+  std::vector<std::unique_ptr<BatchILQR>> shards_;
+  std::vector<int> offset_;
+  ilqr_group* group_;
 };
 
 // ---------------------------------------------------------------------------------------------

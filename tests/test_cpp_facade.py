@@ -163,3 +163,62 @@ def test_user_device_twin_through_the_facade(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bit_identical 1" in r.stdout
+
+
+@pytest.mark.gpu
+def test_sharded_batch_from_cpp_equals_python_shards_and_one_handle(tmp_path):
+    """examples/multi_gpu.cpp: ilqr_amd::ShardedBatchILQR, one C++ process, 8 logical shards (all on device 0 on a one-GPU
+    box: the partition SURVEY.md 8e describes, the gather of the costs through ilqr_group_gather_costs) against the Python
+    side's 8 separate handles and against ONE handle of the whole batch: costs and controls bit for bit, in global order;
+    a ragged last shard too.  And the RCCL gather itself (ncclCommInitAll + ncclAllGather, loaded on demand), forced on one
+    rank, returns the same vector."""
+    import ctypes as C
+    import numpy as np
+    from ilqr_amd import BatchILQR, _build, capi
+    from tests.util import acrobot_x0
+    _build.build()
+    exe = str(tmp_path / "multi_gpu")
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "multi_gpu.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "ilqr_amd", "lib"), "-lilqr_amd", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + os.path.join(ROOT, "ilqr_amd", "lib"), "-Wl,-rpath,/opt/rocm/lib"])
+    T, iters = 120, 3
+    for B, ns in ((1024, 8), (203, 8)):
+        x0 = acrobot_x0(B, scale=0.5, seed=21)
+        x0.tofile(tmp_path / "x0.bin")
+        r = subprocess.run([exe, str(tmp_path / "x0.bin"), str(B), str(T), str(ns), str(iters), str(tmp_path / "out.bin")],
+                           capture_output=True, text=True, cwd=tmp_path)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "gather over copies" in r.stdout  # (one device: the shards are copied, not all-gathered)
+        out = np.fromfile(tmp_path / "out.bin")
+        cost_cpp, us_cpp = out[:B], out[B:].reshape(B, T, 1)
+        # Python: the same partition as separate handles, and one handle of the whole batch
+        per = (B + ns - 1) // ns
+        cost_py, us_py = [], []
+        for i in range(ns):
+            lo, hi = i * per, min(B, (i + 1) * per)
+            if lo >= hi:
+                break
+            g = BatchILQR("acrobot", hi - lo, T, 0.02, u_min=-1.5, u_max=1.5)
+            g.init_traj(x0[lo:hi], np.zeros((hi - lo, T, 1)))
+            g.iterate(iters)
+            cost_py.append(g.cost())
+            us_py.append(g.trajectory()[1])
+            g.close()
+        g = BatchILQR("acrobot", B, T, 0.02, u_min=-1.5, u_max=1.5)
+        g.init_traj(x0, np.zeros((B, T, 1)))
+        g.iterate(iters)
+        assert np.array_equal(cost_cpp, np.concatenate(cost_py)) and np.array_equal(us_cpp, np.concatenate(us_py))
+        assert np.array_equal(cost_cpp, g.cost()) and np.array_equal(us_cpp, g.trajectory()[1])
+        # the RCCL route of the gather on this one device: a group of one shard with RCCL forced
+        lib = g.lib
+        hs = (C.c_void_p * 1)(g.h)
+        grp = C.c_void_p()
+        capi.check(lib.ilqr_group_create(hs, 1, 1, C.byref(grp)), lib)
+        nr = C.c_int(0)
+        assert lib.ilqr_group_uses_rccl(grp, C.byref(nr)) == 1 and nr.value == 1
+        got = np.zeros(B)
+        capi.check(lib.ilqr_group_gather_costs(grp, got.ctypes.data_as(C.POINTER(C.c_double))), lib)
+        lib.ilqr_group_destroy(grp)
+        assert np.array_equal(got, cost_cpp)
+        g.close()
