@@ -84,6 +84,9 @@ def build_user(header, out, verbose=False):
 
 USER_EXAMPLE_HEADER = os.path.join(os.path.dirname(PKG), "examples", "user_model_acrobot.hpp")
 USER_EXAMPLE_LIB = os.path.join(PKG, "lib", "libilqr_amd_user_example.so")
+# a user twin with dimensions of its own (n = 6, m = 2): the generic kernels
+USER_EXAMPLE6_HEADER = os.path.join(os.path.dirname(PKG), "examples", "user_model_linear6.hpp")
+USER_EXAMPLE6_LIB = os.path.join(PKG, "lib", "libilqr_amd_user_linear6.so")
 
 
 if __name__ == "__main__":

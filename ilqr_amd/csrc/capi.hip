@@ -67,6 +67,7 @@ struct ilqr_batch {
   LqModel lq;                   // ILQR_MODEL_LQ: padded matrices on the device
 #ifdef ILQR_HAVE_USER_MODEL
   UserModelT<double> user;      // ILQR_MODEL_USER: the build's user device twin (fp32 handle: the twin the finite differences are taken in)
+  GenericModelOf<UserModelT<double>> user_g;  // ... as the generic kernels take it (any NX <= 32, NU <= 16 that is not a tiled nx = 4 shape)
   UserModelT<float> user_f;
 #endif
   // v is the view every entry point addresses arrays through; for an fp32 handle its trajectory pointers hold
@@ -146,7 +147,9 @@ static int with_model(ilqr_batch* h, F&& f) {
       case ILQR_MODEL_ACROBOT: return f(h->vf, h->acrobot_f, h->acrobot);
       case ILQR_MODEL_DOUBLE_INTEGRATOR: return f(h->vf, h->dint_f, h->dint);
 #ifdef ILQR_HAVE_USER_MODEL
-      case ILQR_MODEL_USER: return f(h->vf, h->user_f, h->user);
+      case ILQR_MODEL_USER:
+        if constexpr (kUserTiled) return f(h->vf, h->user_f, h->user);
+        break;
 #endif
       default: break;
     }
@@ -155,7 +158,9 @@ static int with_model(ilqr_batch* h, F&& f) {
       case ILQR_MODEL_ACROBOT: return f(h->v, h->acrobot, h->acrobot);
       case ILQR_MODEL_DOUBLE_INTEGRATOR: return f(h->v, h->dint, h->dint);
 #ifdef ILQR_HAVE_USER_MODEL
-      case ILQR_MODEL_USER: return f(h->v, h->user, h->user);
+      case ILQR_MODEL_USER:
+        if constexpr (kUserTiled) return f(h->v, h->user, h->user);
+        break;
 #endif
       default: break;
     }
@@ -408,11 +413,28 @@ static int launch_rollout_t(ilqr_batch* h, const V& v, const M& m, bool gains, b
   HIPCHK(hipGetLastError());
   return 0;
 }
+// Does the handle's model have a device twin in the GENERIC kernels (generic.hpp)?  The shipped LQ model, or the build's user
+// model when its dimensions are not a tiled nx = 4 shape.
+static bool generic_twin(const ilqr_batch* h) {
+  return h->model == ILQR_MODEL_LQ || (h->model == ILQR_MODEL_USER && h->aos);
+}
+// f(model) for the handle's generic device twin
+template <class F>
+static int with_generic_model(ilqr_batch* h, F&& f) {
+  if (h->model == ILQR_MODEL_LQ) return f(h->lq);
+#ifdef ILQR_HAVE_USER_MODEL
+  if constexpr (!kUserTiled)
+    if (h->model == ILQR_MODEL_USER) return f(h->user_g);
+#endif
+  return fail(ILQR_ERR_UNSUPPORTED, "model %d has no generic device kernels", h->model);
+}
 // generic path (generic.hpp): what = RG_INIT / RG_SEARCH / RG_COMMIT.  The LQ model rolls out on the
 // matrix cores (k_rollout_lq, one wavefront per trajectory); ILQR_AMD_LQ_THREAD_ROLLOUT=1 selects the
 // generic thread-per-rollout kernel (same results bit for bit; kept as the cross-check and as the
 // template for device models without matrix structure).
-static int launch_rollout_g(ilqr_batch* h, const LqModel& m, int what, const AlphaSet& al, double* cost_out, int mode, int write_cost) {
+template <class M>
+static int launch_rollout_g(ilqr_batch* h, const M& m, int what, const AlphaSet& al, double* cost_out, int mode, int write_cost) {
+  if constexpr (std::is_same<M, LqModel>::value)
   if (!h->env.lq_thread_rollout) {
     const dim3 grid(h->B), block(64);
     if (what == RG_SEARCH)
@@ -424,7 +446,6 @@ static int launch_rollout_g(ilqr_batch* h, const LqModel& m, int what, const Alp
     HIPCHK(hipGetLastError());
     return 0;
   }
-  typedef LqModel M;
   if (what == RG_SEARCH)
     hipLaunchKernelGGL((k_rollout_g<M, RG_SEARCH>), dim3((h->B + kSearchTraj - 1) / kSearchTraj), dim3(64), 0, h->stream, h->v, m, al,
                        cost_out, nullptr, mode, 0);
@@ -443,13 +464,12 @@ static int launch_rollout(ilqr_batch* h, bool gains, bool cand, const AlphaSet& 
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_ROLLOUT, &ev)) return rc;
   int rc;
-  if (h->model == ILQR_MODEL_LQ) {
-    if (!gains)
-      rc = launch_rollout_g(h, h->lq, RG_INIT, al, cost_out, 0, 1);
-    else if (n_alpha == NALPHA)
-      rc = launch_rollout_g(h, h->lq, RG_SEARCH, al, cost_out, mode, 0);
-    else  // a single closed-loop rollout written in place (warm start): slot commit_idx of `al`
-      rc = launch_rollout_g(h, h->lq, RG_COMMIT, al, cost_out, 0, 1);
+  if (generic_twin(h)) {
+    rc = with_generic_model(h, [&](auto& m) {
+      if (!gains) return launch_rollout_g(h, m, RG_INIT, al, cost_out, 0, 1);
+      if (n_alpha == NALPHA) return launch_rollout_g(h, m, RG_SEARCH, al, cost_out, mode, 0);
+      return launch_rollout_g(h, m, RG_COMMIT, al, cost_out, 0, 1);  // a single closed-loop rollout written in place (warm start): slot commit_idx of `al`
+    });
     if (rc) return rc;
     return timer_end(h, ILQR_STAGE_ROLLOUT, ev);
   }
@@ -460,8 +480,8 @@ static int launch_rollout(ilqr_batch* h, bool gains, bool cand, const AlphaSet& 
 
 static AlphaSet line_search_alphas();
 static int launch_commit(ilqr_batch* h) {
-  if (h->model == ILQR_MODEL_LQ)  // no stored candidates on the generic path: re-run the accepted rollout in place
-    return launch_rollout_g(h, h->lq, RG_COMMIT, line_search_alphas(), h->v.cost, 0, 0);
+  if (generic_twin(h))  // no stored candidates on the generic path: re-run the accepted rollout in place
+    return with_generic_model(h, [&](auto& m) { return launch_rollout_g(h, m, RG_COMMIT, line_search_alphas(), h->v.cost, 0, 0); });
   dim3 grid((h->T + 1 + 15) / 16, h->ntiles), block(256);
   if (int rc = with_model(h, [&](auto& v, auto& m, auto&) {
         hipLaunchKernelGGL((k_commit<std::decay_t<decltype(m)>>), grid, block, 0, h->stream, v, m, h->commit_idx);
@@ -496,21 +516,25 @@ static int forget_pending(ilqr_batch* h) {
 static int launch_derivatives(ilqr_batch* h, int force) {
   if (int rc = ensure_records(h)) return rc;
   h->recs = ilqr_batch::REC_VALID;
-  if (h->model == ILQR_MODEL_LQ)  // the generic sweep has no fused commit: rebuild the accepted rollout first
+  if (generic_twin(h))  // the generic sweep has no fused commit: rebuild the accepted rollout first
     if (int rc = flush_commit(h)) return rc;
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_DERIVATIVES, &ev)) return rc;
   dim3 grid((h->T + 1 + 15) / 16, h->ntiles), block(256);
   const int* ci = h->commit_pending ? h->commit_idx : nullptr;
-  if (h->model == ILQR_MODEL_LQ) {
-    if (h->v.analytic) {
+  if (generic_twin(h)) {
+    if (h->v.analytic && h->model == ILQR_MODEL_LQ) {
       const int what = h->env.full_records ? 0 : 1;  // (A/B runs and the bit-identity test)
       const int chunk = (what == 1) ? 4 * kAnalyticChunk : kAnalyticChunk;
       const int nchunk = (h->T + 1 + chunk - 1) / chunk;
       hipLaunchKernelGGL(k_analytic_lq, dim3(h->B * nchunk), dim3(64), 0, h->stream, h->v, h->lq, force, what, h->const_rec, chunk);
       h->records_partial = (what == 1);
     } else {
-      hipLaunchKernelGGL((k_derivatives_g<LqModel>), dim3(h->B * (h->T + 1)), dim3(64), 0, h->stream, h->v, h->lq, force);
+      if (int rc = with_generic_model(h, [&](auto& m) {
+            hipLaunchKernelGGL((k_derivatives_g<std::decay_t<decltype(m)>>), dim3(h->B * (h->T + 1)), dim3(64), 0, h->stream, h->v, m, force);
+            return 0;
+          }))
+        return rc;
     }
     HIPCHK(hipGetLastError());
     return timer_end(h, ILQR_STAGE_DERIVATIVES, ev);
@@ -798,7 +822,11 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     using UM = UserModelT<double>;
     REQUIRE(d->nx == UM::NX && d->nu == UM::NU, "this build's user model is nx=%d nu=%d, got %d/%d", UM::NX, UM::NU, d->nx, d->nu);
     REQUIRE(d->u_min && d->u_max, "ILQR_MODEL_USER needs u_min/u_max (Model::u_min/u_max, include/model.h:17)");
-    REQUIRE(!(d->flags & ILQR_FLAG_ANALYTIC_DERIVATIVES) || has_analytic_record<UM>::value, "this user model has no analytic_record()");
+    REQUIRE(!(d->flags & ILQR_FLAG_ANALYTIC_DERIVATIVES) || (kUserTiled && has_analytic_record<UM>::value), "this user model has no analytic_record()");
+    if (!kUserTiled) {  // not a tiled nx = 4 shape: the generic kernels (fp64), trajectory-contiguous layout like the LQ model's
+      REQUIRE(d->dtype == ILQR_DTYPE_F64, "the generic nx <= 32 path is fp64");
+      h->aos = true;
+    }
     REQUIRE(d->n_user_params >= 0 && (d->n_user_params == 0 || d->user_params), "ILQR_MODEL_USER: n_user_params = %d with user_params = %p", d->n_user_params, (const void*)d->user_params);
     h->user_f.set_params(d->user_params, d->n_user_params);
     if (h->dtype == ILQR_DTYPE_F32) {  // the twin the finite differences are taken in: built from the parameters' FLOAT values, like the shipped models'
@@ -808,6 +836,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     } else {
       h->user.set_params(d->user_params, d->n_user_params);
     }
+    static_cast<UM&>(h->user_g) = h->user;  // (the parameters; set_params ran above)
     for (int j = 0; j < UM::NU; j++) {
       h->user_f.u_min[j] = (float)d->u_min[j];
       h->user_f.u_max[j] = (float)d->u_max[j];
@@ -1190,7 +1219,7 @@ int ilqr_warm_start(ilqr_batch* h, const double* x0) {
   // forward_pass(x_0, us) with the stored gains: u = us[t] + K[t](x - xs[t])  (alpha*k term = 0)
   AlphaSet al;
   for (int i = 0; i < NALPHA; i++) al.a[i] = 0.0;
-  if (h->model == ILQR_MODEL_LQ) {  // generic path: the rollout itself overwrites xs/us (slot 0 of `al` for everyone)
+  if (generic_twin(h)) {  // generic path: the rollout itself overwrites xs/us (slot 0 of `al` for everyone)
     HIPCHK(hipMemsetAsync(h->commit_idx, 0, (size_t)h->Bp * sizeof(int), h->stream));
     if (int rc = launch_rollout(h, true, true, al, 1, h->v.cost, 0)) return rc;
   } else {
@@ -1641,7 +1670,7 @@ const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
       if (h && h->aos) return h->env.backward_w1 ? "k_backward_w" : "k_backward_w2";
       if (h && use_fused_sweep(h)) return "k_sweep_backward";  // what ilqr_iterate launches
       return (h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t";
-    case ILQR_STAGE_ROLLOUT: return (h && h->aos) ? (h->env.lq_thread_rollout ? "k_rollout_g" : "k_rollout_lq") : "k_rollout";
+    case ILQR_STAGE_ROLLOUT: return (h && h->aos) ? ((h->env.lq_thread_rollout || h->model != ILQR_MODEL_LQ) ? "k_rollout_g" : "k_rollout_lq") : "k_rollout";
     case ILQR_STAGE_ACCEPT: return "k_accept";
     case ILQR_STAGE_SOLVE: return (h && use_persistent(h)) ? (fused_variant(h) == 1 ? "k_solve_tile" : fused_variant(h) == 3 ? "k_solve_wide" : "k_solve_tile<2>") : "";
     default: return "";

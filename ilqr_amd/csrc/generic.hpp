@@ -109,6 +109,7 @@ struct LqModel {
 #define ILQR_LQ_SEPARABLE 1  // (0: experiment build that evaluates every point through cost(x, u))
 #endif
   static constexpr bool kSeparableCost = ILQR_LQ_SEPARABLE != 0;
+  static constexpr bool kHasAnalyticRecord = true;
   __device__ __forceinline__ double cost_x(const double* x) const { return quad<GN>((cmem_d*)Q, x); }
   __device__ __forceinline__ double cost_u(const double* u) const { return quad<GM>((cmem_d*)R, u); }
   // P points at once: every matrix element is fetched once and used P times
@@ -228,6 +229,19 @@ struct LqModel {
 // No candidate trajectories are stored on this path: with nx + nu = 48 doubles per knot they
 // would be 11 x 77 KB per trajectory and iteration; re-running the accepted rollout costs 1/11 of
 // the search.
+// A user's device twin (models.hpp: UserModelT<double>, any NX <= 32, NU <= 16 that the tiled nx = 4 kernels do not take) as the
+// generic kernels see a model: compile-time dimensions = runtime dimensions, no structure promised (every perturbed point of
+// the finite-difference sweep is evaluated through dynamics() / cost() / final_cost() as src/derivatives.cpp does).
+template <class U>
+struct GenericModelOf : U {
+  int nx = U::NX, nu = U::NU;
+  static constexpr bool kSeparableCost = false, kQuadraticCostX = false, kLinearDynamics = false, kHasAnalyticRecord = false;
+  __device__ __forceinline__ void cost2(const double* xa, const double* ua, const double* xb, const double* ub, double& fa, double& fb) const {
+    fa = this->cost(xa, ua);
+    fb = this->cost(xb, ub);
+  }
+};
+
 enum { RG_INIT = 0, RG_SEARCH = 1, RG_COMMIT = 2 };
 constexpr int kSearchTraj = 64 / NALPHA;  // trajectories per wavefront in RG_SEARCH (5)
 
@@ -687,9 +701,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int j = 0; j < NU; j++) u[j] = lane_value(uv, j);
   }
 
-  if (v.analytic) {  // opt-in: the model's exact derivatives (reads the knot from memory: runtime indices)
-    model.analytic_record(v.xs + ((size_t)b * (T + 1) + t) * nx, last ? nullptr : v.us + ((size_t)b * T + t) * nu, v.dt, last, D, lane);
-    return;
+  if constexpr (M::kHasAnalyticRecord) {
+    if (v.analytic) {  // opt-in: the model's exact derivatives (reads the knot from memory: runtime indices)
+      model.analytic_record(v.xs + ((size_t)b * (T + 1) + t) * nx, last ? nullptr : v.us + ((size_t)b * T + t) * nu, v.dt, last, D, lane);
+      return;
+    }
   }
 
   // point = knot, then (target 1, index i1) += d1, then (target 2, index i2) += d2; index -1 = none

@@ -308,8 +308,8 @@ struct has_analytic_record<M, std::void_t<decltype(std::declval<const M&>().anal
 //
 //     template <class real_> struct UserModelT {
 //       using real = real_;
-//       static constexpr int NX = 4;             // the lane-quad kernels are written for nx = 4
-//       static constexpr int NU = 1;             // 1 or 2
+//       static constexpr int NX = 4;             // state dimension, <= 32
+//       static constexpr int NU = 1;             // control dimension, <= 16
 //       real u_min[NU], u_max[NU];               // filled by ilqr_create from ilqr_desc.u_min / u_max
 //       ... its own parameters (plain data) ...
 //       void set_params(const double* p, int n);                                  // host: ilqr_desc.user_params
@@ -319,14 +319,19 @@ struct has_analytic_record<M, std::void_t<decltype(std::declval<const M&>().anal
 //       // optional: __device__ void analytic_record(const real* x, const real* u, real dt, bool last, real* rec) const;
 //     };
 //
-// It may use what this file offers (sincos_shared, Rec<>).  Both arithmetic flavours are instantiated (fp32 handles
-// take their finite differences in UserModelT<double>).  examples/user_model_acrobot.hpp is a worked example.
+// It may use what this file offers (sincos_shared, Rec<>).  NX = 4 with NU = 1 or 2 runs in the tiled lane-quad kernels (the
+// persistent routes of the shipped acrobot / double integrator; both arithmetic flavours are instantiated: fp32 handles take
+// their finite differences in UserModelT<double>) -- examples/user_model_acrobot.hpp.  Any other NX <= 32, NU <= 16 runs in
+// the generic kernels (generic.hpp: thread-per-rollout k_rollout_g, wavefront-per-knot finite differences k_derivatives_g,
+// the matrix-core backward pass k_backward_w2; fp64, analytic_record is not used there) -- examples/user_model_linear6.hpp.
 // ------------------------------------------------------------------------------------------
 #ifdef ILQR_USER_MODEL_HEADER
 namespace ilqr {
 #include ILQR_USER_MODEL_HEADER
-static_assert(UserModelT<double>::NX == 4 && (UserModelT<double>::NU == 1 || UserModelT<double>::NU == 2),
-              "user device models run in the nx = 4 kernels: NX == 4, NU in {1, 2}");
+static_assert(UserModelT<double>::NX >= 1 && UserModelT<double>::NX <= MAXN && UserModelT<double>::NU >= 1 && UserModelT<double>::NU <= MAXM,
+              "user device models: 1 <= NX <= 32, 1 <= NU <= 16");
+// which kernels the build's user model runs in
+constexpr bool kUserTiled = UserModelT<double>::NX == 4 && (UserModelT<double>::NU == 1 || UserModelT<double>::NU == 2);
 }  // namespace ilqr
 #define ILQR_HAVE_USER_MODEL 1
 #endif

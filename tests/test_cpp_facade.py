@@ -222,3 +222,19 @@ def test_sharded_batch_from_cpp_equals_python_shards_and_one_handle(tmp_path):
         lib.ilqr_group_destroy(grp)
         assert np.array_equal(got, cost_cpp)
         g.close()
+
+
+@pytest.mark.gpu
+def test_user_twin_with_its_own_dimensions_against_host_virtuals(tmp_path):
+    """examples/user_model_generic.cpp: a six-state Model solved through its device twin in the generic kernels
+    (examples/user_model_linear6.hpp, ILQR_MODEL_USER), through its host virtuals (ILQR_MODEL_HOST) and through the shipped LQ
+    twin: costs after three iterations within 1e-6 of each other."""
+    from ilqr_amd import _build
+    lib = _build.build_user(_build.USER_EXAMPLE6_HEADER, _build.USER_EXAMPLE6_LIB)
+    exe = str(tmp_path / "user_model_generic")
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "user_model_generic.cpp"), "-o", exe, lib, "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "agree 1" in r.stdout

@@ -83,3 +83,55 @@ def test_builds_say_what_they_carry(user_lib):
         BatchILQR("user", 4, 5, DT, u_min=-1.0, u_max=1.0, nx=4, nu=1)  # the stock library has no user model
     with pytest.raises(capi.ILQRError, match="analytic_record"):
         BatchILQR("user", 4, 5, DT, u_min=-1.0, u_max=1.0, nx=4, nu=1, lib=user_lib, flags=capi.FLAG_ANALYTIC_DERIVATIVES)
+
+
+@pytest.fixture(scope="module")
+def user6_lib():
+    from ilqr_amd import _build
+    return _build.build_user(_build.USER_EXAMPLE6_HEADER, _build.USER_EXAMPLE6_LIB)
+
+
+def test_user_model_with_dimensions_of_its_own(user6_lib, oracle):
+    """A user twin that is not an nx = 4 shape (examples/user_model_linear6.hpp: n = 6, m = 2, written as plain loops over
+    its own matrices) runs in the generic kernels: thread-per-rollout forward passes, wavefront-per-knot finite differences
+    through the model's own dynamics() / cost() / final_cost(), the matrix-core backward pass.  Every iteration of a
+    free-running solve against the oracle's LQ model with the same matrices (tests/parity.py: device-driven walk, 1e-6 per
+    knot or a proven tie), and against the SHIPPED LQ twin at n = 6, m = 2 (whose sums run in the matrix cores' order:
+    agreement to the finite differences' rounding, not to the bit)."""
+    from ilqr_amd import BatchILQR, capi
+    from tests.parity import walk_iterations
+    from tests.test_gpu_lq_end_to_end import dense_mats
+    n, m, B, T, lim = 6, 2, 37, 60, 0.4
+    mats = dense_mats(n, m, seed=5)
+    params = np.concatenate([np.ascontiguousarray(a).ravel() for a in mats])
+    rng = np.random.default_rng(3)
+    x0 = rng.uniform(-1, 1, (B, n))
+    u0 = rng.normal(size=(B, T, m)) * 0.1
+    g = BatchILQR("user", B, T, DT, u_min=-lim, u_max=lim, lib=user6_lib, nx=n, nu=m, user_params=params)
+    assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("derivatives")) == b"k_derivatives_g"
+    assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("rollout")) == b"k_rollout_g"
+    om = oracle.Model("lq", lq=mats, u_lim=lim)
+    r = walk_iterations(oracle, om, g, x0, u0, DT, 6, drive="gpu")
+    print("user n=6 m=2 walk:", {kk: v for kk, v in r.items() if kk not in ("per_iter", "tied")})
+    assert r["checked"] >= 3 * B and len(r["tied"]) <= B // 8, r
+    # the same problem through the shipped LQ twin
+    c_user, (k_user, K_user) = None, (None, None)
+    g.init_traj(x0, u0)
+    g.iterate(3)
+    c_user, (k_user, K_user) = g.cost(), g.gains()
+    g2 = BatchILQR("lq", B, T, DT, u_min=-lim, u_max=lim, lq=mats)
+    g2.init_traj(x0, u0)
+    g2.iterate(3)
+    ok = np.abs(c_user - g2.cost()) <= 1e-6 * np.abs(c_user)
+    assert ok.mean() > 0.9, ok.mean()  # (a clamp tie on one side moves a trajectory's cost: counted, not hidden)
+    k2, K2 = g2.gains()
+    assert np.abs(k_user[ok] - k2[ok]).max() <= 1e-6 * max(1.0, np.abs(k2).max())
+    # getters, stage calls and the full solve work on this route like on any other
+    g.generate_trajectory()
+    assert g.count_running() == 0 and np.all(np.isfinite(g.cost())) and np.all(g.cost() <= c_user * (1 + 1e-9))
+    with pytest.raises(capi.ILQRError, match="analytic_record"):
+        BatchILQR("user", 4, 5, DT, u_min=-1.0, u_max=1.0, nx=n, nu=m, lib=user6_lib, user_params=params, flags=capi.FLAG_ANALYTIC_DERIVATIVES)
+    with pytest.raises(capi.ILQRError, match="fp64"):
+        BatchILQR("user", 4, 5, DT, u_min=-1.0, u_max=1.0, nx=n, nu=m, lib=user6_lib, user_params=params, dtype="f32")
+    g.close()
+    g2.close()
