@@ -28,6 +28,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $C --kernel-trace -d $OUT/sat_pmc_$C -o $R -- $SAT > /dev/null 2> $OUT/sat_pmc_$C.err
 done
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace -d $OUT/sat_pmc_sq1 -o $R -- $SAT > /dev/null 2> $OUT/sat_pmc_sq1.err
+timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $OUT/sat_pmc_sq2 -o $R -- $SAT > /dev/null 2> $OUT/sat_pmc_sq2.err
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/sat_pmc_sq3 -o $R -- $SAT > /dev/null 2> $OUT/sat_pmc_sq3.err
 # the per-stage route of the same workload (ILQR_FLAG_STAGED = 32): one launch per phase, for the per-phase traffic
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -41,8 +42,11 @@ timeout 300 rocprofv3 --pmc MeanOccupancyPerCU MeanOccupancyPerActiveCU --kernel
 ILQR_AMD_BACKWARD_W1=1 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $OUT/lq_w1_pmc_sq -o $R -- $LQ > /dev/null 2> $OUT/lq_w1_pmc_sq.err
 ILQR_AMD_BACKWARD_W1=1 timeout 300 rocprofv3 --pmc MeanOccupancyPerCU MeanOccupancyPerActiveCU --kernel-trace -d $OUT/lq_w1_pmc_occ -o $R -- $LQ > /dev/null 2> $OUT/lq_w1_pmc_occ.err
 cd $ROOT
-scripts/ubench/lat > $OUT/ubench_lat.txt 2>/dev/null
-for d in stats stats5 pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq1 pmc_sq2 pmc_sq3 sat_stats5 sat_pmc_FETCH_SIZE sat_pmc_WRITE_SIZE sat_pmc_sq1 sat_pmc_sq3 staged_pmc_FETCH_SIZE staged_pmc_WRITE_SIZE staged_stats lq_pmc_sq lq_pmc_occ lq_w1_pmc_sq lq_w1_pmc_occ; do
+for U in lat ldsmix; do  # microbenchmarks quoted in DESIGN.md, re-run on this box
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $OUT/$U scripts/ubench/$U.hip 2> /dev/null && $OUT/$U > $OUT/ubench_$U.txt 2>/dev/null
+  rm -f $OUT/$U
+done
+for d in stats stats5 pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq1 pmc_sq2 pmc_sq3 sat_stats5 sat_pmc_FETCH_SIZE sat_pmc_WRITE_SIZE sat_pmc_sq1 sat_pmc_sq2 sat_pmc_sq3 staged_pmc_FETCH_SIZE staged_pmc_WRITE_SIZE staged_stats lq_pmc_sq lq_pmc_occ lq_w1_pmc_sq lq_w1_pmc_occ; do
   f=$(find $OUT/$d -name "*.db" | head -1)
   [ -n "$f" ] && python scripts/prof_summary.py $f > $OUT/$d.txt 2>&1
 done

@@ -2,8 +2,9 @@
 
     python scripts/make_traffic.py gpurun_out/prof_r02a r02a > profiles/traffic.json
 
-FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: gfx950 reports half of a coalesced stream), WRITE_SIZE is
-taken as is; both are in KB = 1024 B.  The persistent kernel k_solve_tile runs a different number of iterations
+FETCH_SIZE is doubled, WRITE_SIZE is taken as is; both are in KB = 1024 B.  The factors are calibrated on THIS path's access
+shapes (scripts/fetch_calibration.sh, profiles/r04_fetch_calibration.txt: 8-byte-per-lane loads of 128-byte tile rows, 8- and
+16-byte streams: true bytes / FETCH_SIZE bytes = 2.000; stores 1.000), not only on the guide's 16 B/lane stream.  The persistent kernel k_solve_tile runs a different number of iterations
 per launch (warm-up 3, timed 5 in the counter runs), so its figures are normalised PER ITERATION; bench.py scales
 them to the launch it times."""
 import json
@@ -51,8 +52,10 @@ def solve_entry(d, prefix, key, B, T, f, w):
     valu = read("%s/%spmc_sq1.txt" % (d, prefix), "SQ_INSTS_VALU")
     wavecyc = read("%s/%spmc_sq3.txt" % (d, prefix), "SQ_WAVE_CYCLES")
     waitany = read("%s/%spmc_sq3.txt" % (d, prefix), "SQ_WAIT_ANY")
-    bank = read("%s/%spmc_sq2.txt" % (d, prefix), "SQ_LDS_BANK_CONFLICT") if prefix == "" else {}
-    ldsact = read("%s/%spmc_sq2.txt" % (d, prefix), "SQ_LDS_IDX_ACTIVE") if prefix == "" else {}
+    import os
+    have_sq2 = os.path.exists("%s/%spmc_sq2.txt" % (d, prefix))
+    bank = read("%s/%spmc_sq2.txt" % (d, prefix), "SQ_LDS_BANK_CONFLICT") if have_sq2 else {}
+    ldsact = read("%s/%spmc_sq2.txt" % (d, prefix), "SQ_LDS_IDX_ACTIVE") if have_sq2 else {}
     dur = durations("%s/%sstats5.txt" % (d, prefix))
     fr, wr = f.get(key, (0.0, 1))[0], w.get(key, (0.0, 1))[0]
     e = {"fetch_size_kb": fr, "write_size_kb": wr, "hbm_read_bytes": 2 * fr * 1024, "hbm_write_bytes": wr * 1024,
@@ -99,8 +102,8 @@ def main(d, tag):
             if key in fs or key in ws:
                 kernels[key] = solve_entry(d, "sat_", key, 32768, T, fs, ws)
     json.dump({"source": "rocprofv3 passes of `bench.py --no-cpu-baseline --no-extra-configs --steps 5 --warmup 3` on MI355X, one counter "
-                         "set per run with --kernel-trace only (scripts/collect_profiles.sh; summaries profiles/%s_*.txt): FETCH_SIZE doubled per "
-                         "MI355X_MICROARCH.md (gfx950 reports half of a coalesced stream), WRITE_SIZE as is, KB = 1024 B; k_sweep_backward / "
+                         "set per run with --kernel-trace only (scripts/collect_profiles.sh; summaries profiles/%s_*.txt): FETCH_SIZE x 2.000, WRITE_SIZE x 1.000 "
+                         "as calibrated on 8-byte row loads / stores of known size (profiles/r04_fetch_calibration.txt), KB = 1024 B; k_sweep_backward / "
                          "k_rollout rows from the same workload launched per stage (--flags 32); k_solve_wide (the saturated batch) from the same command with "
                          "--batch 32768" % tag,
                "source_hash": _build._source_hash(),
