@@ -200,6 +200,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="only the headline workload")
     ap.add_argument("--flags", type=int, default=0, help="extra ilqr_flags (kernel variant selection)")
+    ap.add_argument("--route", type=int, default=0, help="enum ilqr_route for the headline handle (A/B runs of equivalent kernels)")
     args = ap.parse_args()
 
     import torch
@@ -257,7 +258,8 @@ def main():
         x0 = acrobot_x0(B * world)[lo:hi]
         # max_iter beyond the run: ILQR_FLAG_FIXED_WORK keeps every trajectory running (checked below)
         g = BatchILQR("acrobot", B, T, dt, u_min=-lim, u_max=lim, device=local_rank, dtype=dtype,
-                      flags=capi.FLAG_FIXED_WORK | flags, stream=stream, params=dict(max_iter=warmup + steps + 1))
+                      flags=capi.FLAG_FIXED_WORK | flags, stream=stream, params=dict(max_iter=warmup + steps + 1),
+                      route=args.route if (B == args.batch and dtype == args.dtype) else 0)
         g.init_traj(x0, np.zeros((B, T, m)))
         g.iterate(warmup)
         g.profile(True)

@@ -37,11 +37,12 @@ def _p(a):
 
 class BatchILQR:
     def __init__(self, model, B, T, dt, u_min=None, u_max=None, goal=None, device=0, flags=0,
-                 stream=None, params=None, nx=None, nu=None, lq=None, dtype="f64", lib=None, user_params=None):
+                 stream=None, params=None, nx=None, nu=None, lq=None, dtype="f64", lib=None, user_params=None, route=0, assume_cus=0):
         self.lib = capi.load(path=lib)
         self._check = lambda rc: capi.check(rc, self.lib)
         self._ctor = dict(model=model, B=B, T=T, dt=dt, u_min=u_min, u_max=u_max, goal=goal, device=device, flags=flags,
-                          stream=stream, params=params, nx=nx, nu=nu, lq=lq, dtype=dtype, lib=lib, user_params=user_params)
+                          stream=stream, params=params, nx=nx, nu=nu, lq=lq, dtype=dtype, lib=lib, user_params=user_params,
+                          route=route, assume_cus=assume_cus)
         mid, mnx, mnu = _MODELS[model]
         if lq is not None:
             lq = [_c(a) for a in lq]
@@ -53,6 +54,7 @@ class BatchILQR:
         d.abi_version = capi.ABI_VERSION
         d.model, d.nx, d.nu, d.T, d.B, d.dt = mid, nx, nu, self.T, self.B, self.dt
         d.device, d.flags = device, flags
+        d.route, d.assume_cus = int(route), int(assume_cus)  # enum ilqr_route: equivalent kernels (A/B runs, bit-identity tests)
         d.dtype = {"f64": capi.DTYPE_F64, "f32": capi.DTYPE_F32}[dtype]
         self.dtype = dtype
         for name, val, n in (("u_min", u_min, nu), ("u_max", u_max, nu), ("goal", goal, nx)):

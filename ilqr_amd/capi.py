@@ -4,10 +4,13 @@ import os
 
 from . import _build
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MODEL_ACROBOT, MODEL_DOUBLE_INTEGRATOR, MODEL_LQ, MODEL_HOST, MODEL_USER = 0, 1, 2, 3, 4
 FLAG_FIXED_WORK, FLAG_BACKWARD_THREAD_PER_TRAJ, _FLAG_RESERVED_4, FLAG_UNFUSED, FLAG_ANALYTIC_DERIVATIVES, FLAG_STAGED, FLAG_REFERENCE_FIXES, FLAG_REGULARIZE_VXX = 1, 2, 4, 8, 16, 32, 64, 128
 DTYPE_F64, DTYPE_F32 = 0, 1
+# enum ilqr_route (include/ilqr_amd.h): which of several equivalent kernels a handle uses; 0 = by batch size
+ROUTE_TILE_PER_CU, ROUTE_TWO_TILES_PER_CU, ROUTE_WIDE_TILES = 1, 2, 3
+ROUTE_WIDE_ONE_PER_CU, ROUTE_WIDE_TWO_PER_CU, ROUTE_NO_COMPACTION, ROUTE_FULL_RECORDS, ROUTE_LQ_THREAD_ROLLOUT, ROUTE_BACKWARD_LDS = 4, 8, 16, 32, 64, 128
 NUM_STAGES = 5
 STAGE_NAMES = ("derivatives", "backward", "rollout", "accept", "solve")
 
@@ -27,7 +30,8 @@ class Desc(C.Structure):
                 ("T", C.c_int), ("B", C.c_int), ("dt", C.c_double), ("device", C.c_int),
                 ("flags", C.c_int), ("dtype", C.c_int), ("u_min", _dp), ("u_max", _dp), ("goal", _dp),
                 ("lq_A", _dp), ("lq_B", _dp), ("lq_Q", _dp), ("lq_R", _dp), ("lq_Qf", _dp),
-                ("stream", C.c_void_p), ("params", C.POINTER(Params)), ("user_params", _dp), ("n_user_params", C.c_int)]
+                ("stream", C.c_void_p), ("params", C.POINTER(Params)), ("user_params", _dp), ("n_user_params", C.c_int),
+                ("route", C.c_int), ("assume_cus", C.c_int)]
 
 
 # every symbol include/ilqr_amd.h declares: name -> (restype, argtypes)

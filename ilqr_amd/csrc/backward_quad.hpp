@@ -151,11 +151,17 @@ struct NoGate {
 // ONESET: one register set for the records instead of two (ring only): the load of a step is issued at the top of that step
 // and waited for -- ~150 exposed cycles per step, 72 registers less: what lets two tiles share a CU (k_solve_tile<.., 2>),
 // where the other tile's wavefronts fill the gap.
+// Arithmetic.  `real` (M::real) is what is STORED per knot: records, controls, gains.  The recursion itself -- Vx, Vxx, the Q
+// blocks, the box-QP, the value update -- runs in `creal` = double for every handle: an fp32 handle's chain is the fp64 chain
+// on float records (the mixed mode of DESIGN.md 3.6: float cannot resolve Quu = cuu + fu'Vxx fu once lambda has reached 0;
+// the chain is bound by instruction issue, not by bytes, so the price is the conversions).  The stored gains are the
+// roundings of the double ones; the warm start of the next box-QP is the STORED k (as the reference reads k[i+1] back).
 template <class M, class Gate, int RING_KB = ILQR_RING_KB, bool FIXES = true, bool ONESET = false>
 __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>& v, const M& model, const SolverParams& sp, int mode,
-                                              int tile, int lane, const typename M::real* __restrict__ lds_steps, Gate& gate,
+                                              int tile, int lane, const double* __restrict__ lds_steps, Gate& gate,
                                               const typename M::real* ring = nullptr) {
   using real = typename M::real;
+  using creal = double;
   static_assert(M::NX == 4, "quad kernel: one lane per state dimension");
   constexpr int NX = 4, NU = M::NU;
   using R = Rec<NX, NU>;
@@ -222,8 +228,8 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
   auto one_pass = [&]() __attribute__((always_inline)) {
     gate.begin_pass();
     // carried state: full Vxx / Vx in every lane
-    real Vx[4], Vxx[16], kprev[NU];
-    const real lam_r = (real)lambda;  // the regularisation of this pass in the handle's arithmetic (:367)
+    creal Vx[4], Vxx[16], kprev[NU];
+    const creal lam_r = (creal)lambda;  // the regularisation of this pass (:367)
     {
       gate.wait(T);
       if constexpr (RP) {
@@ -250,8 +256,8 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
     real* __restrict__ Kt_i = Kt + (unsigned)(((T - 1) * NU * NX + NU * s) * TW);  // this lane's K(:, s) and k of step i
     real* __restrict__ kt_i = kt + (unsigned)((T - 1) * NU * TW);
     auto step = [&](int i, const QuadStep<NU, real>& raw) -> bool {
-      struct {  // the record, unpacked (register renames: the loads have landed, see QuadStep)
-        real fx[16], fxc[4], fu[4 * NU], cu[NU], cuu[NU * NU], us[NU], cx, cxx[4], cxu[NU];
+      struct {  // the record, unpacked (register renames: the loads have landed, see QuadStep) and widened to the chain's arithmetic
+        creal fx[16], fxc[4], fu[4 * NU], cu[NU], cuu[NU * NU], us[NU], cx, cxx[4], cxu[NU];
       } d;
 #pragma unroll
       for (int e = 0; e < 8; e++) {
@@ -271,7 +277,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         d.fu[2 * e + 1] = raw.fu[e].y;
       }
       {
-        real tail[NU + NU * NU];
+        creal tail[NU + NU * NU];
 #pragma unroll
         for (int e = 0; e < (NU + NU * NU) / 2; e++) {
           tail[2 * e] = raw.tail[e].x;
@@ -289,70 +295,70 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         d.us[a] = raw.us[a];
       }
       // W = Vxx' * fx[:, s]   (column s)
-      real W[4];
+      creal W[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        real acc = 0;
+        creal acc = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) acc += Vxx[r + 4 * q] * d.fxc[q];
         W[r] = acc;
       }
       // Qxx[:, s] = cxx[:, s] + fx' W      :361
-      real Qxxc[4];
+      creal Qxxc[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        real acc = 0;
+        creal acc = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) acc += d.fx[q + 4 * r] * W[q];
         Qxxc[r] = d.cxx[r] + acc;
       }
       // Qx[s] = cx[s] + fx[:, s]' Vx'      :359
-      real Qxs;
+      creal Qxs;
       {
-        real acc = 0;
+        creal acc = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) acc += d.fxc[q] * Vx[q];
         Qxs = d.cx + acc;
       }
       // Qux[:, s] = cxu[s, :]' + fu' W     :362/:366
-      real Quxc[NU];
+      creal Quxc[NU];
 #pragma unroll
       for (int a = 0; a < NU; a++) {
-        real acc = 0;
+        creal acc = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) acc += d.fu[q + 4 * a] * W[q];
         Quxc[a] = d.cxu[a] + acc;
       }
       // replicated: Qu, wv = Vxx' fu, Quu, QuuF     :360, :363, :367
-      real Qu[NU], Quu[NU * NU], QuuF[NU * NU];
+      creal Qu[NU], Quu[NU * NU], QuuF[NU * NU];
 #pragma unroll
       for (int a = 0; a < NU; a++) {
-        real acc = 0;
+        creal acc = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) acc += d.fu[q + 4 * a] * Vx[q];
         Qu[a] = d.cu[a] + acc;
       }
 #pragma unroll
       for (int c = 0; c < NU; c++) {
-        real wv[4];
+        creal wv[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          real acc = 0;
+          creal acc = 0;
 #pragma unroll
           for (int q = 0; q < 4; q++) acc += Vxx[r + 4 * q] * d.fu[q + 4 * c];
           wv[r] = acc;
         }
 #pragma unroll
         for (int a = 0; a < NU; a++) {
-          real acc = 0;
+          creal acc = 0;
 #pragma unroll
           for (int q = 0; q < 4; q++) acc += d.fu[q + 4 * a] * wv[q];
           Quu[a + NU * c] = d.cuu[a + NU * c] + acc;
-          QuuF[a + NU * c] = (d.cuu[a + NU * c] + ((a == c) ? lam_r : real(0))) + acc;
+          QuuF[a + NU * c] = (d.cuu[a + NU * c] + ((a == c) ? lam_r : creal(0))) + acc;
         }
       }
       // opt-in (sp.fixes & 4, see k_backward_t): Quu_reg = Quu + lambda fu'fu, Qux_reg[:, s] = Qux[:, s] + lambda fu'fx[:, s]
-      real Quxr[NU];
+      creal Quxr[NU];
 #pragma unroll
       for (int a = 0; a < NU; a++) Quxr[a] = Quxc[a];
       const bool reg_vxx = FIXES && (sp.fixes & 4) != 0;
@@ -361,19 +367,19 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         for (int a = 0; a < NU; a++) {
 #pragma unroll
           for (int c = 0; c < NU; c++) {
-            real acc = 0;
+            creal acc = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) acc += d.fu[q + 4 * a] * d.fu[q + 4 * c];
             QuuF[a + NU * c] = Quu[a + NU * c] + lam_r * acc;
           }
-          real acc = 0;
+          creal acc = 0;
 #pragma unroll
           for (int q = 0; q < 4; q++) acc += d.fu[q + 4 * a] * d.fxc[q];
           Quxr[a] = Quxc[a] + lam_r * acc;
         }
       }
       // :369  box-QP (replicated in the quad)
-      real lo[NU], hi[NU];
+      creal lo[NU], hi[NU];
 #pragma unroll
       for (int a = 0; a < NU; a++) {
         lo[a] = model.u_min[a] - d.us[a];
@@ -381,18 +387,18 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       }
       // :371  a failed QP ends the pass.  No early return: the rest of the step is computed
       // anyway (its results are discarded) so that the vmcnt wait below sits on every path.
-      struct { real x[NU]; } qp;
-      real Kc[NU];
+      struct { creal x[NU]; } qp;
+      creal Kc[NU];
       bool ok;
-      real k_scale = 0;    // (NU == 1: what K is scaled from, see the exchange below)
+      creal k_scale = 0;    // (NU == 1: what K is scaled from, see the exchange below)
       if constexpr (NU == 1) {
         int free0;
-        real minv;
-        QP1StateT<real> q1;
+        creal minv;
+        QP1StateT<creal> q1;
         qp1_begin<false>(QuuF[0], Qu[0], kprev[0], lo[0], hi[0], q1, FIXES && (sp.fixes & 2) != 0);
         if (__builtin_expect(!qp1_search_quad(q1, s, lane, lds_steps), 0)) {  // fallback: rare, out of line
           q1.step = 1;
-          q1.x1 = qp1_trial(q1, real(1));
+          q1.x1 = qp1_trial(q1, creal(1));
           q1.v1 = qp1_value(q1, q1.x1);
           qp1_backtrack_seq(q1);
         }
@@ -401,30 +407,30 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         if (goes_on)  // the QP goes on (rare early in a solve, a quarter of the steps of some tiles later)
           ok = qp1_continue(
                    q1,
-                   [&](QP1StateT<real>& qs) __attribute__((always_inline)) {
+                   [&](QP1StateT<creal>& qs) __attribute__((always_inline)) {
                      if (__builtin_expect(!qp1_search_quad(qs, s, lane, lds_steps), 0)) {
                        qp1_line_search_seq(qs);
                      }
                    },
                    qp.x[0], free0) >= 1;
         // :373-385  K = -(R^-1 R^-T) Qux on a free control, 0 on a clamped one: one scale for the row (0 x Qux = +-0)
-        k_scale = free0 ? -minv : real(0);
+        k_scale = free0 ? -minv : creal(0);
         Kc[0] = k_scale * Quxr[0];
       } else if constexpr (NU == 2) {
         // m = 2: the scalarised solver (boxqp.hpp: box_qp2); K[:, s] = -(R^-1 R^-T) Qux[free, s] scattered to the free rows (:373-385)
-        BoxQP2Result<real> r;
+        BoxQP2Result<creal> r;
         box_qp2(QuuF, Qu, kprev, lo, hi, r, FIXES && (sp.fixes & 2) != 0);
         ok = r.result >= 1;
         qp.x[0] = r.x[0];
         qp.x[1] = r.x[1];
         const bool both = r.free0 & r.free1;
-        const real q0 = r.free0 ? Quxr[0] : Quxr[1];  // rows_w_ind(Qux_reg, v_free)(:, s), by rank
-        const real kA = (r.nfR == 2) ? (-r.m00 * q0 + -r.m01 * Quxr[1]) : -r.m00 * q0;  // rank 0 (the second term only if both are free)
-        const real kB = -r.m01 * Quxr[0] + -r.m11 * Quxr[1];                              // rank 1
-        Kc[0] = r.free0 ? kA : real(0);
-        Kc[1] = r.free1 ? (both ? kB : kA) : real(0);
+        const creal q0 = r.free0 ? Quxr[0] : Quxr[1];  // rows_w_ind(Qux_reg, v_free)(:, s), by rank
+        const creal kA = (r.nfR == 2) ? (-r.m00 * q0 + -r.m01 * Quxr[1]) : -r.m00 * q0;  // rank 0 (the second term only if both are free)
+        const creal kB = -r.m01 * Quxr[0] + -r.m11 * Quxr[1];                              // rank 1
+        Kc[0] = r.free0 ? kA : creal(0);
+        Kc[1] = r.free1 ? (both ? kB : kA) : creal(0);
       } else {
-        BoxQPResult<NU, real> r;
+        BoxQPResult<NU, creal> r;
         box_qp<NU>(QuuF, Qu, kprev, lo, hi, r, FIXES && (sp.fixes & 2) != 0);
         ok = r.result >= 1;
 #pragma unroll
@@ -440,12 +446,12 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
           nf += r.v_free[a] ? 1 : 0;
         }
         if (nf > 0) {
-          real Minv[NU * NU], qf[NU];
+          creal Minv[NU * NU], qf[NU];
           rinv_rinvT<NU>(r.nfR, r.R, Minv);
           const int nuse = (nf < r.nfR) ? nf : r.nfR;
 #pragma unroll
           for (int a = 0; a < NU; a++) {
-            real val = 0;
+            creal val = 0;
 #pragma unroll
             for (int j = 0; j < NU; j++)
               if (r.v_free[j] && rank[j] == a) val = Quxr[j];
@@ -454,11 +460,11 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
 #pragma unroll
           for (int j = 0; j < NU; j++)
             if (r.v_free[j] && rank[j] < nuse) {
-              real acc = 0;
+              creal acc = 0;
 #pragma unroll
               for (int a = 0; a < NU; a++)
                 if (a < nuse) {
-                  real mrow = 0;
+                  creal mrow = 0;
 #pragma unroll
                   for (int rr = 0; rr < NU; rr++)
                     if (rr == rank[j]) mrow = Minv[rr + NU * a];
@@ -471,33 +477,33 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       if (!ok) diverge = i;
       // :388-389
       {
-        real d0 = 0;
+        creal d0 = 0;
 #pragma unroll
         for (int a = 0; a < NU; a++) d0 += qp.x[a] * Qu[a];
         if (ok) dV0 += (double)d0;
-        real d1 = 0;
+        creal d1 = 0;
 #pragma unroll
         for (int c = 0; c < NU; c++) {
-          real r = 0;
+          creal r = 0;
 #pragma unroll
-          for (int a = 0; a < NU; a++) r += (real(0.5) * qp.x[a]) * Quu[a + NU * c];
+          for (int a = 0; a < NU; a++) r += (creal(0.5) * qp.x[a]) * Quu[a + NU * c];
           d1 += r * qp.x[c];
         }
         if (ok) dV1 += (double)d1;
       }
       // T1s[c] = (K' Quu)[s, c]
-      real T1s[NU];
+      creal T1s[NU];
 #pragma unroll
       for (int c = 0; c < NU; c++) {
-        real acc = 0;
+        creal acc = 0;
 #pragma unroll
         for (int q = 0; q < NU; q++) acc += Kc[q] * Quu[q + NU * c];
         T1s[c] = acc;
       }
       // :391  Vx[s]
-      real Vxs;
+      creal Vxs;
       {
-        real t1 = 0, t2 = 0, t3 = 0;
+        creal t1 = 0, t2 = 0, t3 = 0;
 #pragma unroll
         for (int c = 0; c < NU; c++) {
           t1 += T1s[c] * qp.x[c];
@@ -507,7 +513,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         Vxs = ((Qxs + t1) + t2) + t3;
       }
       // exchange K, Qux, K'Quu columns inside the quad
-      real Kall[NU][4], Qall[NU][4], T1all[NU][4];
+      creal Kall[NU][4], Qall[NU][4], T1all[NU][4];
 #pragma unroll
       for (int a = 0; a < NU; a++) quad_gather(Quxc[a], Qall[a]);  // (does not wait for the box-QP)
       if (NU == 1 && !reg_vxx) {
@@ -522,16 +528,16 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       for (int c = 0; c < NU; c++)  // (K'Quu)[r, c] for every r, from the gathered K (no third exchange)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          real acc = 0;
+          creal acc = 0;
 #pragma unroll
           for (int q = 0; q < NU; q++) acc += Kall[q][r] * Quu[q + NU * c];
           T1all[c][r] = acc;
         }
       // :392  Vn[r, s] = Qxx[r,s] + (K'Quu)[r,:] K[:,s] + K[:,r]' Qux[:,s] + Qux[:,r]' K[:,s]
-      real Vn[4];
+      creal Vn[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        real t1 = 0, t2 = 0, t3 = 0;
+        creal t1 = 0, t2 = 0, t3 = 0;
 #pragma unroll
         for (int q = 0; q < NU; q++) {
           t1 += T1all[q][r] * Kc[q];
@@ -541,10 +547,10 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         Vn[r] = ((Qxxc[r] + t1) + t2) + t3;
       }
       // all-gather, then :393 symmetrise (every lane keeps the full matrix)
-      real Vf[16];
+      creal Vf[16];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        real col[4];
+        creal col[4];
         quad_gather(Vn[r], col);  // col[c] = Vn[r, c]
 #pragma unroll
         for (int c = 0; c < 4; c++) Vf[r + 4 * c] = col[c];
@@ -556,7 +562,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
         Vxx[r + 4 * r] = Vf[r + 4 * r];
 #pragma unroll
         for (int c = r + 1; c < 4; c++) {
-          const real sym = real(0.5) * (Vf[r + 4 * c] + Vf[c + 4 * r]);
+          const creal sym = creal(0.5) * (Vf[r + 4 * c] + Vf[c + 4 * r]);
           Vxx[r + 4 * c] = sym;
           Vxx[c + 4 * r] = sym;
         }
@@ -564,10 +570,11 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       quad_gather(Vxs, Vx);
       // :405-412 term of the gradient norm for this step (summed here in descending t)
       {
-        real mx = 0;
+        creal mx = 0;
 #pragma unroll
         for (int a = 0; a < NU; a++) {
-          const real val = abs_of(qp.x[a]) * ((RP && NU == 1) ? raw.usw : recip(abs_of(d.us[a]) + 1));
+          // (the weight 1 / (|u| + 1) in the STORED arithmetic on every route: the ring's producers computed it there)
+          const creal val = abs_of(qp.x[a]) * ((RP && NU == 1) ? (creal)raw.usw : (creal)recip((real)abs_of(d.us[a]) + real(1)));
           mx = (a == 0 || val > mx) ? val : mx;
         }
         if (ok) gacc += (double)mx;
@@ -586,12 +593,12 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
       if (ok) {
 #pragma unroll
         for (int a = 0; a < NU; a++) {
-          kprev[a] = qp.x[a];
-          Kt_i[a * TW] = Kc[a];
+          kprev[a] = (creal)(real)qp.x[a];  // the stored gain, as the reference reads k[i + 1] back (:369)
+          Kt_i[a * TW] = (real)Kc[a];
         }
         if (s == 0) {
 #pragma unroll
-          for (int a = 0; a < NU; a++) kt_i[a * TW] = qp.x[a];
+          for (int a = 0; a < NU; a++) kt_i[a * TW] = (real)qp.x[a];
         }
       }
       // (running per-lane pointers, not base + i * stride: the scalar index cost two SGPRs whose zero high word the
@@ -707,6 +714,7 @@ __device__ __forceinline__ void backward_quad(const BatchViewT<typename M::real>
   }
 }
 
+// (the chain runs in double for every handle: the double table)
 template <class real>
 __device__ __forceinline__ void load_step_table(real* lds_steps) {
   const real* tab = step_table(real(0));
@@ -718,7 +726,7 @@ __device__ __forceinline__ void load_step_table(real* lds_steps) {
 template <class M>
 __global__ __launch_bounds__(64) void k_backward_q(BatchViewT<typename M::real> v, M model, SolverParams sp, int mode) {
   using real = typename M::real;
-  __shared__ real lds_steps[104];  // backtracking step sizes (per-lane indexed -> LDS, not constant cache)
+  __shared__ double lds_steps[104];  // backtracking step sizes (per-lane indexed -> LDS, not constant cache)
   load_step_table(lds_steps);
   NoGate gate;
   if (sp.fixes)

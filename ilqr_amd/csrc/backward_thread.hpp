@@ -13,7 +13,8 @@ namespace ilqr {
 //         the pass diverges (ilqr_core.cpp:136-150), then the gradient-norm test (:153-159).
 template <class M>
 __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> v, M model, SolverParams sp, int mode) {
-  using real = typename M::real;
+  using real = typename M::real;  // what is stored per knot
+  using creal = double;           // what the recursion computes in (backward_quad.hpp: the mixed mode of fp32 handles)
   constexpr int NX = M::NX, NU = M::NU;
   using R = Rec<NX, NU>;
   const int b = blockIdx.x * 64 + threadIdx.x;
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
   bool done = false;
   double dV0 = 0, dV1 = 0;  // (per-trajectory accumulators: double in both modes)
   while (true) {
-    real Vx[NX], Vxx[NX * NX], kprev[NU];
+    creal Vx[NX], Vxx[NX * NX], kprev[NU];
 #pragma unroll
     for (int i = 0; i < NX; i++) Vx[i] = rec(T, R::CX + i);  // :353
 #pragma unroll
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
     diverge = 0;
 
     for (int i = T - 1; i >= 0; i--) {
-      real fx[NX * NX], fu[NX * NU], cx[NX], cu[NU], cxx[NX * NX], cxu[NX * NU], cuu[NU * NU], us[NU];
+      creal fx[NX * NX], fu[NX * NU], cx[NX], cu[NU], cxx[NX * NX], cxu[NX * NU], cuu[NU * NU], us[NU];
 #pragma unroll
       for (int e = 0; e < NX * NX; e++) fx[e] = rec(i, R::FX + e);
 #pragma unroll
@@ -58,19 +59,19 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
 #pragma unroll
       for (int j = 0; j < NU; j++) us[j] = v.us[tidx(tile, i, j, l, T, NU)];
 
-      real Qx[NX], Qu[NU], Qxx[NX * NX], Qux[NU * NX], Quu[NU * NU], QuuF[NU * NU];
-      real A1[NX * NX], A2[NU * NX];
+      creal Qx[NX], Qu[NU], Qxx[NX * NX], Qux[NU * NX], Quu[NU * NU], QuuF[NU * NU];
+      creal A1[NX * NX], A2[NU * NX];
       // :359-360
 #pragma unroll
       for (int a = 0; a < NX; a++) {
-        real acc = 0;
+        creal acc = 0;
 #pragma unroll
         for (int q = 0; q < NX; q++) acc += fx[q + NX * a] * Vx[q];
         Qx[a] = cx[a] + acc;
       }
 #pragma unroll
       for (int a = 0; a < NU; a++) {
-        real acc = 0;
+        creal acc = 0;
 #pragma unroll
         for (int q = 0; q < NX; q++) acc += fu[q + NX * a] * Vx[q];
         Qu[a] = cu[a] + acc;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
       for (int a = 0; a < NX; a++)
 #pragma unroll
         for (int c = 0; c < NX; c++) {
-          real acc = 0;
+          creal acc = 0;
 #pragma unroll
           for (int q = 0; q < NX; q++) acc += fx[q + NX * a] * Vxx[q + NX * c];
           A1[a + NX * c] = acc;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
       for (int a = 0; a < NX; a++)
 #pragma unroll
         for (int c = 0; c < NX; c++) {
-          real acc = 0;
+          creal acc = 0;
 #pragma unroll
           for (int q = 0; q < NX; q++) acc += A1[a + NX * q] * fx[q + NX * c];
           Qxx[a + NX * c] = cxx[a + NX * c] + acc;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
       for (int a = 0; a < NU; a++)
 #pragma unroll
         for (int c = 0; c < NX; c++) {
-          real acc = 0;
+          creal acc = 0;
 #pragma unroll
           for (int q = 0; q < NX; q++) acc += fu[q + NX * a] * Vxx[q + NX * c];
           A2[a + NU * c] = acc;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
       for (int a = 0; a < NU; a++)
 #pragma unroll
         for (int c = 0; c < NX; c++) {
-          real acc = 0;
+          creal acc = 0;
 #pragma unroll
           for (int q = 0; q < NX; q++) acc += A2[a + NU * q] * fx[q + NX * c];
           Qux[a + NU * c] = cxu[c + NX * a] + acc;
@@ -118,31 +119,31 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
       for (int a = 0; a < NU; a++)
 #pragma unroll
         for (int c = 0; c < NU; c++) {
-          real acc = 0;
+          creal acc = 0;
 #pragma unroll
           for (int q = 0; q < NX; q++) acc += A2[a + NU * q] * fu[q + NX * c];
           Quu[a + NU * c] = cuu[a + NU * c] + acc;
-          QuuF[a + NU * c] = (cuu[a + NU * c] + ((a == c) ? (real)lambda : real(0))) + acc;
+          QuuF[a + NU * c] = (cuu[a + NU * c] + ((a == c) ? (creal)lambda : creal(0))) + acc;
         }
       // opt-in (sp.fixes & 4): lambda regularises Vxx' ([Tassa 2012] eq. 10) instead of Quu:
       // Quu_reg = Quu + lambda fu'fu, Qux_reg = Qux + lambda fu'fx; the value update keeps Quu, Qux
-      real Quxr[NU * NX];
+      creal Quxr[NU * NX];
 #pragma unroll
       for (int e = 0; e < NU * NX; e++) Quxr[e] = Qux[e];
       if (sp.fixes & 4) {
-        const real lam = (real)lambda;
+        const creal lam = (creal)lambda;
 #pragma unroll
         for (int a = 0; a < NU; a++) {
 #pragma unroll
           for (int c = 0; c < NU; c++) {
-            real acc = 0;
+            creal acc = 0;
 #pragma unroll
             for (int q = 0; q < NX; q++) acc += fu[q + NX * a] * fu[q + NX * c];
             QuuF[a + NU * c] = Quu[a + NU * c] + lam * acc;
           }
 #pragma unroll
           for (int c = 0; c < NX; c++) {
-            real acc = 0;
+            creal acc = 0;
 #pragma unroll
             for (int q = 0; q < NX; q++) acc += fu[q + NX * a] * fx[q + NX * c];
             Quxr[a + NU * c] = Qux[a + NU * c] + lam * acc;
@@ -151,13 +152,13 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
       }
 
       // :369
-      real lo[NU], hi[NU];
+      creal lo[NU], hi[NU];
 #pragma unroll
       for (int j = 0; j < NU; j++) {
         lo[j] = model.u_min[j] - us[j];
         hi[j] = model.u_max[j] - us[j];
       }
-      BoxQPResult<NU, real> qp;
+      BoxQPResult<NU, creal> qp;
       box_qp<NU>(QuuF, Qu, kprev, lo, hi, qp, (sp.fixes & 2) != 0);
       if (qp.result < 1) {  // :371
         diverge = i;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
       }
 
       // :373-385
-      real K[NU * NX];
+      creal K[NU * NX];
 #pragma unroll
       for (int e = 0; e < NU * NX; e++) K[e] = 0;
       {
@@ -176,15 +177,15 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
           nf += qp.v_free[j] ? 1 : 0;
         }
         if (nf > 0) {
-          real Minv[NU * NU];
+          creal Minv[NU * NU];
           rinv_rinvT<NU>(qp.nfR, qp.R, Minv);
           const int nuse = (nf < qp.nfR) ? nf : qp.nfR;
 #pragma unroll
           for (int c = 0; c < NX; c++) {
-            real qf[NU];  // rows_w_ind(Qux_reg, v_free)(:, c)
+            creal qf[NU];  // rows_w_ind(Qux_reg, v_free)(:, c)
 #pragma unroll
             for (int a = 0; a < NU; a++) {
-              real val = 0;
+              creal val = 0;
 #pragma unroll
               for (int j = 0; j < NU; j++)
                 if (qp.v_free[j] && rank[j] == a) val = Quxr[j + NU * c];
@@ -193,11 +194,11 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
 #pragma unroll
             for (int j = 0; j < NU; j++) {
               if (qp.v_free[j] && rank[j] < nuse) {
-                real acc = 0;
+                creal acc = 0;
 #pragma unroll
                 for (int a = 0; a < NU; a++)
                   if (a < nuse) {
-                    real mrow = 0;  // Minv[rank[j]][a]
+                    creal mrow = 0;  // Minv[rank[j]][a]
 #pragma unroll
                     for (int r = 0; r < NU; r++)
                       if (r == rank[j]) mrow = Minv[r + NU * a];
@@ -212,36 +213,36 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
 
       // :388-389
       {
-        real d0 = 0;
+        creal d0 = 0;
 #pragma unroll
         for (int j = 0; j < NU; j++) d0 += qp.x[j] * Qu[j];
         dV0 += (double)d0;
-        real d1 = 0;
+        creal d1 = 0;
 #pragma unroll
         for (int c = 0; c < NU; c++) {
-          real r = 0;
+          creal r = 0;
 #pragma unroll
-          for (int a = 0; a < NU; a++) r += (real(0.5) * qp.x[a]) * Quu[a + NU * c];
+          for (int a = 0; a < NU; a++) r += (creal(0.5) * qp.x[a]) * Quu[a + NU * c];
           d1 += r * qp.x[c];
         }
         dV1 += (double)d1;
       }
       // :391-393
       {
-        real T1[NX * NU];  // K' Quu  (NX x NU)
+        creal T1[NX * NU];  // K' Quu  (NX x NU)
 #pragma unroll
         for (int a = 0; a < NX; a++)
 #pragma unroll
           for (int c = 0; c < NU; c++) {
-            real acc = 0;
+            creal acc = 0;
 #pragma unroll
             for (int q = 0; q < NU; q++) acc += K[q + NU * a] * Quu[q + NU * c];
             T1[a + NX * c] = acc;
           }
-        real Vxn[NX], Vn[NX * NX];
+        creal Vxn[NX], Vn[NX * NX];
 #pragma unroll
         for (int a = 0; a < NX; a++) {
-          real t1 = 0, t2 = 0, t3 = 0;
+          creal t1 = 0, t2 = 0, t3 = 0;
 #pragma unroll
           for (int c = 0; c < NU; c++) {
             t1 += T1[a + NX * c] * qp.x[c];
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
         for (int a = 0; a < NX; a++)
 #pragma unroll
           for (int c = 0; c < NX; c++) {
-            real t1 = 0, t2 = 0, t3 = 0;
+            creal t1 = 0, t2 = 0, t3 = 0;
 #pragma unroll
             for (int q = 0; q < NU; q++) {
               t1 += T1[a + NX * q] * K[q + NU * c];
@@ -267,17 +268,17 @@ __global__ __launch_bounds__(64) void k_backward_t(BatchViewT<typename M::real> 
         for (int a = 0; a < NX; a++) {
           Vx[a] = Vxn[a];
 #pragma unroll
-          for (int c = 0; c < NX; c++) Vxx[a + NX * c] = real(0.5) * (Vn[a + NX * c] + Vn[c + NX * a]);
+          for (int c = 0; c < NX; c++) Vxx[a + NX * c] = creal(0.5) * (Vn[a + NX * c] + Vn[c + NX * a]);
         }
       }
       // :396-397
 #pragma unroll
       for (int j = 0; j < NU; j++) {
-        v.kff[tidx(tile, i, j, l, T, NU)] = qp.x[j];
-        kprev[j] = qp.x[j];
+        v.kff[tidx(tile, i, j, l, T, NU)] = (real)qp.x[j];
+        kprev[j] = (creal)(real)qp.x[j];  // the stored gain, as the reference reads k[i + 1] back (:369)
       }
 #pragma unroll
-      for (int e = 0; e < NU * NX; e++) v.Kfb[tidx(tile, i, e, l, T, NU * NX)] = K[e];
+      for (int e = 0; e < NU * NX; e++) v.Kfb[tidx(tile, i, e, l, T, NU * NX)] = (real)K[e];
     }  // for i
 
     if (mode == 0) {

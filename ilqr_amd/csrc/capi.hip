@@ -109,9 +109,8 @@ struct ilqr_batch {
   int* d_perm = nullptr;       // [Bp]
   void* perm_scratch = nullptr;  // as large as the largest per-knot array
   size_t perm_scratch_bytes = 0;
-  // Route switches for A/B runs and the bit-identity tests, read from the environment ONCE, in ilqr_create: a handle
-  // never changes kernels between calls.  (ILQR_AMD_STAGED / _UNFUSED / _FUSED=1|2 / _BACKWARD_W1 / _LQ_THREAD_ROLLOUT /
-  // _FULL_RECORDS / _NUM_CUS)
+  // Route choices for A/B runs and the bit-identity tests: ilqr_desc.route, fixed at ilqr_create -- a handle never changes
+  // kernels between calls, and nothing is read from the environment
   struct {
     bool staged = false, unfused = false, backward_w1 = false, lq_thread_rollout = false, full_records = false, no_compaction = false;
     int fused = 0;  // 0 = by batch size
@@ -429,7 +428,7 @@ static int with_generic_model(ilqr_batch* h, F&& f) {
   return fail(ILQR_ERR_UNSUPPORTED, "model %d has no generic device kernels", h->model);
 }
 // generic path (generic.hpp): what = RG_INIT / RG_SEARCH / RG_COMMIT.  The LQ model rolls out on the
-// matrix cores (k_rollout_lq, one wavefront per trajectory); ILQR_AMD_LQ_THREAD_ROLLOUT=1 selects the
+// matrix cores (k_rollout_lq, one wavefront per trajectory); ILQR_ROUTE_LQ_THREAD_ROLLOUT selects the
 // generic thread-per-rollout kernel (same results bit for bit; kept as the cross-check and as the
 // template for device models without matrix structure).
 template <class M>
@@ -563,7 +562,7 @@ static int launch_backward(ilqr_batch* h, int mode) {
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_BACKWARD, &ev)) return rc;
   if (h->aos) {
-    // the register-resident kernel, two (nx > 16) or more (nx <= 16) wavefronts per SIMD; ILQR_AMD_BACKWARD_W1 forces round
+    // the register-resident kernel, two (nx > 16) or more (nx <= 16) wavefronts per SIMD; ILQR_ROUTE_BACKWARD_LDS forces round
     // 1's LDS kernel -- the two give bit-identical results (tests/test_gpu_generic_backward.py)
     const double* crec = h->records_partial ? h->const_rec : nullptr;
     if (h->env.backward_w1)
@@ -600,7 +599,7 @@ static int launch_backward(ilqr_batch* h, int mode) {
 //                                      or the one-producer variant, two per CU) up to two tiles per CU, beyond that
 //                                      k_derivatives + k_backward_q with the records in HBM
 //   ILQR_FLAG_UNFUSED, AoS (generic) models   always the two-kernel route
-// ILQR_AMD_FUSED=1 / 2 / 3 force a variant for A/B runs and the bit-identity tests.
+// ilqr_desc.route (ILQR_ROUTE_TILE_PER_CU / TWO_TILES_PER_CU / WIDE_TILES) forces a variant for A/B runs and the bit-identity tests.
 static int fused_variant(const ilqr_batch* h) {  // 0: two kernels, 1: one tile per CU, 2: two tiles per CU, 3: wide tiles (64 trajectories, one per CU)
   if (!use_quad_backward(h) || h->aos || (h->flags & ILQR_FLAG_UNFUSED) || h->env.unfused) return 0;
   const bool staged = (h->flags & ILQR_FLAG_STAGED) || h->env.staged;
@@ -648,7 +647,7 @@ static int launch_accept(ilqr_batch* h) {
 }
 
 // Whole iterations per tile in one persistent kernel (k_solve_tile): the one-block-per-CU regime of the fused
-// kernel.  ILQR_FLAG_STAGED / ILQR_AMD_STAGED=1: per-stage launches instead (A/B runs, the bit-identity tests).
+// kernel.  ILQR_FLAG_STAGED: per-stage launches instead (A/B runs, the bit-identity tests).
 static bool use_persistent(const ilqr_batch* h) {
   if (h->aos || (h->flags & ILQR_FLAG_STAGED) || h->env.staged) return false;
   return fused_variant(h) != 0;
@@ -751,16 +750,16 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, d->device) == hipSuccess && khz > 0) h->wall_clock_khz = khz;
   }
-  h->env.staged = getenv("ILQR_AMD_STAGED") != nullptr;
-  h->env.unfused = getenv("ILQR_AMD_UNFUSED") != nullptr;
-  h->env.backward_w1 = getenv("ILQR_AMD_BACKWARD_W1") != nullptr;
-  h->env.lq_thread_rollout = getenv("ILQR_AMD_LQ_THREAD_ROLLOUT") != nullptr;
-  h->env.full_records = getenv("ILQR_AMD_FULL_RECORDS") != nullptr;
-  h->env.no_compaction = getenv("ILQR_AMD_NO_COMPACTION") != nullptr;
-  if (const char* f = getenv("ILQR_AMD_FUSED")) h->env.fused = (f[0] == '3') ? 3 : (f[0] == '2') ? 2 : 1;
-  if (const char* w = getenv("ILQR_AMD_WIDE_OCC")) h->env.wide_occ = (w[0] == '2') ? 2 : 1;
-  if (const char* e = getenv("ILQR_AMD_NUM_CUS"))  // tests: exercise the batch-size thresholds of the route selection on small batches
-    if (atoi(e) > 0) h->num_cus = atoi(e);
+  // route choices come with the descriptor (ilqr_desc.route, include/ilqr_amd.h): the library reads no environment
+  h->env.staged = false;
+  h->env.unfused = false;
+  h->env.backward_w1 = (d->route & ILQR_ROUTE_BACKWARD_LDS) != 0;
+  h->env.lq_thread_rollout = (d->route & ILQR_ROUTE_LQ_THREAD_ROLLOUT) != 0;
+  h->env.full_records = (d->route & ILQR_ROUTE_FULL_RECORDS) != 0;
+  h->env.no_compaction = (d->route & ILQR_ROUTE_NO_COMPACTION) != 0;
+  h->env.fused = d->route & 3;
+  h->env.wide_occ = (d->route & ILQR_ROUTE_WIDE_ONE_PER_CU) ? 1 : (d->route & ILQR_ROUTE_WIDE_TWO_PER_CU) ? 2 : 0;
+  if (d->assume_cus > 0) h->num_cus = d->assume_cus;
   h->device = d->device;
   if (d->stream) {
     h->stream = (hipStream_t)d->stream;

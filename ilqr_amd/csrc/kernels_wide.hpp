@@ -38,7 +38,7 @@ struct WideRing {
 template <class real, int NX, int NU, int kProd, int RING_KB = 148>
 struct WideShared {
   using RS = WideRing<NX, NU, real, RING_KB>;
-  real steps[104];
+  double steps[104];  // (the chain runs in double for every handle, backward_quad.hpp)
   real ring[RS::SLOTS * RS::ELEMS];
   int rounds_done[kProd];
   int consumer_at;
@@ -142,9 +142,10 @@ __device__ __forceinline__ bool qp1_search_lane(QP1StateT<real>& q, const real* 
 // Structure and arithmetic of backward_quad (kernels.hpp) with the column index s as a loop instead of a lane.
 template <class M, class Gate, class RS>
 __device__ __forceinline__ void backward_wide(const BatchViewT<typename M::real>& v, const M& model, const SolverParams& sp, int mode, int wtile,
-                                              int lane, const typename M::real* __restrict__ lds_steps, Gate& gate,
+                                              int lane, const double* __restrict__ lds_steps, Gate& gate,
                                               const typename M::real* __restrict__ ring) {
-  using real = typename M::real;
+  using real = typename M::real;   // what is stored per knot
+  using creal = double;            // what the recursion computes in (backward_quad.hpp: the mixed mode of fp32 handles)
   static_assert(M::NX == 4 && M::NU == 1, "wide tiles: nx = 4, nu = 1");
   using R = Rec<4, 1>;
   typedef real real2_t __attribute__((ext_vector_type(2)));
@@ -165,8 +166,8 @@ __device__ __forceinline__ void backward_wide(const BatchViewT<typename M::real>
   double dV0 = 0, dV1 = 0, gacc = 0;
   auto one_pass = [&]() __attribute__((always_inline)) {
     gate.begin_pass();
-    real Vx[4], Vxx[16], kprev;
-    const real lam_r = (real)lambda;
+    creal Vx[4], Vxx[16], kprev;
+    const creal lam_r = (creal)lambda;
     {
       gate.wait(T);
       lds_cd* r = (lds_cd*)(ring + gate.slot(T) * RS::ELEMS + lane * 2);
@@ -218,7 +219,7 @@ __device__ __forceinline__ void backward_wide(const BatchViewT<typename M::real>
       fetch(i, cur);
       lds_cd* r = (lds_cd*)(ring + cur.slot * RS::ELEMS + lane * 2);
       auto pair = [&](int e) { return *(lds_cd2*)(r + (e >> 1) * RS::ROW); };
-      real fx[16], fu[4], cx[4], cxu[4];
+      creal fx[16], fu[4], cx[4], cxu[4];
 #pragma unroll
       for (int e = 0; e < 16; e++) fx[e] = cur.fx[e];
 #pragma unroll
@@ -227,72 +228,72 @@ __device__ __forceinline__ void backward_wide(const BatchViewT<typename M::real>
         cx[e] = cur.cx[e];
         cxu[e] = cur.cxu[e];
       }
-      const real cu = cur.cu, cuu = cur.cuu, us = cur.us, usw = cur.usw;
+      const creal cu = cur.cu, cuu = cur.cuu, us = cur.us, usw = cur.usw;
       // replicated in the quad kernel: Qu, wv = Vxx' fu, Quu, QuuF     :360, :363, :367
-      real Qu, Quu, QuuF;
+      creal Qu, Quu, QuuF;
       {
-        real acc = 0;
+        creal acc = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) acc += fu[q] * Vx[q];
         Qu = cu + acc;
-        real wv[4];
+        creal wv[4];
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
-          real a2 = 0;
+          creal a2 = 0;
 #pragma unroll
           for (int q = 0; q < 4; q++) a2 += Vxx[rr + 4 * q] * fu[q];
           wv[rr] = a2;
         }
-        real a3 = 0;
+        creal a3 = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) a3 += fu[q] * wv[q];
         Quu = cuu + a3;
         QuuF = (cuu + lam_r) + a3;
       }
       // the quad kernel's lane s, for s = 0..3: W = Vxx' fx[:, s];  Qxx[:, s], Qx[s], Qux[s]     :359, :361, :362
-      real Qxx[16], Qx[4], Qux[4];
+      creal Qxx[16], Qx[4], Qux[4];
 #pragma unroll
       for (int s = 0; s < 4; s++) {
         const real2_t c0 = pair(R::CXX + 4 * s), c1 = pair(R::CXX + 4 * s + 2);
-        const real cxxc[4] = {c0.x, c0.y, c1.x, c1.y};
-        real W[4];
+        const creal cxxc[4] = {c0.x, c0.y, c1.x, c1.y};
+        creal W[4];
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
-          real acc = 0;
+          creal acc = 0;
 #pragma unroll
           for (int q = 0; q < 4; q++) acc += Vxx[rr + 4 * q] * fx[q + 4 * s];
           W[rr] = acc;
         }
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
-          real acc = 0;
+          creal acc = 0;
 #pragma unroll
           for (int q = 0; q < 4; q++) acc += fx[q + 4 * rr] * W[q];
           Qxx[rr + 4 * s] = cxxc[rr] + acc;
         }
         {
-          real acc = 0;
+          creal acc = 0;
 #pragma unroll
           for (int q = 0; q < 4; q++) acc += fx[q + 4 * s] * Vx[q];
           Qx[s] = cx[s] + acc;
         }
         {
-          real acc = 0;
+          creal acc = 0;
 #pragma unroll
           for (int q = 0; q < 4; q++) acc += fu[q] * W[q];
           Qux[s] = cxu[s] + acc;
         }
       }
       // :369  box-QP
-      const real lo = model.u_min[0] - us, hi = model.u_max[0] - us;
-      real x;
+      const creal lo = model.u_min[0] - us, hi = model.u_max[0] - us;
+      creal x;
       int free0;
-      real minv;
-      QP1StateT<real> q1;
+      creal minv;
+      QP1StateT<creal> q1;
       qp1_begin<false>(QuuF, Qu, kprev, lo, hi, q1, false);
       if (__builtin_expect(!qp1_search_lane(q1, lds_steps), 0)) {
         q1.step = 1;
-        q1.x1 = qp1_trial(q1, real(1));
+        q1.x1 = qp1_trial(q1, creal(1));
         q1.v1 = qp1_value(q1, q1.x1);
         qp1_backtrack_seq(q1);
       }
@@ -301,44 +302,44 @@ __device__ __forceinline__ void backward_wide(const BatchViewT<typename M::real>
       if (goes_on)
         ok = qp1_continue(
                  q1,
-                 [&](QP1StateT<real>& qs) __attribute__((always_inline)) {
+                 [&](QP1StateT<creal>& qs) __attribute__((always_inline)) {
                    if (__builtin_expect(!qp1_search_lane(qs, lds_steps), 0)) qp1_line_search_seq(qs);
                  },
                  x, free0) >= 1;
       if (!ok) diverge = i;
-      real K[4];  // :373-385
-      const real k_scale = free0 ? -minv : real(0);
+      creal K[4];  // :373-385
+      const creal k_scale = free0 ? -minv : creal(0);
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) K[rr] = k_scale * Qux[rr];
       // :388-389
       {
-        real d0 = 0;
+        creal d0 = 0;
         d0 += x * Qu;
         if (ok) dV0 += (double)d0;
-        real rq = 0;
-        rq += (real(0.5) * x) * Quu;
-        real d1 = 0;
+        creal rq = 0;
+        rq += (creal(0.5) * x) * Quu;
+        creal d1 = 0;
         d1 += rq * x;
         if (ok) dV1 += (double)d1;
       }
       // :391-393
-      real T1[4], Vxn[4], Vn[16];
+      creal T1[4], Vxn[4], Vn[16];
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
-        real acc = 0;
+        creal acc = 0;
         acc += K[rr] * Quu;
         T1[rr] = acc;
       }
 #pragma unroll
       for (int s = 0; s < 4; s++) {
-        real t1 = 0, t2 = 0, t3 = 0;
+        creal t1 = 0, t2 = 0, t3 = 0;
         t1 += T1[s] * x;
         t2 += K[s] * Qu;
         t3 += Qux[s] * x;
         Vxn[s] = ((Qx[s] + t1) + t2) + t3;
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
-          real u1 = 0, u2 = 0, u3 = 0;
+          creal u1 = 0, u2 = 0, u3 = 0;
           u1 += T1[rr] * K[s];
           u2 += K[rr] * Qux[s];
           u3 += Qux[rr] * K[s];
@@ -350,7 +351,7 @@ __device__ __forceinline__ void backward_wide(const BatchViewT<typename M::real>
         Vxx[rr + 4 * rr] = Vn[rr + 4 * rr];
 #pragma unroll
         for (int c = rr + 1; c < 4; c++) {
-          const real sym = real(0.5) * (Vn[rr + 4 * c] + Vn[c + 4 * rr]);
+          const creal sym = creal(0.5) * (Vn[rr + 4 * c] + Vn[c + 4 * rr]);
           Vxx[rr + 4 * c] = sym;
           Vxx[c + 4 * rr] = sym;
         }
@@ -358,15 +359,15 @@ __device__ __forceinline__ void backward_wide(const BatchViewT<typename M::real>
       }
       // :405-412 term of the gradient norm
       {
-        const real mx = abs_of(x) * usw;
+        const creal mx = abs_of(x) * usw;
         if (ok) gacc += (double)mx;
       }
       // :396-397
       if (ok) {
-        kprev = x;
+        kprev = (creal)(real)x;  // the stored gain, as the reference reads k[i + 1] back (:369)
 #pragma unroll
-        for (int s = 0; s < 4; s++) Kt[(unsigned)((i * 4 + s) * TW)] = K[s];
-        kt[(unsigned)(i * TW)] = x;
+        for (int s = 0; s < 4; s++) Kt[(unsigned)((i * 4 + s) * TW)] = (real)K[s];
+        kt[(unsigned)(i * TW)] = (real)x;
       }
       if (!ok) break;
     }

@@ -22,6 +22,12 @@ namespace ilqr {
 // Deliberately branch-free: a library fallback for huge arguments put ~20 taken branches into
 // every rollout step.  NaN/Inf propagate to NaN as in libm; a finite |x| beyond ~1e9 (a rollout
 // that has already diverged -- the line search rejects it on cost) loses accuracy gracefully.
+// double -> int32 as the hardware does it (round toward zero, out-of-range values saturate, NaN gives 0)
+__device__ __forceinline__ int cvt_i32_saturating(double v) {
+  int r;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
 __device__ __forceinline__ void sincos_shared(double x, double& s_out, double& c_out) {
   // contraction by the source, not by the optimiser: every inlined copy of this function (rollout kernels, the
   // persistent kernel, the commit / getter re-integration, the finite differences) must round identically
@@ -46,8 +52,9 @@ __device__ __forceinline__ void sincos_shared(double x, double& s_out, double& c
   const double w = 1.0 - hz;
   const double cr = w + (((1.0 - w) - hz) + z * pc);
   // quadrant: one v_cvt_i32_f64 (the 64-bit conversion this replaced was six instructions: ldexp, floor, two cvt, ...; twenty
-  // sincos per finite-difference knot).  |j| >= 2^31 -- |x| beyond 3e9, a rollout long since rejected on cost -- saturates.
-  const int q = (int)j & 3;
+  // sincos per finite-difference knot).  |j| >= 2^31 -- |x| beyond 3e9, a rollout long since rejected on cost -- saturates:
+  // that is the INSTRUCTION's behaviour; a C++ cast out of range is undefined (poison to the optimiser), hence the asm.
+  const int q = cvt_i32_saturating(j) & 3;
   const double sa = (q & 1) ? cr : sr;
   const double ca = (q & 1) ? sr : cr;
   s_out = (q & 2) ? -sa : sa;
@@ -68,7 +75,7 @@ __device__ __forceinline__ void sincos_shared(float x, float& s_out, float& c_ou
   const float z = r * r;
   const float sr = r + (z * r) * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
   const float cr = (1.0f - 0.5f * z) + (z * z) * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
-  const int q = (int)j & 3;  // (|j| >= 2^31 saturates: see the double version)
+  const int q = cvt_i32_saturating(j) & 3;  // (|j| >= 2^31 saturates: see the double version)
   const float sa = (q & 1) ? cr : sr;
   const float ca = (q & 1) ? sr : cr;
   s_out = (q & 2) ? -sa : sa;

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ILQR_AMD_ABI_VERSION 3 /* 2: ilqr_desc.dtype; 3: ILQR_MODEL_USER, ilqr_desc.user_params */
+#define ILQR_AMD_ABI_VERSION 4 /* 2: ilqr_desc.dtype; 3: ILQR_MODEL_USER, ilqr_desc.user_params; 4: ilqr_desc.route, assume_cus (the library reads no environment) */
 
 typedef struct ilqr_batch ilqr_batch; /* opaque: owns all device memory of one batch */
 
@@ -156,7 +156,25 @@ typedef struct ilqr_desc {
   const ilqr_params* params; /* NULL = reference defaults */
   const double* user_params; /* ILQR_MODEL_USER: [n_user_params] handed to UserModelT::set_params (its constructor's arguments) */
   int n_user_params;
+  int route;       /* enum ilqr_route bits; 0 = the library picks the kernels by batch size (what every caller wants) */
+  int assume_cus;  /* 0 = the device's CU count; > 0: choose routes as if the device had this many (the tests exercise the
+                      batch-size thresholds on small batches) */
 } ilqr_desc;
+
+/* Which of several equivalent kernels a handle uses.  Every choice leaves the same bits (tests/test_gpu_fused_sweep.py,
+ * scripts/soak.py): these exist for A/B measurements and for those tests.  The library reads NO environment variables. */
+enum ilqr_route {
+  ILQR_ROUTE_AUTO = 0,
+  ILQR_ROUTE_TILE_PER_CU = 1,       /* ilqr_iterate: persistent 16-trajectory tiles, one per CU (k_solve_tile<..,1>) */
+  ILQR_ROUTE_TWO_TILES_PER_CU = 2,  /* ... two per CU (k_solve_tile<..,2>; with ILQR_FLAG_STAGED the one-producer k_sweep_backward) */
+  ILQR_ROUTE_WIDE_TILES = 3,        /* ... 64-trajectory wide tiles (k_solve_wide; m = 1 without opt-in fixes, else as 2) */
+  ILQR_ROUTE_WIDE_ONE_PER_CU = 4,   /* wide tiles: one per CU whatever the batch size */
+  ILQR_ROUTE_WIDE_TWO_PER_CU = 8,   /* wide tiles: two per CU whatever the batch size */
+  ILQR_ROUTE_NO_COMPACTION = 16,    /* ilqr_generate_trajectory without re-packing running trajectories between chunks */
+  ILQR_ROUTE_FULL_RECORDS = 32,     /* LQ model, exact derivatives: whole per-knot records instead of one shared copy of the constant blocks */
+  ILQR_ROUTE_LQ_THREAD_ROLLOUT = 64,/* LQ model: thread-per-rollout k_rollout_g instead of the matrix-core k_rollout_lq */
+  ILQR_ROUTE_BACKWARD_LDS = 128     /* generic path: round 1's LDS kernel k_backward_w instead of the register kernel k_backward_w2 */
+};
 
 const char* ilqr_last_error(void);
 int ilqr_abi_version(void);

@@ -51,11 +51,7 @@ static const orc_f64 Alpha[ORC_NALPHA] = {1.0000, 0.5012, 0.2512, 0.1259, 0.0631
                                          0.0158, 0.0079, 0.0040, 0.0020, 0.0010};
 /* include/boxqp.h:19-24 */
 static const int qp_maxIter = 100;
-static const orc_real minGrad = 1e-8;
-static const orc_real minRelImprove = 1e-8;
-static const orc_real stepDec = 0.6;
-static const orc_real minStep = 1e-22;
-static const orc_real Armijo = 0.1;
+/* (minGrad 1e-8, minRelImprove 1e-8, stepDec 0.6, minStep 1e-22, Armijo 0.1: orc_bw.inc) */
 
 /* ------------------------------------------------------------------------------------------ */
 /* Models                                                                                      */
@@ -159,257 +155,7 @@ static void integrate_dynamics_fd(const orc_model* m, const orc_fd* x, const orc
 /* box-QP                                                                                      */
 /* ------------------------------------------------------------------------------------------ */
 
-/* include/boxqp.h:48-51: upper.cwiseMin(x.cwiseMax(lower)) */
-void orc_clamp_to_limits(int n, const orc_real* x, const orc_real* lo, const orc_real* hi, orc_real* out) {
-  for (int i = 0; i < n; i++) {
-    const orc_real a = (x[i] < lo[i]) ? lo[i] : x[i]; /* cwiseMax(lower) */
-    out[i] = (hi[i] < a) ? hi[i] : a;               /* upper.cwiseMin(.) */
-  }
-}
-
-/* include/boxqp.h:53-55: 0.5*x.transpose()*Q*x + x.dot(c), evaluated ((0.5 x')Q) x + x.c */
-orc_real orc_quad_cost(int n, const orc_real* Q, const orc_real* c, const orc_real* x) {
-  orc_real quad = 0, lin = 0;
-  for (int j = 0; j < n; j++) {
-    orc_real r = 0;
-    for (int i = 0; i < n; i++) r += ((orc_real)0.5 * x[i]) * Q[i + n * j];
-    quad += r * x[j];
-  }
-  for (int i = 0; i < n; i++) lin += x[i] * c[i];
-  return quad + lin;
-}
-
-static void matvec(int n, const orc_real* Q, const orc_real* x, orc_real* y) {
-  for (int i = 0; i < n; i++) {
-    orc_real s = 0;
-    for (int j = 0; j < n; j++) s += Q[i + n * j] * x[j];
-    y[i] = s;
-  }
-}
-
-/* src/boxqp.cpp:143-178 */
-int orc_quadclamp_line_search(int n, const orc_real* x0, const orc_real* dir, const orc_real* Q,
-                              const orc_real* c, const orc_real* lo, const orc_real* hi, orc_real* x_opt,
-                              orc_real* v_opt, int* n_steps) {
-  orc_real step = 1;
-  orc_real grad[ORC_MAXM], x_reach[ORC_MAXM], x_clamped[ORC_MAXM];
-  int nsteps = 0;
-  int failed = 0;
-  matvec(n, Q, x0, grad);
-  for (int i = 0; i < n; i++) grad[i] += c[i]; /* :149 */
-  orc_real local_slope = 0;
-  for (int i = 0; i < n; i++) local_slope += dir[i] * grad[i]; /* :150 */
-  if (local_slope >= 0) { /* :151-154: result fields left untouched */
-    if (n_steps) *n_steps = 0;
-    return 1;
-  }
-  for (int i = 0; i < n; i++) x_reach[i] = x0[i] + step * dir[i]; /* :156 */
-  orc_clamp_to_limits(n, x_reach, lo, hi, x_clamped);
-  orc_real v = orc_quad_cost(n, Q, c, x_clamped);
-  const orc_real old_v = orc_quad_cost(n, Q, c, x0);
-  while ((v - old_v) / (step * local_slope) < Armijo) { /* :161 */
-    step *= stepDec;
-    nsteps++;
-    for (int i = 0; i < n; i++) x_reach[i] = x0[i] + step * dir[i];
-    orc_clamp_to_limits(n, x_reach, lo, hi, x_clamped);
-    v = orc_quad_cost(n, Q, c, x_clamped);
-    if (step < minStep) { /* :169-172 */
-      failed = 1;
-      break;
-    }
-  }
-  for (int i = 0; i < n; i++) x_opt[i] = x_clamped[i]; /* :175-176 */
-  *v_opt = v;
-  if (n_steps) *n_steps = nsteps;
-  return failed;
-}
-
-/* Eigen 3.3.4 Cholesky/LLT.h:302-325, llt_inplace<Scalar,Lower>::unblocked (used for every
- * size < 32, LLT.h:332-333).  Only the lower triangle is read/written.  On a non-positive pivot
- * it returns k and leaves column k.. untouched -- and src/boxqp.cpp:85-88 never looks at info(),
- * so that partial factor IS used downstream. */
-int orc_llt_lower_unblocked(int n, orc_real* A) {
-  for (int k = 0; k < n; k++) {
-    const int rs = n - k - 1;
-    orc_real x = A[k + n * k];
-    if (k > 0) {
-      orc_real sq = 0;
-      for (int j = 0; j < k; j++) sq += A[k + n * j] * A[k + n * j]; /* A10.squaredNorm() */
-      x -= sq;
-    }
-    if (x <= (orc_real)0.0) return k;
-    A[k + n * k] = x = sqrt(x);
-    if (k > 0 && rs > 0) { /* A21 -= A20 * A10' */
-      for (int i = k + 1; i < n; i++) {
-        orc_real s = 0;
-        for (int j = 0; j < k; j++) s += A[i + n * j] * A[k + n * j];
-        A[i + n * k] -= s;
-      }
-    }
-    if (rs > 0)
-      for (int i = k + 1; i < n; i++) A[i + n * k] /= x;
-  }
-  return -1;
-}
-
-/* M = R^-1 * R^-T for upper-triangular R (nf x nf, ld nf).  The reference forms it with two
- * dynamic-size .inverse() calls = partialPivLu().inverse() (LU/InverseImpl.h:22-29) and one
- * product (boxqp.cpp:105-112, ilqr_core.cpp:379); a triangular inverse agrees with that to
- * rounding*cond(R). */
-static void rinv_rinvT(int nf, const orc_real* R, orc_real* M) {
-  orc_real Ri[ORC_MAXM * ORC_MAXM];
-  /* upper-triangular inverse by back substitution, column by column */
-  for (int j = 0; j < nf; j++) {
-    for (int i = 0; i < nf; i++) Ri[i + nf * j] = 0;
-    Ri[j + nf * j] = (orc_real)1.0 / R[j + nf * j];
-    for (int i = j - 1; i >= 0; i--) {
-      orc_real s = 0;
-      for (int l = i + 1; l <= j; l++) s += R[i + nf * l] * Ri[l + nf * j];
-      Ri[i + nf * j] = -s / R[i + nf * i];
-    }
-  }
-  for (int i = 0; i < nf; i++)
-    for (int j = 0; j < nf; j++) {
-      orc_real s = 0;
-      for (int l = 0; l < nf; l++) s += Ri[i + nf * l] * Ri[j + nf * l]; /* Ri * Ri' */
-      M[i + nf * j] = s;
-    }
-}
-
-/* src/boxqp.cpp:26-139.  R_free/v_free follow boxQPResult (include/boxqp.h:35-43). */
-int orc_boxqp(int n, const orc_real* Q, const orc_real* c, const orc_real* x0, const orc_real* lo,
-              const orc_real* hi, orc_real* x_opt, int* v_free, orc_real* R_free, int* nfree_out,
-              int* iters_out) {
-  orc_real x[ORC_MAXM], grad[ORC_MAXM], grad_clamped[ORC_MAXM], search[ORC_MAXM];
-  orc_real clamped[ORC_MAXM], old_clamped[ORC_MAXM], tmp[ORC_MAXM];
-  orc_real Qfree[ORC_MAXM * ORC_MAXM], Minv[ORC_MAXM * ORC_MAXM];
-  int result = 0;
-  int nfree_R = 0; /* size of the factor currently held in R_free */
-  int iter;
-
-  orc_clamp_to_limits(n, x0, lo, hi, x); /* :35 */
-  /* :36  val = x'Qx + x.c  -- note: no 0.5 */
-  orc_real val;
-  {
-    orc_real quad = 0, lin = 0;
-    for (int j = 0; j < n; j++) {
-      orc_real r = 0;
-      for (int i = 0; i < n; i++) r += x[i] * Q[i + n * j];
-      quad += r * x[j];
-    }
-    for (int i = 0; i < n; i++) lin += x[i] * c[i];
-    val = quad + lin;
-  }
-  orc_real oldvalue = 0;
-  for (int i = 0; i < n; i++) {
-    clamped[i] = 0; /* uninitialised in the reference; only read when iter>0 */
-    old_clamped[i] = 0;
-    v_free[i] = 0;
-  }
-
-  for (iter = 0; iter <= qp_maxIter; iter++) { /* :50, inclusive bound */
-    if (result != 0) break;                    /* :51 */
-    if (iter > 0 && (oldvalue - val) < minRelImprove * fabs(oldvalue)) { /* :54-57 */
-      result = 4;
-      break;
-    }
-    matvec(n, Q, x, grad);
-    for (int i = 0; i < n; i++) grad[i] += c[i]; /* :58 */
-    oldvalue = val;                              /* :59 */
-
-    int all_clamped = 1;
-    for (int i = 0; i < n; i++) { /* :62-71 */
-      old_clamped[i] = clamped[i];
-      clamped[i] = 0;
-      v_free[i] = 1;
-      if ((fabs(x[i] - lo[i]) < (orc_real)1e-4 && grad[i] > 0) || (fabs(x[i] - hi[i]) < (orc_real)1e-4 && grad[i] < 0)) {
-        clamped[i] = 1;
-        v_free[i] = 0;
-      }
-      if (clamped[i] == 0) all_clamped = 0;
-    }
-    if (all_clamped) { /* :74-77 */
-      result = 6;
-      break;
-    }
-
-    orc_real dsum = 0;
-    for (int i = 0; i < n; i++) dsum += old_clamped[i] - clamped[i];
-    if (iter == 0 || dsum != 0) { /* :80: refactor only if the COUNT of clamped dims changed */
-      int nf = 0;
-      int idx[ORC_MAXM];
-      for (int i = 0; i < n; i++)
-        if (v_free[i] != 0) idx[nf++] = i;
-      for (int a = 0; a < nf; a++) /* include/eigen_helpers.h:46-61 */
-        for (int b = 0; b < nf; b++) Qfree[a + nf * b] = Q[idx[a] + n * idx[b]];
-      const int llt_info = orc_llt_lower_unblocked(nf, Qfree); /* :85, info() ignored */
-      if ((referenceFixes & 2) && llt_info >= 0) { /* opt-in: not positive definite on the free subspace */
-        result = -1;
-        break;
-      }
-      /* :86-88  R_free = matrixL().transpose(): dense upper triangle, zeros below */
-      for (int a = 0; a < nf; a++)
-        for (int b = 0; b < nf; b++) R_free[a + nf * b] = (a <= b) ? Qfree[b + nf * a] : (orc_real)0.0;
-      nfree_R = nf;
-    }
-
-    /* :93-97 */
-    orc_real gn2 = 0;
-    int nf_now = 0;
-    for (int i = 0; i < n; i++)
-      if (v_free[i] > 0) {
-        gn2 += grad[i] * grad[i];
-        nf_now++;
-      }
-    if (sqrt(gn2) < minGrad) {
-      result = 5;
-      break;
-    }
-
-    /* :100  grad_clamped = Q*(x .* clamped) + c */
-    for (int i = 0; i < n; i++) tmp[i] = x[i] * clamped[i];
-    matvec(n, Q, tmp, grad_clamped);
-    for (int i = 0; i < n; i++) grad_clamped[i] += c[i];
-
-    /* :103-119  search(free) = -(R^-1 R^-T) grad_clamped(free) - x(free); 0 elsewhere.
-     * (A stale factor of equal size is used if the clamp set swapped members, :80.) */
-    for (int i = 0; i < n; i++) search[i] = 0;
-    {
-      const int nf = nfree_R;
-      orc_real gfree[ORC_MAXM], xfree[ORC_MAXM];
-      int idx[ORC_MAXM], a = 0;
-      for (int i = 0; i < n; i++)
-        if (v_free[i] > 0) {
-          if (a < ORC_MAXM) {
-            idx[a] = i;
-            gfree[a] = grad_clamped[i];
-            xfree[a] = x[i];
-          }
-          a++;
-        }
-      (void)nf_now;
-      rinv_rinvT(nf, R_free, Minv);
-      for (int r = 0; r < nf; r++) {
-        orc_real s = 0;
-        for (int l = 0; l < nf; l++) s += -Minv[r + nf * l] * gfree[l];
-        search[idx[r]] = s - xfree[r];
-      }
-    }
-
-    orc_real ls_x[ORC_MAXM], ls_v = 0;
-    const int failed = orc_quadclamp_line_search(n, x, search, Q, c, lo, hi, ls_x, &ls_v, 0); /* :121 */
-    if (failed) { /* :122-125: x is NOT updated */
-      result = 2;
-      break;
-    }
-    for (int i = 0; i < n; i++) x[i] = ls_x[i]; /* :133-134 */
-    val = ls_v;
-  }
-  for (int i = 0; i < n; i++) x_opt[i] = x[i]; /* :137 */
-  if (nfree_out) *nfree_out = nfree_R;
-  if (iters_out) *iters_out = iter;
-  return result;
-}
+/* (the functions of this section and the backward pass live in orc_bw.inc, included further down: they need the trajectory type) */
 
 /* ------------------------------------------------------------------------------------------ */
 /* Trajectory state                                                                            */
@@ -652,176 +398,21 @@ void orc_compute_derivatives(const orc_model* m, orc_traj* s) { /* ilqr_core.cpp
 /* Backward pass                                                                               */
 /* ------------------------------------------------------------------------------------------ */
 
-/* C(nr x nc) = A' (A is k x nr) * B (k x nc) */
-static void mul_AtB(int k, int nr, int nc, const orc_real* A, const orc_real* B, orc_real* C) {
-  for (int i = 0; i < nr; i++)
-    for (int j = 0; j < nc; j++) {
-      orc_real s = 0;
-      for (int l = 0; l < k; l++) s += A[l + k * i] * B[l + k * j];
-      C[i + nr * j] = s;
-    }
-}
-/* C(nr x nc) = A (nr x k) * B (k x nc) */
-static void mul_AB(int nr, int k, int nc, const orc_real* A, const orc_real* B, orc_real* C) {
-  for (int i = 0; i < nr; i++)
-    for (int j = 0; j < nc; j++) {
-      orc_real s = 0;
-      for (int l = 0; l < k; l++) s += A[i + nr * l] * B[l + k * j];
-      C[i + nr * j] = s;
-    }
-}
-
-/* src/ilqr_core.cpp:350-401.  Returns the failing timestep i (so a failure at i==0 reads as
- * success, :371 vs :142) or 0. */
-int orc_backward_pass(const orc_model* m, orc_traj* s) {
-  const int n = s->nx, mu = s->nu, T = s->T;
-  orc_real Qx[ORC_MAXN], Qu[ORC_MAXM], k_i[ORC_MAXM], lo[ORC_MAXM], hi[ORC_MAXM];
-  static _Thread_local orc_real Qxx[ORC_MAXN * ORC_MAXN], Qux[ORC_MAXM * ORC_MAXN], Quu[ORC_MAXM * ORC_MAXM],
-      QuuF[ORC_MAXM * ORC_MAXM], K_i[ORC_MAXM * ORC_MAXN], A1[ORC_MAXN * ORC_MAXN], A2[ORC_MAXM * ORC_MAXN],
-      R[ORC_MAXM * ORC_MAXM], Minv[ORC_MAXM * ORC_MAXM], T1[ORC_MAXM * ORC_MAXN], T2[ORC_MAXN * ORC_MAXN];
-  int v_free[ORC_MAXM];
-  s->n_backward++;
-
-  memcpy(&s->Vx[(size_t)T * n], &s->cx[(size_t)T * n], sizeof(orc_real) * n);           /* :353 */
-  memcpy(&s->Vxx[(size_t)T * n * n], &s->cxx[(size_t)T * n * n], sizeof(orc_real) * n * n); /* :354 */
-  s->dV[0] = s->dV[1] = 0; /* :356 */
-
-  for (int i = T - 1; i >= 0; i--) {
-    const orc_real* fx = &s->fx[(size_t)i * n * n];
-    const orc_real* fu = &s->fu[(size_t)i * n * mu];
-    const orc_real* cx = &s->cx[(size_t)i * n];
-    const orc_real* cu = &s->cu[(size_t)i * mu];
-    const orc_real* cxx = &s->cxx[(size_t)i * n * n];
-    const orc_real* cxu = &s->cxu[(size_t)i * n * mu];
-    const orc_real* cuu = &s->cuu[(size_t)i * mu * mu];
-    const orc_real* Vx1 = &s->Vx[(size_t)(i + 1) * n];
-    const orc_real* Vxx1 = &s->Vxx[(size_t)(i + 1) * n * n];
-
-    /* :359-360 */
-    for (int a = 0; a < n; a++) {
-      orc_real acc = 0;
-      for (int l = 0; l < n; l++) acc += fx[l + n * a] * Vx1[l];
-      Qx[a] = cx[a] + acc;
-    }
-    for (int a = 0; a < mu; a++) {
-      orc_real acc = 0;
-      for (int l = 0; l < n; l++) acc += fu[l + n * a] * Vx1[l];
-      Qu[a] = cu[a] + acc;
-    }
-    /* :361  Qxx = cxx + (fx' Vxx) fx */
-    mul_AtB(n, n, n, fx, Vxx1, A1);
-    mul_AB(n, n, n, A1, fx, Qxx);
-    for (int e = 0; e < n * n; e++) Qxx[e] = cxx[e] + Qxx[e];
-    /* :362  Qux = cxu' + (fu' Vxx) fx   (identical to Qux_reg, :366) */
-    mul_AtB(n, mu, n, fu, Vxx1, A2);
-    mul_AB(mu, n, n, A2, fx, Qux);
-    for (int a = 0; a < mu; a++)
-      for (int j = 0; j < n; j++) Qux[a + mu * j] = cxu[j + n * a] + Qux[a + mu * j];
-    /* :363  Quu = cuu + (fu' Vxx) fu ;  :367  QuuF = cuu + lambda I + (fu' Vxx) fu */
-    mul_AB(mu, n, mu, A2, fu, Quu);
-    for (int a = 0; a < mu; a++)
-      for (int b = 0; b < mu; b++) {
-        const orc_real f = Quu[a + mu * b];
-        Quu[a + mu * b] = cuu[a + mu * b] + f;
-        QuuF[a + mu * b] = (cuu[a + mu * b] + ((a == b) ? (orc_real)s->lambda : (orc_real)0.0)) + f;
-      }
-    /* opt-in (bit 2 of the fixes): regularise Vxx' instead of Quu -- [Tassa 2012] eq. 10a/10b, which :365 says the
-     * reference's lambda*I on Quu is "similar to": Quu_reg = cuu + fu'(Vxx' + lambda I) fu = Quu + lambda fu'fu,
-     * Qux_reg = cxu' + fu'(Vxx' + lambda I) fx = Qux + lambda fu'fx.  The value update keeps the unregularised Quu, Qux. */
-    orc_real Qux_reg[ORC_MAXM * ORC_MAXN];
-    for (int e = 0; e < mu * n; e++) Qux_reg[e] = Qux[e];
-    if (referenceFixes & 4) {
-      const orc_real lam = (orc_real)s->lambda;
-      for (int a = 0; a < mu; a++) {
-        for (int b = 0; b < mu; b++) {
-          orc_real acc = 0;
-          for (int l = 0; l < n; l++) acc += fu[l + n * a] * fu[l + n * b];
-          QuuF[a + mu * b] = Quu[a + mu * b] + lam * acc;
-        }
-        for (int j = 0; j < n; j++) {
-          orc_real acc = 0;
-          for (int l = 0; l < n; l++) acc += fu[l + n * a] * fx[l + n * j];
-          Qux_reg[a + mu * j] = Qux[a + mu * j] + lam * acc;
-        }
-      }
-    }
-
-    /* :369  boxQP(QuuF, Qu, k[min(i+1,T-1)], u_min-us[i], u_max-us[i]) */
-    const int iw = (i + 1 < T - 1) ? i + 1 : T - 1;
-    for (int a = 0; a < mu; a++) {
-      lo[a] = m->u_min[a] - s->us[(size_t)i * mu + a];
-      hi[a] = m->u_max[a] - s->us[(size_t)i * mu + a];
-    }
-    int nfree = 0;
-    const int result = orc_boxqp(mu, QuuF, Qu, &s->k[(size_t)iw * mu], lo, hi, k_i, v_free, R, &nfree, 0);
-    if (result < 1) return i; /* :371 */
-
-    /* :376-385  K_i[free rows] = -(R^-1 R^-T) Qux_reg[free rows] */
-    for (int e = 0; e < mu * n; e++) K_i[e] = 0;
-    int any = 0, idx[ORC_MAXM], nf = 0;
-    for (int a = 0; a < mu; a++)
-      if (v_free[a]) {
-        any = 1;
-        idx[nf++] = a;
-      }
-    if (any) {
-      rinv_rinvT(nfree, R, Minv);
-      /* rows_w_ind(Qux_reg, v_free) (eigen_helpers.h:29-42) has nf rows; nf == nfree unless a
-       * stale factor is in play, in which case Eigen would assert on the size mismatch. */
-      for (int r = 0; r < nf && r < nfree; r++)
-        for (int j = 0; j < n; j++) {
-          orc_real acc = 0;
-          for (int l = 0; l < nfree && l < nf; l++) acc += -Minv[r + nfree * l] * Qux_reg[idx[l] + mu * j];
-          K_i[idx[r] + mu * j] = acc;
-        }
-    }
-
-    /* :388-389 */
-    {
-      orc_real d0 = 0;
-      for (int a = 0; a < mu; a++) d0 += k_i[a] * Qu[a];
-      s->dV[0] += d0;
-      orc_real d1 = 0;
-      for (int b = 0; b < mu; b++) {
-        orc_real r = 0;
-        for (int a = 0; a < mu; a++) r += ((orc_real)0.5 * k_i[a]) * Quu[a + mu * b];
-        d1 += r * k_i[b];
-      }
-      s->dV[1] += d1;
-    }
-
-    /* :391  Vx = Qx + K'Quu k + K'Qu + Qux'k */
-    {
-      orc_real Quuk[ORC_MAXM];
-      mul_AtB(mu, n, mu, K_i, Quu, T1); /* T1 = K' Quu  (n x mu) */
-      for (int a = 0; a < n; a++) {
-        orc_real t1 = 0, t2 = 0, t3 = 0;
-        for (int b = 0; b < mu; b++) t1 += T1[a + n * b] * k_i[b];
-        for (int b = 0; b < mu; b++) t2 += K_i[b + mu * a] * Qu[b];
-        for (int b = 0; b < mu; b++) t3 += Qux[b + mu * a] * k_i[b];
-        s->Vx[(size_t)i * n + a] = ((Qx[a] + t1) + t2) + t3;
-      }
-      (void)Quuk;
-      /* :392  Vxx = Qxx + K'Quu K + K'Qux + Qux'K ; :393 symmetrise */
-      orc_real* Vxx = &s->Vxx[(size_t)i * n * n];
-      mul_AB(n, mu, n, T1, K_i, T2); /* K'Quu K */
-      for (int a = 0; a < n; a++)
-        for (int b = 0; b < n; b++) {
-          orc_real t2 = 0, t3 = 0;
-          for (int l = 0; l < mu; l++) t2 += K_i[l + mu * a] * Qux[l + mu * b];
-          for (int l = 0; l < mu; l++) t3 += Qux[l + mu * a] * K_i[l + mu * b];
-          A1[a + n * b] = ((Qxx[a + n * b] + T2[a + n * b]) + t2) + t3;
-        }
-      for (int a = 0; a < n; a++)
-        for (int b = 0; b < n; b++) Vxx[a + n * b] = (orc_real)0.5 * (A1[a + n * b] + A1[b + n * a]);
-    }
-
-    /* :396-397 */
-    for (int a = 0; a < mu; a++) s->k[(size_t)i * mu + a] = k_i[a];
-    memcpy(&s->K[(size_t)i * mu * n], K_i, sizeof(orc_real) * mu * n);
-  }
-  return 0;
-}
+#define BWR orc_real
+#define BWN(name) name
+#include "orc_bw.inc" /* box-QP + backward pass in the build's arithmetic, under the exported names */
+#undef BWR
+#undef BWN
+#ifdef ORC_BW_IS_DOUBLE /* fp32 build: the mixed backward pass the outer loop uses (orc_bw.inc) */
+#define BWR double
+#define BWN(name) name##_bw64
+#include "orc_bw.inc"
+#undef BWR
+#undef BWN
+#define ORC_BACKWARD_PASS orc_backward_pass_bw64
+#else
+#define ORC_BACKWARD_PASS orc_backward_pass
+#endif
 
 /* src/ilqr_core.cpp:405-412: mean_t max_i |k_i|/(|u_i|+1) */
 orc_acc orc_gradient_norm(const orc_traj* s) {
@@ -891,7 +482,7 @@ int orc_iterate_once(const orc_model* m, orc_traj* s, int* flg_change, int fixed
   /* STEP 2 :136-150 */
   int backPassDone = 0;
   while (!backPassDone) {
-    const int diverge = orc_backward_pass(m, s);
+    const int diverge = ORC_BACKWARD_PASS(m, s);
     if (diverge != 0) {
       s->dlambda = fmax(s->dlambda * lambdaFactor, lambdaFactor);
       s->lambda = fmax(s->lambda * s->dlambda, lambdaMin);
@@ -1115,7 +706,7 @@ int orc_batch_backward(const orc_model* m, int B, int T, const orc_real* us, con
     memcpy(s->cuu, &cuu[(size_t)b * T1 * mu * mu], sizeof(orc_real) * T1 * mu * mu);
     if (k_prev) memcpy(s->k, &k_prev[(size_t)b * T * mu], sizeof(orc_real) * (size_t)T * mu);
     s->lambda = lambda ? lambda[b] : 1.0;
-    const int div = orc_backward_pass(m, s);
+    const int div = ORC_BACKWARD_PASS(m, s);
     memcpy(&k_out[(size_t)b * T * mu], s->k, sizeof(orc_real) * (size_t)T * mu);
     memcpy(&K_out[(size_t)b * T * mu * n], s->K, sizeof(orc_real) * (size_t)T * mu * n);
     dV_out[2 * b] = s->dV[0];

@@ -39,8 +39,8 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/staged_stats -o $R -- $SHOR
 LQ="python $ROOT/scripts/bench_lq.py 8192 2 16"
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $OUT/lq_pmc_sq -o $R -- $LQ > /dev/null 2> $OUT/lq_pmc_sq.err
 timeout 300 rocprofv3 --pmc MeanOccupancyPerCU MeanOccupancyPerActiveCU --kernel-trace -d $OUT/lq_pmc_occ -o $R -- $LQ > /dev/null 2> $OUT/lq_pmc_occ.err
-ILQR_AMD_BACKWARD_W1=1 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $OUT/lq_w1_pmc_sq -o $R -- $LQ > /dev/null 2> $OUT/lq_w1_pmc_sq.err
-ILQR_AMD_BACKWARD_W1=1 timeout 300 rocprofv3 --pmc MeanOccupancyPerCU MeanOccupancyPerActiveCU --kernel-trace -d $OUT/lq_w1_pmc_occ -o $R -- $LQ > /dev/null 2> $OUT/lq_w1_pmc_occ.err
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $OUT/lq_w1_pmc_sq -o $R -- $LQ 128 > /dev/null 2> $OUT/lq_w1_pmc_sq.err
+timeout 300 rocprofv3 --pmc MeanOccupancyPerCU MeanOccupancyPerActiveCU --kernel-trace -d $OUT/lq_w1_pmc_occ -o $R -- $LQ 128 > /dev/null 2> $OUT/lq_w1_pmc_occ.err
 cd $ROOT
 for U in lat ldsmix; do  # microbenchmarks quoted in DESIGN.md, re-run on this box
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $OUT/$U scripts/ubench/$U.hip 2> /dev/null && $OUT/$U > $OUT/ubench_$U.txt 2>/dev/null

@@ -3,15 +3,13 @@ trajectories between chunks (ilqr_generate_trajectory): wall time and identity o
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ilqr_amd import BatchILQR
+from ilqr_amd import BatchILQR, capi
 from tests.util import acrobot_x0, integrator_x0
 
 def run(name, B, T, x0, kw, nu):
     res = {}
-    for label, env in (("compaction", None), ("no compaction", "1")):
-        if env: os.environ["ILQR_AMD_NO_COMPACTION"] = env
-        else: os.environ.pop("ILQR_AMD_NO_COMPACTION", None)
-        g = BatchILQR(name, B, T, 0.02, **kw)
+    for label, route in (("compaction", 0), ("no compaction", capi.ROUTE_NO_COMPACTION)):
+        g = BatchILQR(name, B, T, 0.02, route=route, **kw)
         u0 = np.zeros((B, T, nu))
         g.generate_trajectory(x0, u0)  # warm-up (code load, allocations)
         g.init_traj(x0, u0)

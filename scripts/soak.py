@@ -67,18 +67,16 @@ def main():
                                ("thread", capi.FLAG_UNFUSED | capi.FLAG_BACKWARD_THREAD_PER_TRAJ, {}),
                                # the routes big batches take, forced on these small ones: two tiles per CU, wide tiles (one / two per
                                # CU; m = 2 falls back to two tiles per CU), and compaction of running trajectories between chunks
-                               ("quad1", 0, {"ILQR_AMD_FUSED": "1"}), ("occ2", 0, {"ILQR_AMD_FUSED": "2"}), ("wide1", 0, {"ILQR_AMD_FUSED": "3", "ILQR_AMD_WIDE_OCC": "1"}),
-                               ("wide2", 0, {"ILQR_AMD_FUSED": "3", "ILQR_AMD_WIDE_OCC": "2"}),
-                               ("compact", 0, {"ILQR_AMD_NUM_CUS": "2"})):
-            for kk in ("ILQR_AMD_FUSED", "ILQR_AMD_WIDE_OCC", "ILQR_AMD_NUM_CUS"):
-                os.environ.pop(kk, None)
-            os.environ.update(env)
-            g = BatchILQR(name, B, T, DT, flags=fl, params=dict(max_iter=iters), **kw)
+                               ("quad1", 0, dict(route=capi.ROUTE_TILE_PER_CU)), ("occ2", 0, dict(route=capi.ROUTE_TWO_TILES_PER_CU)),
+                               ("wide1", 0, dict(route=capi.ROUTE_WIDE_TILES | capi.ROUTE_WIDE_ONE_PER_CU)),
+                               ("wide2", 0, dict(route=capi.ROUTE_WIDE_TILES | capi.ROUTE_WIDE_TWO_PER_CU)),
+                               ("compact", 0, dict(assume_cus=2))):
+            g = BatchILQR(name, B, T, DT, flags=fl, params=dict(max_iter=iters), **dict(kw, **env))
             g.init_traj(x0, u0)
             g.generate_trajectory()
             outs[label] = state(g)
             g.close()
-        for other in ("staged", "unfused", "occ2", "wide1", "wide2", "compact"):  # every route leaves the same bits
+        for other in ("staged", "unfused", "quad1", "occ2", "wide1", "wide2", "compact"):  # every route leaves the same bits
             for key in outs["fused"]:
                 if not np.array_equal(outs["fused"][key], outs[other][key], equal_nan=True):
                     print("FAIL persistent != %s:" % other, key, desc, "seed", seed)

@@ -2,7 +2,7 @@
 
 Every case draws dimensions n <= 32, m <= 16, a batch, a horizon, limits, lambda and (sometimes) a negative shift
 of one diagonal entry of cuu (indefinite Quu: partial factors, stale factors, aborted passes), then checks
-  * k_backward_w2 (matrices in registers) == k_backward_w (matrices in LDS, ILQR_AMD_BACKWARD_W1=1), bit for bit:
+  * k_backward_w2 (matrices in registers) == k_backward_w (matrices in LDS, ILQR_ROUTE_BACKWARD_LDS), bit for bit:
     gains, dV, divergence index, gradient norm;
   * k_backward_w2 against the oracle's backward_pass per knot (tests/parity.check_backward: 1e-6, deviations must be
     clamp knife edges or fp64-conditioning-limited against the fp80 oracle).
@@ -16,7 +16,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-from ilqr_amd import BatchILQR
+from ilqr_amd import BatchILQR, capi
 from oracle import oracle as O
 from tests.parity import check_backward
 from tests.util import mat
@@ -54,10 +54,8 @@ def main():
         desc = "n=%d m=%d B=%d T=%d lim=%g lam=%g shifted=%s seed=%d" % (n, m, B, T, lim, lam, shifted, seed)
         outs = []
         for force_lds in (False, True):
-            if force_lds:
-                os.environ["ILQR_AMD_BACKWARD_W1"] = "1"
             try:
-                g = BatchILQR("host", B, T, DT, nx=n, nu=m, u_min=om.u_min, u_max=om.u_max)
+                g = BatchILQR("host", B, T, DT, nx=n, nu=m, u_min=om.u_min, u_max=om.u_max, route=capi.ROUTE_BACKWARD_LDS if force_lds else 0)
                 g.set_trajectory(x0=x0, xs=xs, us=us, cost=cost)
                 g.set_derivatives(**{k: (dv[k] if k in ("cx", "cu") else mat(dv[k])) for k in dv})
                 g.set_gains(k=k_prev, K=np.zeros((B, T, m, n)))
@@ -67,7 +65,7 @@ def main():
                 outs.append(dict(div=div, k=k, K=K, dV=g.dV(), gnorm=g.gnorm()))
                 g.close()
             finally:
-                os.environ.pop("ILQR_AMD_BACKWARD_W1", None)
+                pass
         for key in outs[0]:
             if not np.array_equal(outs[0][key], outs[1][key], equal_nan=True):
                 print("FAIL register kernel != LDS kernel:", key, desc)

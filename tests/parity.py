@@ -117,10 +117,16 @@ def conditioning_verdict(k, K, k64, K64, k80, K80, us, tol=TOL):
 # oracle's float build ("f32") is the twin the device must match, the fp64 oracle is the yardstick.
 TOL32 = 1e-4   # float eps 6e-8 x O(100) operations per Riccati step x tens of steps of a recursion whose
                # condition grows with the horizon: what two correct fp32 evaluations agree to per knot
+# what a closed-loop float rollout over T = 499 knots of an unstable system is good for (p90 of the ORACLE's own float rollouts
+# against fp64 on the bench workload: 6e-4; scripts/f32_rollout_check.py)
+ROLLOUT_NOISE = {"f32": 2e-3}
 PRECISIONS = {
     # flavour the device is compared with, yardstick flavour, tolerance, relative cost change that counts as a tie
-    "f64": dict(twin="f64", yard="f80", tol=TOL, tie_rel=1e-9),
-    "f32": dict(twin="f32", yard="f64", tol=TOL32, tie_rel=1e-5),
+    # gtol: per-knot tolerance of the GAINS.  An fp32 handle's backward pass runs in double on float records, and
+    # its twin's does too: the two see the same records almost always (the finite differences are taken in double and differ at
+    # 1e-13 before they are rounded to float), so the gains agree far better than float rollouts do.
+    "f64": dict(twin="f64", yard="f80", tol=TOL, gtol=TOL, tie_rel=1e-9),
+    "f32": dict(twin="f32", yard="f64", tol=TOL32, gtol=1e-5, tie_rel=1e-5),
 }
 
 
@@ -157,7 +163,7 @@ def check_backward(oracle, om, us, derivs, k_prev, lam, k, K, dV, div, ro, max_t
     the same diverge flag -- or fp64 rounding shown to be the limit (conditioning_verdict) -- or a proven
     clamp knife edge (at most max_ties of those).  Returns dict(good, ties, conditioned)."""
     prec = PRECISIONS[precision]
-    tol = prec["tol"]
+    tol = prec["gtol"]  # (a teacher-forced backward pass: gains and dV; no float rollout is involved)
     ro = {kk: (_f64(v) if v.dtype.kind == "f" else v) for kk, v in ro.items()}
     us = _f64(us)
     Ko = mat(ro["K"])
@@ -224,7 +230,7 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
     p = dict(tol_fun=1e-6, lambda_max=1e11, tol_grad=1e-6)
     p.update(params or {})
     prec = PRECISIONS[precision]
-    tol = prec["tol"]
+    tol, gtol = prec["tol"], prec["gtol"]
     B, T = u0.shape[:2]
     aux = None
     if drive == "oracle":
@@ -260,7 +266,7 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
             pit["n"] += 1
             same_disc = gs["alpha"][b] == nx["alpha"][b] and g_status[b] == nx["status"][b]
             lam_ok = np.isclose(gs["lam"][b], nx["lam"][b], rtol=1e-12, atol=0) and np.isclose(gs["dlam"][b], nx["dlam"][b], rtol=1e-12)  # (double on both sides in both modes)
-            if same_disc and lam_ok and eg[b] < tol and ec[b] < tol:
+            if same_disc and lam_ok and eg[b] < gtol and ec[b] < tol:
                 # get_gradient_norm (ilqr_core.cpp:405-412) and dV of the pass both sides agree on
                 assert abs(gs["gnorm"][b] - nx["gnorm"][b]) <= tol * max(nx["gnorm"][b], 1e-3), (gs["gnorm"][b], nx["gnorm"][b])
                 assert np.allclose(gs["dV"][b], nx["dV"][b], rtol=tol, atol=tol * abs(st["cost"][b])), (gs["dV"][b], nx["dV"][b])
@@ -272,9 +278,9 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
                 it, b, gs["alpha"][b], nx["alpha"][b], g_status[b], nx["status"][b], gs["lam"][b], nx["lam"][b], ec[b], eg[b])
             if verbose:
                 print("deviation:", where)
-            if eg[b] >= tol:
+            if eg[b] >= gtol:
                 # the backward passes (incl. their lambda retries) differ: a clamp knife edge ...
-                if first_gain_mismatch_is_knife_edge(gs["k"][b], gs["K"][b], nx["k"][b], nx["K"][b], st["us"][b], lo[b], hi[b], tol):
+                if first_gain_mismatch_is_knife_edge(gs["k"][b], gs["K"][b], nx["k"][b], nx["K"][b], st["us"][b], lo[b], hi[b], gtol):
                     out["ties_backward"] += 1
                     out["tied"].add(int(b))
                     pit["knife_edge"] += 1
@@ -287,7 +293,7 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
                 # device's records reproduces the device's gains to the plain tolerance.
                 if aux is None:
                     aux = g.clone()
-                if _explained_by_records(oracle, om, prec, aux, x0, st, int(b), gs, tol, plain_only=True):
+                if _explained_by_records(oracle, om, prec, aux, x0, st, int(b), gs, gtol, plain_only=True):
                     pit["plain_on_device_records"] += 1
                     out["plain_on_device_records"] = out.get("plain_on_device_records", 0) + 1
                     if not (same_disc and lam_ok):  # the 1e-6-level gain difference then moved the line search / exit too
@@ -295,9 +301,9 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
                     continue
                 # ... or fp64 rounding, not the implementation, limits the per-knot agreement
                 if cond_ok is None:
-                    sel = np.flatnonzero(running & (eg >= tol))
+                    sel = np.flatnonzero(running & (eg >= gtol))
                     k80, K80 = iterate_f80(oracle, om, x0, st, dt, fixed_work, sel, yard=prec["yard"])
-                    e_dev, e_orc, okc = conditioning_verdict(gs["k"][sel], gs["K"][sel], nx["k"][sel], nx["K"][sel], k80, K80, st["us"][sel], tol)
+                    e_dev, e_orc, okc = conditioning_verdict(gs["k"][sel], gs["K"][sel], nx["k"][sel], nx["K"][sel], k80, K80, st["us"][sel], gtol)
                     cond_ok = {int(bb): (bool(okc[i]), float(e_dev[i]), float(e_orc[i])) for i, bb in enumerate(sel)}
                 okb, e_d, e_o = cond_ok[int(b)]
                 where += " [vs yardstick: device %.2e, twin oracle %.2e]" % (e_d, e_o)
@@ -316,15 +322,15 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
                     # Proof: the ORACLE's backward pass on the DEVICE's own records of this nominal must reproduce the device's gains.
                     if aux is None:
                         aux = g.clone()
-                    if _explained_by_records(oracle, om, prec, aux, x0, st, int(b), gs, tol):
+                    if _explained_by_records(oracle, om, prec, aux, x0, st, int(b), gs, gtol):
                         out["explained_by_records"] = out.get("explained_by_records", 0) + 1
                         out["tied"].add(int(b))
                         pit["explained_by_records"] += 1
                         continue
                 assert okb, "backward passes differ away from a clamp tie and beyond conditioning -- " + where
                 out["conditioned"] += 1
-                out["cond_over10"] += int(e_d > max(tol, COND_FACTOR * e_o))
-                pit["cond_le100" if e_d > max(tol, COND_FACTOR * e_o) else "cond_le10"] += 1
+                out["cond_over10"] += int(e_d > max(gtol, COND_FACTOR * e_o))
+                pit["cond_le100" if e_d > max(gtol, COND_FACTOR * e_o) else "cond_le10"] += 1
                 out["worst_cond_ratio"] = max(out["worst_cond_ratio"], e_d / max(e_o, 1e-300))
                 if same_disc and lam_ok and ec[b] < max(tol, COND_HARD * e_o):
                     continue
@@ -367,7 +373,21 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
                     omt = _tw(om, prec["twin"])
                     xs_r, us_r, c_r = oracle.batch_rollout(omt, x0[b:b + 1], st["us"][b:b + 1] + ALPHAS[a] * gs["k"][b:b + 1], dt,
                                                            xs_nom=st["xs"][b:b + 1], K=gs["K"][b:b + 1])
-                assert abs(gs["cost"][b] - float(c_r[0])) <= tol * abs(float(c_r[0])), "rollout of the device's own gains differs -- " + where
+                if not abs(gs["cost"][b] - float(c_r[0])) <= tol * abs(float(c_r[0])):
+                    # two roundings of the SAME closed-loop rollout (same gains, same alpha) differ by more than tol: judge both
+                    # against the rollout in the yardstick precision -- the device may be no further from it than 10 x the twin is
+                    with oracle.flavour(prec["yard"]):
+                        omy = _tw(om, prec["yard"])
+                        yt = np.asarray(st["us"][b:b + 1] + ALPHAS[a] * gs["k"][b:b + 1])
+                        xs_y, us_y, c_y = oracle.batch_rollout(omy, x0[b:b + 1], yt, dt, xs_nom=st["xs"][b:b + 1], K=gs["K"][b:b + 1])
+                    c_y = float(c_y[0])
+                    e_dev, e_twin = abs(gs["cost"][b] - c_y) / abs(c_y), abs(float(c_r[0]) - c_y) / abs(c_y)
+                    # (single realisations of rounding noise: scripts/f32_rollout_check.py -- device and oracle float rollouts of the
+                    #  same gains sit at the same distance from the fp64 rollout in distribution, median 2e-6, p90 6e-4 at T = 499,
+                    #  and one is > 10 x the other in 4 % of the cases: those are counted with the > 10 x conditioning cases)
+                    lax = max(COND_HARD * e_twin, ROLLOUT_NOISE.get(precision, 0.0))
+                    assert e_dev <= max(tol, lax), "rollout of the device's own gains differs -- %s [vs yardstick: device %.2e, twin %.2e]" % (where, e_dev, e_twin)
+                    out["cond_over10"] += int(e_dev > max(tol, COND_FACTOR * e_twin))
                 out["amplified"] = out.get("amplified", 0) + 1
                 out["worst_gain"] = max(out["worst_gain"], float(eg[b]))
                 pit["amplified"] += 1
@@ -459,7 +479,7 @@ def publish(name, r, **meta):
     os.makedirs(os.path.dirname(path), exist_ok=True)
     doc = json.load(open(path)) if os.path.exists(path) else {}
     tot = {kk: sum(p[kk] for p in r["per_iter"]) for kk in r["per_iter"][0] if kk != "iteration"} if r["per_iter"] else {}
-    doc[name] = dict(meta, tolerance=PRECISIONS[meta.get("precision", "f64")]["tol"], checked=r["checked"], totals=tot,
+    doc[name] = dict(meta, tolerance=PRECISIONS[meta.get("precision", "f64")]["tol"], gain_tolerance=PRECISIONS[meta.get("precision", "f64")]["gtol"], checked=r["checked"], totals=tot,
                      plain_fraction=(tot["plain"] / max(tot["n"], 1)) if tot else None,
                      plain_or_plain_on_device_records_fraction=((tot["plain"] + tot["plain_on_device_records"]) / max(tot["n"], 1)) if tot else None,
                      worst_cond_ratio=r["worst_cond_ratio"], worst_gain_err_plain=r["worst_gain"], worst_cost_err_plain=r["worst_cost"],

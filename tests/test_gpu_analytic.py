@@ -102,7 +102,7 @@ def test_solves_with_exact_derivatives_reach_the_same_optimum():
 @pytest.mark.parametrize("n,m", [(32, 16), (5, 2)])
 def test_lq_partial_records_equal_whole_records(n, m, monkeypatch):
     """With exact derivatives the LQ sweep writes the knot-independent matrices once (const_rec) and per
-    knot only cx, cu; k_backward_w reads the shared copy.  ILQR_AMD_FULL_RECORDS=1 writes and reads whole
+    knot only cx, cu; k_backward_w reads the shared copy.  ILQR_ROUTE_FULL_RECORDS writes and reads whole
     records: same solve bit for bit, same records from the getter (which fills the matrices in on demand),
     also after ilqr_set_derivatives replaced them."""
     from ilqr_amd import BatchILQR, capi
@@ -114,11 +114,8 @@ def test_lq_partial_records_equal_whole_records(n, m, monkeypatch):
     u0 = rng.normal(size=(B, T, m)) * 0.3
     out = []
     for full in (False, True):
-        if full:
-            monkeypatch.setenv("ILQR_AMD_FULL_RECORDS", "1")
-        else:
-            monkeypatch.delenv("ILQR_AMD_FULL_RECORDS", raising=False)
-        g = BatchILQR("lq", B, T, DT, u_min=-0.4, u_max=0.4, lq=mats, flags=capi.FLAG_ANALYTIC_DERIVATIVES)
+        g = BatchILQR("lq", B, T, DT, u_min=-0.4, u_max=0.4, lq=mats, flags=capi.FLAG_ANALYTIC_DERIVATIVES,
+                      route=capi.ROUTE_FULL_RECORDS if full else 0)
         g.init_traj(x0, u0)
         g.iterate(3)
         d = g.derivatives()

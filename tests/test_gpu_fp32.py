@@ -163,14 +163,16 @@ def test_full_size_properties(oracle):
     B, T, lim = 4096, 499, 5.0
     g = BatchILQR("acrobot", B, T, DT, u_min=-lim, u_max=lim, dtype="f32")
     x0 = f32(acrobot_x0(B))
-    NIT = 5  # (beyond that float cannot resolve its own gains: DESIGN.md 3.6)
+    NIT = 10
     r = sampled_walk(oracle, oracle.Model("acrobot", u_lim=lim), g, x0, np.zeros((B, T, 1)), DT, NIT, precision="f32")
     print("configs[3] shard, sampled walk:", publish("configs[3] shard acrobot T=499 B=4096 +-5 fp32", r, B=B, T=T, u_lim=lim, n_sample=len(r["sel"]), precision="f32"))
     # (x0 at full scale, T = 499: from the second iteration on float conditioning, not the implementation, limits most
     #  trajectories' per-knot agreement -- every one of them is judged against the fp64 yardstick by the walk; "tied" are
     #  the ones whose line search then also branched differently, or whose gains float cannot resolve at all)
-    assert_walk(r, NIT, min_plain_it0=0.0, tied_div=8, over10_div=8)  # (float: nothing at this scale is plain even at iteration 0; see profiles/parity_r04.json)
-    assert r["unresolved"] <= r["checked"] // 8, r["unresolved"]
+    # mixed arithmetic (the backward pass in double on float records): the gains are held to 1e-5 per knot, costs to 1e-4; what is
+    # not plain is a float ROLLOUT whose 499 steps amplified its rounding ("amplified": judged against the fp64 rollout)
+    assert_walk(r, NIT, min_plain_it0=0.8)
+    assert r["unresolved"] == 0, r["unresolved"]
     x0[1] = x0[0]
     x0[B - 1] = x0[0]
     c0 = g.init_traj(x0, np.zeros((B, T, 1)))

@@ -39,7 +39,7 @@ def test_integrator_batch_full_solve(oracle):
 
 def test_acrobot_batch_full_solve_statistics(oracle):
     from ilqr_amd import BatchILQR
-    B, T = 256, 499
+    B, T = 1024, 499  # (1024 problems: the paired medians of two rounding realisations differ by < 0.1 decades)
     om = oracle.Model("acrobot")
     x0 = acrobot_x0(B, scale=1.0, seed=77)
     u0 = np.zeros((B, T, 1))
@@ -54,9 +54,14 @@ def test_acrobot_batch_full_solve_statistics(oracle):
     ro = oracle.batch_solve(om, x0, u0, DT)
     # same problems, chaotic dynamics: compare distributions, not trajectories
     for s in (2, 3, 4):
-        assert abs((st == s).mean() - (ro["status"] == s).mean()) < 0.12, (s, (st == s).mean(), (ro["status"] == s).mean())
+        assert abs((st == s).mean() - (ro["status"] == s).mean()) < 0.08, (s, (st == s).mean(), (ro["status"] == s).mean())
     lg, lo = np.log10(cost), np.log10(ro["cost"])
-    assert abs(np.median(lg) - np.median(lo)) < 0.3  # (256 chaotic problems x 100 iterations: the paired medians differ by 0.1 ... 0.2 from one rounding realisation to the next)
+    # The distribution of final costs is bimodal with the median between the modes (it moves by 0.1 ... 0.17 decades between two
+    # rounding realisations of 1024 problems, scripts/free_run_stats.py); the MEAN of log10 cost moves by < 0.06: a 1.3 x
+    # convergence regression shows.  (Per iteration, the device-driven walks hold every step of such solves to the oracle:
+    # scripts/long_walk.py, tests/test_gpu_parity.py.)
+    assert abs(np.mean(lg) - np.mean(lo)) < 0.1, (np.mean(lg), np.mean(lo))
+    assert abs(np.median(lg) - np.median(lo)) < 0.3, (np.median(lg), np.median(lo))
     assert abs(np.mean(it) - np.mean(ro["iters"])) < 8
     # and the trajectories that DID follow the same path agree tightly
     same = np.isclose(cost, ro["cost"], rtol=1e-6)
@@ -73,13 +78,12 @@ def _everything(g):
 
 @pytest.mark.parametrize("name,dtype", [("integrator", "f64"), ("acrobot", "f64"), ("acrobot", "f32")])
 def test_compaction_of_running_trajectories_changes_nothing(name, dtype, monkeypatch):
-    """ilqr_generate_trajectory on a batch with more tiles than CUs (ILQR_AMD_NUM_CUS = 2 scales that down to test size)
+    """ilqr_generate_trajectory on a batch with more tiles than CUs (ilqr_desc.assume_cus = 2 scales that down to test size)
     re-packs the trajectories that still run into the leading tiles between chunks of iterations and launches only those
     (notes.md:16, src/ilqr_core.cpp:180-183: the reference's own TODO).  Against the same solve with compaction switched
-    off (ILQR_AMD_NO_COMPACTION=1): every array and scalar bit-identical, in the caller's order -- and the compacting
+    off (ILQR_ROUTE_NO_COMPACTION): every array and scalar bit-identical, in the caller's order -- and the compacting
     solve must actually have compacted (trajectories leave their loops at different iterations here)."""
-    from ilqr_amd import BatchILQR
-    monkeypatch.setenv("ILQR_AMD_NUM_CUS", "2")
+    from ilqr_amd import BatchILQR, capi
     if name == "integrator":
         B, T, nu = 203, 99, 2
         x0, kw = integrator_x0(B), dict(goal=[1.0, 0.5, 0.0, 0.0])
@@ -93,11 +97,7 @@ def test_compaction_of_running_trajectories_changes_nothing(name, dtype, monkeyp
     u0 = np.zeros((B, T, nu))
     out = []
     for off in (False, True):
-        if off:
-            monkeypatch.setenv("ILQR_AMD_NO_COMPACTION", "1")
-        else:
-            monkeypatch.delenv("ILQR_AMD_NO_COMPACTION", raising=False)
-        g = BatchILQR(name, B, T, DT, dtype=dtype, **kw)
+        g = BatchILQR(name, B, T, DT, dtype=dtype, assume_cus=2, route=capi.ROUTE_NO_COMPACTION if off else 0, **kw)
         g.generate_trajectory(x0, u0)
         assert g.count_running() == 0
         out.append(_everything(g))

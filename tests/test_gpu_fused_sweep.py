@@ -115,12 +115,8 @@ def test_two_tiles_per_cu_variants_equal_unfused(name, dtype, monkeypatch):
         x0, nu, kw = integrator_x0(B), 2, dict(goal=[1.0, 0.5, 0.0, 0.0])
     u0 = np.zeros((B, T, nu))
     out = []
-    for fl, env in ((0, "2"), (capi.FLAG_STAGED, "2"), (capi.FLAG_UNFUSED, None)):
-        if env:
-            monkeypatch.setenv("ILQR_AMD_FUSED", env)
-        else:
-            monkeypatch.delenv("ILQR_AMD_FUSED", raising=False)
-        g = BatchILQR(name, B, T, DT, flags=fl, dtype=dtype, **kw)
+    for fl, route in ((0, capi.ROUTE_TWO_TILES_PER_CU), (capi.FLAG_STAGED, capi.ROUTE_TWO_TILES_PER_CU), (capi.FLAG_UNFUSED, 0)):
+        g = BatchILQR(name, B, T, DT, flags=fl, dtype=dtype, route=route, **kw)
         g.generate_trajectory(x0, u0)
         out.append(_state(g))
         g.close()
@@ -138,18 +134,14 @@ def test_wide_tiles_equal_unfused(B, T, dtype, occ, monkeypatch):
     the two-kernel route: every array and scalar bit-identical.  occ: one wide tile per CU (8 wavefronts, 148 KB ring) or two
     (4 wavefronts each, 74 KB ring = three slots in fp64, roles by SIMD)."""
     from ilqr_amd import BatchILQR, capi
-    monkeypatch.setenv("ILQR_AMD_WIDE_OCC", occ)
+    wide = capi.ROUTE_WIDE_TILES | (capi.ROUTE_WIDE_ONE_PER_CU if occ == "1" else capi.ROUTE_WIDE_TWO_PER_CU)
     x0 = acrobot_x0(B, scale=0.3, seed=B + T)
     u0 = np.zeros((B, T, 1))
     kw = dict(u_min=-1.5, u_max=1.5, params=dict(max_iter=14), dtype=dtype)
     sv = capi.STAGE_NAMES.index("solve")
     out = []
-    for fl, env in ((0, "3"), (capi.FLAG_UNFUSED, None)):
-        if env:
-            monkeypatch.setenv("ILQR_AMD_FUSED", env)
-        else:
-            monkeypatch.delenv("ILQR_AMD_FUSED", raising=False)
-        g = BatchILQR("acrobot", B, T, DT, flags=fl, **kw)
+    for fl, env in ((0, wide), (capi.FLAG_UNFUSED, 0)):
+        g = BatchILQR("acrobot", B, T, DT, flags=fl, route=env, **kw)
         if env:
             assert g.lib.ilqr_stage_kernel_name(g.h, sv) == b"k_solve_wide"
         g.init_traj(x0, u0)
@@ -162,13 +154,12 @@ def test_wide_tiles_equal_unfused(B, T, dtype, occ, monkeypatch):
 
 
 def test_route_selection_by_batch_size(monkeypatch):
-    """Route selection by batch size (ILQR_AMD_NUM_CUS scales the thresholds down to test sizes): up to one tile per CU
+    """Route selection by batch size (ilqr_desc.assume_cus scales the thresholds down to test sizes): up to one tile per CU
     the persistent kernel with a CU per tile, beyond that -- at ANY batch size -- the persistent kernel with two tiles per
     CU (the records never reach HBM); with ILQR_FLAG_STAGED the per-stage kernels, and two kernels beyond two tiles per CU.
     Every route leaves the same bits."""
     from ilqr_amd import BatchILQR, capi
     cus = 6
-    monkeypatch.setenv("ILQR_AMD_NUM_CUS", str(cus))
     T = 20
     bw, sv = capi.STAGE_NAMES.index("backward"), capi.STAGE_NAMES.index("solve")
     for B in (16 * cus + 16, 48 * cus + 3, 80 * cus + 3):  # one tile more than one per CU; three per CU; five per CU and a ragged last tile
@@ -176,7 +167,7 @@ def test_route_selection_by_batch_size(monkeypatch):
         u0 = np.zeros((B, T, 1))
         out = []
         for fl in (0, capi.FLAG_STAGED, capi.FLAG_UNFUSED):
-            g = BatchILQR("acrobot", B, T, DT, u_min=-1.5, u_max=1.5, flags=fl)
+            g = BatchILQR("acrobot", B, T, DT, u_min=-1.5, u_max=1.5, flags=fl, assume_cus=cus)
             name = lambda st: g.lib.ilqr_stage_kernel_name(g.h, st)
             if fl == 0:  # two tiles per CU, and wide (64-trajectory) tiles once every CU gets one
                 assert name(sv) == (b"k_solve_tile<2>" if B < 64 * cus else b"k_solve_wide")
@@ -190,7 +181,7 @@ def test_route_selection_by_batch_size(monkeypatch):
             g.close()
         _same(out[0], out[1])
         _same(out[0], out[2])
-    g = BatchILQR("acrobot", 64, 4, DT)  # four tiles on "six CUs"
+    g = BatchILQR("acrobot", 64, 4, DT, assume_cus=cus)  # four tiles on "six CUs"
     assert g.lib.ilqr_stage_kernel_name(g.h, sv) == b"k_solve_tile"
     g.close()
 

@@ -122,11 +122,10 @@ def test_register_kernel_equals_lds_kernel(oracle, n, m, lim, shift):
         dv["cuu"] = dv["cuu"] + np.diag(s)[None, None]
     k_prev = rng.normal(size=(B, T, m)) * 0.1
     outs = []
+    from ilqr_amd import capi
     for force_lds in (False, True):
-        if force_lds:
-            os.environ["ILQR_AMD_BACKWARD_W1"] = "1"
         try:
-            g = BatchILQR("host", B, T, DT, nx=n, nu=m, u_min=om.u_min, u_max=om.u_max)
+            g = BatchILQR("host", B, T, DT, nx=n, nu=m, u_min=om.u_min, u_max=om.u_max, route=capi.ROUTE_BACKWARD_LDS if force_lds else 0)
             g.set_trajectory(x0=x0, xs=xs, us=us, cost=cost)
             g.set_derivatives(**{k: (dv[k] if k in ("cx", "cu") else mat(dv[k])) for k in dv})
             g.set_gains(k=k_prev, K=np.zeros((B, T, m, n)))
@@ -136,6 +135,6 @@ def test_register_kernel_equals_lds_kernel(oracle, n, m, lim, shift):
             outs.append(dict(div=np.asarray(div), k=k, K=K, dV=g.dV(), gnorm=g.gnorm()))
             g.close()
         finally:
-            os.environ.pop("ILQR_AMD_BACKWARD_W1", None)
+            pass
     for key in outs[0]:
         assert np.array_equal(outs[0][key], outs[1][key], equal_nan=True), key

@@ -153,7 +153,7 @@ def test_lq_full_solve_and_warm_start(oracle):
 def test_lq_matrix_core_rollout_equals_thread_per_rollout(n, m, B, T, monkeypatch):
     """k_rollout_lq (one wavefront per trajectory, every product a v_mfma_f64_16x16x4_f64 chain over the
     11 candidate columns) against the generic thread-per-rollout kernel k_rollout_g
-    (ILQR_AMD_LQ_THREAD_ROLLOUT=1): the chains run in the order of the scalar sums, so init rollout,
+    (ILQR_ROUTE_LQ_THREAD_ROLLOUT): the chains run in the order of the scalar sums, so init rollout,
     the 11 search costs, the committed trajectory and everything downstream are bit-identical."""
     from ilqr_amd import BatchILQR, capi
     mats = dense_mats(n, m)
@@ -162,11 +162,8 @@ def test_lq_matrix_core_rollout_equals_thread_per_rollout(n, m, B, T, monkeypatc
     u0 = rng.normal(size=(B, T, m)) * 0.3
     out = []
     for thread in (False, True):
-        if thread:
-            monkeypatch.setenv("ILQR_AMD_LQ_THREAD_ROLLOUT", "1")
-        else:
-            monkeypatch.delenv("ILQR_AMD_LQ_THREAD_ROLLOUT", raising=False)
-        g = BatchILQR("lq", B, T, DT, u_min=-0.4, u_max=0.4, lq=mats, flags=capi.FLAG_ANALYTIC_DERIVATIVES)
+        g = BatchILQR("lq", B, T, DT, u_min=-0.4, u_max=0.4, lq=mats, flags=capi.FLAG_ANALYTIC_DERIVATIVES,
+                      route=capi.ROUTE_LQ_THREAD_ROLLOUT if thread else 0)
         name = g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("rollout"))
         assert name == (b"k_rollout_g" if thread else b"k_rollout_lq")
         c0 = g.init_traj(x0, u0)
