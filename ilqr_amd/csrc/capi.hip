@@ -112,7 +112,7 @@ struct ilqr_batch {
   // Route choices for A/B runs and the bit-identity tests: ilqr_desc.route, fixed at ilqr_create -- a handle never changes
   // kernels between calls, and nothing is read from the environment
   struct {
-    bool staged = false, unfused = false, backward_w1 = false, lq_thread_rollout = false, full_records = false, no_compaction = false;
+    bool staged = false, unfused = false, backward_w1 = false, lq_thread_rollout = false, full_records = false, no_compaction = false, quad_chain = false;
     int fused = 0;  // 0 = by batch size
     int wide_occ = 0;  // wide tiles per CU: 0 = by batch size
   } env;
@@ -591,7 +591,8 @@ static int launch_backward(ilqr_batch* h, int mode) {
 }
 
 // Which route ilqr_iterate takes.  All of them leave the same bits (tests/test_gpu_fused_sweep.py):
-//   ntiles <= #CU                      one persistent 16-trajectory tile per CU            k_solve_tile<.., 1>
+//   ntiles <= #CU, m = 1, no fixes     one persistent tile per CU, its backward pass as four matrix-core chains   k_solve_hex
+//   ntiles <= #CU otherwise            one persistent 16-trajectory tile per CU            k_solve_tile<.., 1>
 //   m = 1, no opt-in fixes, >= 4 tiles per CU   64-trajectory wide tiles, one or two per CU   k_solve_wide
 //   anything larger otherwise          persistent 16-trajectory tiles, two per CU (the dispatcher hands a CU its next
 //                                      tile when one is through)                           k_solve_tile<.., 2>
@@ -600,12 +601,13 @@ static int launch_backward(ilqr_batch* h, int mode) {
 //                                      k_derivatives + k_backward_q with the records in HBM
 //   ILQR_FLAG_UNFUSED, AoS (generic) models   always the two-kernel route
 // ilqr_desc.route (ILQR_ROUTE_TILE_PER_CU / TWO_TILES_PER_CU / WIDE_TILES) forces a variant for A/B runs and the bit-identity tests.
-static int fused_variant(const ilqr_batch* h) {  // 0: two kernels, 1: one tile per CU, 2: two tiles per CU, 3: wide tiles (64 trajectories, one per CU)
+static int fused_variant(const ilqr_batch* h) {  // 0: two kernels, 1: one tile per CU, 2: two tiles per CU, 3: wide tiles (64 trajectories, one per CU), 4: one tile per CU, matrix-core chains
   if (!use_quad_backward(h) || h->aos || (h->flags & ILQR_FLAG_UNFUSED) || h->env.unfused) return 0;
   const bool staged = (h->flags & ILQR_FLAG_STAGED) || h->env.staged;
   const bool wide_ok = !staged && h->nu == 1 && h->sp.fixes == 0;  // wide tiles (kernels_wide.hpp): persistent route, m = 1, no opt-in fixes
-  if (h->env.fused) return (h->env.fused == 3 && !wide_ok) ? 2 : h->env.fused;
-  if (h->ntiles <= h->num_cus) return 1;
+  const int one_per_cu = (wide_ok && !h->env.quad_chain) ? 4 : 1;  // k_solve_hex (backward_hex.hpp) shares the wide tiles' conditions
+  if (h->env.fused) return (h->env.fused == 3 && !wide_ok) ? 2 : (h->env.fused == 1 ? one_per_cu : h->env.fused);
+  if (h->ntiles <= h->num_cus) return one_per_cu;
   if (wide_ok && h->ntiles >= 4 * h->num_cus) return 3;  // a 64-trajectory wide tile for every CU: the thread-per-trajectory chain
   if (!staged) return 2;  // persistent tiles, two per CU, for ANY larger batch: the dispatcher hands a CU its next tile when one is through
   return (h->ntiles <= 2 * h->num_cus) ? 2 : 0;
@@ -673,6 +675,9 @@ static int launch_solve_tiles(ilqr_batch* h, int n_iters) {
             else
               hipLaunchKernelGGL((k_solve_wide<MM, MF, 2>), dim3((grid_tiles + 3) / 4), dim3(256), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
           }
+        } else if (occ == 4) {
+          if constexpr (MM::NU == 1)
+            hipLaunchKernelGGL((k_solve_hex<MM, MF>), dim3(grid_tiles), dim3(512), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
         } else if (occ == 1)
           hipLaunchKernelGGL((k_solve_tile<MM, MF, 1>), dim3(grid_tiles), dim3(256), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
         else
@@ -681,7 +686,7 @@ static int launch_solve_tiles(ilqr_batch* h, int n_iters) {
       }))
     return rc;
   HIPCHK(hipGetLastError());
-  h->commit_pending = true;   // the last iteration's accepts (flushed by the caller)
+  h->commit_pending = (occ != 4);   // the last iteration's accepts (flushed by the caller); k_solve_hex commits every iteration's itself
   h->recs = ilqr_batch::REC_STALE;
   return timer_end(h, ILQR_STAGE_SOLVE, ev);
 }
@@ -757,6 +762,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   h->env.lq_thread_rollout = (d->route & ILQR_ROUTE_LQ_THREAD_ROLLOUT) != 0;
   h->env.full_records = (d->route & ILQR_ROUTE_FULL_RECORDS) != 0;
   h->env.no_compaction = (d->route & ILQR_ROUTE_NO_COMPACTION) != 0;
+  h->env.quad_chain = (d->route & ILQR_ROUTE_QUAD_CHAIN) != 0;
   h->env.fused = d->route & 3;
   h->env.wide_occ = (d->route & ILQR_ROUTE_WIDE_ONE_PER_CU) ? 1 : (d->route & ILQR_ROUTE_WIDE_TWO_PER_CU) ? 2 : 0;
   if (d->assume_cus > 0) h->num_cus = d->assume_cus;
@@ -1671,7 +1677,7 @@ const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
       return (h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t";
     case ILQR_STAGE_ROLLOUT: return (h && h->aos) ? ((h->env.lq_thread_rollout || h->model != ILQR_MODEL_LQ) ? "k_rollout_g" : "k_rollout_lq") : "k_rollout";
     case ILQR_STAGE_ACCEPT: return "k_accept";
-    case ILQR_STAGE_SOLVE: return (h && use_persistent(h)) ? (fused_variant(h) == 1 ? "k_solve_tile" : fused_variant(h) == 3 ? "k_solve_wide" : "k_solve_tile<2>") : "";
+    case ILQR_STAGE_SOLVE: return (h && use_persistent(h)) ? (fused_variant(h) == 1 ? "k_solve_tile" : fused_variant(h) == 3 ? "k_solve_wide" : fused_variant(h) == 4 ? "k_solve_hex" : "k_solve_tile<2>") : "";
     default: return "";
   }
 }

@@ -6,6 +6,7 @@
 //   backward_thread.hpp  k_backward_t (one thread per trajectory; cross-check)
 //   backward_quad.hpp    backward_quad, k_backward_q (four lanes per trajectory)
 //   solve_tile.hpp       the LDS ring, k_sweep_backward, k_solve_tile (persistent tiles), k_commit
+//   backward_hex.hpp     k_solve_hex: one tile per CU, its backward pass as four matrix-core chains (the metric batch)
 //   (kernels_wide.hpp    64-trajectory wide tiles for saturating batches; generic.hpp, backward_wave*.hpp: nx <= 32)
 #pragma once
 #include "backward_quad.hpp"
@@ -14,3 +15,4 @@
 #include "layout.hpp"
 #include "rollout.hpp"
 #include "solve_tile.hpp"
+#include "backward_hex.hpp"

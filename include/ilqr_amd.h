@@ -165,7 +165,7 @@ typedef struct ilqr_desc {
  * scripts/soak.py): these exist for A/B measurements and for those tests.  The library reads NO environment variables. */
 enum ilqr_route {
   ILQR_ROUTE_AUTO = 0,
-  ILQR_ROUTE_TILE_PER_CU = 1,       /* ilqr_iterate: persistent 16-trajectory tiles, one per CU (k_solve_tile<..,1>) */
+  ILQR_ROUTE_TILE_PER_CU = 1,       /* ilqr_iterate: persistent 16-trajectory tiles, one per CU (k_solve_hex for m = 1 without opt-in fixes, else k_solve_tile<..,1>) */
   ILQR_ROUTE_TWO_TILES_PER_CU = 2,  /* ... two per CU (k_solve_tile<..,2>; with ILQR_FLAG_STAGED the one-producer k_sweep_backward) */
   ILQR_ROUTE_WIDE_TILES = 3,        /* ... 64-trajectory wide tiles (k_solve_wide; m = 1 without opt-in fixes, else as 2) */
   ILQR_ROUTE_WIDE_ONE_PER_CU = 4,   /* wide tiles: one per CU whatever the batch size */
@@ -173,7 +173,8 @@ enum ilqr_route {
   ILQR_ROUTE_NO_COMPACTION = 16,    /* ilqr_generate_trajectory without re-packing running trajectories between chunks */
   ILQR_ROUTE_FULL_RECORDS = 32,     /* LQ model, exact derivatives: whole per-knot records instead of one shared copy of the constant blocks */
   ILQR_ROUTE_LQ_THREAD_ROLLOUT = 64,/* LQ model: thread-per-rollout k_rollout_g instead of the matrix-core k_rollout_lq */
-  ILQR_ROUTE_BACKWARD_LDS = 128     /* generic path: round 1's LDS kernel k_backward_w instead of the register kernel k_backward_w2 */
+  ILQR_ROUTE_BACKWARD_LDS = 128,    /* generic path: round 1's LDS kernel k_backward_w instead of the register kernel k_backward_w2 */
+  ILQR_ROUTE_QUAD_CHAIN = 256       /* one tile per CU: the 4-lane DPP chain (k_solve_tile<..,1>) also where the matrix-core chains (k_solve_hex: m = 1, no opt-in fixes) would run */
 };
 
 const char* ilqr_last_error(void);

@@ -67,7 +67,7 @@ def main():
                                ("thread", capi.FLAG_UNFUSED | capi.FLAG_BACKWARD_THREAD_PER_TRAJ, {}),
                                # the routes big batches take, forced on these small ones: two tiles per CU, wide tiles (one / two per
                                # CU; m = 2 falls back to two tiles per CU), and compaction of running trajectories between chunks
-                               ("quad1", 0, dict(route=capi.ROUTE_TILE_PER_CU)), ("occ2", 0, dict(route=capi.ROUTE_TWO_TILES_PER_CU)),
+                               ("quad1", 0, dict(route=capi.ROUTE_QUAD_CHAIN)), ("occ2", 0, dict(route=capi.ROUTE_TWO_TILES_PER_CU)),
                                ("wide1", 0, dict(route=capi.ROUTE_WIDE_TILES | capi.ROUTE_WIDE_ONE_PER_CU)),
                                ("wide2", 0, dict(route=capi.ROUTE_WIDE_TILES | capi.ROUTE_WIDE_TWO_PER_CU)),
                                ("compact", 0, dict(assume_cus=2))):

@@ -93,7 +93,7 @@ def main():
         ro_s = {kk: v[sane] for kk, v in ro.items()}
         try:
             r = check_backward(O, om, sub(us), {kk: v[sane] for kk, v in dv.items()}, sub(k_prev), lam, sub(outs[0]["k"]), sub(outs[0]["K"]),
-                               sub(outs[0]["dV"]), sub(outs[0]["div"]), ro_s, max_ties=max(1, B // 4))
+                               sub(outs[0]["dV"]), sub(outs[0]["div"]), ro_s, max_ties=max(1, B // 4), max_over10=max(1, B // 16))
         except AssertionError as e:
             print("FAIL oracle parity:", desc, str(e)[:300])
             return 1

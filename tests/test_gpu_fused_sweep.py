@@ -70,6 +70,12 @@ def test_stage_kernel_name_reports_the_fused_kernel():
     from ilqr_amd import BatchILQR, capi
     g = BatchILQR("acrobot", 16, 10, DT)
     assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("backward")) == b"k_sweep_backward"
+    assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("solve")) == b"k_solve_hex"  # m = 1: four matrix-core chains per tile
+    g.close()
+    g = BatchILQR("integrator", 16, 10, DT)
+    assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("solve")) == b"k_solve_tile"  # m = 2: the quad chain
+    g.close()
+    g = BatchILQR("acrobot", 16, 10, DT, route=capi.ROUTE_QUAD_CHAIN)
     assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("solve")) == b"k_solve_tile"
     g.close()
     g = BatchILQR("acrobot", 16, 10, DT, flags=capi.FLAG_STAGED)
@@ -182,8 +188,37 @@ def test_route_selection_by_batch_size(monkeypatch):
         _same(out[0], out[1])
         _same(out[0], out[2])
     g = BatchILQR("acrobot", 64, 4, DT, assume_cus=cus)  # four tiles on "six CUs"
-    assert g.lib.ilqr_stage_kernel_name(g.h, sv) == b"k_solve_tile"
+    assert g.lib.ilqr_stage_kernel_name(g.h, sv) == b"k_solve_hex"
     g.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("B,T,lim", [(64, 60, 1.5), (37, 123, 0.4), (200, 499, 1.5), (5, 1, 1.5), (16, 7, 5.0)])
+def test_matrix_core_chains_equal_the_quad_chain(B, T, lim, dtype):
+    """One tile per CU, m = 1: k_solve_hex (four chains per tile on the matrix cores -- v_mfma_f64_4x4x4_4b_f64 --, 16 step sizes
+    per Armijo pass, the commit right after the line search) against k_solve_tile<1> (one 4-lane DPP chain, the quad search, the
+    commit on the producers' way) and the two-kernel route: every array and scalar bit-identical, through late iterations (lambda
+    retries, slow QP exits), partial tiles and sub-tiles, horizons shorter than a producer round."""
+    from ilqr_amd import BatchILQR, capi
+    x0 = acrobot_x0(B, scale=0.6, seed=11)
+    if dtype == "f32":
+        x0 = x0.astype(np.float32).astype(np.float64)
+    u0 = np.zeros((B, T, 1))
+    out = []
+    for fl, route, name in ((0, 0, b"k_solve_hex"), (0, capi.ROUTE_QUAD_CHAIN, b"k_solve_tile"), (capi.FLAG_UNFUSED, 0, None)):
+        g = BatchILQR("acrobot", B, T, DT, u_min=-lim, u_max=lim, flags=fl, dtype=dtype, route=route, params=dict(max_iter=40))
+        if name:
+            assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("solve")) == name
+        g.init_traj(x0, u0)
+        g.iterate(3)
+        s = _state(g)
+        g.iterate(1)
+        g.generate_trajectory()
+        s.update({"end_" + n: a for n, a in _state(g).items()})
+        out.append(s)
+        g.close()
+    _same(out[0], out[1])
+    _same(out[0], out[2])
 
 
 @pytest.mark.parametrize("name", ["acrobot", "integrator"])
