@@ -99,10 +99,11 @@ struct HexGate {
 // The lanes of trajectory t sit at 16 r + 4 t + c, ascending with j: the lowest set bit of the ballot under the trajectory's lane
 // mask IS the first k.  The winner's step comes back from the table and every lane recomputes the
 // winner's trial point and value (same expression, same operands: the winner's bits).
-// position (bit index in the wavefront's ballot) of the first candidate of this trajectory whose bit is set; >= 52 if none.
-// tmask = 0x000F000F000F000F << 4 t: the trajectory's lanes 16 r + 4 t + c, ascending with the candidate index j = 4 r + c.
-__device__ __forceinline__ int hex_first(unsigned long long bal, unsigned long long tmask) {
-  return __builtin_ctzll((bal & tmask) | 0x8000000000000000ull);
+// position 16 r + c of the first candidate of trajectory t whose bit is set in the wavefront's ballot; 63 (>= 52) if none.
+// The trajectory's lanes are 16 r + 4 t + c, ascending with the candidate index j = 4 r + c: shifted down by 4 t they are the
+// bits 0x000F000F000F000F, the highest of them 51 -- bit 63 is free to be the "none" mark.
+__device__ __forceinline__ int hex_first(unsigned long long bal, int t4) {
+  return __builtin_ctzll(((bal >> t4) & 0x000F000F000F000Full) | 0x8000000000000000ull);
 }
 // v_max_f64 / v_min_f64 as the instructions (the builtins canonicalise their operands first -- one more instruction per
 // operand -- to quiet signalling NaNs; for every other input the result is the same bits)
@@ -112,7 +113,7 @@ __device__ __forceinline__ double hex_clamp(double v, double lo, double hi) {
   asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(t), "v"(hi));
   return r;
 }
-__device__ __forceinline__ void qp1_search_hex(QP1StateT<double>& q, int j, unsigned long long tmask, double step_j0, const double* __restrict__ lds_steps) {
+__device__ __forceinline__ void qp1_search_hex(QP1StateT<double>& q, int j, int t4, double step_j0, const double* __restrict__ lds_steps) {
   // First pass, k = j, straight-line for every lane (an early exit's lanes compute along: the caller's selects ignore their
   // x1 / v1): the reference's loop ends inside it for all but a few per cent of the QPs.  A trial that lands on x itself ("stuck":
   // failure, qp1_backtrack_seq) has value == old value and fails the test, and so does every shorter step after it: a passing k
@@ -120,7 +121,7 @@ __device__ __forceinline__ void qp1_search_hex(QP1StateT<double>& q, int j, unsi
   const double t_x1 = hex_clamp(q.x + step_j0 * q.search, q.lo, q.hi);   // qp1_trial
   const double t_v1 = qp1_value(q, t_x1);
   const bool t_pass = !qp1_armijo_fails(q, t_v1, step_j0);
-  const int pp = hex_first(__ballot(t_pass), tmask);
+  const int pp = hex_first(__ballot(t_pass), t4);
   const bool success = pp < 52;            // a set bit
   const int jw = success ? (((pp >> 4) << 2) | (pp & 3)) : 0;
   q.step = lds_steps[jw];
@@ -128,16 +129,26 @@ __device__ __forceinline__ void qp1_search_hex(QP1StateT<double>& q, int j, unsi
   q.v1 = qp1_value(q, q.x1);
   bool more = p_and(!success, !q.early);
   if (__builtin_expect(__ballot(more) == 0ull, 1)) return;  // (wave-uniform)
-  // No k <= 15 passes for some trajectory of this wavefront: the loop as written, 16 step sizes per pass, from k = 0 again
-  // (now with the "stuck" and minStep exits, boxqp.cpp:167-171)
-  for (int base = 0;; base += 16) {
+  // No k <= 15 passes for some trajectory of this wavefront (the search direction is rounding noise: x is the optimum already).
+  // The loop as written now needs its "stuck" and minStep exits (boxqp.cpp:167-171).  k = 1 .. 15 first, from the trial points
+  // at hand (every step size here is above minStep): a stuck trial among them ends the search, no k <= 15 having passed.
+  {
+    const bool stuck = p_and(j >= 1, t_x1 == q.x);
+    const int qs = hex_first(__ballot(p_and(stuck, more)), t4);
+    if (p_and(more, qs < 52)) {
+      q.ls_failed = true;
+      more = false;
+    }
+    if (__ballot(more) == 0ull) return;
+  }
+  for (int base = 16;; base += 16) {  // 16 step sizes per pass
     const int kn = base + j;
     const double my_step = lds_steps[kn < 104 ? kn : 103];  // (k = 100 is below minStep: the loop never gets further)
     const double my_x1 = qp1_trial(q, my_step);
     const double my_v1 = qp1_value(q, my_x1);
     const bool pass = !qp1_armijo_fails(q, my_v1, my_step);
-    const bool stuck = p_and(kn >= 1, p_or(my_step < kMinStep, my_x1 == q.x));
-    const int qp = hex_first(__ballot(p_and(pass, more)), tmask), qs = hex_first(__ballot(p_and(stuck, more)), tmask);
+    const bool stuck = p_or(my_step < kMinStep, my_x1 == q.x);
+    const int qp = hex_first(__ballot(p_and(pass, more)), t4), qs = hex_first(__ballot(p_and(stuck, more)), t4);
     if (more) {
       if (qp < qs) {
         q.step = lds_steps[base + (((qp >> 4) << 2) | (qp & 3))];
@@ -170,7 +181,7 @@ __device__ __forceinline__ void backward_hex(const BatchViewT<typename M::real>&
   using R = Rec<4, 1>;
   typedef real real2_t __attribute__((ext_vector_type(2)));
   const int r_ = lane >> 4, t_ = (lane >> 2) & 3, c_ = lane & 3, j16 = 4 * r_ + c_;
-  const unsigned long long tmask = 0x000F000F000F000Full << (4 * t_);  // this trajectory's lanes in a ballot
+  const int t4 = 4 * t_;  // this trajectory's lanes in a ballot: 0x000F000F000F000F << t4
   const int l = sub * HT + t_;
   const int b = tile * TW + l;
   if (b >= v.B) return;                        // uniform over the trajectory's lanes
@@ -251,12 +262,12 @@ __device__ __forceinline__ void backward_hex(const BatchViewT<typename M::real>&
       creal minv;
       QP1StateT<creal> q1;
       qp1_begin<false>(QuuF, Qu, kprev, lo, hi, q1, false);
-      qp1_search_hex(q1, j16, tmask, step_j0, lds_steps);
+      qp1_search_hex(q1, j16, t4, step_j0, lds_steps);
       bool goes_on;
       bool ok = qp1_finish_ok(q1, x, free0, minv, goes_on);
       if (goes_on)
         ok = qp1_continue(
-                 q1, [&](QP1StateT<creal>& qs) __attribute__((always_inline)) { qp1_search_hex(qs, j16, tmask, step_j0, lds_steps); }, x, free0) >= 1;
+                 q1, [&](QP1StateT<creal>& qs) __attribute__((always_inline)) { qp1_search_hex(qs, j16, t4, step_j0, lds_steps); }, x, free0) >= 1;
       if (!ok) diverge = i;
       // :373-385  K = -(R^-1 R^-T) Qux on a free control, 0 on a clamped one
       const creal k_scale = free0 ? -minv : creal(0);
