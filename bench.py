@@ -319,7 +319,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "contract_frac": achieved / HBM_PEAK_GBS, "bound_frac": None,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_ts[dom] * B * T, "avg_launch_ms": stages[dom]["ms_per_launch"],
-                "limiter": "VALU issue + latency of dependent chains (one Riccati chain per tile, then three rollout wavefronts), not "
+                "limiter": "VALU issue + latency of dependent chains (the Riccati chains of a tile -- four on the matrix cores at one tile per CU --, then its rollout wavefronts), not "
                            "bytes: see roofline_issue; HBM is the contract's nominal bound for this byte-light path"}
 
 

@@ -28,26 +28,36 @@ __device__ __forceinline__ int cvt_i32_saturating(double v) {
   asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(v));
   return r;
 }
+// A double constant held in a vector register.  A VOP3 instruction takes one scalar (or literal) operand, so the first FMA of a
+// Horner chain -- two constants -- needs one of them in a VGPR, and under the scalar-register pressure of the persistent kernels
+// the compiler re-materialised those and the reduction's in every rollout step and finite-difference point (18 s_mov_b32 +
+// 2 v_mov_b64 of the 185 instructions of a rollout step; an s_mov costs a wavefront that has its SIMD to itself the same
+// 5 cycles as a v_fma_f64, scripts/ubench/operands.hip).  Opaque to the optimiser: the value stays in its register.  Same bits.
+// (All sixteen coefficients this way was measured slower: the compiler then copies each one into the two-address v_fmac.)
+__device__ __forceinline__ double vreg_const(double c) {
+  asm("" : "+v"(c));
+  return c;
+}
 __device__ __forceinline__ void sincos_shared(double x, double& s_out, double& c_out) {
   // contraction by the source, not by the optimiser: every inlined copy of this function (rollout kernels, the
   // persistent kernel, the commit / getter re-integration, the finite differences) must round identically
 #pragma clang fp contract(on)
-  const double j = __builtin_rint(x * 6.36619772367581382433e-01);  // 2/pi
-  double r = __builtin_fma(-j, 1.57079632679489655800e+00, x);      // pi/2, leading 53 bits
-  r = __builtin_fma(-j, 6.12323399573676603587e-17, r);             // next 53 bits
-  r = __builtin_fma(-j, -1.49738490485916983294e-33, r);            // and the rest
+  const double j = __builtin_rint(x * vreg_const(6.36619772367581382433e-01));  // 2/pi
+  double r = __builtin_fma(-j, vreg_const(1.57079632679489655800e+00), x);      // pi/2, leading 53 bits
+  r = __builtin_fma(-j, vreg_const(6.12323399573676603587e-17), r);             // next 53 bits
+  r = __builtin_fma(-j, vreg_const(-1.49738490485916983294e-33), r);            // and the rest
   const double z = r * r;
   // sin(r) = r + r^3 (S1 + z (S2 + ... ))
   const double ps = 8.33333333332248946124e-03 +
                     z * (-1.98412698298579493134e-04 +
-                         z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+                         z * (2.75573137070700676789e-06 + z * (vreg_const(-2.50507602534068634195e-08) + z * 1.58969099521155010221e-10)));
   const double sr = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
   // cos(r) = 1 - z/2 + z^2 (C1 + z (C2 + ... )), summed so that the 1 - z/2 rounding is compensated
   const double pc = z * (4.16666666666666019037e-02 +
                          z * (-1.38888888888741095749e-03 +
                               z * (2.48015872894767294178e-05 +
                                    z * (-2.75573143513906633035e-07 +
-                                        z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+                                        z * (vreg_const(2.08757232129817482790e-09) + z * -1.13596475577881948265e-11)))));
   const double hz = 0.5 * z;
   const double w = 1.0 - hz;
   const double cr = w + (((1.0 - w) - hz) + z * pc);

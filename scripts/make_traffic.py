@@ -11,7 +11,7 @@ import json
 import re
 import sys
 
-WARMUP, STEPS = 3, 5   # iterations of the two k_solve_tile launches of the counter runs (collect_profiles.sh)
+WARMUP, STEPS = 3, 5   # iterations of the two persistent-kernel launches of the counter runs (collect_profiles.sh)
 
 
 def read(path, counter):
@@ -87,7 +87,7 @@ def main(d, tag):
     for k in sorted(set(f) | set(w)):
         if not k.startswith("k_"):
             continue
-        if k == "k_solve_tile":
+        if k in ("k_solve_tile", "k_solve_hex"):  # the headline batch: the matrix-core chains (the quad chain under --route 256)
             kernels[k] = solve_entry(d, "", k, B, T, f, w)
             continue
         fr, wr = f.get(k, (0.0, 1))[0], w.get(k, (0.0, 1))[0]
