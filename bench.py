@@ -305,12 +305,13 @@ def main():
             stages["solve"]["iterations_per_launch"] = iters_per_call
         return stages, bytes_ts
 
-    def roofline_of(stages, bytes_ts, B):
+    def roofline_of(stages, bytes_ts, B, dtype="f64"):
         real_launches = {k: v for k, v in stages.items() if "clock" not in v}
         dom = max(real_launches, key=lambda k: stages[k]["ms_per_launch"])
         kern = stages[dom]["kernel"]
         achieved = stages[dom]["algorithmic_GBps"]
-        traffic, traffic_src = pmc_traffic(kern, stages[dom].get("iterations_per_launch", 1))
+        # (the counter passes are of the fp64 workloads: a float instantiation has an entry of its own in traffic.json, or none)
+        traffic, traffic_src = pmc_traffic(kern + ("_f32" if dtype == "f32" else ""), stages[dom].get("iterations_per_launch", 1))
         # `bound` names the limiter this build claims for the kernel.  achieved / peak / unit / frac stay the figures of the
         # contract's roofline for the path (HBM: algorithmic bytes over the launch duration) -- repeated as
         # contract_bound / contract_frac so that nobody reads 0.11 as "11 % of the limiter"; the limiter's own fraction is
@@ -354,7 +355,7 @@ def main():
         sts, bts = stage_table(gs, profs, Bs, s_bytes, steps)
         sclk = gs.sclk_mhz
         gs.close()
-        roofs = roofline_of(sts, bts, Bs)
+        roofs = roofline_of(sts, bts, Bs, args.dtype)
         roofs["bound_frac"] = issue_roofline(roofs["kernel"], els / steps * 1e3, sclk, Bs * T)["frac"]
         extra["saturated"] = {
             "workload": "the headline workload at B=%d per GPU (persistent wide tiles of 64 trajectories, two per CU, thread-per-trajectory "
@@ -370,7 +371,7 @@ def main():
             "workload": "acrobot T=499 B=32768 on one GPU, u in [-5,5], %s (BASELINE configs[3] at its stated size, unsharded); the 8 x 4096 partition of "
                         "the same batch gives the same bits (tests/test_gpu_fp32.py)" % other,
             "dtype": other, "value": 32768 * T * steps / el5, "unit": "trajectory-timesteps/s", "ms_per_step": el5 / steps * 1e3,
-            "stages": st5, "roofline": roofline_of(st5, bt5, 32768)}
+            "stages": st5, "roofline": roofline_of(st5, bt5, 32768, other)}
     if not args.no_extra_configs:
         # late in a solve: iterations 4..103 of the same workload -- box-QPs leave the fast path
         # once lambda has reached 0, the launch lasts as long as its slowest tile
@@ -393,7 +394,7 @@ def main():
                             "per-GPU shard; x %d GPUs)" % (other, ", exact model derivatives instead of finite differences" if fl else
                                                              ("; finite differences taken in double from the float knot" if other == "f32" else ""), world),
                 "dtype": other, "value": world * 4096 * T * steps / el3, "unit": "trajectory-timesteps/s", "ms_per_step": el3 / steps * 1e3,
-                "n_gpus": world, "stages": st3, "roofline": roofline_of(st3, bt3, 4096)}
+                "n_gpus": world, "stages": st3, "roofline": roofline_of(st3, bt3, 4096, other)}
             g3.close()
     if not args.no_extra_configs and world == 1:
         # BASELINE configs[1]: acrobot B=1024, limits +-5
@@ -481,7 +482,7 @@ def main():
         assert np.all(np.isfinite(costs)), "non-finite cost in the gathered result"
         value = world * B * T * steps / elapsed
         bytes_bw = algorithmic_bytes_per_timestep(n, m, s_bytes)["backward"]
-        roof = roofline_of(stages, bytes_ts, B)
+        roof = roofline_of(stages, bytes_ts, B, args.dtype)
         roof_issue = issue_roofline(roof["kernel"], elapsed / steps * 1e3, headline_sclk, B * T)
         roof["bound_frac"] = roof_issue["frac"]
         out = {

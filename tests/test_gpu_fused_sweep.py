@@ -1,4 +1,4 @@
-"""ilqr_iterate runs whole iterations of a tile in one persistent kernel (k_solve_tile: the fused sweep + backward
+"""ilqr_iterate runs whole iterations of a tile in one persistent kernel (k_solve_hex, k_solve_tile, k_solve_wide: the fused sweep + backward
 pass, producer wavefronts + the quad backward wavefront of a tile sharing a CU and an LDS ring, then the rollouts
 and the accept logic, again and again); ILQR_FLAG_STAGED launches the same two phases as kernels of their own per
 iteration (k_sweep_backward, k_rollout); the stage calls, and ILQR_FLAG_UNFUSED, run sweep and backward pass as

@@ -272,10 +272,12 @@ def test_full_size_properties(oracle):
     from ilqr_amd import BatchILQR
     B, T, lim = 4096, 499, 1.5
     g = BatchILQR("acrobot", B, T, DT, u_min=-lim, u_max=lim)
+    from ilqr_amd import capi
+    assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("solve")) == b"k_solve_hex"  # the route bench.py's headline takes
     x0 = acrobot_x0(B)
     # 25 iterations: the regime bench.py times (its iterations 6-25), every one of them against the oracle
     r = sampled_walk(oracle, oracle.Model("acrobot", u_lim=lim), g, x0, np.zeros((B, T, 1)), DT, 25)
-    print("configs[2] sampled walk:", publish("configs[2] acrobot T=499 B=4096 +-1.5 fp64 (k_solve_tile, one tile per CU)", r, B=B, T=T, u_lim=lim, n_sample=len(r["sel"])))
+    print("configs[2] sampled walk:", publish("configs[2] acrobot T=499 B=4096 +-1.5 fp64 (k_solve_hex, one tile per CU)", r, B=B, T=T, u_lim=lim, n_sample=len(r["sel"])))
     assert_walk(r, 25)
     x0[1] = x0[0]
     x0[B - 1] = x0[0]  # duplicates across tiles / waves
