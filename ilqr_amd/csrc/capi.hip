@@ -95,6 +95,7 @@ struct ilqr_batch {
   std::vector<void*> allocs;
   bool initialised = false;  // init_traj / set_trajectory has run
   bool commit_pending = false;  // an accepted candidate is not yet copied into xs/us
+  bool lq_cands_kept = false;   // LQ model: the last search rollout (k_rollout_lq<RG_SEARCH>) stored its candidates in v.cand_x / v.cand_u
   // cand_u / cand_x / cost_c hold, slot for slot, the last rollouts of the trajectories now in those slots.  Compaction
   // (ilqr_generate_trajectory) moves trajectories without moving their candidates: after it they belong to nobody.
   bool cands_valid = false;
@@ -436,9 +437,10 @@ static int launch_rollout_g(ilqr_batch* h, const M& m, int what, const AlphaSet&
   if constexpr (std::is_same<M, LqModel>::value)
   if (!h->env.lq_thread_rollout) {
     const dim3 grid(h->B), block(64);
-    if (what == RG_SEARCH)
+    if (what == RG_SEARCH) {
       hipLaunchKernelGGL((k_rollout_lq<RG_SEARCH>), grid, block, 0, h->stream, h->v, m, al, cost_out, nullptr, mode, 0);
-    else if (what == RG_INIT)
+      h->lq_cands_kept = h->v.cand_x != nullptr;  // the commit of what the next accept chooses is a copy (launch_commit)
+    } else if (what == RG_INIT)
       hipLaunchKernelGGL((k_rollout_lq<RG_INIT>), grid, block, 0, h->stream, h->v, m, al, cost_out, nullptr, 0, 1);
     else
       hipLaunchKernelGGL((k_rollout_lq<RG_COMMIT>), grid, block, 0, h->stream, h->v, m, al, cost_out, h->commit_idx, 0, write_cost);
@@ -479,8 +481,15 @@ static int launch_rollout(ilqr_batch* h, bool gains, bool cand, const AlphaSet& 
 
 static AlphaSet line_search_alphas();
 static int launch_commit(ilqr_batch* h) {
-  if (generic_twin(h))  // no stored candidates on the generic path: re-run the accepted rollout in place
+  if (generic_twin(h)) {
+    if (h->model == ILQR_MODEL_LQ && h->lq_cands_kept) {  // the matrix-core search kept its eleven rollouts: copy the accepted one
+      hipLaunchKernelGGL(k_commit_lq, dim3(h->B), dim3(256), 0, h->stream, h->v, h->nx, h->nu, h->commit_idx);
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
+    // no stored candidates otherwise on the generic path: re-run the accepted rollout in place
     return with_generic_model(h, [&](auto& m) { return launch_rollout_g(h, m, RG_COMMIT, line_search_alphas(), h->v.cost, 0, 0); });
+  }
   dim3 grid((h->T + 1 + 15) / 16, h->ntiles), block(256);
   if (int rc = with_model(h, [&](auto& v, auto& m, auto&) {
         hipLaunchKernelGGL((k_commit<std::decay_t<decltype(m)>>), grid, block, 0, h->stream, v, m, h->commit_idx);
@@ -886,6 +895,11 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     rc |= dev_alloc(h, &h->d_umax, nu);
     v.cand_u = nullptr;
     v.cand_x = nullptr;
+    if (d->model == ILQR_MODEL_LQ && !h->env.lq_thread_rollout && !(d->route & ILQR_ROUTE_LQ_RECOMMIT)) {
+      // the eleven rollouts of the matrix-core search, whole ([b][alpha][t][row]): the commit is then a copy, not a twelfth rollout
+      rc |= dev_alloc(h, &v.cand_x, Bn * NALPHA * T1 * nx);
+      rc |= dev_alloc(h, &v.cand_u, Bn * NALPHA * T * nu);
+    }
     rc |= dev_alloc(h, &v.cost_c, (size_t)NALPHA * Bp);  // the 11 candidate costs (device or caller-evaluated)
     if (d->model == ILQR_MODEL_LQ) {
       // zero-padded copies of the model matrices at the kernels' maximum dimensions

@@ -493,7 +493,9 @@ __global__ __launch_bounds__(64) void k_analytic_lq(BatchView v, LqModel model, 
 // Each chain runs k ascending from a zero accumulator, as the sums of LqModel::dynamics / quad do,
 // so the results are those of k_rollout_g bit for bit (tests/test_gpu_lq_end_to_end.py compares them).
 // Modes as above.  RG_COMMIT / RG_INIT run the same block with every column on the same rollout and
-// store column 0.
+// store column 0.  RG_SEARCH with candidate buffers (v.cand_x / v.cand_u, [b][alpha][t][row]): every column stores its
+// states and controls on the way, so that the commit of the accepted one is a copy (k_commit_lq) instead of a twelfth
+// rollout as long as the eleven (the 3.5 KB per step and trajectory leave under the MFMA chains).
 template <int MODE>
 __global__ __launch_bounds__(64) void k_rollout_lq(BatchView v, LqModel model, AlphaSet alphas, double* __restrict__ cost_out,
                                                    const int* __restrict__ commit_idx, int mode, int write_cost) {
@@ -556,6 +558,11 @@ __global__ __launch_bounds__(64) void k_rollout_lq(BatchView v, LqModel model, A
     }
   };
 
+  // the candidate of column p (RG_SEARCH with buffers)
+  const bool keep = MODE == RG_SEARCH && v.cand_x != nullptr && p < NALPHA;
+  double* cxb = keep ? v.cand_x + ((size_t)b * NALPHA + p) * (T + 1) * nx : nullptr;
+  double* cub = keep ? v.cand_u + ((size_t)b * NALPHA + p) * T * nu : nullptr;
+
   double x[8];  // X rows 4ks+g, column p
 #pragma unroll
   for (int ks = 0; ks < 8; ks++) x[ks] = (4 * ks + g < nx) ? v.x0[(size_t)b * nx + 4 * ks + g] : 0.0;
@@ -607,6 +614,14 @@ __global__ __launch_bounds__(64) void k_rollout_lq(BatchView v, LqModel model, A
       for (int r = 0; r < 4; r++)
         if (g + 4 * r < nu) usb[(size_t)t * nu + g + 4 * r] = u[r];
     }
+    if (keep) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++)
+        if (4 * ks + g < nx) cxb[(size_t)t * nx + 4 * ks + g] = x[ks];
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (g + 4 * r < nu) cub[(size_t)t * nu + g + 4 * r] = u[r];
+    }
     // :324 cost = 0.5 (x'Qx + u'Ru)
     double4_t ru = zero4, cx = zero4, cu = zero4;
 #pragma unroll
@@ -634,6 +649,11 @@ __global__ __launch_bounds__(64) void k_rollout_lq(BatchView v, LqModel model, A
     for (int ks = 0; ks < 8; ks++)
       if (4 * ks + g < nx) xsb[(size_t)T * nx + 4 * ks + g] = x[ks];
   }
+  if (keep) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++)
+      if (4 * ks + g < nx) cxb[(size_t)T * nx + 4 * ks + g] = x[ks];
+  }
   {  // :335 final cost 0.5 x'Qf x
     double4_t qf[2] = {zero4, zero4}, cf = zero4;
 #pragma unroll
@@ -657,6 +677,22 @@ __global__ __launch_bounds__(64) void k_rollout_lq(BatchView v, LqModel model, A
       cost_out[b] = mine;
     }
   }
+}
+
+// The commit of the accepted candidates (ilqr_core.cpp:210-213) when k_rollout_lq<RG_SEARCH> kept them: one block per
+// trajectory copies states and controls of column commit_idx[b] over the nominal ones.  The bits of the rollout that was scored.
+__global__ __launch_bounds__(256) void k_commit_lq(BatchView v, int nx, int nu, const int* __restrict__ commit_idx) {
+  const int b = blockIdx.x;
+  const int a = commit_idx[b];
+  if (a < 0) return;
+  const int T = v.T;
+  const size_t nxs = (size_t)(T + 1) * nx, nus = (size_t)T * nu;
+  const double* __restrict__ cx = v.cand_x + ((size_t)b * NALPHA + a) * nxs;
+  const double* __restrict__ cu = v.cand_u + ((size_t)b * NALPHA + a) * nus;
+  double* __restrict__ xs = v.xs + (size_t)b * nxs;
+  double* __restrict__ us = v.us + (size_t)b * nus;
+  for (size_t i = threadIdx.x; i < nxs; i += blockDim.x) xs[i] = cx[i];
+  for (size_t i = threadIdx.x; i < nus; i += blockDim.x) us[i] = cu[i];
 }
 
 // ------------------------------------------------------------------------------------------

@@ -161,20 +161,25 @@ def test_lq_matrix_core_rollout_equals_thread_per_rollout(n, m, B, T, monkeypatc
     x0 = rng.uniform(-1, 1, (B, n))
     u0 = rng.normal(size=(B, T, m)) * 0.3
     out = []
-    for thread in (False, True):
-        g = BatchILQR("lq", B, T, DT, u_min=-0.4, u_max=0.4, lq=mats, flags=capi.FLAG_ANALYTIC_DERIVATIVES,
-                      route=capi.ROUTE_LQ_THREAD_ROLLOUT if thread else 0)
+    # default: the matrix-core search keeps its eleven rollouts and the commit is a copy (k_commit_lq); ILQR_ROUTE_LQ_RECOMMIT:
+    # no candidate buffers, the accepted rollout is run a second time; ILQR_ROUTE_LQ_THREAD_ROLLOUT: the generic kernel
+    for route, kernel in ((0, b"k_rollout_lq"), (capi.ROUTE_LQ_RECOMMIT, b"k_rollout_lq"), (capi.ROUTE_LQ_THREAD_ROLLOUT, b"k_rollout_g")):
+        g = BatchILQR("lq", B, T, DT, u_min=-0.4, u_max=0.4, lq=mats, flags=capi.FLAG_ANALYTIC_DERIVATIVES, route=route)
         name = g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("rollout"))
-        assert name == (b"k_rollout_g" if thread else b"k_rollout_lq")
+        assert name == kernel
         c0 = g.init_traj(x0, u0)
         g.iterate(3)
         xs, us = g.trajectory()
         k, K = g.gains()
         st, it, al = g.status()
-        out.append(dict(c0=c0, xs=xs, us=us, k=k, K=K, cost=g.cost(), al=al, it=it))
+        mid = dict(xs=xs, us=us, cost=g.cost())
+        g.generate_trajectory()   # to the end of the solve: per-trajectory exits (commit_idx = -1 for the ones that have left)
+        xe, ue = g.trajectory()
+        out.append(dict(c0=c0, k=k, K=K, al=al, it=it, end_xs=xe, end_us=ue, end_cost=g.cost(), end_status=g.status()[0], **mid))
         g.close()
-    for key in out[0]:
-        assert np.array_equal(out[0][key], out[1][key], equal_nan=True), key
+    for o in out[1:]:
+        for key in out[0]:
+            assert np.array_equal(out[0][key], o[key], equal_nan=True), key
     assert np.all(out[0]["cost"] < out[0]["c0"])
 
 
