@@ -550,7 +550,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       t_sweep += t1 - t0;
       t0 = t1;
     }
-    rollout_tile<M, true, true, kDeepPrefetch<M>, true, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, commit_idx, tile, lds_cost, /*count_running=*/it == n_iters - 1, rwave,
+    rollout_tile<M, true, true, kDeepPrefetch<M>, true, true, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, commit_idx, tile, lds_cost, /*count_running=*/it == n_iters - 1, rwave,
                                                pairs[role & 3].ring);
     // (accept_one ran in threads 0 .. TW-1 at the end of rollout_tile: each hands its trajectory's accepted alpha on through LDS;
     //  the candidates themselves were stored by this block's rollout wavefronts and are waited for)

@@ -945,8 +945,9 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   rc |= dev_alloc_real(h, &v.Kfb, nt * T * nu * nx * TW);
   v.D = nullptr;  // on first use (ensure_records)
   v.nch = h->T / CT + 1;
-  rc |= dev_alloc_real(h, &v.cand_u, (size_t)NALPHA * nt * T * nu * TW);
-  rc |= dev_alloc_real(h, &v.cand_x, (size_t)NALPHA * nt * v.nch * nx * TW);
+  // (one plane more than there are alphas: where the rollout lanes without a rollout of their own put their stores, rollout.hpp)
+  rc |= dev_alloc_real(h, &v.cand_u, (size_t)(NALPHA + 1) * nt * T * nu * TW);
+  rc |= dev_alloc_real(h, &v.cand_x, (size_t)(NALPHA + 1) * nt * v.nch * nx * TW);
   rc |= dev_alloc(h, &v.cost_c, (size_t)NALPHA * Bp);
   }
   rc |= dev_alloc(h, &v.cost, Bp);

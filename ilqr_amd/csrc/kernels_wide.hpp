@@ -619,7 +619,7 @@ __global__ __launch_bounds__(64 * WideCfg<OCC>::kWaves) __attribute__((amdgpu_wa
     // 12 rollout units (tile of the wide tile, alpha group) over the wavefronts that roll out.  (Handing units out
     // dynamically, as wavefronts become free, measured 3 % slower than this fixed assignment.)
     for (int u = rwave; u < (WT / TW) * 3; u += roll_waves)
-      rollout_tile<M, true, true, 4, false, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, nullptr, wtile * (WT / TW) + u / 3, nullptr, false, u % 3, roll_share);
+      rollout_tile<M, true, true, 4, false, true, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, nullptr, wtile * (WT / TW) + u / 3, nullptr, false, u % 3, roll_share);
     phase_barrier();  // the candidates' costs are in memory
     if (threadIdx.x < WT)
       accept_one(v, sp, wtile * WT + (int)threadIdx.x, [&](int a) { return v.cost_c[(size_t)a * v.Bp + wtile * WT + threadIdx.x]; }, commit_idx,

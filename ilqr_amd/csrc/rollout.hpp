@@ -106,7 +106,9 @@ constexpr int kDeepPrefetch = (M::NU * M::NX + M::NX + 2 * M::NU <= 10) ? 8 : 4;
 // ten values back with broadcast reads.  Same values: bit-identical.  It pays even with one rollout wavefront per SIMD
 // (the 16-trajectory kernel at B <= 16 x #CU: 0.205 -> 0.191 ms per rollout phase); the stage kernel k_rollout, which has
 // no LDS to spare a priori, keeps the per-lane loads.
-template <class M, bool GAINS, bool CAND, int PD, bool ACCEPT, bool SHARE = false>
+// NOFIX: the caller's route is never taken with the opt-in fixes (sp.fixes == 0: the persistent matrix-core and wide kernels) --
+// the clamp of ilqr_core.cpp:327-329's "right way" and its selects leave the step (4 of its ~170 instructions).
+template <class M, bool GAINS, bool CAND, int PD, bool ACCEPT, bool SHARE = false, bool NOFIX = false>
 __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>& v, const M& model, const AlphaSet& alphas, int n_alpha,
                                              double* __restrict__ cost_out, int mode, const SolverParams& sp,
                                              int* __restrict__ commit_idx, int tile, double* lds_cost, bool count_running = true, int rwave = -1,
@@ -159,11 +161,15 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
       for (int i = 0; i < NX; i++) d.xnom[i] = v.xs[tidx(tile, t, i, l, T + 1, NX)];
     }
   };
-  auto emit_knot = [&](int t, const real* xx, const real* uu) __attribute__((always_inline)) {  // knot t = (x_t, u_t)
-    if (SHARE && !active) return;
+  // SHARE && CAND: a lane without a rollout of its own (an alpha group beyond the last alpha, a finished trajectory) stores too,
+  // into the spare plane behind the last alpha's (the buffers hold NALPHA + 1): no predicate around the stores of every step
+  const int ta_store = ((SHARE && CAND && !active) ? NALPHA : a) * v.ntiles + tile;
+  // knot t = (x_t, u_t); with_u: a step's call (t < T by construction: no test in the step), false for the final state
+  auto emit_knot = [&](int t, const real* xx, const real* uu, auto with_u) __attribute__((always_inline)) {
+    if (SHARE && !CAND && !active) return;
     if (CAND) {
-      const int ta = a * v.ntiles + tile;
-      if (t < T) {
+      const int ta = ta_store;
+      if (with_u) {
 #pragma unroll
         for (int q = 0; q < NU; q++) v.cand_u[tidx(ta, t, q, l, T, NU)] = uu[q];
       }
@@ -174,7 +180,7 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
     } else {
 #pragma unroll
       for (int i = 0; i < NX; i++) v.xs[tidx(tile, t, i, l, T + 1, NX)] = xx[i];
-      if (t < T) {
+      if (with_u) {
 #pragma unroll
         for (int q = 0; q < NU; q++) v.us[tidx(tile, t, q, l, T, NU)] = uu[q];  // :323 (no clamping)
       }
@@ -194,11 +200,11 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
         u[j] += acc;  // :316
       }
     }
-    if (sp.fixes & 1) {  // opt-in fix: "the right way" of ilqr_core.cpp:327-329 -- the clamped control is stored and integrated
+    if (!NOFIX && (sp.fixes & 1)) {  // opt-in fix: "the right way" of ilqr_core.cpp:327-329 -- the clamped control is stored and integrated
 #pragma unroll
       for (int j = 0; j < NU; j++) u[j] = min_of(max_of(u[j], model.u_min[j]), model.u_max[j]);
     }
-    emit_knot(t, x, u);
+    emit_knot(t, x, u, std::true_type());
     total += (double)model.cost(x, u);  // :324
     real x1[NX];
     integrate_dynamics(model, x, u, dt, x1);  // :325
@@ -299,7 +305,7 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
     real uz[NU];
 #pragma unroll
     for (int q = 0; q < NU; q++) uz[q] = 0;
-    emit_knot(T, x, uz);
+    emit_knot(T, x, uz, std::false_type());
   }
   total += (double)model.final_cost(x);  // :335
   if (active) {
