@@ -327,8 +327,11 @@ __device__ __forceinline__ void backward_hex(const BatchViewT<typename M::real>&
       }
       if (ok) {
         kprev = (creal)(real)x;  // the stored gain, as the reference reads k[i + 1] back (:369)
-        if (r_ == 0) Kt_i[0] = (real)K_c;
-        if (j16 == 0) kt_i[0] = (real)x;
+        // K[c] is the same bits on the four lanes r of (t, c), k on all sixteen of t (products of replicated operands: the matrix
+        // unit runs the same sum for each): every lane stores -- four / sixteen writes of one value to one address -- and the
+        // step has no lane predicates (each cost an exec save / restore around its store, their masks two v_readlane each)
+        Kt_i[0] = (real)K_c;
+        kt_i[0] = (real)x;
       }
       Kt_i -= 4 * TW;
       kt_i -= TW;
