@@ -105,27 +105,19 @@ struct HexGate {
 __device__ __forceinline__ int hex_first(unsigned long long bal, int t4) {
   return __builtin_ctzll(((bal >> t4) & 0x000F000F000F000Full) | 0x8000000000000000ull);
 }
-// v_max_f64 / v_min_f64 as the instructions (the builtins canonicalise their operands first -- one more instruction per
-// operand -- to quiet signalling NaNs; for every other input the result is the same bits)
-__device__ __forceinline__ double hex_clamp(double v, double lo, double hi) {
-  double t, r;
-  asm("v_max_f64 %0, %1, %2" : "=v"(t) : "v"(v), "v"(lo));
-  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(t), "v"(hi));
-  return r;
-}
 __device__ __forceinline__ void qp1_search_hex(QP1StateT<double>& q, int j, int t4, double step_j0, const double* __restrict__ lds_steps) {
   // First pass, k = j, straight-line for every lane (an early exit's lanes compute along: the caller's selects ignore their
   // x1 / v1): the reference's loop ends inside it for all but a few per cent of the QPs.  A trial that lands on x itself ("stuck":
   // failure, qp1_backtrack_seq) has value == old value and fails the test, and so does every shorter step after it: a passing k
   // is never preceded by a stuck one, so the first set bit of the "passes" ballot is the loop's answer whenever there is one.
-  const double t_x1 = hex_clamp(q.x + step_j0 * q.search, q.lo, q.hi);   // qp1_trial
+  const double t_x1 = clamp_of(q.x + step_j0 * q.search, q.lo, q.hi);   // qp1_trial
   const double t_v1 = qp1_value(q, t_x1);
   const bool t_pass = !qp1_armijo_fails(q, t_v1, step_j0);
   const int pp = hex_first(__ballot(t_pass), t4);
   const bool success = pp < 52;            // a set bit
   const int jw = success ? (((pp >> 4) << 2) | (pp & 3)) : 0;
   q.step = lds_steps[jw];
-  q.x1 = hex_clamp(q.x + q.step * q.search, q.lo, q.hi);   // the winner's trial point and value, by the winner's expressions
+  q.x1 = clamp_of(q.x + q.step * q.search, q.lo, q.hi);   // the winner's trial point and value, by the winner's expressions
   q.v1 = qp1_value(q, q.x1);
   bool more = p_and(!success, !q.early);
   if (__builtin_expect(__ballot(more) == 0ull, 1)) return;  // (wave-uniform)
@@ -272,16 +264,13 @@ __device__ __forceinline__ void backward_hex(const BatchViewT<typename M::real>&
       // :373-385  K = -(R^-1 R^-T) Qux on a free control, 0 on a clamped one
       const creal k_scale = free0 ? -minv : creal(0);
       const creal K_r = k_scale * Qux_r, K_c = k_scale * Qux_c;
-      // :388-389
+      // :388-389  (added to dV below, with everything else a successful step leaves behind: one predicated block)
+      creal d0 = 0, d1 = 0;
       {
-        creal d0 = 0;
         d0 += x * Qu;
-        if (ok) dV0 += (double)d0;
         creal rq = 0;
         rq += (creal(0.5) * x) * Quu;
-        creal d1 = 0;
         d1 += rq * x;
-        if (ok) dV1 += (double)d1;
       }
       // :391-393
       creal T1_r, T1_c;
@@ -321,11 +310,10 @@ __device__ __forceinline__ void backward_hex(const BatchViewT<typename M::real>&
       V = creal(0.5) * (Vn_rc + Vn_cr);
       RVx = Vxn_r;
       // :405-412 term of the gradient norm; :396-397 the gains
-      {
-        const creal mx = abs_of(x) * usw;
-        if (ok) gacc += (double)mx;
-      }
       if (ok) {
+        dV0 += (double)d0;
+        dV1 += (double)d1;
+        gacc += (double)(abs_of(x) * usw);
         kprev = (creal)(real)x;  // the stored gain, as the reference reads k[i + 1] back (:369)
         // K[c] is the same bits on the four lanes r of (t, c), k on all sixteen of t (products of replicated operands: the matrix
         // unit runs the same sum for each): every lane stores -- four / sixteen writes of one value to one address -- and the

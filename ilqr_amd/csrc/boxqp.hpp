@@ -77,6 +77,29 @@ ILQR_HD double min_of(double a, double b) { return __builtin_fmin(a, b); }
 ILQR_HD float min_of(float a, float b) { return __builtin_fminf(a, b); }
 ILQR_HD double max_of(double a, double b) { return __builtin_fmax(a, b); }
 ILQR_HD float max_of(float a, float b) { return __builtin_fmaxf(a, b); }
+// min(max(v, lo), hi).  On the device as the two instructions: the builtins first canonicalise every operand the compiler cannot
+// prove quiet (one v_max_f64 v, v, v each -- three per box-QP in the backward chains) to quiet signalling NaNs, which nothing
+// here produces; for every other input, -0 / +0 and quiet NaNs included, the result is the same bits.
+ILQR_HD double clamp_of(double v, double lo, double hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double t, r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(t) : "v"(v), "v"(lo));
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(t), "v"(hi));
+  return r;
+#else
+  return min_of(max_of(v, lo), hi);
+#endif
+}
+ILQR_HD float clamp_of(float v, float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float t, r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(t) : "v"(v), "v"(lo));
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(hi));
+  return r;
+#else
+  return min_of(max_of(v, lo), hi);
+#endif
+}
 
 template <int M, class real>
 ILQR_HD void clamp_to_limits(const real* x, const real* lo, const real* hi, real* out) {
@@ -772,7 +795,7 @@ struct QP1StateT {
 template <class real>
 ILQR_HD real qp1_value(const QP1StateT<real>& q, real xx) { return ((real(0.5) * xx) * q.Q) * xx + xx * q.c; }
 template <class real>
-ILQR_HD real qp1_trial(const QP1StateT<real>& q, real step) { return min_of(max_of(q.x + step * q.search, q.lo), q.hi); }
+ILQR_HD real qp1_trial(const QP1StateT<real>& q, real step) { return clamp_of(q.x + step * q.search, q.lo, q.hi); }
 // Armijo test of boxqp.cpp:161 without the division (step*slope < 0 on this path)
 template <class real>
 ILQR_HD bool qp1_armijo_fails(const QP1StateT<real>& q, real v, real step) {
@@ -785,7 +808,7 @@ ILQR_HD void qp1_begin(real Q, real c, real x0, real lo, real hi, QP1StateT<real
   q.c = c;
   q.lo = lo;
   q.hi = hi;
-  q.x = min_of(max_of(x0, lo), hi);  // == clamp_to_limits for non-NaN input
+  q.x = clamp_of(x0, lo, hi);  // == clamp_to_limits for non-NaN input
   q.val0 = (q.x * Q) * q.x + q.x * c;  // boxqp.cpp:36 (no 1/2)
   q.g0 = Q * q.x + c;
   const real den = (Q > real(0)) ? Q : Q * Q;
@@ -846,7 +869,7 @@ ILQR_HD int qp1_finish(const QP1StateT<real>& q, real& x_out, int& free_out, rea
   // at every k, the reference's loop runs down to minStep and reports failure (boxqp.cpp:167-171 -> result 2, x
   // kept).  Same outcome without the continue loop: 100-iteration average 0.93 -> 0.91 ms (fp64), 0.84 -> 0.76 ms
   // (fp32), for 4 more instructions per step in the first iterations (0.566 -> 0.571 ms).
-  const bool exH = min_of(max_of(q.x1 + search1, q.lo), q.hi) == q.x1;
+  const bool exH = clamp_of(q.x1 + search1, q.lo, q.hi) == q.x1;
   minv_out = q.minv;
   // the reference's order of tests, as selects (no branches)
   const bool stay = q.clA | q.indef | q.exB | q.exC | q.ls_failed;  // x is not updated
@@ -879,7 +902,7 @@ ILQR_HD bool qp1_finish_ok(const QP1StateT<real>& q, real& x_out, int& free_out,
   // at every k, the reference's loop runs down to minStep and reports failure (boxqp.cpp:167-171 -> result 2, x
   // kept).  Same outcome without the continue loop: 100-iteration average 0.93 -> 0.91 ms (fp64), 0.84 -> 0.76 ms
   // (fp32), for 4 more instructions per step in the first iterations (0.566 -> 0.571 ms).
-  const bool exH = min_of(max_of(q.x1 + search1, q.lo), q.hi) == q.x1;
+  const bool exH = clamp_of(q.x1 + search1, q.lo, q.hi) == q.x1;
   minv_out = q.minv;
   // the reference's order of tests, as selects (no branches)
   const bool stay = p_or(p_or(p_or(q.clA, q.indef), p_or(q.exB, q.exC)), q.ls_failed);  // x is not updated
@@ -914,7 +937,7 @@ ILQR_HD int qp1_continue(QP1StateT<real>& q, LineSearch line_search, real& x_out
     const real g1 = q.Q * x + q.c;
     const real s1 = -q.minv * q.c - x;
     const real slope1 = s1 * g1;
-    const real x2 = min_of(max_of(x + real(1) * s1, q.lo), q.hi);  // qp1_trial at step 1
+    const real x2 = clamp_of(x + real(1) * s1, q.lo, q.hi);  // qp1_trial at step 1
     const real v2 = qp1_value(q, x2);
     const bool unit_passes = !((v2 - val) > real(kArmijo) * (real(1) * slope1));  // qp1_armijo_fails, old_v = value(x1) = val
     const bool moved = x2 != x;  // (x2 == x is exit H's business: the caller has excluded it, but stay exact)
