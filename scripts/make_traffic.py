@@ -70,6 +70,10 @@ def solve_entry(d, prefix, key, B, T, f, w):
         e["timesteps_per_iteration"] = B * T
         e["wait_fraction_of_wave_cycles"] = waitany[key][0] / wavecyc[key][0] if key in waitany and key in wavecyc else None
         e["lds_bank_conflict_fraction"] = bank[key][0] / ldsact[key][0] if key in bank and key in ldsact and ldsact[key][0] else None
+        if os.path.exists("%s/%spmc_sq4.txt" % (d, prefix)):  # the matrix unit (k_solve_hex: nine v_mfma_f64_4x4x4 per chain step)
+            mf = read("%s/%spmc_sq4.txt" % (d, prefix), "SQ_INSTS_MFMA")
+            if key in mf:
+                e["mfma_insts_per_iteration"] = mf[key][0] / its
     return e
 
 
