@@ -567,6 +567,10 @@ struct WideCfg {
   static constexpr int kWaves = (OCC == 1) ? 8 : 4;
   static constexpr int kProd = (OCC == 1) ? 3 : 2;
   static constexpr int kRingKb = (OCC == 1) ? 148 : 74;
+  // rollout prefetch depth (steps of nominal rows in flight per wavefront).  Measured, alternating builds on one box: with two
+  // tiles per CU depth 8 is 7.35e9/s against 6.96e9/s at B = 32768, with one tile per CU depth 4 is 6.21e9/s against 5.97e9/s at
+  // B = 16384 -- in both cases through phase 1 (the register allocation of the whole kernel moves), not through the rollouts.
+  static constexpr int kPrefetch = (OCC == 1) ? 4 : 8;
 };
 
 // Whole iterations for ONE wide tile (see k_solve_tile).  grid = ntiles / 4, block = 64 x kWaves.
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(64 * WideCfg<OCC>::kWaves) __attribute__((amdgpu_wa
     // 12 rollout units (tile of the wide tile, alpha group) over the wavefronts that roll out.  (Handing units out
     // dynamically, as wavefronts become free, measured 3 % slower than this fixed assignment.)
     for (int u = rwave; u < (WT / TW) * 3; u += roll_waves)
-      rollout_tile<M, true, true, 4, false, true, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, nullptr, wtile * (WT / TW) + u / 3, nullptr, false, u % 3, roll_share);
+      rollout_tile<M, true, true, Cfg::kPrefetch, false, true, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, nullptr, wtile * (WT / TW) + u / 3, nullptr, false, u % 3, roll_share);
     phase_barrier();  // the candidates' costs are in memory
     if (threadIdx.x < WT)
       accept_one(v, sp, wtile * WT + (int)threadIdx.x, [&](int a) { return v.cost_c[(size_t)a * v.Bp + wtile * WT + threadIdx.x]; }, commit_idx,
