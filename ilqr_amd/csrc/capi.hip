@@ -602,7 +602,7 @@ static int launch_backward(ilqr_batch* h, int mode) {
 // Which route ilqr_iterate takes.  All of them leave the same bits (tests/test_gpu_fused_sweep.py):
 //   ntiles <= #CU, m = 1, no fixes     one persistent tile per CU, its backward pass as four matrix-core chains   k_solve_hex
 //   ntiles <= #CU otherwise            one persistent 16-trajectory tile per CU            k_solve_tile<.., 1>
-//   m = 1, no opt-in fixes, >= 4 tiles per CU   64-trajectory wide tiles, one or two per CU   k_solve_wide
+//   m = 1, no opt-in fixes, > 2 tiles per CU    64-trajectory wide tiles, one or two per CU   k_solve_wide
 //   anything larger otherwise          persistent 16-trajectory tiles, two per CU (the dispatcher hands a CU its next
 //                                      tile when one is through)                           k_solve_tile<.., 2>
 //   ILQR_FLAG_STAGED                   one launch per stage: k_sweep_backward (records in the LDS ring, one block per CU
@@ -617,7 +617,10 @@ static int fused_variant(const ilqr_batch* h) {  // 0: two kernels, 1: one tile 
   const int one_per_cu = (wide_ok && !h->env.quad_chain) ? 4 : 1;  // k_solve_hex (backward_hex.hpp) shares the wide tiles' conditions
   if (h->env.fused) return (h->env.fused == 3 && !wide_ok) ? 2 : (h->env.fused == 1 ? one_per_cu : h->env.fused);
   if (h->ntiles <= h->num_cus) return one_per_cu;
-  if (wide_ok && h->ntiles >= 4 * h->num_cus) return 3;  // a 64-trajectory wide tile for every CU: the thread-per-trajectory chain
+  // beyond two 16-trajectory tiles per CU: 64-trajectory wide tiles, the thread-per-trajectory chain (one per CU up to 64 #CU
+  // trajectories -- a third tile per CU would be a second round of the two-per-CU kernel: 1.49 against 1.16-1.27 ms at
+  // B = 8448 .. 14336 --, two per CU beyond)
+  if (wide_ok && h->ntiles > 2 * h->num_cus) return 3;
   if (!staged) return 2;  // persistent tiles, two per CU, for ANY larger batch: the dispatcher hands a CU its next tile when one is through
   return (h->ntiles <= 2 * h->num_cus) ? 2 : 0;
 }

@@ -161,22 +161,22 @@ def test_wide_tiles_equal_unfused(B, T, dtype, occ, monkeypatch):
 
 def test_route_selection_by_batch_size(monkeypatch):
     """Route selection by batch size (ilqr_desc.assume_cus scales the thresholds down to test sizes): up to one tile per CU
-    the persistent kernel with a CU per tile, beyond that -- at ANY batch size -- the persistent kernel with two tiles per
-    CU (the records never reach HBM); with ILQR_FLAG_STAGED the per-stage kernels, and two kernels beyond two tiles per CU.
+    the persistent kernel with a CU per tile, up to two per CU the persistent kernel with two tiles per CU, beyond that -- at ANY
+    batch size -- persistent wide tiles (the records never reach HBM); with ILQR_FLAG_STAGED the per-stage kernels, and two kernels beyond two tiles per CU.
     Every route leaves the same bits."""
     from ilqr_amd import BatchILQR, capi
     cus = 6
     T = 20
     bw, sv = capi.STAGE_NAMES.index("backward"), capi.STAGE_NAMES.index("solve")
-    for B in (16 * cus + 16, 48 * cus + 3, 80 * cus + 3):  # one tile more than one per CU; three per CU; five per CU and a ragged last tile
+    for B in (16 * cus + 16, 32 * cus, 48 * cus + 3, 80 * cus + 3):  # one tile more than one per CU; two; three per CU; five per CU and a ragged last tile
         x0 = acrobot_x0(B, scale=0.3, seed=4)
         u0 = np.zeros((B, T, 1))
         out = []
         for fl in (0, capi.FLAG_STAGED, capi.FLAG_UNFUSED):
             g = BatchILQR("acrobot", B, T, DT, u_min=-1.5, u_max=1.5, flags=fl, assume_cus=cus)
             name = lambda st: g.lib.ilqr_stage_kernel_name(g.h, st)
-            if fl == 0:  # two tiles per CU, and wide (64-trajectory) tiles once every CU gets one
-                assert name(sv) == (b"k_solve_tile<2>" if B < 64 * cus else b"k_solve_wide")
+            if fl == 0:  # up to two tiles per CU the 16-trajectory kernel, beyond that wide (64-trajectory) tiles
+                assert name(sv) == (b"k_solve_tile<2>" if B <= 32 * cus else b"k_solve_wide")
             elif fl == capi.FLAG_STAGED:
                 assert name(sv) == b"" and name(bw) == (b"k_sweep_backward" if B <= 32 * cus else b"k_backward_q")
             else:
