@@ -37,6 +37,23 @@ def test_abi_version_and_defaults():
     assert (p.lambda_factor, p.lambda_max, p.lambda_min, p.z_min) == (1.6, 1e11, 1e-8, 0.0)
 
 
+def test_route_and_flag_constants_match_the_header():
+    """ilqr_amd/capi.py mirrors enum ilqr_route / ilqr_flags by value: a constant that drifts selects another kernel silently."""
+    from ilqr_amd import capi
+    src = open(os.path.join(ROOT, "include", "ilqr_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    enums = {k: int(v, 0) for k, v in re.findall(r"\b(ILQR_(?:ROUTE|FLAG)_[A-Z0-9_]+)\s*=\s*(0x[0-9a-fA-F]+|\d+)", src)}
+    routes = {k: v for k, v in enums.items() if k.startswith("ILQR_ROUTE_")}
+    assert len(routes) >= 12
+    for k, v in routes.items():
+        if k == "ILQR_ROUTE_AUTO":
+            continue
+        assert getattr(capi, k[len("ILQR_"):]) == v, k
+    for k, v in enums.items():
+        if k.startswith("ILQR_FLAG_") and hasattr(capi, k[len("ILQR_"):]):
+            assert getattr(capi, k[len("ILQR_"):]) == v, k
+
+
 def test_bad_arguments_are_rejected():
     from ilqr_amd import capi
     lib = capi.load()
