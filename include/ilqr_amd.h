@@ -152,9 +152,6 @@ typedef struct ilqr_desc {
   const double* u_max; /* [nu] */
   const double* goal;  /* [nx] DoubleIntegrator(goal) (double_integrator.h:14); NULL = (1,.5,0,0); acrobot ignores it */
   const double *lq_A, *lq_B, *lq_Q, *lq_R, *lq_Qf; /* ILQR_MODEL_LQ: row-major [nx][nx],[nx][nu],[nx][nx],[nu][nu],[nx][nx] */
-                                                   /* (device memory of an LQ handle: besides the records, 11 x the nominal trajectory for
-                                                      the line search's rollouts, whose accepted one is committed by a copy;
-                                                      ILQR_ROUTE_LQ_RECOMMIT does without them and rolls the accepted one out again) */
   void* stream;             /* hipStream_t to enqueue on; NULL = the library creates one */
   const ilqr_params* params; /* NULL = reference defaults */
   const double* user_params; /* ILQR_MODEL_USER: [n_user_params] handed to UserModelT::set_params (its constructor's arguments) */
