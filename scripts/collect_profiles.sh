@@ -23,6 +23,8 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_L
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/pmc_sq3 -o $R -- $SHORT > /dev/null 2> $OUT/pmc_sq3.err
 # the matrix unit in the headline kernel (k_solve_hex: nine v_mfma_f64_4x4x4 per chain step)
 timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace -d $OUT/pmc_sq4 -o $R -- $SHORT > /dev/null 2> $OUT/pmc_sq4.err
+# the same launches on round 3's route (ILQR_ROUTE_QUAD_CHAIN = 256: k_solve_tile<..,1>), for the comparison of the two kernels
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/quad_stats5 -o $R -- $SHORT --route 256 > /dev/null 2> $OUT/quad_stats5.err
 # the saturated batch (B = 32768: two 64-trajectory wide tiles per CU, k_solve_wide<.., 2>)
 SAT="$SHORT --batch 32768"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/sat_stats5 -o $R -- $SAT > /dev/null 2> $OUT/sat_stats5.err
@@ -48,7 +50,7 @@ for U in lat ldsmix; do  # microbenchmarks quoted in DESIGN.md, re-run on this b
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $OUT/$U scripts/ubench/$U.hip 2> /dev/null && $OUT/$U > $OUT/ubench_$U.txt 2>/dev/null
   rm -f $OUT/$U
 done
-for d in stats stats5 pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq1 pmc_sq2 pmc_sq3 pmc_sq4 sat_stats5 sat_pmc_FETCH_SIZE sat_pmc_WRITE_SIZE sat_pmc_sq1 sat_pmc_sq2 sat_pmc_sq3 staged_pmc_FETCH_SIZE staged_pmc_WRITE_SIZE staged_stats lq_pmc_sq lq_pmc_occ lq_w1_pmc_sq lq_w1_pmc_occ; do
+for d in stats stats5 quad_stats5 pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq1 pmc_sq2 pmc_sq3 pmc_sq4 sat_stats5 sat_pmc_FETCH_SIZE sat_pmc_WRITE_SIZE sat_pmc_sq1 sat_pmc_sq2 sat_pmc_sq3 staged_pmc_FETCH_SIZE staged_pmc_WRITE_SIZE staged_stats lq_pmc_sq lq_pmc_occ lq_w1_pmc_sq lq_w1_pmc_occ; do
   f=$(find $OUT/$d -name "*.db" | head -1)
   [ -n "$f" ] && python scripts/prof_summary.py $f > $OUT/$d.txt 2>&1
 done
