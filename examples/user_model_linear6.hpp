@@ -4,13 +4,16 @@
 // -DILQR_USER_MODEL_HEADER (ilqr_amd._build.build_user); not 4 states, so it runs in the generic kernels (generic.hpp):
 // thread-per-rollout forward passes, wavefront-per-knot finite differences that evaluate every perturbed point through
 // dynamics() / cost() / final_cost() exactly as src/derivatives.cpp does, the matrix-core backward pass.
-//   user_params: A [6][6], B [6][2], Q [6][6], R [2][2], Qf [6][6], row-major (124 doubles)
+//   user_params: A [6][6], B [6][2], Q [6][6], R [2][2], Qf [6][6], row-major (124 doubles), optionally followed by wb: the weight of
+//   a soft penalty wb sum_j (u_j / u_max_j)^2 on the controls -- a cost that reads the model's own limits, as a Model subclass may
+//   (include/model.h:17: u_min / u_max are public members set by the subclass)
 template <class real_>
 struct UserModelT {
   using real = real_;
   static constexpr int NX = 6, NU = 2;
   real u_min[NU], u_max[NU];
   real A[NX][NX], B[NX][NU], Q[NX][NX], R[NU][NU], Qf[NX][NX];
+  real wb;
 
   void set_params(const double* p, int n) {
     const int need = 3 * NX * NX + NX * NU + NU * NU;
@@ -24,6 +27,7 @@ struct UserModelT {
       for (int j = 0; j < NU; j++) B[i][j] = (n >= need) ? (real)p[NX * NX + i * NU + j] : real(0);
     for (int i = 0; i < NU; i++)
       for (int j = 0; j < NU; j++) R[i][j] = (n >= need) ? (real)p[2 * NX * NX + NX * NU + i * NU + j] : real(i == j);
+    wb = (n > need) ? (real)p[need] : real(0);
   }
   __device__ void dynamics(const real* x, const real* u, real* dx) const {
     for (int i = 0; i < NX; i++) {
@@ -43,6 +47,11 @@ struct UserModelT {
     }
     return s;
   }
-  __device__ real cost(const real* x, const real* u) const { return real(0.5) * (quad<NX>(Q, x) + quad<NU>(R, u)); }
+  __device__ real cost(const real* x, const real* u) const {
+    real c = real(0.5) * (quad<NX>(Q, x) + quad<NU>(R, u));
+    if (wb != real(0))
+      for (int j = 0; j < NU; j++) c += wb * (u[j] / u_max[j]) * (u[j] / u_max[j]);
+    return c;
+  }
   __device__ real final_cost(const real* x) const { return real(0.5) * quad<NX>(Qf, x); }
 };

@@ -67,6 +67,49 @@ struct WaveLds {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// Experiment builds (-DILQR_W2_TIMING, scripts/w2_sections.sh): shader cycles per section of the generic backward step and of its
+// box-QP, summed by the first wavefront of the grid and printed by ilqr_destroy.  Product builds compile the marks to nothing.
+#ifdef ILQR_W2_TIMING
+__device__ long long g_w2_cycles[8];   // step sections 0..7
+__device__ long long g_q_cycles[8];    // box-QP sections 0..5
+__device__ long long g_q_counts[4];    // QPs, projected-Newton iterations, factorisations, Armijo trips beyond the first
+struct W2Clock {
+  long long t, step[8], qp[8], cnt[4];
+  __device__ void start() {
+    for (int i = 0; i < 8; i++) step[i] = qp[i] = 0;
+    for (int i = 0; i < 4; i++) cnt[i] = 0;
+    t = __builtin_amdgcn_s_memtime();
+  }
+  __device__ __forceinline__ void mark(long long* acc, int k) {
+    __builtin_amdgcn_sched_barrier(0);
+    const long long n = __builtin_amdgcn_s_memtime();
+    acc[k] += n - t;
+    t = n;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ void flush() {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      for (int i = 0; i < 8; i++) {
+        atomicAdd((unsigned long long*)&g_w2_cycles[i], (unsigned long long)step[i]);
+        atomicAdd((unsigned long long*)&g_q_cycles[i], (unsigned long long)qp[i]);
+      }
+      for (int i = 0; i < 4; i++) atomicAdd((unsigned long long*)&g_q_counts[i], (unsigned long long)cnt[i]);
+    }
+  }
+};
+#define ILQR_W2CLOCK_ARG , W2Clock& clk
+#define ILQR_W2CLOCK_PASS , clk
+#define ILQR_W2MARK(k) clk.mark(clk.step, k);
+#define ILQR_QMARK(k) clk.mark(clk.qp, k);
+#define ILQR_QCOUNT(k) clk.cnt[k] += 1;
+#else
+#define ILQR_W2CLOCK_ARG
+#define ILQR_W2CLOCK_PASS
+#define ILQR_W2MARK(k)
+#define ILQR_QMARK(k)
+#define ILQR_QCOUNT(k)
+#endif
+
 // One 16x16 output tile: acc += sum_k A(i,k) B(k,j) over `ksteps` k-steps of 4.  Lane l feeds
 // A(i = l&15, k = 4 ks + (l>>4)) and B(k, j = l&15); it ends with D(row = (l>>4) + 4 r, col = l&15),
 // r = 0..3 (the f64 C/D map of v_mfma_f64_16x16x4_f64).
@@ -189,8 +232,8 @@ __device__ __forceinline__ double w_quad_cost(int m, const double* Q, const doub
 // src/boxqp.cpp:26-139 for one trajectory per wavefront.  Inputs in LDS: QuuF (Q), Qu (c), kprev
 // (x0), lo, hi.  Outputs: L.x (solution), L.vfree, L.Minv (R^-1 R^-T of the last factor, ld LDM), nfR.
 template <class LDS>
-__device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
-#define ILQR_QMARK(k)
+__device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out ILQR_W2CLOCK_ARG) {
+  ILQR_QCOUNT(0)
   const double* Q = L.QuuF();
   const double* c = L.Qu;
   // :35 clamp
@@ -215,6 +258,7 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
   double oldvalue = 0;
   int result = 0, nfR = 0;
   for (int iter = 0; iter <= kQpMaxIter; iter++) {
+    ILQR_QCOUNT(1)
     if (iter > 0 && (oldvalue - val) < kMinRelImprove * fabs(oldvalue)) {  // :54-57
       result = 4;
       break;
@@ -244,8 +288,9 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
     // ascending list of free dims (order-preserving compaction, eigen_helpers.h:15-61)
     if (lane < m && !cl) L.idx[__popcll(free_mask & ((1ull << lane) - 1ull))] = lane;
     lds_sync();
-    ILQR_QMARK(7)
+    ILQR_QMARK(0)
     if (iter == 0 || dsum != 0) {  // :80
+      ILQR_QCOUNT(2)
       // Qfree = Q[free, free], row i on lane i, in registers: the factorisation and the inversion
       // below are chains of short dot products with a square root / division between them; through
       // LDS every link of the chain paid a write -> read round trip (~35 K cycles per QP at nf = 16),
@@ -299,7 +344,7 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
         }
       }
       nfR = nf;
-      ILQR_QMARK(4)
+      ILQR_QMARK(1)
       // :86-88 R = L' (upper); Ri = R^-1 (upper triangular, column j on lane j), Minv = Ri Ri'
       // (:105-112).  The reference inverts R in every iteration; R only changes here, so the product
       // is computed here and kept (same values) -- for the iterations that reuse a stale factor and
@@ -335,7 +380,7 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
         for (int r = 0; r < 4; r++) L.Minv()[(r0 + 4 * r) + LDM * col] = acc[r];
       }
       lds_sync();
-      ILQR_QMARK(5)
+      ILQR_QMARK(2)
     }
     // :93-97
     {
@@ -368,7 +413,7 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
       L.search[L.idx[lane]] = s - L.xfree[lane];
     }
     lds_sync();
-    ILQR_QMARK(7)
+    ILQR_QMARK(3)
     // :121 quadclamp_line_search (src/boxqp.cpp:143-178)
     bool failed = false;
     double v = 0;
@@ -393,6 +438,7 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
         const double old_v = w_quad_cost(m, Q, c, L.x, lane);
         while ((v - old_v) > kArmijo * (step * slope)) {  // (the reference's quotient test without the division: step * slope < 0 here; boxqp.hpp)
           step *= kStepDec;
+          ILQR_QCOUNT(3)
           lds_sync();
           if (lane < m) {
             const double xr = L.x[lane] + step * L.search[lane];
@@ -408,7 +454,7 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
         }
       }
     }
-    ILQR_QMARK(6)
+    ILQR_QMARK(4)
     if (failed) {  // :122-125, x not updated
       result = 2;
       break;
@@ -419,6 +465,7 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out) {
     lds_sync();
   }
   lds_sync();
+  ILQR_QMARK(5)
   nfR_out = nfR;
   return result;
 }
@@ -529,6 +576,10 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
     diverge = 0;
     lds_sync();
 #define ILQR_WMARK(k)
+#ifdef ILQR_W2_TIMING
+    W2Clock clk;
+    clk.start();
+#endif
     RecA cur;
     load_rec_a(T - 1, cur);
     for (int i = T - 1; i >= 0; i--) {
@@ -709,7 +760,7 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
       lds_sync();
       ILQR_WMARK(2)
       int nfR = 0;
-      const int result = w_box_qp(m, L, lane, nfR);
+      const int result = w_box_qp(m, L, lane, nfR ILQR_W2CLOCK_PASS);
       ILQR_WMARK(3)
       if (result < 1) {  // :371
         diverge = i;

@@ -139,6 +139,10 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w2(BatchView v
   int diverge = 0;
   bool done = false;
   double dV0 = 0, dV1 = 0;
+#ifdef ILQR_W2_TIMING
+  W2Clock clk;
+  clk.start();
+#endif
   while (true) {
     double Vxx[NT][NT][4];
     {  // :353-354
@@ -158,7 +162,6 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w2(BatchView v
     dV0 = dV1 = 0;
     diverge = 0;
     lds_sync();
-#define ILQR_W2MARK(k)
     for (int i = T - 1; i >= 0; i--) {
       ILQR_W2MARK(7)
       // No prefetch of the next record, unlike k_backward_w: its 54 registers, held through the box-QP (61 ms) or
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w2(BatchView v
       lds_sync();
       ILQR_W2MARK(2)
       int nfR = 0;
-      const int result = w_box_qp(m, L, lane, nfR);
+      const int result = w_box_qp(m, L, lane, nfR ILQR_W2CLOCK_PASS);
       ILQR_W2MARK(3)
       if (result < 1) {  // :371
         diverge = i;
@@ -431,6 +434,7 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w2(BatchView v
           if (a < m && c < n) Kb[(size_t)i * m * n + a + m * c] = K[tj][rr];
         }
       lds_sync();
+      ILQR_W2MARK(6)
     }
     if (mode == 0) {
       done = (diverge == 0);
@@ -445,6 +449,9 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w2(BatchView v
     done = true;
     break;
   }
+#ifdef ILQR_W2_TIMING
+  clk.flush();
+#endif
   // :153 / :405-412 gradient norm: mean_t max_j |k_j| / (|u_j| + 1), ascending t
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);

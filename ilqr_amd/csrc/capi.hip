@@ -746,6 +746,19 @@ void ilqr_destroy(ilqr_batch* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+#ifdef ILQR_W2_TIMING
+  if (h->aos) {  // experiment build: what the first wavefront of every k_backward_w2 launch spent where (backward_wave.hpp)
+    long long st[8], qp[8], cnt[4];
+    if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_w2_cycles), sizeof(st)) == hipSuccess && hipMemcpyFromSymbol(qp, HIP_SYMBOL(g_q_cycles), sizeof(qp)) == hipSuccess &&
+        hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_q_counts), sizeof(cnt)) == hipSuccess && cnt[0] > 0) {
+      const double q = (double)cnt[0];
+      fprintf(stderr, "[k_backward_w2, wavefront 0] shader cycles per step: load+Qx/Qu %.0f  Vxx'fx,Vxx'fu %.0f  Qxx/Qux/Quu %.0f  box-QP %.0f  K %.0f  dV+T1+Vx %.0f  Vn+symmetrise+stores %.0f  (loop top %.0f)\n",
+              st[0] / q, st[1] / q, st[2] / q, st[3] / q, st[4] / q, st[5] / q, st[6] / q, st[7] / q);
+      fprintf(stderr, "[box-QP] per QP: %.2f iterations, %.2f factorisations, %.2f Armijo trips beyond the first; cycles: gradient+clamp set %.0f  Cholesky %.0f  inverse+R^-1R^-T %.0f  direction %.0f  line search %.0f  rest %.0f\n",
+              cnt[1] / q, cnt[2] / q, cnt[3] / q, qp[0] / q, qp[1] / q, qp[2] / q, qp[3] / q, qp[4] / q, qp[5] / q);
+    }
+  }
+#endif
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->staging) (void)hipFree(h->staging);
   if (h->d_perm) (void)hipFree(h->d_perm);
@@ -853,7 +866,6 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     } else {
       h->user.set_params(d->user_params, d->n_user_params);
     }
-    static_cast<UM&>(h->user_g) = h->user;  // (the parameters; set_params ran above)
     for (int j = 0; j < UM::NU; j++) {
       h->user_f.u_min[j] = (float)d->u_min[j];
       h->user_f.u_max[j] = (float)d->u_max[j];
@@ -861,6 +873,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
       h->user.u_min[j] = (h->dtype == ILQR_DTYPE_F32) ? (double)h->user_f.u_min[j] : d->u_min[j];
       h->user.u_max[j] = (h->dtype == ILQR_DTYPE_F32) ? (double)h->user_f.u_max[j] : d->u_max[j];
     }
+    static_cast<UM&>(h->user_g) = h->user;  // the generic kernels' copy: parameters AND limits (a model's cost may read its own u_min / u_max)
 #endif
   } else if (d->model == ILQR_MODEL_HOST || d->model == ILQR_MODEL_LQ) {
     // Generic dimensions: trajectory-contiguous layout, one wavefront per trajectory in the backward

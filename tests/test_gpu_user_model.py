@@ -135,3 +135,29 @@ def test_user_model_with_dimensions_of_its_own(user6_lib, oracle):
         BatchILQR("user", 4, 5, DT, u_min=-1.0, u_max=1.0, nx=n, nu=m, lib=user6_lib, user_params=params, dtype="f32")
     g.close()
     g2.close()
+
+
+def test_generic_user_model_whose_cost_reads_its_own_limits(user6_lib, oracle):
+    """A Model subclass may read its public u_min / u_max members in cost() (include/model.h:17).  The linear6 example's optional
+    penalty wb sum_j (u_j / u_max_j)^2 does: the generic kernels' copy of the model must carry the limits (the rollout cost is
+    checked against numpy), and the solve must be the oracle's LQ solve with R + 2 wb diag(1 / u_max^2)."""
+    from ilqr_amd import BatchILQR
+    from tests.parity import walk_iterations
+    from tests.test_gpu_lq_end_to_end import dense_mats
+    n, m, B, T, wb = 6, 2, 21, 40, 0.35
+    umax = np.array([0.4, 0.7])
+    A, Bm, Q, R, Qf = dense_mats(n, m, seed=9)
+    params = np.concatenate([np.ascontiguousarray(a).ravel() for a in (A, Bm, Q, R, Qf)] + [[wb]])
+    rng = np.random.default_rng(4)
+    x0 = rng.uniform(-1, 1, (B, n))
+    u0 = rng.normal(size=(B, T, m)) * 0.1
+    g = BatchILQR("user", B, T, DT, u_min=-umax, u_max=umax, lib=user6_lib, nx=n, nu=m, user_params=params)
+    c0 = g.init_traj(x0, u0)
+    xs, us = g.trajectory()
+    run = 0.5 * (np.einsum("bti,ij,btj->b", xs[:, :T], Q, xs[:, :T]) + np.einsum("bti,ij,btj->b", us, R, us)) + wb * ((us / umax) ** 2).sum(axis=(1, 2))
+    fin = 0.5 * np.einsum("bi,ij,bj->b", xs[:, T], Qf, xs[:, T])
+    assert np.allclose(c0, run + fin, rtol=1e-12)
+    om = oracle.Model("lq", lq=(A, Bm, Q, R + 2 * wb * np.diag(1 / umax ** 2), Qf), u_min=-umax, u_max=umax)
+    r = walk_iterations(oracle, om, g, x0, u0, DT, 4, drive="gpu")
+    assert r["checked"] >= 2 * B and len(r["tied"]) <= B // 8, r
+    g.close()
