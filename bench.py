@@ -39,7 +39,7 @@ def algorithmic_bytes_per_timestep(n, m, s=8):
         # UNIQUE bytes of the 11-alpha search: the nominal us,k (2m), K (mn), xs (n) are read once per tile and
         # shared by the 11 candidates; every candidate writes its u_t (m) and one checkpoint state per 8 knots.
         # (SURVEY's nominal figure charges the reads to every alpha: 11 x 92 B; that is not what reaches HBM.)
-        "rollout": ((2 * m + m * n + n) + 11 * (m + n / 8.0)) * s,                        # acrobot fp64 204
+        "rollout": ((2 * m + m * n + n) + 11 * (m + n / 8.0)) * s,                        # acrobot fp64 212
         "accept": 2 * (n + m) * s,                                                       # commit copy
         # fused sweep + backward (k_sweep_backward / the first phase of k_solve_tile): the records live in LDS
         # only, so HBM sees: candidate u + 1/8 checkpoint x read, committed x,u written, K and k written, the
@@ -48,11 +48,17 @@ def algorithmic_bytes_per_timestep(n, m, s=8):
     }
 
 
-def cpu_baseline(B_total, T, dt, lim, target_wall_s=4.0):
+def cpu_baseline(B_total, T, dt, lim, target_wall_s=4.0, flavour="f64", backward_only=True):
     """The CPU oracle (plain-C restatement of the reference, OpenMP over trajectories) on a
     bounded sample of the same workload, on this box's host cores: the same fixed-work
-    iterations over as many of the bench's own trajectories as fit the time budget."""
+    iterations over as many of the bench's own trajectories as fit the time budget.
+    flavour "f32": the oracle's float twin (what an fp32 handle is compared with)."""
     from oracle import oracle as O
+    with O.flavour(flavour):
+        return _cpu_baseline_acrobot(O, B_total, T, dt, lim, target_wall_s, flavour, backward_only)
+
+
+def _cpu_baseline_acrobot(O, B_total, T, dt, lim, target_wall_s, flavour, backward_only):
     from tests.util import acrobot_x0
     cores = os.cpu_count() or 1
     om = O.Model("acrobot", u_lim=lim)
@@ -74,6 +80,11 @@ def cpu_baseline(B_total, T, dt, lim, target_wall_s=4.0):
     if nb2 == B_total:                  # the whole batch is still too quick: run more iterations
         iters = int(min(40, max(iters, target_wall_s * rate / (T * nb2))))
     t2 = run(nb2, iters)
+    lib_name = {"f64": "liboracle_ilqr.so", "f32": "liboracle_ilqr_f32.so"}.get(flavour, flavour)
+    if not backward_only:
+        return {"value": nb2 * T * iters / t2, "unit": "trajectory-timesteps/s", "cores": cores, "kind": "port",
+                "sample": "%d trajectories x %d fixed-work iterations of the same acrobot workload (u in [-%g,%g], %s), %.1f s wall, oracle/%s "
+                          "with OpenMP over trajectories on all host threads" % (nb2, iters, lim, lim, flavour, t2, lib_name)}
     # backward pass alone on fixed derivatives (the north star's backward-only figure), same threads
     nb3 = min(B_total, 8 * cores)
     u3 = np.zeros((nb3, T, 1))
@@ -122,6 +133,33 @@ def cpu_baseline_other(kind, T, dt, target_wall_s=3.0):
     return {"value": nb * T * iters / t, "unit": "trajectory-timesteps/s", "cores": cores, "kind": "port",
             "sample": "%d trajectories x %d fixed-work iteration(s) of %s, %.1f s wall, oracle/liboracle_ilqr.so with OpenMP over "
                       "trajectories on all host threads" % (nb, iters, what, t)}
+
+
+def cpu_baseline_lq_exact(T, dt, target_wall_s=3.0):
+    """The LQ workload with EXACT derivatives has no counterpart in the reference (src/derivatives.cpp is finite differences only)
+    and none in the oracle.  What the device's iteration consists of there -- one backward pass with the box-QP, the eleven
+    closed-loop rollouts of the search -- timed with the oracle's own stages on fixed derivative records, OpenMP over trajectories."""
+    from oracle import oracle as O
+    from tests.util import mat
+    cores = os.cpu_count() or 1
+    om = O.Model("lq", lq=lq_mats(32, 16), u_lim=1.0)
+    nb = cores
+    x0 = np.random.default_rng(0).uniform(-1, 1, (nb, 32))
+    xs, us, _ = O.batch_rollout(om, x0, np.zeros((nb, T, 16)), dt, nthreads=cores)
+    dv = O.batch_derivatives(om, xs, us, dt, nthreads=cores)  # (not timed: the exact records are constant up to cx, cu)
+    reps, t_total = 0, 0.0
+    while t_total < target_wall_s and reps < 64:
+        t0 = time.perf_counter()
+        ro = O.batch_backward(om, us, dv, lam=1.0, nthreads=cores)
+        K = mat(ro["K"])  # [B][T][nu][nx]
+        for a in O.ALPHAS:
+            O.batch_rollout(om, x0, us + a * ro["k"], dt, xs_nom=xs, K=K, nthreads=cores)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    return {"value": nb * T * reps / t_total, "unit": "trajectory-timesteps/s", "cores": cores, "kind": "port",
+            "sample": "%d trajectories x %d repetitions of (oracle backward pass + the 11 closed-loop rollouts of the search) on fixed records of "
+                      "the LQ n=32 m=16 T=%d workload, %.1f s wall, oracle/liboracle_ilqr.so with OpenMP over trajectories on all host threads; the "
+                      "reference has no exact-derivative mode, so no sweep is timed" % (nb, reps, T, t_total)}
 
 
 def counters():
@@ -366,12 +404,16 @@ def main():
         other = "f32" if args.dtype == "f64" else "f64"
         g5, el5, prof5, _ = acrobot_run(other, 32768, 5.0, steps, args.warmup, gather=False)
         st5, bt5 = stage_table(g5, prof5, 32768, 4 if other == "f32" else 8, steps)
+        sclk5 = g5.sclk_mhz
         g5.close()
+        roof5 = roofline_of(st5, bt5, 32768, other)
+        issue5 = issue_roofline(roof5["kernel"] + ("_f32" if other == "f32" else ""), el5 / steps * 1e3, sclk5, 32768 * T)
+        roof5["bound_frac"] = issue5["frac"]
         extra["acrobot_T500_B32768_lim5_%s_one_gpu" % other] = {
             "workload": "acrobot T=499 B=32768 on one GPU, u in [-5,5], %s (BASELINE configs[3] at its stated size, unsharded); the 8 x 4096 partition of "
                         "the same batch gives the same bits (tests/test_gpu_fp32.py)" % other,
             "dtype": other, "value": 32768 * T * steps / el5, "unit": "trajectory-timesteps/s", "ms_per_step": el5 / steps * 1e3,
-            "stages": st5, "roofline": roofline_of(st5, bt5, 32768, other)}
+            "stages": st5, "roofline": roof5, "roofline_issue": issue5}
     if not args.no_extra_configs:
         # late in a solve: iterations 4..103 of the same workload -- box-QPs leave the fast path
         # once lambda has reached 0, the launch lasts as long as its slowest tile
@@ -388,13 +430,27 @@ def main():
         for label, fl in ((other, 0), (other + "_analytic", capi.FLAG_ANALYTIC_DERIVATIVES)):
             g3, el3, prof3, ga3 = acrobot_run(other, 4096, 5.0, steps, args.warmup, fl)
             st3, bt3 = stage_table(g3, prof3, 4096, so, steps)
+            roof3 = roofline_of(st3, bt3, 4096, other)
+            # (the counter passes are of the finite-difference run: the exact-derivative line carries the HBM figures only)
+            issue3 = issue_roofline(roof3["kernel"] + ("_f32" if other == "f32" else ""), el3 / steps * 1e3, g3.sclk_mhz, 4096 * T) if not fl else None
+            if issue3:
+                roof3["bound_frac"] = issue3["frac"]
+            else:
+                roof3["traffic"], roof3["traffic_source"] = None, "counter passes exist for the finite-difference run of this workload only"
             assert ga3 is None or bool(torch.isfinite(ga3).all())
+            cpu3 = None
+            if world == 1 and not args.no_cpu_baseline and not fl:
+                cpu3 = cpu_baseline(4096, T, dt, 5.0, target_wall_s=2.0, flavour=other, backward_only=False)
             extra["acrobot_T500_B4096_lim5_" + label] = {
                 "workload": "acrobot T=499 B=4096 per GPU, u in [-5,5], %s%s, fixed-work iterations (BASELINE configs[3] "
                             "per-GPU shard; x %d GPUs)" % (other, ", exact model derivatives instead of finite differences" if fl else
                                                              ("; finite differences taken in double from the float knot" if other == "f32" else ""), world),
                 "dtype": other, "value": world * 4096 * T * steps / el3, "unit": "trajectory-timesteps/s", "ms_per_step": el3 / steps * 1e3,
-                "n_gpus": world, "stages": st3, "roofline": roofline_of(st3, bt3, 4096, other)}
+                "n_gpus": world, "stages": st3, "roofline": roof3}
+            if issue3:
+                extra["acrobot_T500_B4096_lim5_" + label]["roofline_issue"] = issue3
+            if cpu3:
+                extra["acrobot_T500_B4096_lim5_" + label]["cpu_baseline"] = cpu3
             g3.close()
     if not args.no_extra_configs and world == 1:
         # BASELINE configs[1]: acrobot B=1024, limits +-5
@@ -404,6 +460,8 @@ def main():
         extra["acrobot_T500_B1024_lim5_f64"] = {"workload": "acrobot T=499 B=1024, u in [-5,5], fp64 (BASELINE configs[1])",
                                                 "value": 1024 * T * steps / el4, "unit": "trajectory-timesteps/s",
                                                 "ms_per_step": el4 / steps * 1e3, "stages": st4}
+        if not args.no_cpu_baseline:
+            extra["acrobot_T500_B1024_lim5_f64"]["cpu_baseline"] = cpu_baseline(1024, T, dt, 5.0, target_wall_s=2.0, backward_only=False)
         # the reference's other shipped model, batched (north_star: "acrobot/double-integrator problems"; BASELINE configs[0]
         # is its single-trajectory T=100 solve, a parity case): n=4, m=2 -- the generic m x m box-QP inside the quad kernel
         Bd, Td, goal = 4096, 100, [1.0, 0.5, 0.0, 0.0]
@@ -476,6 +534,8 @@ def main():
                     "note": "the same sweep evaluated point by point as the reference does would be %.1f x the flops" % (fd_dense / fd_flops)}
                 if not args.no_cpu_baseline:
                     extra["lq_n32_m16_T200_B8192_" + label]["cpu_baseline"] = cpu_baseline_other("lq", Tq, dt)
+            elif not args.no_cpu_baseline:
+                extra["lq_n32_m16_T200_B8192_" + label]["cpu_baseline"] = cpu_baseline_lq_exact(Tq, dt)
 
     if rank == 0:
         costs = gathered.cpu().numpy()

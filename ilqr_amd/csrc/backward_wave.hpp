@@ -232,7 +232,7 @@ __device__ __forceinline__ double w_quad_cost(int m, const double* Q, const doub
 // src/boxqp.cpp:26-139 for one trajectory per wavefront.  Inputs in LDS: QuuF (Q), Qu (c), kprev
 // (x0), lo, hi.  Outputs: L.x (solution), L.vfree, L.Minv (R^-1 R^-T of the last factor, ld LDM), nfR.
 template <class LDS>
-__device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out ILQR_W2CLOCK_ARG) {
+__device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out ILQR_W2CLOCK_ARG, int* nfact_out = nullptr) {
   ILQR_QCOUNT(0)
   const double* Q = L.QuuF();
   const double* c = L.Qu;
@@ -257,6 +257,7 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out ILQR_W2CLOCK_ARG) 
   }
   double oldvalue = 0;
   int result = 0, nfR = 0;
+  int nfact_last = 0;  // pivots the last factorisation completed (== nfR: the whole block was positive definite)
   for (int iter = 0; iter <= kQpMaxIter; iter++) {
     ILQR_QCOUNT(1)
     if (iter > 0 && (oldvalue - val) < kMinRelImprove * fabs(oldvalue)) {  // :54-57
@@ -344,6 +345,7 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out ILQR_W2CLOCK_ARG) 
         }
       }
       nfR = nf;
+      nfact_last = n_fact;
       ILQR_QMARK(1)
       // :86-88 R = L' (upper); Ri = R^-1 (upper triangular, column j on lane j), Minv = Ri Ri'
       // (:105-112).  The reference inverts R in every iteration; R only changes here, so the product
@@ -467,6 +469,7 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out ILQR_W2CLOCK_ARG) 
   lds_sync();
   ILQR_QMARK(5)
   nfR_out = nfR;
+  if (nfact_out) *nfact_out = nfact_last;
   return result;
 }
 

@@ -16,6 +16,7 @@
 
 #include "backward_wave.hpp"
 #include "backward_wave2.hpp"
+#include "backward_wave3.hpp"
 #include "generic.hpp"
 #include "kernels_wide.hpp"
 #include "kernels.hpp"
@@ -83,8 +84,13 @@ struct ilqr_batch {
   double* staging = nullptr;  // device scratch for canonical <-> tiled conversion
   // LQ model with exact derivatives: the sweep writes one copy of the constant matrices (const_rec) and
   // per knot only cx, cu; records_partial says that D holds no matrices for t < T right now
-  double* const_rec = nullptr;
+  double* const_rec = nullptr;   // [2][REC]: the constant blocks of every knot t < T, then knot T's record
   bool records_partial = false;
+  // ... on the k_backward_w3 route (lq_fused) no sweep runs at all: the backward pass forms cx = cxx x_t, cu = cuu u_t from the knot, and the
+  // record array D is allocated only if somebody asks for records (getters, ilqr_set_derivatives, the finite-difference mode)
+  bool lq_fused = false;          // the handle can take that route (LQ model, exact derivatives, k_backward_w3, no ILQR_ROUTE_FULL_RECORDS)
+  bool lq_fused_stale = false;    // fused iterations have run since D was last written: a getter gets the records of the current nominal computed
+  bool lq_caller_records = false; // ilqr_set_derivatives replaced the model's blocks: the next backward pass reads D, not the model
   // nx = 4 device models: D (0.75 GB per 4096 acrobot trajectories) is allocated the first time somebody wants
   // records in HBM -- the stage calls, the two-kernel route, the getters.  ilqr_iterate's fused kernel keeps them
   // in LDS (kernels.hpp) and leaves D as it was: recs says what D holds.
@@ -113,7 +119,7 @@ struct ilqr_batch {
   // Route choices for A/B runs and the bit-identity tests: ilqr_desc.route, fixed at ilqr_create -- a handle never changes
   // kernels between calls, and nothing is read from the environment
   struct {
-    bool staged = false, unfused = false, backward_w1 = false, lq_thread_rollout = false, full_records = false, no_compaction = false, quad_chain = false;
+    bool staged = false, unfused = false, backward_w1 = false, backward_w2 = false, lq_thread_rollout = false, full_records = false, no_compaction = false, quad_chain = false;
     int fused = 0;  // 0 = by batch size
     int wide_occ = 0;  // wide tiles per CU: 0 = by batch size
   } env;
@@ -310,7 +316,8 @@ static int download(ilqr_batch* h, const void* src_tiled, double* dst, int S, in
 static int launch_derivatives(ilqr_batch* h, int force);
 // the record array of a tiled handle, allocated (zero-filled) on first use
 static int ensure_records(ilqr_batch* h) {
-  if (h->aos || h->v.D) return 0;
+  if (h->v.D) return 0;
+  if (h->aos) return dev_alloc(h, &h->v.D, (size_t)h->B * (h->T + 1) * rec_of(h));  // (generic handles: on first use as well -- 44 GB at configs[4])
   if (int rc = dev_alloc_real(h, &h->v.D, (size_t)h->ntiles * (h->T + 1) * rec_of(h) * TW)) return rc;
   sync_float_view(h);
   return 0;
@@ -319,9 +326,17 @@ static int ensure_records(ilqr_batch* h) {
 // matrices the partial sweep skipped.  nx = 4 handles: have the sweep compute the records of the current nominal
 // trajectory if iterations have run since D was last written.
 static int materialise_records(ilqr_batch* h) {
+  if (int rc = ensure_records(h)) return rc;
   if (!h->aos) {
-    if (int rc = ensure_records(h)) return rc;
     if (h->recs == ilqr_batch::REC_STALE) return launch_derivatives(h, 1);
+    return 0;
+  }
+  if (h->lq_fused_stale) {  // the fused LQ route never wrote D: whole exact records of the current nominal, now
+    h->lq_fused_stale = false;
+    h->records_partial = false;
+    const int nchunk = (h->T + 1 + kAnalyticChunk - 1) / kAnalyticChunk;
+    hipLaunchKernelGGL(k_analytic_lq, dim3(h->B * nchunk), dim3(64), 0, h->stream, h->v, h->lq, 1, 0, h->const_rec, kAnalyticChunk);
+    HIPCHK(hipGetLastError());
     return 0;
   }
   if (!h->records_partial) return 0;
@@ -333,6 +348,7 @@ static int materialise_records(ilqr_batch* h) {
 static int upload_rec(ilqr_batch* h, const double* src, int off, int E) {
   if (int rc = materialise_records(h)) return rc;
   h->records_partial = false;  // the caller's blocks replace the model's: every knot reads its own record again
+  h->lq_caller_records = true;
   h->recs = ilqr_batch::REC_VALID;
 
   const int S = h->T + 1;
@@ -432,18 +448,23 @@ static int with_generic_model(ilqr_batch* h, F&& f) {
 // matrix cores (k_rollout_lq, one wavefront per trajectory); ILQR_ROUTE_LQ_THREAD_ROLLOUT selects the
 // generic thread-per-rollout kernel (same results bit for bit; kept as the cross-check and as the
 // template for device models without matrix structure).
+// Does the handle's search kernel also accept and commit (k_rollout_lq<RG_SEARCH, true>)?  The LQ model's matrix-core rollout with candidate buffers.
+static bool lq_search_accepts(const ilqr_batch* h) { return h->model == ILQR_MODEL_LQ && !h->env.lq_thread_rollout && h->v.cand_x != nullptr; }
 template <class M>
-static int launch_rollout_g(ilqr_batch* h, const M& m, int what, const AlphaSet& al, double* cost_out, int mode, int write_cost) {
+static int launch_rollout_g(ilqr_batch* h, const M& m, int what, const AlphaSet& al, double* cost_out, int mode, int write_cost, bool with_accept = false) {
   if constexpr (std::is_same<M, LqModel>::value)
   if (!h->env.lq_thread_rollout) {
     const dim3 grid(h->B), block(64);
-    if (what == RG_SEARCH) {
-      hipLaunchKernelGGL((k_rollout_lq<RG_SEARCH>), grid, block, 0, h->stream, h->v, m, al, cost_out, nullptr, mode, 0);
+    if (what == RG_SEARCH && with_accept && h->v.cand_x) {
+      hipLaunchKernelGGL((k_rollout_lq<RG_SEARCH, true>), grid, block, 0, h->stream, h->v, m, al, cost_out, h->commit_idx, mode, 0, h->sp);
+      h->lq_cands_kept = true;
+    } else if (what == RG_SEARCH) {
+      hipLaunchKernelGGL((k_rollout_lq<RG_SEARCH>), grid, block, 0, h->stream, h->v, m, al, cost_out, nullptr, mode, 0, h->sp);
       h->lq_cands_kept = h->v.cand_x != nullptr;  // the commit of what the next accept chooses is a copy (launch_commit)
     } else if (what == RG_INIT)
-      hipLaunchKernelGGL((k_rollout_lq<RG_INIT>), grid, block, 0, h->stream, h->v, m, al, cost_out, nullptr, 0, 1);
+      hipLaunchKernelGGL((k_rollout_lq<RG_INIT>), grid, block, 0, h->stream, h->v, m, al, cost_out, nullptr, 0, 1, h->sp);
     else
-      hipLaunchKernelGGL((k_rollout_lq<RG_COMMIT>), grid, block, 0, h->stream, h->v, m, al, cost_out, h->commit_idx, 0, write_cost);
+      hipLaunchKernelGGL((k_rollout_lq<RG_COMMIT>), grid, block, 0, h->stream, h->v, m, al, cost_out, h->commit_idx, 0, write_cost, h->sp);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -468,7 +489,7 @@ static int launch_rollout(ilqr_batch* h, bool gains, bool cand, const AlphaSet& 
   if (generic_twin(h)) {
     rc = with_generic_model(h, [&](auto& m) {
       if (!gains) return launch_rollout_g(h, m, RG_INIT, al, cost_out, 0, 1);
-      if (n_alpha == NALPHA) return launch_rollout_g(h, m, RG_SEARCH, al, cost_out, mode, 0);
+      if (n_alpha == NALPHA) return launch_rollout_g(h, m, RG_SEARCH, al, cost_out, mode, 0, with_accept);
       return launch_rollout_g(h, m, RG_COMMIT, al, cost_out, 0, 1);  // a single closed-loop rollout written in place (warm start): slot commit_idx of `al`
     });
     if (rc) return rc;
@@ -516,16 +537,24 @@ static int flush_commit(ilqr_batch* h) {
 // no matrices" state of an exact-derivative LQ sweep (init_traj promises zeroed records, ilqr_core.cpp:39-45).
 static int forget_pending(ilqr_batch* h) {
   h->records_partial = false;
+  h->lq_fused_stale = false;
+  h->lq_caller_records = false;
+  h->cands_valid = false;  // (candidates of an earlier solve are nobody's)
   h->commit_pending = false;
   HIPCHK(hipMemsetAsync(h->commit_idx, 0xFF, (size_t)h->Bp * sizeof(int), h->stream));  // all -1
   return 0;
 }
 
 static int launch_derivatives(ilqr_batch* h, int force) {
-  if (int rc = ensure_records(h)) return rc;
-  h->recs = ilqr_batch::REC_VALID;
   if (generic_twin(h))  // the generic sweep has no fused commit: rebuild the accepted rollout first
     if (int rc = flush_commit(h)) return rc;
+  if (h->lq_fused) {  // k_backward_w3<.., LQF> forms cx, cu from the knot itself: no sweep, no record array
+    h->lq_fused_stale = true;
+    h->lq_caller_records = false;
+    return 0;
+  }
+  if (int rc = ensure_records(h)) return rc;
+  h->recs = ilqr_batch::REC_VALID;
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_DERIVATIVES, &ev)) return rc;
   dim3 grid((h->T + 1 + 15) / 16, h->ntiles), block(256);
@@ -573,13 +602,26 @@ static int launch_backward(ilqr_batch* h, int mode) {
   if (h->aos) {
     // the register-resident kernel, two (nx > 16) or more (nx <= 16) wavefronts per SIMD; ILQR_ROUTE_BACKWARD_LDS forces round
     // 1's LDS kernel -- the two give bit-identical results (tests/test_gpu_generic_backward.py)
-    const double* crec = h->records_partial ? h->const_rec : nullptr;
+    const bool fused = h->lq_fused && !h->lq_caller_records;  // cx, cu from the knot, the matrices from const_rec: D untouched
+    if (!fused)
+      if (int rc = ensure_records(h)) return rc;
+    const double* crec = (fused || h->records_partial) ? h->const_rec : nullptr;
+    const dim3 grid(h->B), block(64);
+    const bool full = h->nu == WM && (h->nx == 16 || h->nx == 32);
+#define ILQR_W3(NT_, FULL_, LQF_) hipLaunchKernelGGL((k_backward_w3<NT_, FULL_, LQF_>), grid, block, 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec)
     if (h->env.backward_w1)
-      hipLaunchKernelGGL(k_backward_w, dim3(h->B), dim3(64), 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
-    else if (h->nx > 16)
-      hipLaunchKernelGGL(k_backward_w2<2>, dim3(h->B), dim3(64), 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
-    else
-      hipLaunchKernelGGL(k_backward_w2<1>, dim3(h->B), dim3(64), 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
+      hipLaunchKernelGGL(k_backward_w, grid, block, 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
+    else if (h->env.backward_w2 && h->nx > 16)
+      hipLaunchKernelGGL(k_backward_w2<2>, grid, block, 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
+    else if (h->env.backward_w2)
+      hipLaunchKernelGGL(k_backward_w2<1>, grid, block, 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
+    else if (h->nx > 16) {
+      if (fused) { if (full) ILQR_W3(2, true, true); else ILQR_W3(2, false, true); }
+      else { if (full) ILQR_W3(2, true, false); else ILQR_W3(2, false, false); }
+    } else {
+      if (fused) ILQR_W3(1, false, true); else ILQR_W3(1, false, false);
+    }
+#undef ILQR_W3
   } else if (use_quad_backward(h)) {
     dim3 grid(h->ntiles), block(64);  // one wavefront = one tile of 16 trajectories x 4 lanes
     if (int rc = with_model(h, [&](auto& v, auto& m, auto&) {
@@ -751,12 +793,16 @@ void ilqr_destroy(ilqr_batch* h) {
     long long st[8], qp[8], cnt[4];
     if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_w2_cycles), sizeof(st)) == hipSuccess && hipMemcpyFromSymbol(qp, HIP_SYMBOL(g_q_cycles), sizeof(qp)) == hipSuccess &&
         hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_q_counts), sizeof(cnt)) == hipSuccess && cnt[0] > 0) {
-      const double q = (double)cnt[0];
+      const double q = (double)cnt[0];  // (literal box-QPs; on the k_backward_w3 route the step sections are per LITERAL QP too: scale by the counts below)
       fprintf(stderr, "[k_backward_w2, wavefront 0] shader cycles per step: load+Qx/Qu %.0f  Vxx'fx,Vxx'fu %.0f  Qxx/Qux/Quu %.0f  box-QP %.0f  K %.0f  dV+T1+Vx %.0f  Vn+symmetrise+stores %.0f  (loop top %.0f)\n",
               st[0] / q, st[1] / q, st[2] / q, st[3] / q, st[4] / q, st[5] / q, st[6] / q, st[7] / q);
       fprintf(stderr, "[box-QP] per QP: %.2f iterations, %.2f factorisations, %.2f Armijo trips beyond the first; cycles: gradient+clamp set %.0f  Cholesky %.0f  inverse+R^-1R^-T %.0f  direction %.0f  line search %.0f  rest %.0f\n",
               cnt[1] / q, cnt[2] / q, cnt[3] / q, qp[0] / q, qp[1] / q, qp[2] / q, qp[3] / q, qp[4] / q, qp[5] / q);
     }
+    long long w3[4];
+    if (hipMemcpyFromSymbol(w3, HIP_SYMBOL(g_w3_counts), sizeof(w3)) == hipSuccess && w3[0] + w3[1] > 0)
+      fprintf(stderr, "[k_backward_w3, wavefront 0] box-QPs on the matrix-core path %lld, handed to the literal path %lld, Newton-Schulz iterations per refinement %.2f\n",
+              w3[0], w3[1], (double)w3[2] / (double)(w3[0] > 0 ? w3[0] : 1));
   }
 #endif
   for (void* p : h->allocs) (void)hipFree(p);
@@ -784,6 +830,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   h->env.staged = false;
   h->env.unfused = false;
   h->env.backward_w1 = (d->route & ILQR_ROUTE_BACKWARD_LDS) != 0;
+  h->env.backward_w2 = (d->route & ILQR_ROUTE_BACKWARD_W2) != 0;
   h->env.lq_thread_rollout = (d->route & ILQR_ROUTE_LQ_THREAD_ROLLOUT) != 0;
   h->env.full_records = (d->route & ILQR_ROUTE_FULL_RECORDS) != 0;
   h->env.no_compaction = (d->route & ILQR_ROUTE_NO_COMPACTION) != 0;
@@ -905,16 +952,25 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     rc |= dev_alloc(h, &v.us, Bn * T * nu);
     rc |= dev_alloc(h, &v.kff, Bn * T * nu);
     rc |= dev_alloc(h, &v.Kfb, Bn * T * nu * nx);
-    rc |= dev_alloc(h, &v.D, Bn * T1 * REC);
-    rc |= dev_alloc(h, &h->const_rec, REC);
+    v.D = nullptr;  // on first use (ensure_records): the fused LQ route never needs it
+    rc |= dev_alloc(h, &h->const_rec, 2 * REC);
     rc |= dev_alloc(h, &h->d_umin, nu);
     rc |= dev_alloc(h, &h->d_umax, nu);
     v.cand_u = nullptr;
     v.cand_x = nullptr;
     if (d->model == ILQR_MODEL_LQ && !h->env.lq_thread_rollout && !(d->route & ILQR_ROUTE_LQ_RECOMMIT)) {
       // the eleven rollouts of the matrix-core search, whole ([b][alpha][t][row]): the commit is then a copy, not a twelfth rollout
-      rc |= dev_alloc(h, &v.cand_x, Bn * NALPHA * T1 * nx);
-      rc |= dev_alloc(h, &v.cand_u, Bn * NALPHA * T * nu);
+      // (11 x the nominal trajectory, ~7 GB at configs[4]: if the device cannot spare them the handle works without -- the ILQR_ROUTE_LQ_RECOMMIT route)
+      void *cx = nullptr, *cu = nullptr;
+      if (hipMalloc(&cx, Bn * NALPHA * T1 * nx * sizeof(double)) == hipSuccess && hipMalloc(&cu, Bn * NALPHA * T * nu * sizeof(double)) == hipSuccess) {
+        h->allocs.push_back(cx);
+        h->allocs.push_back(cu);
+        v.cand_x = (double*)cx;
+        v.cand_u = (double*)cu;
+      } else {
+        if (cx) (void)hipFree(cx);
+        (void)hipGetLastError();  // (clears the allocation error)
+      }
     }
     rc |= dev_alloc(h, &v.cost_c, (size_t)NALPHA * Bp);  // the 11 candidate costs (device or caller-evaluated)
     if (d->model == ILQR_MODEL_LQ) {
@@ -998,6 +1054,11 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   hipLaunchKernelGGL(k_reset_state<double>, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
                      h->params.dlambda_init);
   HIPCHK(hipGetLastError());
+  h->lq_fused = h->model == ILQR_MODEL_LQ && v.analytic && !h->env.full_records && !h->env.backward_w1 && !h->env.backward_w2;
+  if (h->lq_fused) {  // both constant records, once (what = 3)
+    hipLaunchKernelGGL(k_analytic_lq, dim3(1), dim3(64), 0, h->stream, h->v, h->lq, 1, 3, h->const_rec, kAnalyticChunk);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -1096,6 +1157,10 @@ int ilqr_iterate(ilqr_batch* h, int n_iters) {
     if (!h->aos) {  // STEP 3 + STEP 3/4 in one launch: the rollout block of a tile also accepts for it
       if (int rc = launch_rollout(h, true, true, line_search_alphas(), NALPHA, h->v.cost_c, 1, true)) return rc;
       h->commit_pending = true;
+    } else if (lq_search_accepts(h)) {  // STEP 3 + STEP 3/4 + the commit in one launch (k_rollout_lq<RG_SEARCH, true>)
+      if (int rc = launch_rollout(h, true, true, line_search_alphas(), NALPHA, h->v.cost_c, 1, true)) return rc;
+      h->cands_valid = true;
+      h->commit_pending = false;
     } else {
       if (int rc = do_rollout_candidates(h, 1)) return rc;              // STEP 3
       if (int rc = launch_accept(h)) return rc;                         // STEP 3/4
@@ -1484,6 +1549,15 @@ int ilqr_get_candidate(ilqr_batch* h, int a, double* xs, double* us) {
     return fail(ILQR_ERR_STATE, "no candidates: none rolled out yet, or the solve re-packed running trajectories (compaction) and left the "
                                 "candidate buffers behind -- call ilqr_rollout_candidates / ilqr_iterate first");
   HIPCHK(hipSetDevice(h->device));
+  if (h->aos) {  // generic handles keep candidates only on the LQ matrix-core route: [b][alpha][t][row], whole trajectories
+    if (!(h->model == ILQR_MODEL_LQ && h->lq_cands_kept && h->v.cand_x))
+      return fail(ILQR_ERR_UNSUPPORTED, "this handle's line search keeps no candidate trajectories (only their costs: ilqr_rollout_candidates)");
+    const size_t wx = (size_t)(h->T + 1) * h->nx * sizeof(double), wu = (size_t)h->T * h->nu * sizeof(double);
+    if (xs) HIPCHK(hipMemcpy2DAsync(xs, wx, (const char*)h->v.cand_x + (size_t)a * wx, (size_t)NALPHA * wx, wx, h->B, hipMemcpyDeviceToHost, h->stream));
+    if (us) HIPCHK(hipMemcpy2DAsync(us, wu, (const char*)h->v.cand_u + (size_t)a * wu, (size_t)NALPHA * wu, wu, h->B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+  }
   const size_t nx_el = (size_t)h->B * (h->T + 1) * h->nx, nu_el = (size_t)h->B * h->T * h->nu;
   if (int rc = ensure_staging(h, nx_el + nu_el)) return rc;
   double* dxs = h->staging;
@@ -1701,9 +1775,9 @@ int ilqr_profile_shader_clock(ilqr_batch* h, double* mhz_out) {
 }
 const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
   switch (stage) {
-    case ILQR_STAGE_DERIVATIVES: return (h && h->aos) ? ((h->v.analytic) ? "k_analytic_lq" : "k_derivatives_g") : "k_derivatives";
+    case ILQR_STAGE_DERIVATIVES: return (h && h->aos) ? (h->lq_fused ? "" : (h->v.analytic) ? "k_analytic_lq" : "k_derivatives_g") : "k_derivatives";
     case ILQR_STAGE_BACKWARD:
-      if (h && h->aos) return h->env.backward_w1 ? "k_backward_w" : "k_backward_w2";
+      if (h && h->aos) return h->env.backward_w1 ? "k_backward_w" : h->env.backward_w2 ? "k_backward_w2" : "k_backward_w3";
       if (h && use_fused_sweep(h)) return "k_sweep_backward";  // what ilqr_iterate launches
       return (h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t";
     case ILQR_STAGE_ROLLOUT: return (h && h->aos) ? ((h->env.lq_thread_rollout || h->model != ILQR_MODEL_LQ) ? "k_rollout_g" : "k_rollout_lq") : "k_rollout";

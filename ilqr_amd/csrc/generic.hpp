@@ -348,8 +348,9 @@ __global__ __launch_bounds__(64) void k_analytic_lq(BatchView v, LqModel model, 
   const int lane = threadIdx.x;
   const int nchunk = (T + 1 + chunk - 1) / chunk;  // knots per wavefront: kAnalyticChunk, or more when only cx, cu are written
   const int b = blockIdx.x / nchunk, t0 = (blockIdx.x - b * nchunk) * chunk;
-  if (what != 2 && blockIdx.x == 0 && lane == 0) *v.n_running = 0;  // k_accept of this iteration recounts
-  const bool fill_const = (what == 1 && blockIdx.x == 0);
+  if (what != 2 && what != 3 && blockIdx.x == 0 && lane == 0) *v.n_running = 0;  // k_accept of this iteration recounts
+  const bool fill_const = ((what == 1 || what == 3) && blockIdx.x == 0);  // what = 3: ONLY the two constant records (k_backward_w3's fused route)
+  if (what == 3 && blockIdx.x != 0) return;
   if (what != 2 && !fill_const && !(force || (v.status[b] == 0 && v.flg_change[b]))) return;
   const bool skip_knots = (what == 1) && !(force || (v.status[b] == 0 && v.flg_change[b]));  // (block 0 came for const_rec only)
   const int oFX = 0, oFU = oFX + nx * nx, oCX = oFU + nx * nu, oCXX = oCX + nx, oCXU = oCXX + nx * nx, oCU = oCXU + nx * nu,
@@ -468,6 +469,10 @@ __global__ __launch_bounds__(64) void k_analytic_lq(BatchView v, LqModel model, 
       for (int j = 0; j < 4; j++)
         if (4 * j + cq < nu) D[oCUU + r16 + nu * (4 * j + cq)] = cuu[j];
     }
+    if (what == 3) {  // ... and knot T's record behind it (its cx belongs to nobody's x_T: the fused backward pass forms cx[T] = cxx[T] x_T itself)
+      model.analytic_record(v.xs, nullptr, dt, true, const_rec + REC, lane);
+      return;
+    }
   }
 }
 
@@ -496,16 +501,23 @@ __global__ __launch_bounds__(64) void k_analytic_lq(BatchView v, LqModel model, 
 // store column 0.  RG_SEARCH with candidate buffers (v.cand_x / v.cand_u, [b][alpha][t][row]): every column stores its
 // states and controls on the way, so that the commit of the accepted one is a copy (k_commit_lq) instead of a twelfth
 // rollout as long as the eleven (the 3.5 KB per step and trajectory leave under the MFMA chains).
-template <int MODE>
+// ACCEPT (RG_SEARCH with candidate buffers only): the wavefront also performs STEP 3/4 for its trajectory (accept_one: selection,
+// lambda schedule, termination -- k_accept's work) and copies the accepted candidate over the nominal trajectory (k_commit_lq's):
+// an iteration of the LQ path is then two launches (backward pass, search) instead of four.  commit_idx is written, not read.
+template <int MODE, bool ACCEPT = false>
 __global__ __launch_bounds__(64) void k_rollout_lq(BatchView v, LqModel model, AlphaSet alphas, double* __restrict__ cost_out,
-                                                   const int* __restrict__ commit_idx, int mode, int write_cost) {
+                                                   int* __restrict__ commit_idx, int mode, int write_cost, SolverParams sp) {
   static_assert(GN == 32 && GM == 16, "operand blocks below are written for a 32 x 16 model");
+  static_assert(!ACCEPT || MODE == RG_SEARCH, "the accept epilogue belongs to the search");
   typedef double double4_t __attribute__((ext_vector_type(4)));
   const int nx = model.nx, nu = model.nu, T = v.T;
   const int lane = threadIdx.x, g = lane >> 4, p = lane & 15;
   const int b = blockIdx.x;
   if (b >= v.B) return;
-  if (MODE == RG_SEARCH && mode == 1 && !(v.status[b] == 0 && v.backpass_done[b])) return;
+  if (MODE == RG_SEARCH && mode == 1 && !(v.status[b] == 0 && v.backpass_done[b])) {
+    if (ACCEPT && lane == 0) accept_one(v, sp, b, [](int) { return 0.0; }, commit_idx);  // (no search: the "no step" branch, :264-282; a finished trajectory: commit -1)
+    return;
+  }
   int a = p;
   if (MODE == RG_COMMIT) {
     a = commit_idx[b];
@@ -675,6 +687,39 @@ __global__ __launch_bounds__(64) void k_rollout_lq(BatchView v, LqModel model, A
       if (p < NALPHA) cost_out[(size_t)p * v.Bp + b] = mine;
     } else if (p == 0 && (MODE == RG_INIT || write_cost)) {
       cost_out[b] = mine;
+    }
+  }
+  if constexpr (ACCEPT) {
+    __shared__ double cst[NALPHA];
+    __shared__ int chosen;
+    if (g == (p & 3) && p < NALPHA) cst[p] = mine;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // the candidates' stores are complete and this CU's L1 holds nothing older when they are read back
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      accept_one(v, sp, b, [&](int a2) { return cst[a2]; }, commit_idx);
+      chosen = commit_idx[b];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const int a2 = chosen;
+    if (a2 >= 0) {  // ilqr_core.cpp:210-213: the bits of the rollout that was scored
+      const size_t nxs = (size_t)(T + 1) * nx, nus = (size_t)T * nu;
+      const double* __restrict__ cx2 = v.cand_x + ((size_t)b * NALPHA + a2) * nxs;
+      const double* __restrict__ cu2 = v.cand_u + ((size_t)b * NALPHA + a2) * nus;
+      auto copy = [&](double* __restrict__ dst, const double* __restrict__ src, size_t cnt) __attribute__((always_inline)) {
+        size_t i = lane;
+        for (; i + 7 * 64 < cnt; i += 8 * 64) {  // eight loads in flight per round trip (one wavefront copies 77 KB at configs[4])
+          double t8[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) t8[q] = __builtin_nontemporal_load(src + i + 64 * q);
+#pragma unroll
+          for (int q = 0; q < 8; q++) dst[i + 64 * q] = t8[q];
+        }
+        for (; i < cnt; i += 64) dst[i] = src[i];
+      };
+      copy(xsb, cx2, nxs);
+      copy(usb, cu2, nus);
+      if (lane == 0) commit_idx[b] = -1;  // committed: nothing is left pending
     }
   }
 }

@@ -173,9 +173,12 @@ enum ilqr_route {
   ILQR_ROUTE_NO_COMPACTION = 16,    /* ilqr_generate_trajectory without re-packing running trajectories between chunks */
   ILQR_ROUTE_FULL_RECORDS = 32,     /* LQ model, exact derivatives: whole per-knot records instead of one shared copy of the constant blocks */
   ILQR_ROUTE_LQ_THREAD_ROLLOUT = 64,/* LQ model: thread-per-rollout k_rollout_g instead of the matrix-core k_rollout_lq */
-  ILQR_ROUTE_BACKWARD_LDS = 128,    /* generic path: round 1's LDS kernel k_backward_w instead of the register kernel k_backward_w2 */
+  ILQR_ROUTE_BACKWARD_LDS = 128,    /* generic path: round 1's LDS kernel k_backward_w instead of the register kernels */
   ILQR_ROUTE_QUAD_CHAIN = 256,      /* one tile per CU: the 4-lane DPP chain (k_solve_tile<..,1>) also where the matrix-core chains (k_solve_hex: m = 1, no opt-in fixes) would run */
-  ILQR_ROUTE_LQ_RECOMMIT = 512      /* LQ model: no candidate buffers (11 x the nominal trajectory); the accepted rollout is run again to commit it */
+  ILQR_ROUTE_LQ_RECOMMIT = 512,     /* LQ model: no candidate buffers (11 x the nominal trajectory); the accepted rollout is run again to commit it */
+  ILQR_ROUTE_BACKWARD_W2 = 1024     /* generic path: round 2's register kernel k_backward_w2 (literal Cholesky in every box-QP, per-knot cx / cu records)
+                                       instead of k_backward_w3 (matrix-core refinement of the previous knot's inverse; LQ model with exact
+                                       derivatives: no record array at all) */
 };
 
 const char* ilqr_last_error(void);

@@ -105,6 +105,13 @@ def main(d, tag):
         for key in ("k_solve_wide", "k_solve_tile<2>"):  # what the saturated batch runs: wide tiles (nu = 1), else two tiles per CU
             if key in fs or key in ws:
                 kernels[key] = solve_entry(d, "sat_", key, 32768, T, fs, ws)
+    # BASELINE configs[3] (fp32, limits +-5): the per-GPU shard and the stated size on one GPU, each with passes of its own
+    for prefix, key, Bk in (("f32_", "k_solve_hex_f32", 4096), ("f32sat_", "k_solve_wide_f32", 32768)):
+        if os.path.exists("%s/%spmc_FETCH_SIZE.txt" % (d, prefix)):
+            ff, wf = read("%s/%spmc_FETCH_SIZE.txt" % (d, prefix), "FETCH_SIZE"), read("%s/%spmc_WRITE_SIZE.txt" % (d, prefix), "WRITE_SIZE")
+            if key in ff or key in wf:
+                kernels[key] = solve_entry(d, prefix, key, Bk, T, ff, wf)
+                kernels[key]["workload"] = "acrobot T=499 B=%d fp32 limits +-5" % Bk
     json.dump({"source": "rocprofv3 passes of `bench.py --no-cpu-baseline --no-extra-configs --steps 5 --warmup 3` on MI355X, one counter "
                          "set per run with --kernel-trace only (scripts/collect_profiles.sh; summaries profiles/%s_*.txt): FETCH_SIZE x 2.000, WRITE_SIZE x 1.000 "
                          "as calibrated on 8-byte row loads / stores of known size (profiles/r04_fetch_calibration.txt), KB = 1024 B; k_sweep_backward / "

@@ -101,22 +101,27 @@ def test_solves_with_exact_derivatives_reach_the_same_optimum():
 
 @pytest.mark.parametrize("n,m", [(32, 16), (5, 2)])
 def test_lq_partial_records_equal_whole_records(n, m, monkeypatch):
-    """With exact derivatives the LQ sweep writes the knot-independent matrices once (const_rec) and per
-    knot only cx, cu; k_backward_w reads the shared copy.  ILQR_ROUTE_FULL_RECORDS writes and reads whole
-    records: same solve bit for bit, same records from the getter (which fills the matrices in on demand),
-    also after ilqr_set_derivatives replaced them."""
+    """With exact derivatives the LQ model's record is constant up to cx, cu.  Three routes:
+      * ILQR_ROUTE_BACKWARD_W2: the sweep writes the matrices once (const_rec) and per knot only cx, cu; k_backward_w2 reads the shared copy;
+      * ... | ILQR_ROUTE_FULL_RECORDS: whole per-knot records -- the same solve BIT FOR BIT, the same records from the getter (which fills
+        the matrices in on demand), also after ilqr_set_derivatives replaced them;
+      * the default (k_backward_w3, fused): no sweep and no record array; the backward pass forms cx = cxx x_t, cu = cuu u_t itself, in
+        another summation order: the same solve to rounding.  Its getter computes the records of the CURRENT nominal on demand (the other
+        two return what the last sweep left, one accepted step behind, as the reference's members are), so cx / cu are compared with
+        cxx x / cuu u of the returned trajectory instead."""
     from ilqr_amd import BatchILQR, capi
     from tests.test_gpu_lq_end_to_end import dense_mats
     B, T = 9, 17
     mats = dense_mats(n, m)
-    rng = np.random.default_rng(16)
-    x0 = rng.uniform(-1, 1, (B, n))
-    u0 = rng.normal(size=(B, T, m)) * 0.3
     out = []
-    for full in (False, True):
-        g = BatchILQR("lq", B, T, DT, u_min=-0.4, u_max=0.4, lq=mats, flags=capi.FLAG_ANALYTIC_DERIVATIVES,
-                      route=capi.ROUTE_FULL_RECORDS if full else 0)
+    for route in (capi.ROUTE_BACKWARD_W2, capi.ROUTE_BACKWARD_W2 | capi.ROUTE_FULL_RECORDS, 0):
+        rng = np.random.default_rng(16)
+        x0 = rng.uniform(-1, 1, (B, n))
+        u0 = rng.normal(size=(B, T, m)) * 0.3
+        g = BatchILQR("lq", B, T, DT, u_min=-0.4, u_max=0.4, lq=mats, flags=capi.FLAG_ANALYTIC_DERIVATIVES, route=route)
+        assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("backward")) == (b"k_backward_w3" if route == 0 else b"k_backward_w2")
         g.init_traj(x0, u0)
+        assert all(np.all(vv == 0) for vv in g.derivatives().values())  # what init_traj leaves (ilqr_core.cpp:39-45), on every route
         g.iterate(3)
         d = g.derivatives()
         xs, us = g.trajectory()
@@ -130,7 +135,15 @@ def test_lq_partial_records_equal_whole_records(n, m, monkeypatch):
         k2, K2 = g.gains()
         out.append(dict(xs=xs, us=us, k=k, K=K, cost=g.cost(), k2=k2, K2=K2, **{"d_" + kk: vv for kk, vv in d.items()}))
         g.close()
-        rng = np.random.default_rng(16); rng.uniform(-1, 1, (B, n)); rng.normal(size=(B, T, m))  # same perturbation next round
     for key in out[0]:
         assert np.array_equal(out[0][key], out[1][key], equal_nan=True), key
-    assert not np.array_equal(out[0]["K2"], out[0]["K"])
+    for o in out:
+        assert not np.array_equal(o["K2"], o["K"])
+    f = out[2]
+    for key in ("xs", "us", "k", "K", "cost"):
+        scale = max(1.0, np.abs(out[0][key]).max())
+        assert np.abs(out[0][key] - f[key]).max() <= 1e-9 * scale, (key, np.abs(out[0][key] - f[key]).max())
+    for key in ("d_fx", "d_fu", "d_cxx", "d_cxu", "d_cuu"):  # the constant blocks: the same on every route
+        assert np.array_equal(out[0][key], f[key]), key
+    assert np.allclose(f["d_cx"], np.einsum("btij,btj->bti", f["d_cxx"], f["xs"]), rtol=1e-12, atol=1e-13)
+    assert np.allclose(f["d_cu"][:, :T], np.einsum("btij,btj->bti", f["d_cuu"][:, :T], f["us"]), rtol=1e-12, atol=1e-13)

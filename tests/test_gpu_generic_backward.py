@@ -19,7 +19,7 @@ def lq_model(oracle, n, m, seed=7, lim=1.0):
     return oracle.Model("lq", lq=(A, Bm, Q, R, Q), u_lim=lim)
 
 
-def run_case(oracle, om, B, T, lam, x_scale=1.0, u_scale=0.5, cuu_shift=None):
+def run_case(oracle, om, B, T, lam, x_scale=1.0, u_scale=0.5, cuu_shift=None, route=0, max_unpinned=0):
     from ilqr_amd import BatchILQR
     n, m = om.nx, om.nu
     rng = np.random.default_rng(3)
@@ -31,7 +31,7 @@ def run_case(oracle, om, B, T, lam, x_scale=1.0, u_scale=0.5, cuu_shift=None):
         dv["cuu"] = dv["cuu"] + np.diag(cuu_shift)[None, None]
     k_prev = rng.normal(size=(B, T, m)) * 0.1
     ro = oracle.batch_backward(om, us, dv, k_prev=k_prev, lam=lam)
-    g = BatchILQR("host", B, T, DT, nx=n, nu=m, u_min=om.u_min, u_max=om.u_max)
+    g = BatchILQR("host", B, T, DT, nx=n, nu=m, u_min=om.u_min, u_max=om.u_max, route=route)
     g.set_trajectory(x0=x0, xs=xs, us=us, cost=cost)
     g.set_derivatives(**{k: (dv[k] if k in ("cx", "cu") else mat(dv[k])) for k in dv})
     g.set_gains(k=k_prev, K=np.zeros((B, T, m, n)))
@@ -45,7 +45,7 @@ def run_case(oracle, om, B, T, lam, x_scale=1.0, u_scale=0.5, cuu_shift=None):
     dV = g.dV()
     Ko = mat(ro["K"])
     lo, hi = om.u_min[None, None, :] - us, om.u_max[None, None, :] - us
-    r = check_backward(oracle, om, us, dv, k_prev, lam, k, K, dV, div, ro, max_ties=max(1, B // 8), max_over10=max(1, B // 50))  # gains: per knot
+    r = check_backward(oracle, om, us, dv, k_prev, lam, k, K, dV, div, ro, max_ties=max(1, B // 8), max_over10=max(1, B // 50), max_unpinned=max_unpinned)  # gains: per knot
     ok, ties = r["good"], r["ties"]
     clamped = (np.abs(k - lo) < 1e-9) | (np.abs(k - hi) < 1e-9)
     g.last = dict(div=div, ro=ro, ok=ok, ties=ties)
@@ -79,8 +79,9 @@ def test_host_path_equals_device_model_path(oracle):
         g.iterate(1)
 
 
+@pytest.mark.parametrize("kernel", ["w3", "w2"])
 @pytest.mark.parametrize("n,m,where", [(6, 2, "last"), (6, 2, "first"), (32, 16, "middle"), (32, 16, "first"), (12, 16, "two")])
-def test_non_positive_definite_quu(oracle, n, m, where):
+def test_non_positive_definite_quu(oracle, n, m, where, kernel):
     """Quu NOT positive definite, lambda = 0, through the wave-per-trajectory kernel's own Cholesky / box-QP
     (backward_wave.hpp).  Eigen's unblocked LLT (Cholesky/LLT.h:302-325) stops at the first non-positive
     pivot and leaves the rest of the lower triangle untouched, boxqp.cpp:85-88 never looks at info(), so the
@@ -90,10 +91,15 @@ def test_non_positive_definite_quu(oracle, n, m, where):
     shift = np.zeros(m)
     idx = {"first": [0], "last": [m - 1], "middle": [m // 2], "two": [3, m - 2]}[where]
     shift[idx] = -0.35  # cuu = R = 0.1 I: these diagonal entries become -0.25, fu' Vxx fu adds O(dt^2)
-    frac, g = run_case(oracle, om, B=8, T=10, lam=0.0, u_scale=0.2, cuu_shift=shift)
+    # k_backward_w2 evaluates every sum in the oracle's order.  k_backward_w3 (the default) hands an indefinite block's box-QP to the same
+    # literal code, but its matrix-vector products upstream are summed in another order: where fp64 does not pin the pass at all (the
+    # oracle itself > 100 % off the x87 answer) the two legitimately differ, and only the diverge flag is compared for up to two of eight
+    from ilqr_amd import capi
+    frac, g = run_case(oracle, om, B=8, T=10, lam=0.0, u_scale=0.2, cuu_shift=shift, route=capi.ROUTE_BACKWARD_W2 if kernel == "w2" else 0,
+                       max_unpinned=0 if kernel == "w2" else 2)
     ro, div = g.last["ro"], g.last["div"]
     assert np.array_equal(div, ro["diverge"])
-    assert g.last["ok"].sum() >= 6, g.last  # (ties allowed as everywhere; "ok" includes trajectories where fp64 itself
+    assert g.last["ok"].sum() >= (6 if kernel == "w2" else 5), g.last  # (ties allowed as everywhere; "ok" includes trajectories where fp64 itself
     # cannot pin the answer: a first pivot < 0 leaves R = Q untouched and the "solve" amplifies rounding by 1e15)
     g.close()
 
@@ -123,18 +129,25 @@ def test_register_kernel_equals_lds_kernel(oracle, n, m, lim, shift):
     k_prev = rng.normal(size=(B, T, m)) * 0.1
     outs = []
     from ilqr_amd import capi
-    for force_lds in (False, True):
-        try:
-            g = BatchILQR("host", B, T, DT, nx=n, nu=m, u_min=om.u_min, u_max=om.u_max, route=capi.ROUTE_BACKWARD_LDS if force_lds else 0)
-            g.set_trajectory(x0=x0, xs=xs, us=us, cost=cost)
-            g.set_derivatives(**{k: (dv[k] if k in ("cx", "cu") else mat(dv[k])) for k in dv})
-            g.set_gains(k=k_prev, K=np.zeros((B, T, m, n)))
-            g.set_lambda(1e-3 if shift is None else 0.0, 1.0)
-            div = g.backward_pass()
-            k, K = g.gains()
-            outs.append(dict(div=np.asarray(div), k=k, K=K, dV=g.dV(), gnorm=g.gnorm()))
-            g.close()
-        finally:
-            pass
+    for route in (capi.ROUTE_BACKWARD_W2, capi.ROUTE_BACKWARD_LDS, 0):
+        g = BatchILQR("host", B, T, DT, nx=n, nu=m, u_min=om.u_min, u_max=om.u_max, route=route)
+        assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("backward")) == {capi.ROUTE_BACKWARD_W2: b"k_backward_w2", capi.ROUTE_BACKWARD_LDS: b"k_backward_w", 0: b"k_backward_w3"}[route]
+        g.set_trajectory(x0=x0, xs=xs, us=us, cost=cost)
+        g.set_derivatives(**{k: (dv[k] if k in ("cx", "cu") else mat(dv[k])) for k in dv})
+        g.set_gains(k=k_prev, K=np.zeros((B, T, m, n)))
+        g.set_lambda(1e-3 if shift is None else 0.0, 1.0)
+        div = g.backward_pass()
+        k, K = g.gains()
+        outs.append(dict(div=np.asarray(div), k=k, K=K, dV=g.dV(), gnorm=g.gnorm()))
+        g.close()
     for key in outs[0]:
         assert np.array_equal(outs[0][key], outs[1][key], equal_nan=True), key
+    # k_backward_w3 (the default): the same step with the matrix-vector products as per-lane sums and, where the free set is the
+    # previous knot's, the box-QP's inverse refined on the matrix cores instead of factored -- equal to rounding on the well-conditioned
+    # cases; with an indefinite Quu every box-QP takes the literal path and only the sums' order differs, which the 1e15 amplification
+    # of a failed first pivot (test_non_positive_definite_quu) does not let through a tight bound: there the discrete outcome is compared
+    assert np.array_equal(outs[0]["div"], outs[2]["div"])
+    if shift is None:
+        for key in ("k", "K", "dV", "gnorm"):
+            scale = max(1.0, np.abs(outs[0][key]).max())
+            assert np.abs(outs[0][key] - outs[2][key]).max() <= 1e-9 * scale, (key, np.abs(outs[0][key] - outs[2][key]).max(), scale)

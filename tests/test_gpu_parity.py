@@ -266,6 +266,42 @@ def test_warm_start(oracle):
     assert np.all(c2 <= c_w * (1 + 1e-9))
 
 
+@pytest.mark.parametrize("model", ["integrator", "acrobot", "lq"])
+def test_warm_start_rollout_equals_the_oracles(oracle, model):
+    """The warm start's own rollout (ilqr_core.cpp:65-76: forward_pass(x0, us) with the stored gains, u = us[t] + K[t] (x - xs[t]))
+    against oracle.batch_rollout(xs_nom, K), knot for knot: a handle with max_iter = 0 stops right behind it."""
+    from ilqr_amd import BatchILQR
+    from tests.test_gpu_lq_end_to_end import dense_mats
+    B, T = 24, 90
+    rng = np.random.default_rng(77)
+    if model == "integrator":
+        kw, om, x0, m = dict(goal=[1, .5, 0, 0]), oracle.Model("integrator", goal=[1, .5, 0, 0]), integrator_x0(B), 2
+    elif model == "acrobot":
+        kw, om, x0, m = dict(u_min=-1.5, u_max=1.5), oracle.Model("acrobot", u_lim=1.5), acrobot_x0(B, scale=0.3, seed=4), 1
+    else:
+        mats = dense_mats(6, 3)
+        kw, om, x0, m = dict(lq=mats, u_min=-0.4, u_max=0.4), oracle.Model("lq", lq=mats, u_lim=0.4), rng.uniform(-1, 1, (B, 6)), 3
+    g = BatchILQR(model, B, T, DT, **kw)
+    g.init_traj(x0, np.zeros((B, T, m)))
+    g.iterate(4)  # a nominal trajectory with gains around it
+    xs1, us1 = g.trajectory()
+    k1, K1 = g.gains()
+    c1 = g.cost()
+    g.close()
+    g0 = BatchILQR(model, B, T, DT, params=dict(max_iter=0), **kw)
+    g0.set_trajectory(x0=x0, xs=xs1, us=us1, cost=c1)
+    g0.set_gains(k=k1, K=K1)
+    x0b = x0 + 0.02 * rng.standard_normal(x0.shape)
+    g0.generate_trajectory(x0b)
+    xs_w, us_w = g0.trajectory()
+    xs_o, us_o, c_o = oracle.batch_rollout(om, x0b, us1, DT, xs_nom=xs1, K=K1)
+    assert np.array_equal(xs_w[:, 0], x0b)
+    assert relerr(xs_w, xs_o) < TOL and relerr(us_w, us_o) < TOL
+    assert np.max(np.abs(g0.cost() - c_o) / np.abs(c_o)) < TOL
+    assert np.array_equal(g0.status()[1], np.zeros(B, dtype=np.int32))  # no iteration ran
+    g0.close()
+
+
 def test_full_size_properties(oracle):
     """BASELINE.json configs[2] (acrobot T=499, B=4096, clamps active): size-independent properties of the whole batch,
     and 64 of its trajectories walked against the oracle iteration by iteration (tests/parity.py: Sampled)."""

@@ -157,7 +157,8 @@ def test_generic_user_model_whose_cost_reads_its_own_limits(user6_lib, oracle):
     run = 0.5 * (np.einsum("bti,ij,btj->b", xs[:, :T], Q, xs[:, :T]) + np.einsum("bti,ij,btj->b", us, R, us)) + wb * ((us / umax) ** 2).sum(axis=(1, 2))
     fin = 0.5 * np.einsum("bi,ij,bj->b", xs[:, T], Qf, xs[:, T])
     assert np.allclose(c0, run + fin, rtol=1e-12)
-    om = oracle.Model("lq", lq=(A, Bm, Q, R + 2 * wb * np.diag(1 / umax ** 2), Qf), u_min=-umax, u_max=umax)
+    om = oracle.Model("lq", lq=(A, Bm, Q, R + 2 * wb * np.diag(1 / umax ** 2), Qf), u_lim=1.0)
+    om.set_limits(-umax, umax)
     r = walk_iterations(oracle, om, g, x0, u0, DT, 4, drive="gpu")
     assert r["checked"] >= 2 * B and len(r["tied"]) <= B // 8, r
     g.close()

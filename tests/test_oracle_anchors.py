@@ -55,7 +55,8 @@ def test_acrobot_canonical_solve(oracle):
     assert s.cost == pytest.approx(5.39788253688, rel=1e-9)
     assert s.lam == 0.0
     assert np.abs(s.us).max() == pytest.approx(2.22044, rel=1e-5)
-    assert np.allclose(log[:3], [2.87e3, 2.66e3, 1.96e3], rtol=2e-3)
+    assert np.allclose(log[:3], [2.87e3, 2.66e3, 1.96e3], rtol=2e-3)  # the per-iteration cost table of SURVEY 8c: its first three rows ...
+    assert log[-1] == pytest.approx(5.4, rel=1e-3) and np.all(np.diff(log) <= 0)  # ... its last, and what every row in between obeys
     assert s.s.contents.n_backward == 100
     assert s.s.contents.n_rollouts == 385  # 1 initial + 384 line-search rollouts (3.84/iter)
 
