@@ -230,7 +230,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU")
+    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU (weak scaling: the default)")
+    ap.add_argument("--global-batch", type=int, default=0, help="STRONG scaling: this many trajectories in total, each of the N ranks its contiguous "
+                    "1/N (e.g. 32768: BASELINE configs[3]'s partition at --dtype f32 --limit 5); overrides --batch")
     ap.add_argument("--T", type=int, default=499)
     ap.add_argument("--limit", type=float, default=1.5)
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64", help="arithmetic of the HEADLINE run (the other "
@@ -269,6 +271,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d: one rank per GPU" % (args.gpus, world))
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit("bench.py --global-batch %d is not a multiple of %d ranks" % (args.global_batch, world))
+        args.batch = args.global_batch // world
     if local_rank >= torch.cuda.device_count():
         raise SystemExit("rank %d: no HIP device %d (%d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
@@ -537,6 +543,57 @@ def main():
             elif not args.no_cpu_baseline:
                 extra["lq_n32_m16_T200_B8192_" + label]["cpu_baseline"] = cpu_baseline_lq_exact(Tq, dt)
 
+    if not args.no_extra_configs and world == 1:
+        # a user's own device twin with dimensions of its own (examples/user_model_linear6.hpp: n = 6, m = 2, compiled in from outside the
+        # library): the generic kernels on something other than 32 / 16 -- thread-per-rollout forward passes, a finite-difference sweep that
+        # evaluates every perturbed point through the model's dynamics() / cost(), k_backward_w3<1> (one 16 x 16 tile per matrix)
+        from ilqr_amd import _build
+        if os.path.exists(_build.USER_EXAMPLE6_LIB):
+            nu6, mu6, Tu, Bu, itu = 6, 2, 200, 4096, 5
+            ru = np.random.default_rng(11)
+            A6 = -np.eye(nu6) + 0.3 * ru.normal(size=(nu6, nu6)) / np.sqrt(nu6)
+            B6 = ru.normal(size=(nu6, mu6)) / np.sqrt(nu6)
+            mats6 = (A6, B6, np.eye(nu6), 0.1 * np.eye(mu6), np.eye(nu6))
+            gu = BatchILQR("user", Bu, Tu, dt, u_min=-0.5, u_max=0.5, lib=_build.USER_EXAMPLE6_LIB, nx=nu6, nu=mu6, device=local_rank, stream=stream,
+                           user_params=np.concatenate([np.ascontiguousarray(a).ravel() for a in mats6]), flags=capi.FLAG_FIXED_WORK, params=dict(max_iter=itu + 2))
+            gu.init_traj(ru.uniform(-1, 1, (Bu, nu6)), np.zeros((Bu, Tu, mu6)))
+            gu.iterate(1)
+            gu.profile(True)
+            gu.profile_reset()
+            barrier()
+            t0 = time.perf_counter()
+            gu.iterate(itu)
+            barrier()
+            elu = time.perf_counter() - t0
+            pu_ = gu.profile_read()
+            assert gu.count_running() == Bu
+            namu = {i: gu.lib.ilqr_stage_kernel_name(gu.h, i).decode() for i in range(capi.NUM_STAGES)}
+            stu = {k: {"kernel": namu[capi.STAGE_NAMES.index(k)], "ms_per_launch": ms / ln, "launches": ln} for k, (ms, ln) in pu_.items() if ln}
+            gu.close()
+            flop6 = 4 * nu6 ** 3 + 10 * nu6 * nu6 * mu6 + 6 * nu6 * mu6 * mu6 + mu6 ** 3
+            bwu = stu["backward"]["ms_per_launch"] * 1e-3
+            extra["user_linear6_n6_m2_T200_B4096_fd"] = {
+                "workload": "a user's device twin (examples/user_model_linear6.hpp, n=6 m=2, ILQR_MODEL_USER) T=200 B=4096, u in [-0.5,0.5], fp64, "
+                            "finite differences point by point through the model's own functions, fixed-work iterations",
+                "value": Bu * Tu * itu / elu, "unit": "trajectory-timesteps/s", "ms_per_step": elu / itu * 1e3, "stages": stu,
+                "roofline": {"bound": "fp64 flops", "kernel": stu["backward"]["kernel"], "achieved": flop6 * Bu * Tu / bwu / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": flop6 * Bu * Tu / bwu / 1e12 / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_timestep": flop6,
+                             "avg_launch_ms": bwu * 1e3,
+                             "note": "one wavefront per trajectory and every matrix padded to a 16 x 16 tile: (6/16)^2 of each matrix instruction is this model's"}}
+            if not args.no_cpu_baseline:
+                from oracle import oracle as O
+                cores = os.cpu_count() or 1
+                om6 = O.Model("lq", lq=mats6, u_lim=0.5)
+                nb6 = min(Bu, 8 * cores)
+                x6 = np.random.default_rng(11).uniform(-1, 1, (nb6, nu6))
+                t0 = time.perf_counter()
+                O.batch_solve(om6, x6, np.zeros((nb6, Tu, mu6)), dt, max_iters=4, fixed_work=True, nthreads=cores)
+                t6 = time.perf_counter() - t0
+                extra["user_linear6_n6_m2_T200_B4096_fd"]["cpu_baseline"] = {
+                    "value": nb6 * Tu * 4 / t6, "unit": "trajectory-timesteps/s", "cores": cores, "kind": "port",
+                    "sample": "%d trajectories x 4 fixed-work iterations of the same model as the oracle's LQ model, %.1f s wall, oracle/liboracle_ilqr.so with OpenMP over "
+                              "trajectories on all host threads" % (nb6, t6)}
+
     if rank == 0:
         costs = gathered.cpu().numpy()
         assert np.all(np.isfinite(costs)), "non-finite cost in the gathered result"
@@ -549,12 +606,12 @@ def main():
             "metric": "iLQR iterations/sec (batch x T timesteps/sec), acrobot T=500 batch=4096",
             "value": value, "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": steps,
             "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "acrobot n=4 m=1 T=499 transitions (500 knots) B=%d per GPU, u in [-%.1f,%.1f] "
                                    "(box-QP clamps active), %s, full iteration = FD derivatives + backward/box-QP "
                                    "+ 11-alpha rollouts + accept, fixed work" % (B, lim, lim, args.dtype),
-                       "batch_per_gpu": B, "T": T, "parallelism": "batch-sharded x%d, no data-path collective; "
-                       "one all_gather of per-trajectory costs at the end" % world},
+                       "batch_per_gpu": B, "global_batch": world * B, "T": T, "parallelism": "batch-sharded x%d (%s), no data-path collective; "
+                       "one all_gather of per-trajectory costs at the end" % (world, "a fixed global batch split over the ranks" if args.global_batch else "a fixed batch per rank")},
             "roofline": roof,
             "roofline_issue": roof_issue,
             # how many ranks ran and what carried their one collective (the driver's scaling run reads this)

@@ -3,6 +3,7 @@
 // x0.bin: B x 4 doubles.  Shard i runs on the i-th listed device (default: device i % #devices-visible... all on device 0 when
 // only one is visible: N logical shards on one GPU give the bits N GPUs give).  out.bin: B costs (gathered: RCCL all-gather
 // between distinct devices, copies otherwise), then B x T controls.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -43,6 +44,15 @@ int main(int argc, char* argv[]) {
     solver.iterate(iters);
     const std::vector<double> cost = solver.cost();  // the one exchange of the path
     const std::vector<double> us = solver.controls();
+    {  // self-check: shards on N distinct devices must have gathered over N RCCL ranks -- anything else is a silent fallback
+      std::vector<int> d(devices);
+      std::sort(d.begin(), d.end());
+      const int n_distinct = (int)(std::unique(d.begin(), d.end()) - d.begin());
+      if (n_distinct == ns && ns > 1 && solver.rccl_ranks() != ns) {
+        std::cerr << "multi_gpu: " << ns << " shards on " << ns << " devices, but the gather ran over " << solver.rccl_ranks() << " RCCL rank(s)" << std::endl;
+        return 3;
+      }
+    }
     std::printf("multi_gpu: %d shards, gather over %s (%d ranks), mean cost %.12g\n", solver.shards(),
                 solver.rccl_ranks() ? "RCCL" : "copies", solver.rccl_ranks(), [&] {
                   double s = 0;

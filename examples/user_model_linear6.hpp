@@ -54,4 +54,42 @@ struct UserModelT {
     return c;
   }
   __device__ real final_cost(const real* x) const { return real(0.5) * quad<NX>(Qf, x); }
+  // optional: exact derivatives (ILQR_FLAG_ANALYTIC_DERIVATIVES).  One thread writes the whole record: fx | fu | cx | cxx | cxu | cu | cuu,
+  // matrices column-major, with the conventions of src/derivatives.cpp at the last knot (fx = fu = 0, cx / cxx from final_cost, cu = 0,
+  // cuu from cost(x_T, 0), cxu = 0).
+  __device__ void analytic_record(const real* x, const real* u, real dt, bool last, real* rec) const {
+    real* fx = rec;
+    real* fu = fx + NX * NX;
+    real* cx = fu + NX * NU;
+    real* cxx = cx + NX;
+    real* cxu = cxx + NX * NX;
+    real* cu = cxu + NX * NU;
+    real* cuu = cu + NU;
+    const real(*W)[NX] = last ? Qf : Q;
+    for (int c = 0; c < NX; c++)
+      for (int r = 0; r < NX; r++) {
+        fx[r + NX * c] = last ? real(0) : real(r == c) + dt * A[r][c];
+        cxx[r + NX * c] = real(0.5) * (W[r][c] + W[c][r]);
+      }
+    for (int c = 0; c < NU; c++)
+      for (int r = 0; r < NX; r++) {
+        fu[r + NX * c] = last ? real(0) : dt * B[r][c];
+        cxu[r + NX * c] = real(0);
+      }
+    for (int i = 0; i < NX; i++) {
+      real acc = 0;
+      for (int j = 0; j < NX; j++) acc += real(0.5) * (W[i][j] + W[j][i]) * x[j];
+      cx[i] = acc;
+    }
+    for (int c = 0; c < NU; c++)
+      for (int r = 0; r < NU; r++) cuu[r + NU * c] = real(0.5) * (R[r][c] + R[c][r]) + ((r == c && wb != real(0)) ? real(2) * wb / (u_max[r] * u_max[r]) : real(0));
+    for (int i = 0; i < NU; i++) {
+      real acc = 0;
+      if (!last) {
+        for (int j = 0; j < NU; j++) acc += real(0.5) * (R[i][j] + R[j][i]) * u[j];
+        if (wb != real(0)) acc += real(2) * wb * u[i] / (u_max[i] * u_max[i]);
+      }
+      cu[i] = acc;
+    }
+  }
 };

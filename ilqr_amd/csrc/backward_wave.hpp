@@ -232,7 +232,7 @@ __device__ __forceinline__ double w_quad_cost(int m, const double* Q, const doub
 // src/boxqp.cpp:26-139 for one trajectory per wavefront.  Inputs in LDS: QuuF (Q), Qu (c), kprev
 // (x0), lo, hi.  Outputs: L.x (solution), L.vfree, L.Minv (R^-1 R^-T of the last factor, ld LDM), nfR.
 template <class LDS>
-__device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out ILQR_W2CLOCK_ARG, int* nfact_out = nullptr) {
+__device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out ILQR_W2CLOCK_ARG, int* nfact_out = nullptr, int fixes = 0) {
   ILQR_QCOUNT(0)
   const double* Q = L.QuuF();
   const double* c = L.Qu;
@@ -346,6 +346,10 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out ILQR_W2CLOCK_ARG, 
       }
       nfR = nf;
       nfact_last = n_fact;
+      if ((fixes & 2) && n_fact < nf) {  // opt-in (ILQR_FLAG_REFERENCE_FIXES): not positive definite on the free subspace ends the QP (boxqp.cpp:85-88 ignores info())
+        result = -1;
+        break;
+      }
       ILQR_QMARK(1)
       // :86-88 R = L' (upper); Ri = R^-1 (upper triangular, column j on lane j), Minv = Ri Ri'
       // (:105-112).  The reference inverts R in every iteration; R only changes here, so the product
@@ -763,7 +767,7 @@ __global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, co
       lds_sync();
       ILQR_WMARK(2)
       int nfR = 0;
-      const int result = w_box_qp(m, L, lane, nfR ILQR_W2CLOCK_PASS);
+      const int result = w_box_qp(m, L, lane, nfR ILQR_W2CLOCK_PASS, nullptr, sp.fixes);
       ILQR_WMARK(3)
       if (result < 1) {  // :371
         diverge = i;

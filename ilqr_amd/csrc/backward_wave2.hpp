@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w2(BatchView v
       lds_sync();
       ILQR_W2MARK(2)
       int nfR = 0;
-      const int result = w_box_qp(m, L, lane, nfR ILQR_W2CLOCK_PASS);
+      const int result = w_box_qp(m, L, lane, nfR ILQR_W2CLOCK_PASS, nullptr, sp.fixes);
       ILQR_W2MARK(3)
       if (result < 1) {  // :371
         diverge = i;

@@ -36,6 +36,7 @@ namespace ilqr {
 constexpr int kQpBail = -100;        // the fast box-QP hands the QP to the literal path
 constexpr double kNsStart = 0.03;    // max |I - M X| entry a warm start may have: ||I - M X||_2 <= 16 x that < 1/2
 constexpr double kNsDone = 1e-9;     // ... below which one more update leaves a residual of ~(16 x 1e-9)^2
+constexpr double kNsExact = 4e-15;   // ... and below which the update would change nothing (|I - M X| at rounding level)
 constexpr int kNsMaxIter = 6;
 
 #ifdef ILQR_W2_TIMING
@@ -90,6 +91,10 @@ __device__ __forceinline__ bool ns_refine(LDS& L, const double* Q, double* Xw, u
     for (int ks = 0; ks < 4; ks++) R = __builtin_amdgcn_mfma_f64_16x16x4f64(negM[ks], X[ks], R, 0, 0, 0);  // I - M X
     const double rho = wave_max(fmax(fmax(fabs(R[0]), fabs(R[1])), fmax(fabs(R[2]), fabs(R[3]))));
     if (!(rho < kNsStart)) break;  // not a contraction (or NaN): the literal factorisation
+    if (rho < kNsExact) {          // X is M's inverse to rounding already (a recursion that has reached its fixed point)
+      done = true;
+      break;
+    }
     double4_t Xn = {X[0], X[1], X[2], X[3]};
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(X[ks], R[ks], Xn, 0, 0, 0);  // X + X R
@@ -480,12 +485,12 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w3(BatchView v
 #pragma unroll
         for (int ks = 0; ks < 4 * NT; ks++) {
 #pragma unroll
-          for (int ti = 0; ti < NT; ti++) qxx[ti] = mfma(a1t[ks >> 2][ti][ks & 3], fx[ks >> 2][tj][ks & 3], qxx[ti]);
+          for (int ti = tj; ti < NT; ti++) qxx[ti] = mfma(a1t[ks >> 2][ti][ks & 3], fx[ks >> 2][tj][ks & 3], qxx[ti]);  // (tiles on and below the diagonal: see Vn)
           qux = mfma(a2t[ks >> 2][ks & 3], fx[ks >> 2][tj][ks & 3], qux);
           if (tj == 0) quu = mfma(a2t[ks >> 2][ks & 3], fu[ks >> 2][ks & 3], quu);
         }
 #pragma unroll
-        for (int ti = 0; ti < NT; ti++)
+        for (int ti = tj; ti < NT; ti++)
 #pragma unroll
           for (int rr = 0; rr < 4; rr++) {
             const double val = cxx[ti][rr] + qxx[ti][rr];
@@ -533,7 +538,7 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w3(BatchView v
         slow = true;
         ns.valid = false;
         ILQR_W3COUNT(1, 1)
-        result = w_box_qp(m, L, lane, nfR ILQR_W2CLOCK_PASS, &nfact);
+        result = w_box_qp(m, L, lane, nfR ILQR_W2CLOCK_PASS, &nfact, sp.fixes);
         free_mask = (unsigned)__ballot(lane < m && L.vfree[lane]);
       } else {
         ILQR_W3COUNT(0, 1)
@@ -677,11 +682,14 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w3(BatchView v
       }
       lds_sync();  // (Quu, x, Qu have been read: S may take Vn)
       ILQR_W2MARK(5)
-      // :392 Vn = ((Qxx + T1 K) + K'Qux) + Qux'K ; :393 Vxx = (Vn + Vn')/2 through S
+      // :392 Vn = ((Qxx + T1 K) + K'Qux) + Qux'K ; :393 Vxx = (Vn + Vn')/2 through S.  Vn is symmetric up to rounding (Qxx = cxx + fx'Vxx fx,
+      // K'Quu K, and K'Qux + Qux'K as a pair), so only its 16 x 16 tiles on and below the diagonal are formed: the tile above the
+      // diagonal of the new Vxx is the transpose of the one below it (read back transposed from S), where the reference averages two
+      // roundings of the same number -- 20 of a step's 188 MFMAs at n = 32.
 #pragma unroll
       for (int ti = 0; ti < NT; ti++)
 #pragma unroll
-        for (int tj = 0; tj < NT; tj++) {
+        for (int tj = 0; tj <= ti; tj++) {
           double4_t p1 = zero4, p2 = zero4, p3 = zero4;
 #pragma unroll
           for (int ks = 0; ks < WM / 4; ks++) {
@@ -702,8 +710,11 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w3(BatchView v
 #pragma unroll
         for (int tj = 0; tj < NT; tj++)
 #pragma unroll
-          for (int rr = 0; rr < 4; rr++)
-            Vxx[ti][tj][rr] = 0.5 * (Vxx[ti][tj][rr] + L.S[(16 * tj + p) + LDX * (16 * ti + 4 * rr + g)]);
+          for (int rr = 0; rr < 4; rr++) {
+            const double tr = L.S[(16 * tj + p) + LDX * (16 * ti + 4 * rr + g)];  // Vn(column, row)
+            if (ti == tj) Vxx[ti][tj][rr] = 0.5 * (Vxx[ti][tj][rr] + tr);
+            else if (ti < tj) Vxx[ti][tj][rr] = tr;   // (ti > tj: Vn itself)
+          }
       // :396-397
       if (lane < m) {
         kb[(size_t)i * m + lane] = L.x[lane];

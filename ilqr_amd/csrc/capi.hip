@@ -470,12 +470,12 @@ static int launch_rollout_g(ilqr_batch* h, const M& m, int what, const AlphaSet&
   }
   if (what == RG_SEARCH)
     hipLaunchKernelGGL((k_rollout_g<M, RG_SEARCH>), dim3((h->B + kSearchTraj - 1) / kSearchTraj), dim3(64), 0, h->stream, h->v, m, al,
-                       cost_out, nullptr, mode, 0);
+                       cost_out, nullptr, mode, 0, h->sp.fixes);
   else if (what == RG_INIT)
-    hipLaunchKernelGGL((k_rollout_g<M, RG_INIT>), dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->v, m, al, cost_out, nullptr, 0, 1);
+    hipLaunchKernelGGL((k_rollout_g<M, RG_INIT>), dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->v, m, al, cost_out, nullptr, 0, 1, h->sp.fixes);
   else
     hipLaunchKernelGGL((k_rollout_g<M, RG_COMMIT>), dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->v, m, al, cost_out,
-                       h->commit_idx, 0, write_cost);
+                       h->commit_idx, 0, write_cost, h->sp.fixes);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -899,7 +899,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     using UM = UserModelT<double>;
     REQUIRE(d->nx == UM::NX && d->nu == UM::NU, "this build's user model is nx=%d nu=%d, got %d/%d", UM::NX, UM::NU, d->nx, d->nu);
     REQUIRE(d->u_min && d->u_max, "ILQR_MODEL_USER needs u_min/u_max (Model::u_min/u_max, include/model.h:17)");
-    REQUIRE(!(d->flags & ILQR_FLAG_ANALYTIC_DERIVATIVES) || (kUserTiled && has_analytic_record<UM>::value), "this user model has no analytic_record()");
+    REQUIRE(!(d->flags & ILQR_FLAG_ANALYTIC_DERIVATIVES) || has_analytic_record<UM>::value, "this user model has no analytic_record()");
     if (!kUserTiled) {  // not a tiled nx = 4 shape: the generic kernels (fp64), trajectory-contiguous layout like the LQ model's
       REQUIRE(d->dtype == ILQR_DTYPE_F64, "the generic nx <= 32 path is fp64");
       h->aos = true;
@@ -1003,6 +1003,8 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
         h->lq.Q = pad + nA + nB;
         h->lq.R = pad + 2 * nA + nB;
         h->lq.Qf = pad + 2 * nA + nB + nR;
+        h->lq.umin = h->d_umin;
+        h->lq.umax = h->d_umax;
       }
     }
     if (!rc) {
@@ -1049,7 +1051,10 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   h->sp.z_min = h->params.z_min;
   h->sp.fixed_work = (h->flags & ILQR_FLAG_FIXED_WORK) ? 1 : 0;
   h->sp.fixes = ((h->flags & ILQR_FLAG_REFERENCE_FIXES) ? 3 : 0) | ((h->flags & ILQR_FLAG_REGULARIZE_VXX) ? 4 : 0);
-  if (h->sp.fixes && h->aos) return fail(ILQR_ERR_UNSUPPORTED, "ILQR_FLAG_REFERENCE_FIXES / ILQR_FLAG_REGULARIZE_VXX are implemented for the nx = 4 device models");
+  // generic handles: ILQR_FLAG_REFERENCE_FIXES on the models with a device twin (their rollouts clamp, their box-QP reports a failed factorisation); the
+  // host-evaluated route's rollouts belong to the caller, and lambda on Vxx would be two more products per step of the matrix-core kernels
+  if ((h->sp.fixes & 4) && h->aos) return fail(ILQR_ERR_UNSUPPORTED, "ILQR_FLAG_REGULARIZE_VXX is implemented for the nx = 4 device models");
+  if (h->sp.fixes && h->model == ILQR_MODEL_HOST) return fail(ILQR_ERR_UNSUPPORTED, "ILQR_FLAG_REFERENCE_FIXES on a host-evaluated model: its rollouts are the caller's (clamp there); the flag is implemented for the models with a device twin");
 
   hipLaunchKernelGGL(k_reset_state<double>, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
                      h->params.dlambda_init);
@@ -1157,10 +1162,10 @@ int ilqr_iterate(ilqr_batch* h, int n_iters) {
     if (!h->aos) {  // STEP 3 + STEP 3/4 in one launch: the rollout block of a tile also accepts for it
       if (int rc = launch_rollout(h, true, true, line_search_alphas(), NALPHA, h->v.cost_c, 1, true)) return rc;
       h->commit_pending = true;
-    } else if (lq_search_accepts(h)) {  // STEP 3 + STEP 3/4 + the commit in one launch (k_rollout_lq<RG_SEARCH, true>)
+    } else if (lq_search_accepts(h)) {  // STEP 3 + STEP 3/4 in one launch (k_rollout_lq<RG_SEARCH, true>); the commit is a copy (k_commit_lq)
       if (int rc = launch_rollout(h, true, true, line_search_alphas(), NALPHA, h->v.cost_c, 1, true)) return rc;
       h->cands_valid = true;
-      h->commit_pending = false;
+      h->commit_pending = true;
     } else {
       if (int rc = do_rollout_candidates(h, 1)) return rc;              // STEP 3
       if (int rc = launch_accept(h)) return rc;                         // STEP 3/4
@@ -1584,7 +1589,15 @@ int ilqr_copy_cost_to_device(ilqr_batch* h, void* dst) {
 // ---- shard groups (include/ilqr_amd.h) -------------------------------------------------------
 }  // extern "C"
 #include <dlfcn.h>
+// RCCL is loaded at run time (dlopen below) and only when a group spans devices, so its header must not be a build dependency:
+// the real declarations where the header exists, otherwise the six entry points and three types this file uses (nccl.h's ABI)
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclDouble = 8 } ncclDataType_t;  // ncclFloat64
+#endif
 namespace {
 struct RcclApi {  // librccl.so, loaded on first use: a single-GPU user of the library never maps it
   void* lib = nullptr;
@@ -1692,9 +1705,15 @@ int ilqr_group_gather_costs(ilqr_group* g, double* cost_out) {
   for (int i = 0; i < n; i++)
     if (int rc = ilqr_copy_cost_to_device(g->shards[i], g->send[i])) return rc;
   NCCLCHK(g_rccl.GroupStart());
-  for (int i = 0; i < n; i++) {
-    HIPCHK(hipSetDevice(g->shards[i]->device));
-    NCCLCHK(g_rccl.AllGather(g->send[i], g->recv[i], (size_t)g->per, ncclDouble, g->comms[i], g->shards[i]->stream));  // (stream order: after the copy)
+  for (int i = 0; i < n; i++) {  // (a failure inside the group closes it before returning: the calling thread must not be left inside an open NCCL group)
+    const hipError_t he = hipSetDevice(g->shards[i]->device);
+    const ncclResult_t nr = (he == hipSuccess) ? g_rccl.AllGather(g->send[i], g->recv[i], (size_t)g->per, ncclDouble, g->comms[i], g->shards[i]->stream)  // (stream order: after the copy)
+                                               : ncclSuccess;
+    if (he != hipSuccess || nr != ncclSuccess) {
+      (void)g_rccl.GroupEnd();
+      return he != hipSuccess ? fail(ILQR_ERR_HIP, "hipSetDevice(%d) inside the gather: %s", g->shards[i]->device, hipGetErrorString(he))
+                              : fail(ILQR_ERR_HIP, "ncclAllGather of shard %d: %s", i, g_rccl.GetErrorString(nr));
+    }
   }
   NCCLCHK(g_rccl.GroupEnd());
   std::vector<double> all((size_t)n * g->per);
@@ -1775,7 +1794,7 @@ int ilqr_profile_shader_clock(ilqr_batch* h, double* mhz_out) {
 }
 const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
   switch (stage) {
-    case ILQR_STAGE_DERIVATIVES: return (h && h->aos) ? (h->lq_fused ? "" : (h->v.analytic) ? "k_analytic_lq" : "k_derivatives_g") : "k_derivatives";
+    case ILQR_STAGE_DERIVATIVES: return (h && h->aos) ? (h->lq_fused ? "" : (h->v.analytic && h->model == ILQR_MODEL_LQ) ? "k_analytic_lq" : "k_derivatives_g") : "k_derivatives";
     case ILQR_STAGE_BACKWARD:
       if (h && h->aos) return h->env.backward_w1 ? "k_backward_w" : h->env.backward_w2 ? "k_backward_w2" : "k_backward_w3";
       if (h && use_fused_sweep(h)) return "k_sweep_backward";  // what ilqr_iterate launches

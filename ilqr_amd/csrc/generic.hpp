@@ -36,6 +36,9 @@ struct LqModel {
   static constexpr int NX = GN, NU = GM;
   int nx, nu;
   const double *A, *Bm, *Q, *R, *Qf;  // device: [GN][GN], [GN][GM], [GN][GN], [GM][GM], [GN][GN]
+  const double *umin = nullptr, *umax = nullptr;  // device [nu]: Model::u_min / u_max (only the opt-in clamped rollout reads them)
+  __device__ __forceinline__ double limit_lo(int j) const { return umin[j]; }
+  __device__ __forceinline__ double limit_hi(int j) const { return umax[j]; }
 
   __device__ __forceinline__ void dynamics(const double* x, const double* u, double* dx) const {
     cmem_d* a = (cmem_d*)A;
@@ -235,6 +238,8 @@ struct LqModel {
 template <class U>
 struct GenericModelOf : U {
   int nx = U::NX, nu = U::NU;
+  __device__ __forceinline__ double limit_lo(int j) const { return this->u_min[j]; }
+  __device__ __forceinline__ double limit_hi(int j) const { return this->u_max[j]; }
   static constexpr bool kSeparableCost = false, kQuadraticCostX = false, kLinearDynamics = false, kHasAnalyticRecord = false;
   __device__ __forceinline__ void cost2(const double* xa, const double* ua, const double* xb, const double* ub, double& fa, double& fb) const {
     fa = this->cost(xa, ua);
@@ -247,7 +252,7 @@ constexpr int kSearchTraj = 64 / NALPHA;  // trajectories per wavefront in RG_SE
 
 template <class M, int MODE>
 __global__ __launch_bounds__(64) void k_rollout_g(BatchView v, M model, AlphaSet alphas, double* __restrict__ cost_out,
-                                                  const int* __restrict__ commit_idx, int mode, int write_cost) {
+                                                  const int* __restrict__ commit_idx, int mode, int write_cost, int fixes) {
   constexpr int NX = M::NX, NU = M::NU;
   const int nx = model.nx, nu = model.nu, T = v.T;
   const int lane = threadIdx.x;
@@ -300,6 +305,11 @@ __global__ __launch_bounds__(64) void k_rollout_g(BatchView v, M model, AlphaSet
           u[j] += acc;  // :316
         }
       }
+    }
+    if (fixes & 1) {  // opt-in (ILQR_FLAG_REFERENCE_FIXES): "the right way" of ilqr_core.cpp:327-329 -- the clamped control is stored and integrated
+#pragma unroll
+      for (int j = 0; j < NU; j++)
+        if (j < nu) u[j] = fmin(fmax(u[j], model.limit_lo(j)), model.limit_hi(j));
     }
     if (MODE != RG_SEARCH) {  // :323 (no clamping)
 #pragma unroll
@@ -502,8 +512,8 @@ __global__ __launch_bounds__(64) void k_analytic_lq(BatchView v, LqModel model, 
 // states and controls on the way, so that the commit of the accepted one is a copy (k_commit_lq) instead of a twelfth
 // rollout as long as the eleven (the 3.5 KB per step and trajectory leave under the MFMA chains).
 // ACCEPT (RG_SEARCH with candidate buffers only): the wavefront also performs STEP 3/4 for its trajectory (accept_one: selection,
-// lambda schedule, termination -- k_accept's work) and copies the accepted candidate over the nominal trajectory (k_commit_lq's):
-// an iteration of the LQ path is then two launches (backward pass, search) instead of four.  commit_idx is written, not read.
+// lambda schedule, termination -- k_accept's work); the copy of the accepted candidate stays k_commit_lq's.  An iteration of the LQ
+// path with exact derivatives is then three launches (backward pass, search + accept, commit) instead of five.  commit_idx is written, not read.
 template <int MODE, bool ACCEPT = false>
 __global__ __launch_bounds__(64) void k_rollout_lq(BatchView v, LqModel model, AlphaSet alphas, double* __restrict__ cost_out,
                                                    int* __restrict__ commit_idx, int mode, int write_cost, SolverParams sp) {
@@ -550,6 +560,13 @@ __global__ __launch_bounds__(64) void k_rollout_lq(BatchView v, LqModel model, A
   double* usb = v.us + (size_t)b * T * nu;
   const double* kb = v.kff + (size_t)b * T * nu;
   const double* Kb = v.Kfb + (size_t)b * T * nu * nx;
+  const bool clamp_u = (sp.fixes & 1) != 0;  // opt-in (ILQR_FLAG_REFERENCE_FIXES): the clamped control is stored and integrated, ilqr_core.cpp:327-329
+  double ulo[4], uhi[4];                     // limits of this lane's control rows g + 4 r
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    ulo[r] = (clamp_u && g + 4 * r < nu) ? model.umin[g + 4 * r] : 0.0;
+    uhi[r] = (clamp_u && g + 4 * r < nu) ? model.umax[g + 4 * r] : 0.0;
+  }
 
   // this lane's share of knot t: xs rows 4ks+g, K(p, 4ks+g), us / k rows g+4r
   struct Knot {
@@ -617,6 +634,10 @@ __global__ __launch_bounds__(64) void k_rollout_lq(BatchView v, LqModel model, A
         }
 #pragma unroll
       for (int r = 0; r < 4; r++) u[r] = kn.us[r];
+    }
+    if (clamp_u) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) u[r] = fmin(fmax(u[r], ulo[r]), uhi[r]);
     }
     if (MODE != RG_SEARCH && p == 0) {  // :323 (no clamping)
 #pragma unroll
@@ -691,36 +712,12 @@ __global__ __launch_bounds__(64) void k_rollout_lq(BatchView v, LqModel model, A
   }
   if constexpr (ACCEPT) {
     __shared__ double cst[NALPHA];
-    __shared__ int chosen;
     if (g == (p & 3) && p < NALPHA) cst[p] = mine;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // the candidates' stores are complete and this CU's L1 holds nothing older when they are read back
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // (one wavefront: orders its LDS accesses)
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-      accept_one(v, sp, b, [&](int a2) { return cst[a2]; }, commit_idx);
-      chosen = commit_idx[b];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    const int a2 = chosen;
-    if (a2 >= 0) {  // ilqr_core.cpp:210-213: the bits of the rollout that was scored
-      const size_t nxs = (size_t)(T + 1) * nx, nus = (size_t)T * nu;
-      const double* __restrict__ cx2 = v.cand_x + ((size_t)b * NALPHA + a2) * nxs;
-      const double* __restrict__ cu2 = v.cand_u + ((size_t)b * NALPHA + a2) * nus;
-      auto copy = [&](double* __restrict__ dst, const double* __restrict__ src, size_t cnt) __attribute__((always_inline)) {
-        size_t i = lane;
-        for (; i + 7 * 64 < cnt; i += 8 * 64) {  // eight loads in flight per round trip (one wavefront copies 77 KB at configs[4])
-          double t8[8];
-#pragma unroll
-          for (int q = 0; q < 8; q++) t8[q] = __builtin_nontemporal_load(src + i + 64 * q);
-#pragma unroll
-          for (int q = 0; q < 8; q++) dst[i + 64 * q] = t8[q];
-        }
-        for (; i < cnt; i += 64) dst[i] = src[i];
-      };
-      copy(xsb, cx2, nxs);
-      copy(usb, cu2, nus);
-      if (lane == 0) commit_idx[b] = -1;  // committed: nothing is left pending
-    }
+    if (lane == 0) accept_one(v, sp, b, [&](int a2) { return cst[a2]; }, commit_idx);
+    // (the copy of the accepted candidate over the nominal trajectory stays a launch of its own, k_commit_lq, where every CU streams:
+    //  one wavefront per trajectory copying its 77 KB here was measured 0.25 ms per iteration slower)
   }
 }
 
@@ -785,6 +782,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   if constexpr (M::kHasAnalyticRecord) {
     if (v.analytic) {  // opt-in: the model's exact derivatives (reads the knot from memory: runtime indices)
       model.analytic_record(v.xs + ((size_t)b * (T + 1) + t) * nx, last ? nullptr : v.us + ((size_t)b * T + t) * nu, v.dt, last, D, lane);
+      return;
+    }
+  } else if constexpr (has_analytic_record<M>::value) {
+    // a user twin's own analytic_record (the contract of models.hpp: one thread writes the whole record, Rec<> order, column-major
+    // blocks, derivatives.cpp's conventions at t = T) -- the record's offsets here are that order at nx = NX, nu = NU
+    if (v.analytic) {
+      if (lane == 0) model.analytic_record(x, u, v.dt, last, D);
       return;
     }
   }

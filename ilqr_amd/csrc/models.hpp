@@ -343,7 +343,8 @@ struct has_analytic_record<M, std::void_t<decltype(std::declval<const M&>().anal
 // persistent routes of the shipped acrobot / double integrator; both arithmetic flavours are instantiated: fp32 handles take
 // their finite differences in UserModelT<double>) -- examples/user_model_acrobot.hpp.  Any other NX <= 32, NU <= 16 runs in
 // the generic kernels (generic.hpp: thread-per-rollout k_rollout_g, wavefront-per-knot finite differences k_derivatives_g,
-// the matrix-core backward pass k_backward_w2; fp64, analytic_record is not used there) -- examples/user_model_linear6.hpp.
+// the matrix-core backward pass k_backward_w3; fp64; an analytic_record, if the model has one, is called by one lane per knot under
+// ILQR_FLAG_ANALYTIC_DERIVATIVES) -- examples/user_model_linear6.hpp.
 // ------------------------------------------------------------------------------------------
 #ifdef ILQR_USER_MODEL_HEADER
 namespace ilqr {

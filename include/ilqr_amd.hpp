@@ -299,6 +299,7 @@ class BatchILQR {
   void set_host_threads(int n) { host_threads_ = n < 1 ? 1 : n; }
   int batch() const { return B_; }
   int horizon() const { return T_; }
+  bool host_evaluated() const { return host_; }  // no device twin: rollouts and finite differences call the Model's virtuals on the host
 
   std::vector<double> init_traj(const std::vector<double>& x0, const std::vector<double>& u0) {
     require(x0.size() == (size_t)B_ * n_ && u0.size() == (size_t)B_ * T_ * m_, "init_traj: x0 [B][nx], u0 [B][T][nu]");
@@ -655,8 +656,14 @@ class ShardedBatchILQR {
   void iterate(int n_iters) {
     for (auto& sh : shards_) sh->iterate(n_iters);
   }
-  // whole solves decide on the host when to stop (and re-pack running trajectories between chunks): one host thread per shard
+  // whole solves decide on the host when to stop (and re-pack running trajectories between chunks): one host thread per shard.
+  // A host-evaluated Model (no device twin) is shared by all shards and its methods are non-const (include/model.h:8-10: a subclass may
+  // keep state), so those shards are solved one after the other -- the same rule that makes BatchILQR::set_host_threads default to 1.
   void generate_trajectory() {
+    if (!shards_.empty() && shards_[0]->host_evaluated()) {
+      for (auto& sh : shards_) sh->generate_trajectory();
+      return;
+    }
     each_in_its_own_thread([](BatchILQR& sh) { sh.generate_trajectory(); });
   }
   void generate_trajectory(const std::vector<double>& x0, const std::vector<double>& u0) {

@@ -253,7 +253,7 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
     for it in range(n_iters):
         if not running.any():
             break
-        # what happened to this iteration's trajectories (profiles/parity_r04.json): every checked one lands in exactly one bin
+        # what happened to this iteration's trajectories (profiles/parity_r05.json): every checked one lands in exactly one bin
         pit = dict(iteration=it, n=0, plain=0, knife_edge=0, plain_on_device_records=0, cond_le10=0, cond_le100=0, amplified=0, explained_by_records=0,
                    search_tie=0, stop_tie=0, unresolved=0)
         out["per_iter"].append(pit)
@@ -477,12 +477,12 @@ def _candidate_costs(g, x0, st, b):
 
 
 def publish(name, r, **meta):
-    """Adds the per-iteration bins of a walk to the tracked statistics file (copied to profiles/parity_r04.json from the GPU
+    """Adds the per-iteration bins of a walk to the tracked statistics file (copied to profiles/parity_r05.json from the GPU
     run): which share of the checked trajectory-iterations met the plain 1e-6 criterion and which went through which proof."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.environ.get("ILQR_PARITY_JSON", os.path.join(root, "gpurun_out", "parity_r04.json"))
+    path = os.environ.get("ILQR_PARITY_JSON", os.path.join(root, "gpurun_out", "parity_r05.json"))
     os.makedirs(os.path.dirname(path), exist_ok=True)
     doc = json.load(open(path)) if os.path.exists(path) else {}
     tot = {kk: sum(p[kk] for p in r["per_iter"]) for kk in r["per_iter"][0] if kk != "iteration"} if r["per_iter"] else {}

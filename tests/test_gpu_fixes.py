@@ -88,8 +88,68 @@ def test_indefinite_quu_is_reported_as_divergence(fixed_oracle, name):
 def test_the_flag_is_off_by_default_and_rejected_where_not_implemented():
     from ilqr_amd import BatchILQR, capi
     from ilqr_amd.capi import ILQRError
-    with pytest.raises(ILQRError, match="nx = 4"):
+    with pytest.raises(ILQRError, match="host-evaluated"):
         BatchILQR("host", 2, 5, DT, nx=3, nu=2, u_min=[-1, -1], u_max=[1, 1], flags=capi.FLAG_REFERENCE_FIXES)
+    from tests.test_gpu_lq_end_to_end import dense_mats
+    with pytest.raises(ILQRError, match="REGULARIZE_VXX"):
+        BatchILQR("lq", 2, 5, DT, lq=dense_mats(6, 3), u_min=-1.0, u_max=1.0, flags=capi.FLAG_REGULARIZE_VXX)
+
+
+@pytest.mark.parametrize("n,m,B,T,lim,route", [(6, 3, 30, 40, 0.15, 0), (32, 16, 5, 20, 0.1, 0), (6, 3, 30, 40, 0.15, "thread")])
+def test_generic_path_iterations_with_the_fixes_match_the_oracle(fixed_oracle, n, m, B, T, lim, route):
+    """ILQR_FLAG_REFERENCE_FIXES on the generic path (LQ twin: matrix-core rollouts k_rollout_lq and, forced, the thread-per-rollout
+    kernel every user twin runs): clamped rollouts + a box-QP that reports a failed factorisation, iteration by iteration against the
+    oracle with the same switch; the controls of the solve stay inside their box."""
+    from ilqr_amd import BatchILQR, capi
+    from tests.test_gpu_lq_end_to_end import dense_mats
+    oracle = fixed_oracle
+    mats = dense_mats(n, m)
+    om = oracle.Model("lq", lq=mats, u_lim=lim)
+    g = BatchILQR("lq", B, T, DT, u_min=-lim, u_max=lim, lq=mats, flags=capi.FLAG_REFERENCE_FIXES,
+                  route=capi.ROUTE_LQ_THREAD_ROLLOUT if route == "thread" else 0)
+    rng = np.random.default_rng(21)
+    x0 = rng.uniform(-1, 1, (B, n))
+    u0 = rng.normal(size=(B, T, m)) * 0.3   # beyond the limits: the init rollout clamps too
+    c0 = g.init_traj(x0, u0)
+    xs_o, us_o, c_o = oracle.batch_rollout(om, x0, u0, DT)
+    assert np.abs(us_o).max() <= lim and np.max(np.abs(c0 - c_o) / np.abs(c_o)) < 1e-12
+    r = walk_iterations(oracle, om, g, x0, u0, DT, 5)
+    assert r["checked"] >= 2 * B and len(r["tied"]) <= max(2, r["checked"] // 10), r
+    g.init_traj(x0, u0)
+    g.iterate(5)
+    _, us = g.trajectory()
+    assert np.abs(us).max() <= lim
+    g.close()
+
+
+def test_generic_path_indefinite_quu_is_reported_as_divergence(fixed_oracle):
+    """As test_indefinite_quu_is_reported_as_divergence, through the generic backward kernel's own box-QP (k_backward_w3: the matrix-core
+    refinement never accepts an indefinite block, the literal path it falls back to returns -1 with the fix)."""
+    from ilqr_amd import BatchILQR, capi
+    from tests.test_gpu_lq_end_to_end import dense_mats
+    oracle = fixed_oracle
+    n, m, B, T, lim = 6, 3, 24, 30, 50.0
+    mats = dense_mats(n, m)
+    om = oracle.Model("lq", lq=mats, u_lim=lim)
+    g = BatchILQR("lq", B, T, DT, u_min=-lim, u_max=lim, lq=mats, flags=capi.FLAG_REFERENCE_FIXES)
+    rng = np.random.default_rng(5)
+    x0 = rng.uniform(-1, 1, (B, n))
+    u0 = rng.normal(size=(B, T, m)) * 0.2
+    xs, us, cost = oracle.batch_rollout(om, x0, u0, DT)
+    do = oracle.batch_derivatives(om, xs, us, DT)
+    bad_t = rng.integers(3, T - 3, size=B)
+    for b in range(0, B, 2):
+        do["cuu"][b, bad_t[b]] -= 5.0 * np.eye(m)
+    k_prev = np.zeros((B, T, m))
+    ro = oracle.batch_backward(om, us, do, k_prev=k_prev, lam=0.0)
+    assert (ro["diverge"][0::2] == bad_t[0::2]).mean() > 0.7 and np.all(ro["diverge"][1::2] == 0)
+    g.set_trajectory(x0=x0, xs=xs, us=us, cost=cost)
+    g.set_derivatives(**{k: (do[k] if k in ("cx", "cu") else mat(do[k])) for k in do})
+    g.set_gains(k=k_prev, K=np.zeros((B, T, m, n)))
+    g.set_lambda(0.0, 1.0)
+    div = g.backward_pass()
+    assert np.array_equal(div, ro["diverge"])
+    g.close()
 
 
 @pytest.mark.parametrize("name,B,T,lim", [("acrobot", 40, 120, 5.0), ("integrator", 33, 60, 0.5)])

@@ -389,3 +389,24 @@ def test_saturated_batch_wide_route_25_iterations(oracle):
     print("wide route sampled walk:", publish("saturated acrobot T=499 B=16384 +-1.5 fp64 (k_solve_wide)", r, B=B, T=T, u_lim=lim, n_sample=len(r["sel"])))
     assert_walk(r, 25)
     g.close()
+
+
+@pytest.mark.parametrize("dtype,lim", [("f64", 1.5), ("f32", 5.0)])
+def test_bench_saturated_batch_two_wide_tiles_per_cu_10_iterations(oracle, dtype, lim):
+    """The configurations the bench's `saturated` line (fp64, +-1.5) and its configs[3]-on-one-GPU line (fp32, +-5) time: B = 32768,
+    TWO 64-trajectory wide tiles per CU (k_solve_wide<.., 2>; the test above runs one per CU).  64 trajectories of the batch against
+    the oracle (the float twin for fp32) in each of 10 iterations; the bins go to the tracked statistics file."""
+    from ilqr_amd import BatchILQR, capi
+    B, T = 32768, 499
+    g = BatchILQR("acrobot", B, T, DT, u_min=-lim, u_max=lim, dtype=dtype)
+    assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("solve")) == b"k_solve_wide"
+    x0 = acrobot_x0(B)
+    if dtype == "f32":
+        x0 = x0.astype(np.float32).astype(np.float64)
+    NIT = 10
+    r = sampled_walk(oracle, oracle.Model("acrobot", u_lim=lim), g, x0, np.zeros((B, T, 1)), DT, NIT, precision=dtype)
+    print("B=32768 %s sampled walk:" % dtype, publish("bench saturated acrobot T=499 B=32768 +-%g %s (k_solve_wide, two tiles per CU)" % (lim, "fp64" if dtype == "f64" else "fp32"),
+                                                    r, B=B, T=T, u_lim=lim, n_sample=len(r["sel"]), precision=dtype))
+    assert_walk(r, NIT, min_plain_it0=0.95 if dtype == "f64" else 0.8)
+    assert r["unresolved"] == 0, r["unresolved"]
+    g.close()
