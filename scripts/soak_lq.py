@@ -2,10 +2,13 @@
 
 Every case draws dimensions n <= 32, m <= 16, a batch, a horizon, limits, lambda and (sometimes) a negative shift
 of one diagonal entry of cuu (indefinite Quu: partial factors, stale factors, aborted passes), then checks
-  * k_backward_w2 (matrices in registers) == k_backward_w (matrices in LDS, ILQR_ROUTE_BACKWARD_LDS), bit for bit:
+  * k_backward_w2 (matrices in registers, ILQR_ROUTE_BACKWARD_W2) == k_backward_w (matrices in LDS, ILQR_ROUTE_BACKWARD_LDS), bit for bit:
     gains, dV, divergence index, gradient norm;
-  * k_backward_w2 against the oracle's backward_pass per knot (tests/parity.check_backward: 1e-6, deviations must be
-    clamp knife edges or fp64-conditioning-limited against the fp80 oracle).
+  * k_backward_w2 AND k_backward_w3 (the default: per-lane matrix-vector sums, the box-QP's inverse refined on the matrix cores where the
+    free set is the previous knot's, the literal path elsewhere) against the oracle's backward_pass per knot (tests/parity.check_backward:
+    1e-6, deviations must be clamp knife edges or fp64-conditioning-limited against the fp80 oracle); where the indefinite shift makes the
+    ORACLE itself miss the fp80 answer by more than 100 % per knot, k_backward_w3 is held to the diverge flag only (max_unpinned);
+  * the two against each other at 1e-9 on the unshifted cases.
 
     python scripts/soak_lq.py [seconds] [seed]
 """
@@ -53,9 +56,9 @@ def main():
         k_prev = rng.normal(size=(B, T, m)) * 0.1
         desc = "n=%d m=%d B=%d T=%d lim=%g lam=%g shifted=%s seed=%d" % (n, m, B, T, lim, lam, shifted, seed)
         outs = []
-        for force_lds in (False, True):
+        for route in (capi.ROUTE_BACKWARD_W2, capi.ROUTE_BACKWARD_LDS, 0):
             try:
-                g = BatchILQR("host", B, T, DT, nx=n, nu=m, u_min=om.u_min, u_max=om.u_max, route=capi.ROUTE_BACKWARD_LDS if force_lds else 0)
+                g = BatchILQR("host", B, T, DT, nx=n, nu=m, u_min=om.u_min, u_max=om.u_max, route=route)
                 g.set_trajectory(x0=x0, xs=xs, us=us, cost=cost)
                 g.set_derivatives(**{k: (dv[k] if k in ("cx", "cu") else mat(dv[k])) for k in dv})
                 g.set_gains(k=k_prev, K=np.zeros((B, T, m, n)))
@@ -70,6 +73,15 @@ def main():
             if not np.array_equal(outs[0][key], outs[1][key], equal_nan=True):
                 print("FAIL register kernel != LDS kernel:", key, desc)
                 return 1
+        if not np.array_equal(outs[0]["div"], outs[2]["div"]):
+            print("FAIL k_backward_w3 diverge knots:", desc, outs[0]["div"], outs[2]["div"])
+            return 1
+        if not shifted:
+            for key in ("k", "K", "dV", "gnorm"):
+                scale = max(1.0, np.abs(outs[0][key]).max())
+                if not np.abs(outs[0][key] - outs[2][key]).max() <= 1e-9 * scale:
+                    print("FAIL k_backward_w3 vs k_backward_w2:", key, np.abs(outs[0][key] - outs[2][key]).max(), scale, desc)
+                    return 1
         ro = O.batch_backward(om, us, dv, k_prev=k_prev, lam=lam)
         if (ro["diverge"] == 0).sum() == 0:  # every pass aborts in the oracle: the abort knots must agree
             if not np.array_equal(outs[0]["div"], ro["diverge"]):
@@ -94,9 +106,13 @@ def main():
         try:
             r = check_backward(O, om, sub(us), {kk: v[sane] for kk, v in dv.items()}, sub(k_prev), lam, sub(outs[0]["k"]), sub(outs[0]["K"]),
                                sub(outs[0]["dV"]), sub(outs[0]["div"]), ro_s, max_ties=max(1, B // 4), max_over10=max(1, B // 16))
+            r3 = check_backward(O, om, sub(us), {kk: v[sane] for kk, v in dv.items()}, sub(k_prev), lam, sub(outs[2]["k"]), sub(outs[2]["K"]),
+                                sub(outs[2]["dV"]), sub(outs[2]["div"]), ro_s, max_ties=max(1, B // 4), max_over10=max(1, B // 16),
+                                max_unpinned=(B if shifted else 0))
         except AssertionError as e:
             print("FAIL oracle parity:", desc, str(e)[:300])
             return 1
+        n_ties += int(r3["ties"])
         n_ties += int(r["ties"])
         n_abort += int((outs[0]["div"] != 0).sum())
         n_cases += 1

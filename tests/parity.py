@@ -354,6 +354,28 @@ def walk_iterations(oracle, om, g, x0, u0, dt, n_iters, fixed_work=False, precis
                 a_lo = min(x for x in (gs["alpha"][b], nx["alpha"][b]) if x >= 0)
                 # the earlier-accepted alpha (or every alpha when one side found none) has a cost change of rounding size
                 cand = dcost[a_lo:] if min(gs["alpha"][b], nx["alpha"][b]) < 0 else dcost[a_lo:a_lo + 1]
+                if precision == "f32" and not np.any(np.abs(cand) <= prec["tie_rel"] * abs(st["cost"][b])):
+                    # Not a tie of rounding size -- but are this trajectory's FLOAT rollouts good for a decision at all?  The same gains
+                    # (the device's, within tolerance of the twin's) rolled out by the float twin and by the fp64 yardstick, for every alpha
+                    # up to the later-accepted one: if they disagree by more than what a float rollout over this horizon is good for
+                    # (ROLLOUT_NOISE; overflow to inf / NaN included), the two searches were deciding on amplified rounding.
+                    from oracle.oracle import ALPHAS
+                    a_hi = max(int(gs["alpha"][b]), int(nx["alpha"][b]))
+                    noisy = False
+                    for a in range(a_hi + 1):
+                        ut = np.asarray(st["us"][b:b + 1] + ALPHAS[a] * gs["k"][b:b + 1])
+                        with oracle.flavour(prec["twin"]):
+                            c_t = float(oracle.batch_rollout(_tw(om, prec["twin"]), x0[b:b + 1], ut, dt, xs_nom=st["xs"][b:b + 1], K=gs["K"][b:b + 1])[2][0])
+                        with oracle.flavour(prec["yard"]):
+                            c_y = float(oracle.batch_rollout(_tw(om, prec["yard"]), x0[b:b + 1], ut, dt, xs_nom=st["xs"][b:b + 1], K=gs["K"][b:b + 1])[2][0])
+                        if not (np.isfinite(c_t) and np.isfinite(c_y)) or abs(c_t - c_y) > ROLLOUT_NOISE[precision] * abs(c_y):
+                            noisy = True
+                            break
+                    if noisy:
+                        out["amplified"] = out.get("amplified", 0) + 1
+                        out["tied"].add(int(b))
+                        pit["amplified"] += 1
+                        continue
                 assert np.any(np.abs(cand) <= prec["tie_rel"] * abs(st["cost"][b])), "line searches differ away from a tie (dcost %s) -- %s" % (dcost, where)
                 out["ties_search"] += 1
                 out["tied"].add(int(b))
