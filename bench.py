@@ -521,7 +521,13 @@ def main():
             # performs it (src/derivatives.cpp) would be 2(n+m) Euler maps + 4800 costs of 2(n^2+m^2) flops; the kernel uses
             # the model's separable cost (cost_x(x) + cost_u(u): the parts of a point that did not move are not re-evaluated),
             # which is what it is priced at: (2n + 2n(n+1)) x'Qx + (2m + 2m(m+1)) u'Ru + 2(n+m) Euler maps per knot
-            fd_flops = (2 * nq + 2 * nq * (nq + 1)) * 2 * nq * nq + (2 * mq + 2 * mq * (mq + 1)) * 2 * mq * mq + 2 * (nq + mq) * 2 * nq * (nq + mq)
+            fd_flops_dense_forms = (2 * nq + 2 * nq * (nq + 1)) * 2 * nq * nq + (2 * mq + 2 * mq * (mq + 1)) * 2 * mq * mq + 2 * (nq + mq) * 2 * nq * (nq + mq)
+            # ... and k_derivatives_lq (the default since round 5) evaluates a perturbed point's form from what moved: Q p = Q x + delta_i Q[:,i] + delta_j Q[:,j]
+            # (4n flops), x . (Q p) (2n), the two perturbed rows (~12); Q x and R u once per knot; the Jacobian sweep stays dense
+            fd_flops = ((2 * nq + 2 * nq * (nq + 1)) * (6 * nq + 12) + (2 * mq + 2 * mq * (mq + 1)) * (6 * mq + 12) + 2 * (nq * nq + mq * mq)
+                        + 2 * (nq + mq) * 2 * nq * (nq + mq))
+            if stq.get("derivatives", {}).get("kernel") != "k_derivatives_lq":
+                fd_flops = fd_flops_dense_forms
             fd_dense = 2 * (nq + mq) * 2 * nq * (nq + mq) + (2 * nq + 2 * mq + 2 * nq * (nq + 1) + 2 * mq * (mq + 1) + 4 * nq * mq) * 2 * (nq * nq + mq * mq)
             extra["lq_n32_m16_T200_B8192_" + label] = {
                 "workload": "synthetic LQ n=32 m=16 T=200 B=8192, u in [-1,1], fp64, %s derivatives, fixed-work iterations "
@@ -533,11 +539,14 @@ def main():
             if not fl:
                 dv = stq["derivatives"]["ms_per_launch"] * 1e-3
                 extra["lq_n32_m16_T200_B8192_" + label]["roofline_derivatives"] = {
-                    "bound": "fp64 flops (vector + matrix pipes share the 78.6 TFLOP/s peak)", "kernel": stq["derivatives"]["kernel"],
+                    "bound": "fp64 flops (vector and matrix instructions share one fp64 datapath per SIMD: scripts/ubench/coissue.hip)", "kernel": stq["derivatives"]["kernel"],
                     "achieved": fd_flops * Bq * (Tq + 1) / dv / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": fd_flops * Bq * (Tq + 1) / dv / 1e12 / FP64_MFMA_PEAK_TFLOPS, "executed_flops_per_knot": fd_flops,
                     "reference_dense_flops_per_knot": fd_dense, "avg_launch_ms": dv * 1e3,
-                    "note": "the same sweep evaluated point by point as the reference does would be %.1f x the flops" % (fd_dense / fd_flops)}
+                    "dense_quadratic_forms_flops_per_knot": fd_flops_dense_forms,
+                    "note": "the same sweep evaluated point by point as the reference does would be %.1f x the flops (every point's forms densely on the "
+                            "matrix cores, ILQR_ROUTE_LQ_DENSE_FD: %.1f x); the kernel's time goes into VALU work around few flops: the fraction is not its quality measure, "
+                            "its speed-up over the dense sweep is (profiles/)" % (fd_dense / fd_flops, fd_flops_dense_forms / fd_flops)}
                 if not args.no_cpu_baseline:
                     extra["lq_n32_m16_T200_B8192_" + label]["cpu_baseline"] = cpu_baseline_other("lq", Tq, dt)
             elif not args.no_cpu_baseline:

@@ -99,6 +99,7 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   h->route.unfused = false;
   h->route.backward_w1 = (d->route & ILQR_ROUTE_BACKWARD_LDS) != 0;
   h->route.backward_w2 = (d->route & ILQR_ROUTE_BACKWARD_W2) != 0;
+  h->route.lq_dense_fd = (d->route & ILQR_ROUTE_LQ_DENSE_FD) != 0;
   h->route.lq_thread_rollout = (d->route & ILQR_ROUTE_LQ_THREAD_ROLLOUT) != 0;
   h->route.full_records = (d->route & ILQR_ROUTE_FULL_RECORDS) != 0;
   h->route.no_compaction = (d->route & ILQR_ROUTE_NO_COMPACTION) != 0;

@@ -751,12 +751,13 @@ __global__ __launch_bounds__(256) void k_commit_lq(BatchView v, int nx, int nu, 
 // including the t = T special cases (fx[T] = fu[T] = 0, cx/cxx from final_cost, cu[T] = 0, cuu[T]
 // from cost(x_T, 0), the cxu[T] formula the reference itself marks wrong).
 template <class M>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_derivatives_g(BatchView v, M model, int force) {
+// t_only >= 0: one block per trajectory, knot t_only alone (the last knot behind k_derivatives_lq, which sweeps the knots t < T).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_derivatives_g(BatchView v, M model, int force, int t_only) {
   constexpr int NX = M::NX, NU = M::NU;
   const int nx = model.nx, nu = model.nu, T = v.T;
   const int lane = threadIdx.x;
-  const int b = blockIdx.x / (T + 1), t = blockIdx.x - b * (T + 1);
-  if (blockIdx.x == 0 && lane == 0) *v.n_running = 0;  // k_accept of this iteration recounts
+  const int b = (t_only >= 0) ? blockIdx.x : blockIdx.x / (T + 1), t = (t_only >= 0) ? t_only : blockIdx.x - b * (T + 1);
+  if (t_only < 0 && blockIdx.x == 0 && lane == 0) *v.n_running = 0;  // k_accept of this iteration recounts
   if (!(force || (v.status[b] == 0 && v.flg_change[b]))) return;
   const int oFX = 0, oFU = oFX + nx * nx, oCX = oFU + nx * nu, oCXX = oCX + nx, oCXU = oCXX + nx * nx, oCU = oCXU + nx * nu,
             oCUU = oCU + nu, REC = oCUU + nu * nu;
@@ -1220,6 +1221,273 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     combine(ea, qa, fa);
     combine(eb, qb, fb);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// finite differences of the LQ model, every point evaluated by what moved
+// ------------------------------------------------------------------------------------------
+// k_derivatives_g evaluates every perturbed point of the cost Hessians DENSELY: Y = Q P on the matrix cores for 16 points at a time,
+// 2 177 + 577 matrix-vector products per knot, 88 % of a finite-difference iteration of configs[4] (and fp64 matrix instructions run
+// at the VALU's rate on gfx950: scripts/ubench/coissue.hip).  But a perturbed point differs from the knot in ONE or TWO components, and
+// the model has said that its cost is a quadratic form (kQuadraticCostX, cost_u_matrix): with y0 = Q x formed once per knot,
+//     Q p = y0 + delta_i Q[:, i] + delta_j Q[:, j],      p'Q p = x . (Q p) + delta_i (Q p)_i + delta_j (Q p)_j
+// -- the same function value at the same point (delta = the perturbation as it was actually applied, fl(fl(x_i + d1) + d2) - x_i on the
+// diagonal, finite_diff.h:67-86), from 2 n + 8 multiply-adds instead of n^2; the differences of these values are then taken exactly
+// as before.  The values agree with the dense evaluation to rounding (1e-16 of |x'Qx|, which the second difference amplifies by
+// 1 / 4 eps^2 = 2.5e5 like every other rounding of f), the records with the oracle's to the tolerance they already had.
+// One wavefront sweeps kLqKnotsPerWave knots of a trajectory (Q, R column-wise in LDS, the Jacobian operands in registers: loaded
+// once per wavefront instead of once per knot); lane (g = l >> 4, p = l & 15) holds rows g + 4 r (+ 16) of point p's Q p, 16 points
+// per pass.  The Jacobian sweep stays dense on the matrix cores (96 points).  Knot T (final_cost, the reference's conventions there)
+// is k_derivatives_g's (t_only).  ILQR_ROUTE_LQ_DENSE_FD keeps the dense sweep for every knot (cross-check: tests/test_gpu_lq_end_to_end.py).
+constexpr int kLqKnotsPerWave = 8;
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_derivatives_lq(BatchView v, LqModel model, int force) {
+  static_assert(GN == 32 && GM == 16, "operand blocks below are written for a 32 x 16 model");
+  typedef double double4_t __attribute__((ext_vector_type(4)));
+  typedef double double2_t __attribute__((ext_vector_type(2)));
+  const int nx = model.nx, nu = model.nu, T = v.T;
+  const int lane = threadIdx.x, g = lane >> 4, p = lane & 15;
+  const int nchunk = (T + kLqKnotsPerWave - 1) / kLqKnotsPerWave;  // knots 0 .. T-1
+  const int b = blockIdx.x / nchunk, t0 = (blockIdx.x - b * nchunk) * kLqKnotsPerWave;
+  if (blockIdx.x == 0 && lane == 0) *v.n_running = 0;  // k_accept of this iteration recounts
+  if (!(force || (v.status[b] == 0 && v.flg_change[b]))) return;
+  const int oFX = 0, oFU = oFX + nx * nx, oCX = oFU + nx * nu, oCXX = oCX + nx, oCXU = oCXX + nx * nx, oCU = oCXU + nx * nu,
+            oCUU = oCU + nu, REC = oCUU + nu * nu;
+  // Qc[col][8 g + 4 ib + r] = Q[16 ib + 4 r + g][col]: the eight rows of a column that lane group g holds are 64 contiguous bytes;
+  // Rc[col][4 g + r] = R[4 r + g][col]
+  __shared__ __attribute__((aligned(16))) double Qc[GN * GN];
+  __shared__ __attribute__((aligned(16))) double Rc[GM * GM];
+  __shared__ double xk[GN], uk[GM], y0s[GN], yu0s[GM], sx[2 * GN], su[2 * GM];
+  auto sync = []() __attribute__((always_inline)) {  // one wavefront: the LDS executes its operations in order; only the compiler must not reorder them
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto permq = [](int row) __attribute__((always_inline)) { return ((row & 3) << 3) | ((row >> 4) << 2) | ((row >> 2) & 3); };
+  auto permr = [](int row) __attribute__((always_inline)) { return ((row & 3) << 2) | (row >> 2); };
+  for (int e = lane; e < GN * GN; e += 64) {
+    const int row = e >> 5, col = e & 31;
+    Qc[col * GN + permq(row)] = model.Q[e];
+  }
+  for (int e = lane; e < GM * GM; e += 64) {
+    const int row = e >> 4, col = e & 15;
+    Rc[col * GM + permr(row)] = model.R[e];
+  }
+  // operands that stay in registers for all of the wavefront's knots: A, B (Jacobian sweep), Q, R (y0 = Q x, R u) as A operands
+  double opA[2][8], opB[2][4], qa[2][8], ra[4];
+#pragma unroll
+  for (int ti = 0; ti < 2; ti++) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      opA[ti][ks] = model.A[(16 * ti + p) * GN + 4 * ks + g];
+      qa[ti][ks] = model.Q[(16 * ti + p) * GN + 4 * ks + g];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) opB[ti][ks] = model.Bm[(16 * ti + p) * GM + 4 * ks + g];
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) ra[ks] = model.R[p * GM + 4 * ks + g];
+  auto group_sum = [](double part) __attribute__((always_inline)) {  // over the four lane groups of a point (result in all four)
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    return part;
+  };
+
+  for (int t = t0; t < t0 + kLqKnotsPerWave && t < T; t++) {
+    double* __restrict__ D = v.D + ((size_t)b * (T + 1) + t) * REC;
+    sync();  // (the previous knot's readers of xk .. su are through)
+    {
+      const double xv = (lane < nx) ? v.xs[((size_t)b * (T + 1) + t) * nx + lane] : 0.0;
+      const double uv = (lane < nu) ? v.us[((size_t)b * T + t) * nu + lane] : 0.0;
+      if (lane < GN) xk[lane] = xv;
+      if (lane < GM) uk[lane] = uv;
+    }
+    sync();
+    double xb[8], ub[4];  // this lane's components 4 ks + g of the knot
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) xb[ks] = xk[4 * ks + g];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) ub[ks] = uk[4 * ks + g];
+
+    // ---- fx, fu: F(P) = P + dt (A Px + B Pu), 16 points at a time on the matrix cores (as k_derivatives_g) ----
+    {
+      const int E = 2 * (nx + nu);
+      for (int base = 0; base < E; base += 16) {
+        const int e = base + p;
+        const bool valid = e < E;
+        const int var = e >> 1;
+        const double d = (e & 1) ? -kEps : kEps;
+        const int ix = (valid && var < nx) ? var : -1, iu = (valid && var >= nx) ? var - nx : -1;
+        double bx[8], bu[4];
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) bx[ks] = (4 * ks + g == ix) ? xb[ks] + d : xb[ks];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) bu[ks] = (4 * ks + g == iu) ? ub[ks] + d : ub[ks];
+        double4_t acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+          for (int ti = 0; ti < 2; ti++) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[ti][ks], bx[ks], acc[ti], 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+          for (int ti = 0; ti < 2; ti++) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(opB[ti][ks], bu[ks], acc[ti], 0, 0, 0);
+        double* col = (var < nx) ? D + oFX + nx * var : D + oFU + nx * (var - nx);
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const double F = bx[4 * ti + r] + acc[ti][r] * v.dt;  // include/model.h:12-15
+            const double other = dpp_swap1(F);                    // the point next door: e ^ 1
+            const double val = (F - other) / (2 * kEps);
+            const int row = 16 * ti + g + 4 * r;
+            if (valid && !(e & 1) && row < nx) col[row] = val;
+          }
+      }
+    }
+
+    // ---- y0 = Q x, R u (dense, once per knot): rows g + 4 r (+ 16) on this lane, the same in every column ----
+    double y0[8], yu0[4];
+    {
+      double4_t ya[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, yu = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++) ya[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[ib][ks], xb[ks], ya[ib], 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) yu = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[ks], ub[ks], yu, 0, 0, 0);
+#pragma unroll
+      for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          y0[4 * ib + r] = ya[ib][r];
+          if (p == 0) y0s[16 * ib + 4 * r + g] = ya[ib][r];
+        }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        yu0[r] = yu[r];
+        if (p == 0) yu0s[4 * r + g] = yu[r];
+      }
+    }
+    double qx0, qu0;  // cost_x(x), cost_u(u)
+    {
+      double px = 0, pu = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) px = __builtin_fma(xb[k], y0[k], px);
+#pragma unroll
+      for (int k = 0; k < 4; k++) pu = __builtin_fma(ub[k], yu0[k], pu);
+      qx0 = group_sum(px);
+      qu0 = group_sum(pu);
+    }
+    sync();
+
+    // x'Qx at the knot with component i1 += d1, then component i2 += d2 (index < 0: none; i2 == i1: both on that component)
+    auto form_x = [&](int i1, double d1, int i2, double d2) __attribute__((always_inline)) {
+      const int c1 = (i1 >= 0) ? i1 : 0, c2 = (i2 >= 0) ? i2 : 0;
+      const double x1 = xk[c1], x2 = xk[c2];
+      double p1 = x1 + d1;
+      if (i2 == i1) p1 = p1 + d2;  // finite_diff.h:67-86: one perturbation after the other
+      const double del1 = (i1 >= 0) ? p1 - x1 : 0.0;
+      const double del2 = (i2 >= 0 && i2 != i1) ? (x2 + d2) - x2 : 0.0;
+      const double2_t* q1 = reinterpret_cast<const double2_t*>(&Qc[c1 * GN + 8 * g]);
+      const double2_t* q2 = reinterpret_cast<const double2_t*>(&Qc[c2 * GN + 8 * g]);
+      double part = 0;
+#pragma unroll
+      for (int k2 = 0; k2 < 4; k2++) {
+        const double2_t a = q1[k2], c = q2[k2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) {
+          const int k = 2 * k2 + h2;  // row 16 (k >> 2) + 4 (k & 3) + g = this lane's component xb[k]
+          const double y = __builtin_fma(del2, c[h2], __builtin_fma(del1, a[h2], y0[k]));
+          part = __builtin_fma(xb[k], y, part);
+        }
+      }
+      part = group_sum(part);
+      const int m1 = permq(c1), m2 = permq(c2);
+      const double Y1 = __builtin_fma(del2, Qc[c2 * GN + m1], __builtin_fma(del1, Qc[c1 * GN + m1], y0s[c1]));  // (Q p)[i1]
+      const double Y2 = __builtin_fma(del2, Qc[c2 * GN + m2], __builtin_fma(del1, Qc[c1 * GN + m2], y0s[c2]));  // (Q p)[i2]
+      return __builtin_fma(del2, Y2, __builtin_fma(del1, Y1, part));
+    };
+    auto form_u = [&](int i1, double d1, int i2, double d2) __attribute__((always_inline)) {
+      const int c1 = (i1 >= 0) ? i1 : 0, c2 = (i2 >= 0) ? i2 : 0;
+      const double x1 = uk[c1], x2 = uk[c2];
+      double p1 = x1 + d1;
+      if (i2 == i1) p1 = p1 + d2;
+      const double del1 = (i1 >= 0) ? p1 - x1 : 0.0;
+      const double del2 = (i2 >= 0 && i2 != i1) ? (x2 + d2) - x2 : 0.0;
+      const double2_t* q1 = reinterpret_cast<const double2_t*>(&Rc[c1 * GM + 4 * g]);
+      const double2_t* q2 = reinterpret_cast<const double2_t*>(&Rc[c2 * GM + 4 * g]);
+      double part = 0;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; k2++) {
+        const double2_t a = q1[k2], c = q2[k2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) {
+          const int k = 2 * k2 + h2;  // row 4 k + g = this lane's component ub[k]
+          const double y = __builtin_fma(del2, c[h2], __builtin_fma(del1, a[h2], yu0[k]));
+          part = __builtin_fma(ub[k], y, part);
+        }
+      }
+      part = group_sum(part);
+      const int m1 = permr(c1), m2 = permr(c2);
+      const double Y1 = __builtin_fma(del2, Rc[c2 * GM + m1], __builtin_fma(del1, Rc[c1 * GM + m1], yu0s[c1]));
+      const double Y2 = __builtin_fma(del2, Rc[c2 * GM + m2], __builtin_fma(del1, Rc[c1 * GM + m2], yu0s[c2]));
+      return __builtin_fma(del2, Y2, __builtin_fma(del1, Y1, part));
+    };
+
+    // ---- single perturbations: cost_x(x +- eps e_i), cost_u(u +- eps e_j) ----
+    for (int base = 0; base < 2 * nx; base += 16) {
+      const int e = base + p;
+      const double f = form_x(e < 2 * nx ? (e >> 1) : -1, (e & 1) ? -kEps : kEps, -1, 0.0);
+      if (g == 0 && e < 2 * nx) sx[e] = f;
+    }
+    for (int base = 0; base < 2 * nu; base += 16) {
+      const int e = base + p;
+      const double f = form_u(e < 2 * nu ? (e >> 1) : -1, (e & 1) ? -kEps : kEps, -1, 0.0);
+      if (g == 0 && e < 2 * nu) su[e] = f;
+    }
+    sync();
+    // cx, cu (derivatives.cpp:44-47)
+    for (int i = lane; i < nx; i += 64)
+      D[oCX + i] = (LqModel::cost_from_parts(sx[2 * i], qu0) - LqModel::cost_from_parts(sx[2 * i + 1], qu0)) / (2 * kEps);
+    for (int j = lane; j < nu; j += 64)
+      D[oCU + j] = (LqModel::cost_from_parts(qx0, su[2 * j]) - LqModel::cost_from_parts(qx0, su[2 * j + 1])) / (2 * kEps);
+    // cxu (derivatives.cpp:114-144): c(px,pu) - c(mx,pu) - c(px,mu) + c(mx,mu)
+    for (int q = lane; q < nx * nu; q += 64) {
+      const int i = q / nu, j = q - i * nu;
+      const double v4 = LqModel::cost_from_parts(sx[2 * i], su[2 * j]) - LqModel::cost_from_parts(sx[2 * i + 1], su[2 * j]) -
+                        LqModel::cost_from_parts(sx[2 * i], su[2 * j + 1]) + LqModel::cost_from_parts(sx[2 * i + 1], su[2 * j + 1]);
+      D[oCXU + i + nx * j] = v4 / (4 * kEps * kEps);
+    }
+    // ---- cxx, cuu: the upper triangle, four sign combinations per pair (finite_diff.h:67-86); a pass = 16 points = 4 pairs ----
+    auto hessian = [&](auto on_x, int n, int oH, double other) __attribute__((always_inline)) {
+      constexpr bool X = decltype(on_x)::value;
+      const int npts = 2 * n * (n + 1);
+      int pi = 0, prem = p >> 2;  // this lane's pair (i, i + rem), advanced incrementally
+      auto normalise = [&](int& i, int& rem) __attribute__((always_inline)) {
+        while (i < n && rem >= n - i) {
+          rem -= n - i;
+          i++;
+        }
+      };
+      normalise(pi, prem);
+      for (int base = 0; base < npts; base += 16) {
+        const int e = base + p;
+        const int ti = (e < npts) ? pi : -1, tj = (e < npts) ? pi + prem : -1;
+        const double d1 = (e & 1) ? -kEps : kEps, d2 = (e & 2) ? -kEps : kEps;
+        prem += 4;  // the next pass's pair
+        normalise(pi, prem);
+        const double f = X ? form_x(ti, d1, tj, d2) : form_u(ti, d1, tj, d2);
+        const double fv = X ? LqModel::cost_from_parts(f, other) : LqModel::cost_from_parts(other, f);
+        const double f0 = quad_bcast<0>(fv), f1 = quad_bcast<1>(fv), f2 = quad_bcast<2>(fv), f3 = quad_bcast<3>(fv);
+        if (e < npts && (e & 3) == 0 && g == 0) {
+          const double val = (f0 - f1 - f2 + f3) / (4 * kEps * kEps);
+          D[oH + ti + n * tj] = val;
+          D[oH + tj + n * ti] = val;
+        }
+      }
+    };
+    hessian(std::true_type{}, nx, oCXX, qu0);
+    hessian(std::false_type{}, nu, oCUU, qx0);
   }
 }
 

@@ -166,8 +166,13 @@ static int launch_derivatives(ilqr_batch* h, int force) {
       hipLaunchKernelGGL(k_analytic_lq, dim3(h->B * nchunk), dim3(64), 0, h->stream, h->v, h->lq, force, what, h->const_rec, chunk);
       h->records_partial = (what == 1);
     } else {
-      if (int rc = with_generic_model(h, [&](auto& m) {
-            hipLaunchKernelGGL((k_derivatives_g<std::decay_t<decltype(m)>>), dim3(h->B * (h->T + 1)), dim3(64), 0, h->stream, h->v, m, force);
+      if (h->model == ILQR_MODEL_LQ && !h->route.lq_dense_fd) {
+        // the LQ twin: every perturbed point of the knots t < T evaluated by what moved (k_derivatives_lq), knot T by the generic sweep
+        const int nchunk = (h->T + kLqKnotsPerWave - 1) / kLqKnotsPerWave;
+        hipLaunchKernelGGL(k_derivatives_lq, dim3(h->B * nchunk), dim3(64), 0, h->stream, h->v, h->lq, force);
+        hipLaunchKernelGGL((k_derivatives_g<LqModel>), dim3(h->B), dim3(64), 0, h->stream, h->v, h->lq, force, h->T);
+      } else if (int rc = with_generic_model(h, [&](auto& m) {
+            hipLaunchKernelGGL((k_derivatives_g<std::decay_t<decltype(m)>>), dim3(h->B * (h->T + 1)), dim3(64), 0, h->stream, h->v, m, force, -1);
             return 0;
           }))
         return rc;

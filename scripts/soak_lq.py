@@ -21,7 +21,7 @@ import numpy as np
 
 from ilqr_amd import BatchILQR, capi
 from oracle import oracle as O
-from tests.parity import check_backward
+from tests.parity import check_backward, first_gain_mismatch_is_knife_edge
 from tests.util import mat
 
 DT = 0.02
@@ -76,12 +76,23 @@ def main():
         if not np.array_equal(outs[0]["div"], outs[2]["div"]):
             print("FAIL k_backward_w3 diverge knots:", desc, outs[0]["div"], outs[2]["div"])
             return 1
-        if not shifted:
-            for key in ("k", "K", "dV", "gnorm"):
-                scale = max(1.0, np.abs(outs[0][key]).max())
-                if not np.abs(outs[0][key] - outs[2][key]).max() <= 1e-9 * scale:
-                    print("FAIL k_backward_w3 vs k_backward_w2:", key, np.abs(outs[0][key] - outs[2][key]).max(), scale, desc)
-                    return 1
+        if not shifted:  # the two register kernels against each other: 1e-9, or a clamp knife edge (a component inside the 1e-4 band of a bound
+            # that one of them reads as clamped: tests/parity.py) -- bounded like the ties against the oracle
+            lo_b, hi_b = om.u_min[None, None, :] - us, om.u_max[None, None, :] - us
+            n_edge = 0
+            for bb in range(B):
+                close = all(np.abs(outs[0][key][bb] - outs[2][key][bb]).max() <= 1e-9 * max(1.0, np.abs(outs[0][key][bb]).max()) for key in ("k", "K", "dV", "gnorm"))
+                if close:
+                    continue
+                if first_gain_mismatch_is_knife_edge(outs[2]["k"][bb], outs[2]["K"][bb], outs[0]["k"][bb], outs[0]["K"][bb], us[bb], lo_b[bb], hi_b[bb], 1e-9):
+                    n_edge += 1
+                    continue
+                print("FAIL k_backward_w3 vs k_backward_w2 (not a clamp knife edge): trajectory", bb, np.abs(outs[0]["k"][bb] - outs[2]["k"][bb]).max(), desc)
+                return 1
+            if n_edge > max(1, B // 4):
+                print("FAIL too many knife edges between the two kernels:", n_edge, desc)
+                return 1
+            n_ties += n_edge
         ro = O.batch_backward(om, us, dv, k_prev=k_prev, lam=lam)
         if (ro["diverge"] == 0).sum() == 0:  # every pass aborts in the oracle: the abort knots must agree
             if not np.array_equal(outs[0]["div"], ro["diverge"]):

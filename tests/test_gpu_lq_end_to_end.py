@@ -92,6 +92,35 @@ def test_lq_stages_match_oracle(oracle, n, m, B, T, dense):
     g.close()
 
 
+@pytest.mark.parametrize("n,m,B,T", [(32, 16, 5, 9), (32, 16, 3, 17), (6, 3, 30, 20), (5, 2, 40, 8), (1, 1, 3, 2), (2, 16, 5, 3), (31, 1, 2, 9), (17, 9, 4, 16)])
+def test_lq_incremental_finite_differences_equal_the_dense_sweep(n, m, B, T):
+    """k_derivatives_lq evaluates every perturbed point of the LQ model by what moved (Q p = Q x + delta_i Q[:, i] + delta_j Q[:, j]: the same
+    function value at the same point from 2 n multiply-adds instead of n^2); ILQR_ROUTE_LQ_DENSE_FD keeps the dense matrix-core evaluation of
+    every point (k_derivatives_g).  The two sweeps' records: first differences to 1e-9, second differences -- rounding of f amplified by
+    1 / 4 eps^2 on both sides -- to the tolerance either has against the oracle; horizons that are not a multiple of the knots per wavefront."""
+    from ilqr_amd import BatchILQR, capi
+    mats = dense_mats(n, m, seed=23)
+    mats = (mats[0], mats[1], mats[2] + 0.1 * np.triu(np.ones((n, n)), 1), mats[3], mats[4])  # a NON-symmetric Q: x'Qx uses rows and columns
+    rng = np.random.default_rng(31)
+    x0 = rng.uniform(-1, 1, (B, n))
+    u0 = rng.normal(size=(B, T, m)) * 0.4
+    recs = []
+    for route, kernel in ((0, b"k_derivatives_lq"), (capi.ROUTE_LQ_DENSE_FD, b"k_derivatives_g")):
+        g = BatchILQR("lq", B, T, DT, u_min=-1.0, u_max=1.0, lq=mats, route=route)
+        assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("derivatives")) == kernel
+        g.init_traj(x0, u0)
+        g.compute_derivatives()
+        recs.append(g.derivatives())
+        g.close()
+    a, b = recs
+    for name in ("fx", "fu", "cx", "cu"):
+        assert np.abs(a[name] - b[name]).max() <= 1e-9 * max(1.0, np.abs(b[name]).max()), name
+    for name in ("cxx", "cuu", "cxu"):
+        assert relerr_abs(a[name], b[name], 1e-2) < TOL, name
+    for name in a:  # knot T is the generic sweep's on both routes
+        assert np.array_equal(a[name][:, T], b[name][:, T]), name
+
+
 def oracle_closed_loop(oracle, om, x0, xs_nom, us_nom, k, K, alpha):
     """forward_pass(x0, us + alpha k) with feedback K around xs_nom (ilqr_core.cpp:188-190, 305-337)."""
     return oracle.batch_rollout(om, x0, us_nom + alpha * k, DT, xs_nom=xs_nom, K=K)
