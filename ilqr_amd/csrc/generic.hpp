@@ -1258,6 +1258,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
   __shared__ __attribute__((aligned(16))) double Qc[GN * GN];
   __shared__ __attribute__((aligned(16))) double Rc[GM * GM];
   __shared__ double xk[GN], uk[GM], y0s[GN], yu0s[GM], sx[2 * GN], su[2 * GM];
+  __shared__ unsigned short pair_x[GN * (GN + 1) / 2], pair_u[GM * (GM + 1) / 2];  // pair q of the upper triangle, row by row (finite_diff.h:70-71): i | j << 8
   auto sync = []() __attribute__((always_inline)) {  // one wavefront: the LDS executes its operations in order; only the compiler must not reorder them
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1272,6 +1273,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
     const int row = e >> 4, col = e & 15;
     Rc[col * GM + permr(row)] = model.R[e];
   }
+  for (int i = 0; i < nx; i++)
+    for (int j = i + lane; j < nx; j += 64) pair_x[i * nx - i * (i - 1) / 2 + (j - i)] = (unsigned short)(i | (j << 8));
+  for (int i = 0; i < nu; i++)
+    for (int j = i + lane; j < nu; j += 64) pair_u[i * nu - i * (i - 1) / 2 + (j - i)] = (unsigned short)(i | (j << 8));
   // operands that stay in registers for all of the wavefront's knots: A, B (Jacobian sweep), Q, R (y0 = Q x, R u) as A operands
   double opA[2][8], opB[2][4], qa[2][8], ra[4];
 #pragma unroll
@@ -1458,31 +1463,65 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
                         LqModel::cost_from_parts(sx[2 * i], su[2 * j + 1]) + LqModel::cost_from_parts(sx[2 * i + 1], su[2 * j + 1]);
       D[oCXU + i + nx * j] = v4 / (4 * kEps * kEps);
     }
-    // ---- cxx, cuu: the upper triangle, four sign combinations per pair (finite_diff.h:67-86); a pass = 16 points = 4 pairs ----
+    // ---- cxx, cuu: the upper triangle, four sign combinations per pair (finite_diff.h:67-86).  A pass = 16 PAIRS: lane (g, p) evaluates its
+    // eight (four) rows of Q p for all four points of pair p -- the two columns of Q are fetched once for the four --, pp, mp, pm, mm ----
     auto hessian = [&](auto on_x, int n, int oH, double other) __attribute__((always_inline)) {
       constexpr bool X = decltype(on_x)::value;
-      const int npts = 2 * n * (n + 1);
-      int pi = 0, prem = p >> 2;  // this lane's pair (i, i + rem), advanced incrementally
-      auto normalise = [&](int& i, int& rem) __attribute__((always_inline)) {
-        while (i < n && rem >= n - i) {
-          rem -= n - i;
-          i++;
+      constexpr int NR = X ? 8 : 4;           // rows per lane
+      constexpr int LD = X ? GN : GM;
+      const double* Mc = X ? Qc : Rc;
+      const double* zk = X ? xk : uk;
+      const double* y0k = X ? y0s : yu0s;
+      const unsigned short* tab = X ? pair_x : pair_u;
+      const int npairs = n * (n + 1) / 2;
+      constexpr double inv4e2 = 1.0 / (4 * kEps * kEps);  // (the quotient of finite_diff.h:84 as a product: <= 1 ulp of an entry, as derivatives.hpp does)
+      for (int base = 0; base < npairs; base += 16) {
+        const int q = base + p;
+        const bool valid = q < npairs;
+        const unsigned ij = tab[valid ? q : 0];
+        const int i = ij & 0xff, j = ij >> 8;
+        const bool diag = i == j;
+        const double x1 = zk[i], x2 = zk[j];
+        // the perturbations as they are applied: +-eps on component i, then +-eps on component j (the same component on the diagonal)
+        const double p1p = x1 + kEps, p1m = x1 - kEps;
+        double del1[4], del2[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const double first = (c & 1) ? p1m : p1p, d2 = (c & 2) ? -kEps : kEps;
+          del1[c] = (diag ? first + d2 : first) - x1;
+          del2[c] = diag ? 0.0 : (x2 + d2) - x2;
         }
-      };
-      normalise(pi, prem);
-      for (int base = 0; base < npts; base += 16) {
-        const int e = base + p;
-        const int ti = (e < npts) ? pi : -1, tj = (e < npts) ? pi + prem : -1;
-        const double d1 = (e & 1) ? -kEps : kEps, d2 = (e & 2) ? -kEps : kEps;
-        prem += 4;  // the next pass's pair
-        normalise(pi, prem);
-        const double f = X ? form_x(ti, d1, tj, d2) : form_u(ti, d1, tj, d2);
-        const double fv = X ? LqModel::cost_from_parts(f, other) : LqModel::cost_from_parts(other, f);
-        const double f0 = quad_bcast<0>(fv), f1 = quad_bcast<1>(fv), f2 = quad_bcast<2>(fv), f3 = quad_bcast<3>(fv);
-        if (e < npts && (e & 3) == 0 && g == 0) {
-          const double val = (f0 - f1 - f2 + f3) / (4 * kEps * kEps);
-          D[oH + ti + n * tj] = val;
-          D[oH + tj + n * ti] = val;
+        const double2_t* q1 = reinterpret_cast<const double2_t*>(&Mc[i * LD + NR * g]);
+        const double2_t* q2 = reinterpret_cast<const double2_t*>(&Mc[j * LD + NR * g]);
+        double part[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k2 = 0; k2 < NR / 2; k2++) {
+          const double2_t a = q1[k2], cc = q2[k2];
+#pragma unroll
+          for (int h2 = 0; h2 < 2; h2++) {
+            const int k = 2 * k2 + h2;
+            const double zb = X ? xb[k] : ub[k & 3], yk = X ? y0[k] : yu0[k & 3];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+              const double y = __builtin_fma(del2[c], cc[h2], __builtin_fma(del1[c], a[h2], yk));
+              part[c] = __builtin_fma(zb, y, part[c]);
+            }
+          }
+        }
+        const int m1 = X ? permq(i) : permr(i), m2 = X ? permq(j) : permr(j);
+        const double Mii = Mc[i * LD + m1], Mij = Mc[j * LD + m1], Mji = Mc[i * LD + m2], Mjj = Mc[j * LD + m2], yi = y0k[i], yj = y0k[j];
+        double fv[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const double Y1 = __builtin_fma(del2[c], Mij, __builtin_fma(del1[c], Mii, yi));  // (M p)[i]
+          const double Y2 = __builtin_fma(del2[c], Mjj, __builtin_fma(del1[c], Mji, yj));  // (M p)[j]
+          const double f = __builtin_fma(del2[c], Y2, __builtin_fma(del1[c], Y1, group_sum(part[c])));
+          fv[c] = X ? LqModel::cost_from_parts(f, other) : LqModel::cost_from_parts(other, f);
+        }
+        if (valid && g == 0) {
+          const double val = (fv[0] - fv[1] - fv[2] + fv[3]) * inv4e2;
+          D[oH + i + n * j] = val;
+          D[oH + j + n * i] = val;
         }
       }
     };
