@@ -524,8 +524,9 @@ def main():
             fd_flops_dense_forms = (2 * nq + 2 * nq * (nq + 1)) * 2 * nq * nq + (2 * mq + 2 * mq * (mq + 1)) * 2 * mq * mq + 2 * (nq + mq) * 2 * nq * (nq + mq)
             # ... and k_derivatives_lq (the default since round 5) evaluates a perturbed point's form from what moved: Q p = Q x + delta_i Q[:,i] + delta_j Q[:,j]
             # (4n flops), x . (Q p) (2n), the two perturbed rows (~12); Q x and R u once per knot; the Jacobian sweep stays dense
+            # (A x + B u once per knot as well, the Jacobian sweep's points from it: 4n flops each)
             fd_flops = ((2 * nq + 2 * nq * (nq + 1)) * (6 * nq + 12) + (2 * mq + 2 * mq * (mq + 1)) * (6 * mq + 12) + 2 * (nq * nq + mq * mq)
-                        + 2 * (nq + mq) * 2 * nq * (nq + mq))
+                        + 2 * nq * (nq + mq) + 2 * (nq + mq) * 4 * nq)
             if stq.get("derivatives", {}).get("kernel") != "k_derivatives_lq":
                 fd_flops = fd_flops_dense_forms
             fd_dense = 2 * (nq + mq) * 2 * nq * (nq + mq) + (2 * nq + 2 * mq + 2 * nq * (nq + 1) + 2 * mq * (mq + 1) + 4 * nq * mq) * 2 * (nq * nq + mq * mq)

@@ -1238,10 +1238,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // 1 / 4 eps^2 = 2.5e5 like every other rounding of f), the records with the oracle's to the tolerance they already had.
 // One wavefront sweeps kLqKnotsPerWave knots of a trajectory (Q, R column-wise in LDS, the Jacobian operands in registers: loaded
 // once per wavefront instead of once per knot); lane (g = l >> 4, p = l & 15) holds rows g + 4 r (+ 16) of point p's Q p, 16 points
-// per pass.  The Jacobian sweep stays dense on the matrix cores (96 points).  Knot T (final_cost, the reference's conventions there)
-// is k_derivatives_g's (t_only).  ILQR_ROUTE_LQ_DENSE_FD keeps the dense sweep for every knot (cross-check: tests/test_gpu_lq_end_to_end.py).
+// pairs (= 64 points: the four sign combinations of a pair share its two columns) per pass.  The Jacobian sweep likewise: A x + B u once per
+// knot, a point's image from it and one column.  Three wavefronts per SIMD (13 KB of LDS, <= 168 registers: 40.8 against 44.5 ms at two).
+// Knot T (final_cost, the reference's conventions there) is k_derivatives_g's (t_only).  ILQR_ROUTE_LQ_DENSE_FD keeps the dense sweep for every knot (cross-check: tests/test_gpu_lq_end_to_end.py).
 constexpr int kLqKnotsPerWave = 8;
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_derivatives_lq(BatchView v, LqModel model, int force) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_derivatives_lq(BatchView v, LqModel model, int force) {
   static_assert(GN == 32 && GM == 16, "operand blocks below are written for a 32 x 16 model");
   typedef double double4_t __attribute__((ext_vector_type(4)));
   typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -1277,20 +1278,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
     for (int j = i + lane; j < nx; j += 64) pair_x[i * nx - i * (i - 1) / 2 + (j - i)] = (unsigned short)(i | (j << 8));
   for (int i = 0; i < nu; i++)
     for (int j = i + lane; j < nu; j += 64) pair_u[i * nu - i * (i - 1) / 2 + (j - i)] = (unsigned short)(i | (j << 8));
-  // operands that stay in registers for all of the wavefront's knots: A, B (Jacobian sweep), Q, R (y0 = Q x, R u) as A operands
-  double opA[2][8], opB[2][4], qa[2][8], ra[4];
-#pragma unroll
-  for (int ti = 0; ti < 2; ti++) {
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) {
-      opA[ti][ks] = model.A[(16 * ti + p) * GN + 4 * ks + g];
-      qa[ti][ks] = model.Q[(16 * ti + p) * GN + 4 * ks + g];
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) opB[ti][ks] = model.Bm[(16 * ti + p) * GM + 4 * ks + g];
-  }
-#pragma unroll
-  for (int ks = 0; ks < 4; ks++) ra[ks] = model.R[p * GM + 4 * ks + g];
+  // (A, B, Q, R as matrix-core A operands -- 44 doubles per lane -- are fetched where a knot's two dense products use them, not kept: the
+  //  registers they would hold for the whole wavefront are what a third wavefront per SIMD needs)
   auto group_sum = [](double part) __attribute__((always_inline)) {  // over the four lane groups of a point (result in all four)
     part += __shfl_xor(part, 16, 64);
     part += __shfl_xor(part, 32, 64);
@@ -1313,40 +1302,56 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) ub[ks] = uk[4 * ks + g];
 
-    // ---- fx, fu: F(P) = P + dt (A Px + B Pu), 16 points at a time on the matrix cores (as k_derivatives_g) ----
+    // ---- fx, fu (finite_diff.h:35-47): F(p) = p + dt (A p_x + B p_u).  dx0 = A x + B u once per knot on the matrix cores; a point that
+    // differs from the knot in one component by delta has A p_x + B p_u = dx0 + delta A[:, i] (or delta B[:, j]): rows g + 4 r (+ 16) of 16
+    // points per pass, the column read from the model's matrix (L2-resident: 8 KB) ----
     {
+      double4_t acc0[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+      {
+        double opA[2][8], opB[2][4];
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++) {
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) opA[ti][ks] = model.A[(16 * ti + p) * GN + 4 * ks + g];
+#pragma unroll
+          for (int ks = 0; ks < 4; ks++) opB[ti][ks] = model.Bm[(16 * ti + p) * GM + 4 * ks + g];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+          for (int ti = 0; ti < 2; ti++) acc0[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[ti][ks], xb[ks], acc0[ti], 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+          for (int ti = 0; ti < 2; ti++) acc0[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(opB[ti][ks], ub[ks], acc0[ti], 0, 0, 0);
+      }
+      constexpr double inv2e = 1.0 / (2 * kEps);  // (the quotient of finite_diff.h:44 as a product, as derivatives.hpp does)
       const int E = 2 * (nx + nu);
       for (int base = 0; base < E; base += 16) {
         const int e = base + p;
         const bool valid = e < E;
-        const int var = e >> 1;
-        const double d = (e & 1) ? -kEps : kEps;
-        const int ix = (valid && var < nx) ? var : -1, iu = (valid && var >= nx) ? var - nx : -1;
-        double bx[8], bu[4];
+        const int var = valid ? (e >> 1) : 0;
+        const bool isx = var < nx;
+        const int idx = isx ? var : var - nx;
+        const double z = isx ? xk[idx] : uk[idx];
+        const double pz = z + ((e & 1) ? -kEps : kEps);
+        const double del = valid ? pz - z : 0.0;
+        const double* __restrict__ colp = isx ? model.A + idx : model.Bm + idx;  // element (row, idx): + row * GN or row * GM
+        const int ld = isx ? GN : GM;
+        double cv[8];
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++) bx[ks] = (4 * ks + g == ix) ? xb[ks] + d : xb[ks];
+        for (int k = 0; k < 8; k++) cv[k] = colp[(16 * (k >> 2) + 4 * (k & 3) + g) * ld];
+        double* col = isx ? D + oFX + nx * idx : D + oFU + nx * idx;
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) bu[ks] = (4 * ks + g == iu) ? ub[ks] + d : ub[ks];
-        double4_t acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++)
-#pragma unroll
-          for (int ti = 0; ti < 2; ti++) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[ti][ks], bx[ks], acc[ti], 0, 0, 0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++)
-#pragma unroll
-          for (int ti = 0; ti < 2; ti++) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(opB[ti][ks], bu[ks], acc[ti], 0, 0, 0);
-        double* col = (var < nx) ? D + oFX + nx * var : D + oFU + nx * (var - nx);
-#pragma unroll
-        for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const double F = bx[4 * ti + r] + acc[ti][r] * v.dt;  // include/model.h:12-15
-            const double other = dpp_swap1(F);                    // the point next door: e ^ 1
-            const double val = (F - other) / (2 * kEps);
-            const int row = 16 * ti + g + 4 * r;
-            if (valid && !(e & 1) && row < nx) col[row] = val;
-          }
+        for (int k = 0; k < 8; k++) {
+          const int row = 16 * (k >> 2) + 4 * (k & 3) + g;
+          const double dxr = __builtin_fma(del, cv[k], acc0[k >> 2][k & 3]);
+          const double pr = (isx && row == idx) ? pz : xb[k];
+          const double F = pr + dxr * v.dt;          // include/model.h:12-15
+          const double other = dpp_swap1(F);          // the point next door: e ^ 1
+          const double val = (F - other) * inv2e;
+          if (valid && !(e & 1) && row < nx) col[row] = val;
+        }
       }
     }
 
@@ -1354,6 +1359,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
     double y0[8], yu0[4];
     {
       double4_t ya[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, yu = {0.0, 0.0, 0.0, 0.0};
+      double qa[2][8], ra[4];
+#pragma unroll
+      for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) qa[ti][ks] = model.Q[(16 * ti + p) * GN + 4 * ks + g];
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) ra[ks] = model.R[p * GM + 4 * ks + g];
 #pragma unroll
       for (int ks = 0; ks < 8; ks++)
 #pragma unroll
