@@ -518,7 +518,7 @@ def publish(name, r, **meta):
     return doc[name]
 
 
-def assert_walk(r, n_iters, min_plain_it0=0.95, tied_div=16, over10_div=24):
+def assert_walk(r, n_iters, min_plain_it0=0.95, tied_div=16, over10_div=24, min_plain=None, max_on_records=0.30):
     """The bounds every full-size walk is held to: every sampled trajectory checked in every iteration it ran; at iteration 0
     (lambda = 1) at least 95 % of them within the PLAIN tolerance -- end to end, or stage by stage (records to tol, and the
     oracle's backward pass on the device's records to tol: the two sides' finite differences are different realisations of
@@ -530,6 +530,15 @@ def assert_walk(r, n_iters, min_plain_it0=0.95, tied_div=16, over10_div=24):
     assert r["cond_over10"] <= max(2, r["checked"] // over10_div), r["cond_over10"]
     ties = sum(p["knife_edge"] + p["search_tie"] + p["stop_tie"] for p in r["per_iter"])
     assert ties <= max(2, r["checked"] // tied_div), ties
+    # The strict END-TO-END share over the whole walk, kept apart from the stage-by-stage one: it may not fall below the baseline recorded
+    # for this configuration (profiles/parity_r05.json minus a sampling margin; the caller states it), and the share that needs the
+    # "plain on the device's records" argument is bounded -- that bin must not quietly absorb a regression of the kernels.
+    n_all = max(1, sum(p["n"] for p in r["per_iter"]))
+    plain = sum(p["plain"] for p in r["per_iter"]) / n_all
+    on_records = sum(p["plain_on_device_records"] for p in r["per_iter"]) / n_all
+    if min_plain is not None:
+        assert plain >= min_plain, ("end-to-end plain share below the recorded baseline", plain, min_plain)
+    assert on_records <= max_on_records, ("plain-on-device-records share", on_records, max_on_records)
 
 
 class Sampled:

@@ -229,7 +229,7 @@ def test_lq_full_size_properties(oracle, lim):
     NIT = 10
     r = sampled_walk(oracle, oracle.Model("lq", lq=mats, u_lim=lim), g, x0, np.zeros((B, T, m)), DT, NIT, n_sample=24)
     print("configs[4] lim", lim, "sampled walk:", publish("configs[4] LQ n=32 m=16 T=200 B=8192 +-%g fp64 (finite differences)" % lim, r, B=B, T=T, u_lim=lim, n_sample=len(r["sel"])))
-    assert_walk(r, NIT)
+    assert_walk(r, NIT, min_plain=0.93, max_on_records=0.05)  # (recorded: 0.97 - 1.00 plain, nothing on the device's records)
     c0 = g.init_traj(x0, np.zeros((B, T, m)))
     g.iterate(2)
     cost = g.cost()

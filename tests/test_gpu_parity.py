@@ -314,7 +314,7 @@ def test_full_size_properties(oracle):
     # 25 iterations: the regime bench.py times (its iterations 6-25), every one of them against the oracle
     r = sampled_walk(oracle, oracle.Model("acrobot", u_lim=lim), g, x0, np.zeros((B, T, 1)), DT, 25)
     print("configs[2] sampled walk:", publish("configs[2] acrobot T=499 B=4096 +-1.5 fp64 (k_solve_hex, one tile per CU)", r, B=B, T=T, u_lim=lim, n_sample=len(r["sel"])))
-    assert_walk(r, 25)
+    assert_walk(r, 25, min_plain=0.70)  # (recorded: 0.77)
     x0[1] = x0[0]
     x0[B - 1] = x0[0]  # duplicates across tiles / waves
     c0 = g.init_traj(x0, np.zeros((B, T, 1)))
@@ -345,7 +345,7 @@ def test_config1_full_size(oracle):
     u0 = np.zeros((B, T, 1))
     r = sampled_walk(oracle, oracle.Model("acrobot", u_lim=lim), g, x0, u0, DT, 25)
     print("configs[1] sampled walk:", publish("configs[1] acrobot T=499 B=1024 +-5 fp64", r, B=B, T=T, u_lim=lim, n_sample=len(r["sel"])))
-    assert_walk(r, 25)
+    assert_walk(r, 25, min_plain=0.70)  # (recorded: 0.78)
     c0 = g.init_traj(x0, u0)
     g.iterate(3)
     cost = g.cost()
@@ -387,7 +387,7 @@ def test_saturated_batch_wide_route_25_iterations(oracle):
     x0 = acrobot_x0(B)
     r = sampled_walk(oracle, oracle.Model("acrobot", u_lim=lim), g, x0, np.zeros((B, T, 1)), DT, 25)
     print("wide route sampled walk:", publish("saturated acrobot T=499 B=16384 +-1.5 fp64 (k_solve_wide)", r, B=B, T=T, u_lim=lim, n_sample=len(r["sel"])))
-    assert_walk(r, 25)
+    assert_walk(r, 25, min_plain=0.66)  # (recorded: 0.74)
     g.close()
 
 
@@ -407,6 +407,8 @@ def test_bench_saturated_batch_two_wide_tiles_per_cu_10_iterations(oracle, dtype
     r = sampled_walk(oracle, oracle.Model("acrobot", u_lim=lim), g, x0, np.zeros((B, T, 1)), DT, NIT, precision=dtype)
     print("B=32768 %s sampled walk:" % dtype, publish("bench saturated acrobot T=499 B=32768 +-%g %s (k_solve_wide, two tiles per CU)" % (lim, "fp64" if dtype == "f64" else "fp32"),
                                                     r, B=B, T=T, u_lim=lim, n_sample=len(r["sel"]), precision=dtype))
-    assert_walk(r, NIT, min_plain_it0=0.95 if dtype == "f64" else 0.8)
+    # (10 iterations: the first, where 60 % of the fp64 trajectories need the stage-by-stage argument, weighs 2.5 x what it does in a 25-iteration
+    #  walk.  Recorded: fp64 0.67 plain / 0.31 on the device's records)
+    assert_walk(r, NIT, min_plain_it0=0.95 if dtype == "f64" else 0.8, min_plain=0.58 if dtype == "f64" else 0.75, max_on_records=0.42)
     assert r["unresolved"] == 0, r["unresolved"]
     g.close()
