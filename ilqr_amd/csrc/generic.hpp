@@ -1235,7 +1235,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // -- the same function value at the same point (delta = the perturbation as it was actually applied, fl(fl(x_i + d1) + d2) - x_i on the
 // diagonal, finite_diff.h:67-86), from 2 n + 8 multiply-adds instead of n^2; the differences of these values are then taken exactly
 // as before.  The values agree with the dense evaluation to rounding (1e-16 of |x'Qx|, which the second difference amplifies by
-// 1 / 4 eps^2 = 2.5e5 like every other rounding of f), the records with the oracle's to the tolerance they already had.
+// 1 / 4 eps^2 = 2.5e5 like every other rounding of f), the records with the reference's to the tolerance they already had.
 // One wavefront sweeps kLqKnotsPerWave knots of a trajectory (Q, R column-wise in LDS, the Jacobian operands in registers: loaded
 // once per wavefront instead of once per knot); lane (g = l >> 4, p = l & 15) holds rows g + 4 r (+ 16) of point p's Q p, 16 points
 // pairs (= 64 points: the four sign combinations of a pair share its two columns) per pass.  The Jacobian sweep likewise: A x + B u once per
