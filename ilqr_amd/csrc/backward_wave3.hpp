@@ -272,6 +272,52 @@ __device__ int w3_box_qp_fast(int m, LDS& L, int lane, double* Xw, NsState& ns, 
   return result;
 }
 
+// m <= 2 (what most models outside configs[4] have: one or two controls): the box-QP as the thread-level solvers of boxqp.hpp that the
+// nx = 4 kernels use (box_qp_scalar / box_qp2: registers, no LDS round trips), every lane on the same values; the outputs go where
+// w_box_qp leaves its own (L.x, L.vfree, the compact R^-1 R^-T in L.Minv()), so the step continues exactly as after the literal path.
+// A sixteen-lane wave-level QP for a 1 x 1 or 2 x 2 block was 10-15 K cycles of a 30 K-cycle step at n = 6, m = 2.
+template <class LDS>
+__device__ __forceinline__ int w3_box_qp_small(int m, LDS& L, int lane, int& nfR_out, int fixes) {
+  const double* Qm = L.QuuF();
+  int result, nfR;
+  if (m == 1) {
+    double x;
+    int fr;
+    double minv;
+    result = box_qp_scalar(Qm[0], L.Qu[0], L.kprev[0], L.lo[0], L.hi[0], x, fr, minv);
+    // (box_qp_scalar has no "failed factorisation" exit: Q <= 0 with the opt-in fix ends the QP as boxqp.cpp:85-88 would with info() checked)
+    if ((fixes & 2) && fr && !(Qm[0] > 0.0)) result = -1;
+    nfR = fr ? 1 : 0;
+    lds_sync();
+    if (lane == 0) {
+      L.x[0] = x;
+      L.vfree[0] = fr;
+      L.Minv()[0] = minv;
+    }
+  } else {
+    const double Q2[4] = {Qm[0], Qm[1], Qm[LDM], Qm[1 + LDM]};
+    const double c2[2] = {L.Qu[0], L.Qu[1]}, x02[2] = {L.kprev[0], L.kprev[1]}, lo2[2] = {L.lo[0], L.lo[1]}, hi2[2] = {L.hi[0], L.hi[1]};
+    BoxQP2Result<double> r;
+    box_qp2(Q2, c2, x02, lo2, hi2, r, (fixes & 2) != 0);
+    result = r.result;
+    nfR = r.nfR;
+    lds_sync();
+    if (lane == 0) {
+      L.x[0] = r.x[0];
+      L.x[1] = r.x[1];
+      L.vfree[0] = r.free0 ? 1 : 0;
+      L.vfree[1] = r.free1 ? 1 : 0;
+      L.Minv()[0] = r.m00;
+      L.Minv()[1] = r.m01;
+      L.Minv()[LDM] = r.m01;
+      L.Minv()[1 + LDM] = r.m11;
+    }
+  }
+  lds_sync();
+  nfR_out = nfR;
+  return result;
+}
+
 // n <= 16 NT, m <= 16.  Arguments as k_backward_w2; LQF: const_rec holds TWO records (the constant blocks of the knots t < T,
 // then knot T's) and v.D is not touched.
 template <int NT, bool FULL, bool LQF>
@@ -533,8 +579,13 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w3(BatchView v
       unsigned free_mask = 0;
       int nfR = 0, nfact = 0;
       bool slow = false;
-      int result = w3_box_qp_fast(m, L, lane, Xw, ns, Xm, free_mask);
-      if (result == kQpBail) {
+      int result;
+      if (m <= 2) {  // one or two controls: the scalar solvers (w3_box_qp_small); K by the literal path's code below
+        slow = true;
+        nfact = -1;  // (no warm start for the matrix-core refinement is kept on this route)
+        result = w3_box_qp_small(m, L, lane, nfR, sp.fixes);
+        free_mask = (unsigned)__ballot(lane < m && L.vfree[lane]);
+      } else if ((result = w3_box_qp_fast(m, L, lane, Xw, ns, Xm, free_mask)) == kQpBail) {
         slow = true;
         ns.valid = false;
         ILQR_W3COUNT(1, 1)
