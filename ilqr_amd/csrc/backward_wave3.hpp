@@ -284,10 +284,17 @@ __device__ __forceinline__ int w3_box_qp_small(int m, LDS& L, int lane, int& nfR
     double x;
     int fr;
     double minv;
-    result = box_qp_scalar(Qm[0], L.Qu[0], L.kprev[0], L.lo[0], L.hi[0], x, fr, minv);
-    // (box_qp_scalar has no "failed factorisation" exit: Q <= 0 with the opt-in fix ends the QP as boxqp.cpp:85-88 would with info() checked)
-    if ((fixes & 2) && fr && !(Qm[0] > 0.0)) result = -1;
-    nfR = fr ? 1 : 0;
+    const double Q1 = Qm[0], c1 = L.Qu[0], k0 = L.kprev[0], lo1 = L.lo[0], hi1 = L.hi[0];
+    result = box_qp_scalar(Q1, c1, k0, lo1, hi1, x, fr, minv);
+    if (fixes & 2) {  // opt-in: a failed factorisation ends the QP (boxqp.cpp:85-88 with info() checked).  The 1 x 1 block is factored in
+      // iteration 0 unless the start is clamped there (:62-77)
+      const double xs0 = (hi1 < ((k0 < lo1) ? lo1 : k0)) ? hi1 : ((k0 < lo1) ? lo1 : k0), g0 = Q1 * xs0 + c1;
+      const bool clamped0 = (fabs(xs0 - lo1) < kClampTol && g0 > 0) || (fabs(xs0 - hi1) < kClampTol && g0 < 0);
+      if (!clamped0 && !(Q1 > 0.0)) result = -1;
+    }
+    nfR = 1;  // (the factor the solver holds at its exit is 1 x 1 whenever one was formed; nothing free: K = 0 below)
+    lds_sync();
+    for (int e = lane; e < LDM * WM; e += 64) L.Minv()[e] = 0.0;  // (the tile is read whole by the K product: S's leftovers are not zeros)
     lds_sync();
     if (lane == 0) {
       L.x[0] = x;
@@ -301,6 +308,8 @@ __device__ __forceinline__ int w3_box_qp_small(int m, LDS& L, int lane, int& nfR
     box_qp2(Q2, c2, x02, lo2, hi2, r, (fixes & 2) != 0);
     result = r.result;
     nfR = r.nfR;
+    lds_sync();
+    for (int e = lane; e < LDM * WM; e += 64) L.Minv()[e] = 0.0;
     lds_sync();
     if (lane == 0) {
       L.x[0] = r.x[0];
@@ -580,7 +589,7 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w3(BatchView v
       int nfR = 0, nfact = 0;
       bool slow = false;
       int result;
-      if (m <= 2) {  // one or two controls: the scalar solvers (w3_box_qp_small); K by the literal path's code below
+      if (!FULL && m <= 2) {  // one or two controls: the scalar solvers (w3_box_qp_small); K by the literal path's code below
         slow = true;
         nfact = -1;  // (no warm start for the matrix-core refinement is kept on this route)
         result = w3_box_qp_small(m, L, lane, nfR, sp.fixes);

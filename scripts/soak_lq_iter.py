@@ -64,7 +64,12 @@ def main():
         rel = np.abs(a["cost"] - b["cost"]) / np.maximum(np.abs(b["cost"]), 1e-300)
         du = np.abs(a["us"] - b["us"]).reshape(B, -1).max(axis=1) if T * m else np.zeros(B)
         dk = np.abs(a["k"] - b["k"]).reshape(B, -1).max(axis=1) if T * m else np.zeros(B)  # (a knife edge in the LAST backward pass has not reached us yet)
-        moved = (rel > 1e-8) | (du > 1e-7) | (dk > 1e-7 * max(1.0, np.abs(b["k"]).max()))
+        # (... or shows only in K: a control within 1e-4 of a bound is clamped on one side -- its gain row exactly zero, ilqr_core.cpp:373-385 --
+        #  and free on the other, with k the same to 1e-8)
+        za = (np.abs(a["K"]).max(axis=-1) == 0) if T * m else np.zeros((B, 0, 0), dtype=bool)
+        zb = (np.abs(b["K"]).max(axis=-1) == 0) if T * m else np.zeros((B, 0, 0), dtype=bool)
+        row_flip = (za != zb).reshape(B, -1).any(axis=1) if T * m else np.zeros(B, dtype=bool)
+        moved = (rel > 1e-8) | (du > 1e-7) | (dk > 1e-7 * max(1.0, np.abs(b["k"]).max())) | row_flip
         ok = ~moved
         for key in ("xs", "us", "k", "K"):
             scale = max(1.0, np.abs(b[key]).max())
