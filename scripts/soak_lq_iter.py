@@ -37,7 +37,7 @@ def main():
 
         def spd(k, s):
             W = rng.normal(size=(k, k)) / np.sqrt(k)
-            return s * (np.eye(k) + 0.25 * (W + W.T))
+            return s * (np.eye(k) + 0.25 * (W @ W.T))  # positive definite whatever the draw (an indefinite weight makes the problem unbounded and every rounding decisive)
         mats = (A, Bm, spd(n, 1.0), spd(m, 0.2), spd(n, 3.0))
         x0 = rng.uniform(-1, 1, (B, n))
         u0 = rng.normal(size=(B, T, m)) * 0.2

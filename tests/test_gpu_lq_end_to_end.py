@@ -89,6 +89,9 @@ def test_lq_stages_match_oracle(oracle, n, m, B, T, dense):
         xa, ua, ca = oracle_closed_loop(oracle, om, x0, xs_o, us_o, ro["k"], Ko, ALPHAS[a])
         fin = np.isfinite(ca)
         assert np.max(np.abs(costs[fin, a] - ca[fin]) / np.abs(ca[fin])) < 1e-9, a
+        # the matrix-core search keeps its eleven rollouts whole: ilqr_get_candidate hands them out (knot for knot the oracle's)
+        xc, uc = g.candidate(a)
+        assert relerr(xc[fin], xa[fin]) < 1e-9 and relerr_abs(uc[fin], ua[fin], 1e-3) < 1e-9, a
     g.close()
 
 

@@ -365,7 +365,7 @@ def test_saturated_batch_wide_route_against_the_oracle(oracle):
     x0 = acrobot_x0(B)
     u0 = np.zeros((B, T, 1))
     r = sampled_walk(oracle, oracle.Model("acrobot", u_lim=lim), g, x0, u0, DT, 2)
-    assert_walk(r, 2)
+    assert_walk(r, 2, max_on_records=0.65)  # (two iterations: the first, where 60 % need the stage-by-stage argument, is half of the walk)
     cost_big = g.cost()  # (two free-running iterations, left by the walk)
     st_big, it_big, al_big = g.status()
     g.close()
