@@ -76,7 +76,7 @@ def main():
             if ok.any() and not np.abs(a[key][ok] - b[key][ok]).max() <= 1e-6 * scale:
                 print("FAIL", key, np.abs(a[key][ok] - b[key][ok]).max(), scale, desc)
                 return 1
-        if moved.any() and not (rel[moved].max() < 1e-2 and du[moved].max() < 0.5 * lim + 1e-2):
+        if moved.any() and not rel[moved].max() < 1e-2:  # (its controls may sit anywhere in the box: with more controls than states many are equivalent)
             print("FAIL a moved trajectory is far off:", rel[moved].max(), du[moved].max(), desc)
             return 1
         # whole solves: the same end cost; a different STATUS at the same cost is a termination tie (the absolute stopping tests met an
