@@ -1230,22 +1230,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // k_derivatives_g evaluates every perturbed point of the cost Hessians DENSELY: Y = Q P on the matrix cores for 16 points at a time,
 // 2 177 + 577 matrix-vector products per knot, 88 % of a finite-difference iteration of configs[4] (and fp64 matrix instructions run
 // at the VALU's rate on gfx950: scripts/ubench/coissue.hip).  But a perturbed point differs from the knot in ONE or TWO components, and
-// the model has said that its cost is a quadratic form (kQuadraticCostX, cost_u_matrix): with y0 = Q x formed once per knot,
-//     Q p = y0 + delta_i Q[:, i] + delta_j Q[:, j],      p'Q p = x . (Q p) + delta_i (Q p)_i + delta_j (Q p)_j
+// the model has said that its cost is a quadratic form (kQuadraticCostX, cost_u_matrix): with y = Q x and z = Q'x formed once per knot,
+//     (Q p)_i = y_i + delta_i Q[i][i] + delta_j Q[i][j],      x . (Q p) = x . y + delta_i z_i + delta_j z_j,
+//     p'Q p = x . (Q p) + delta_i (Q p)_i + delta_j (Q p)_j
 // -- the same function value at the same point (delta = the perturbation as it was actually applied, fl(fl(x_i + d1) + d2) - x_i on the
-// diagonal, finite_diff.h:67-86), from 2 n + 8 multiply-adds instead of n^2; the differences of these values are then taken exactly
+// diagonal, finite_diff.h:67-86), from a dozen multiply-adds instead of n^2; the differences of these values are then taken exactly
 // as before.  The values agree with the dense evaluation to rounding (1e-16 of |x'Qx|, which the second difference amplifies by
 // 1 / 4 eps^2 = 2.5e5 like every other rounding of f), the records with the reference's to the tolerance they already had.
-// One wavefront sweeps kLqKnotsPerWave knots of a trajectory (Q, R column-wise in LDS, the Jacobian operands in registers: loaded
-// once per wavefront instead of once per knot); lane (g = l >> 4, p = l & 15) holds rows g + 4 r (+ 16) of point p's Q p, 16 points
-// pairs (= 64 points: the four sign combinations of a pair share its two columns) per pass.  The Jacobian sweep likewise: A x + B u once per
-// knot, a point's image from it and one column.  Three wavefronts per SIMD (13 KB of LDS, <= 168 registers: 40.8 against 44.5 ms at two).
+// One wavefront sweeps kLqKnotsPerWave knots of a trajectory (Q, R in LDS, padded so that rows and columns both read without bank
+// conflicts: loaded once per wavefront instead of once per knot).  A point is ONE lane's work: the 2 n singles in one pass, the
+// Hessians' upper triangles as 8 x 8 blocks of pairs (lane = (i & 7) + 8 (j & 7): both mirror images of an entry leave as 64-byte
+// runs), the four sign combinations of a pair on its lane.  The Jacobian sweep: A x + B u once per knot on the matrix cores, a point's
+// image from it and one column.  Three wavefronts per SIMD (12.5 KB of LDS, <= 168 registers).
 // Knot T (final_cost, the reference's conventions there) is k_derivatives_g's (t_only).  ILQR_ROUTE_LQ_DENSE_FD keeps the dense sweep for every knot (cross-check: tests/test_gpu_lq_end_to_end.py).
 constexpr int kLqKnotsPerWave = 8;
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_derivatives_lq(BatchView v, LqModel model, int force) {
   static_assert(GN == 32 && GM == 16, "operand blocks below are written for a 32 x 16 model");
   typedef double double4_t __attribute__((ext_vector_type(4)));
-  typedef double double2_t __attribute__((ext_vector_type(2)));
   const int nx = model.nx, nu = model.nu, T = v.T;
   const int lane = threadIdx.x, g = lane >> 4, p = lane & 15;
   const int nchunk = (T + kLqKnotsPerWave - 1) / kLqKnotsPerWave;  // knots 0 .. T-1
@@ -1254,37 +1255,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   if (!(force || (v.status[b] == 0 && v.flg_change[b]))) return;
   const int oFX = 0, oFU = oFX + nx * nx, oCX = oFU + nx * nu, oCXX = oCX + nx, oCXU = oCXX + nx * nx, oCU = oCXU + nx * nu,
             oCUU = oCU + nu, REC = oCUU + nu * nu;
-  // Qc[col][8 g + 4 ib + r] = Q[16 ib + 4 r + g][col]: the eight rows of a column that lane group g holds are 64 contiguous bytes;
-  // Rc[col][4 g + r] = R[4 r + g][col]
-  __shared__ __attribute__((aligned(16))) double Qc[GN * GN];
-  __shared__ __attribute__((aligned(16))) double Rc[GM * GM];
-  __shared__ double xk[GN], uk[GM], y0s[GN], yu0s[GM], sx[2 * GN], su[2 * GM];
-  __shared__ unsigned short pair_x[GN * (GN + 1) / 2], pair_u[GM * (GM + 1) / 2];  // pair q of the upper triangle, row by row (finite_diff.h:70-71): i | j << 8
+  constexpr int LQ = GN + 1, LR = GM + 1;  // Qc[col * LQ + row] = Q[row][col]: a column across lanes is contiguous, a row has stride 33 doubles -- neither conflicts
+  __shared__ double Qc[GN * LQ], Rc[GM * LR];
+  __shared__ double xk[GN], uk[GM], y0s[GN], zxs[GN], yu0s[GM], zus[GM], sx[2 * GN], su[2 * GM];
   auto sync = []() __attribute__((always_inline)) {  // one wavefront: the LDS executes its operations in order; only the compiler must not reorder them
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
-  auto permq = [](int row) __attribute__((always_inline)) { return ((row & 3) << 3) | ((row >> 4) << 2) | ((row >> 2) & 3); };
-  auto permr = [](int row) __attribute__((always_inline)) { return ((row & 3) << 2) | (row >> 2); };
-  for (int e = lane; e < GN * GN; e += 64) {
-    const int row = e >> 5, col = e & 31;
-    Qc[col * GN + permq(row)] = model.Q[e];
-  }
-  for (int e = lane; e < GM * GM; e += 64) {
-    const int row = e >> 4, col = e & 15;
-    Rc[col * GM + permr(row)] = model.R[e];
-  }
-  for (int i = 0; i < nx; i++)
-    for (int j = i + lane; j < nx; j += 64) pair_x[i * nx - i * (i - 1) / 2 + (j - i)] = (unsigned short)(i | (j << 8));
-  for (int i = 0; i < nu; i++)
-    for (int j = i + lane; j < nu; j += 64) pair_u[i * nu - i * (i - 1) / 2 + (j - i)] = (unsigned short)(i | (j << 8));
-  // (A, B, Q, R as matrix-core A operands -- 44 doubles per lane -- are fetched where a knot's two dense products use them, not kept: the
-  //  registers they would hold for the whole wavefront are what a third wavefront per SIMD needs)
-  auto group_sum = [](double part) __attribute__((always_inline)) {  // over the four lane groups of a point (result in all four)
-    part += __shfl_xor(part, 16, 64);
-    part += __shfl_xor(part, 32, 64);
-    return part;
-  };
+  for (int e = lane; e < GN * GN; e += 64) Qc[(e & 31) * LQ + (e >> 5)] = model.Q[e];   // e = row * GN + col
+  for (int e = lane; e < GM * GM; e += 64) Rc[(e & 15) * LR + (e >> 4)] = model.R[e];
+  // (A, B as matrix-core A operands are fetched where a knot's dense product uses them, not kept: the registers they would hold for
+  //  the whole wavefront are what a third wavefront per SIMD needs)
 
   for (int t = t0; t < t0 + kLqKnotsPerWave && t < T; t++) {
     double* __restrict__ D = v.D + ((size_t)b * (T + 1) + t) * REC;
@@ -1355,112 +1336,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       }
     }
 
-    // ---- y0 = Q x, R u (dense, once per knot): rows g + 4 r (+ 16) on this lane, the same in every column ----
-    double y0[8], yu0[4];
+    // ---- y = Q x (lanes 0..31: one row each), z = Q'x (lanes 32..63: one column each); R u, R'u likewise on lanes 0..15, 16..31 ----
     {
-      double4_t ya[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, yu = {0.0, 0.0, 0.0, 0.0};
-      double qa[2][8], ra[4];
-#pragma unroll
-      for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) qa[ti][ks] = model.Q[(16 * ti + p) * GN + 4 * ks + g];
-#pragma unroll
-      for (int ks = 0; ks < 4; ks++) ra[ks] = model.R[p * GM + 4 * ks + g];
-#pragma unroll
-      for (int ks = 0; ks < 8; ks++)
-#pragma unroll
-        for (int ib = 0; ib < 2; ib++) ya[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[ib][ks], xb[ks], ya[ib], 0, 0, 0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ks++) yu = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[ks], ub[ks], yu, 0, 0, 0);
-#pragma unroll
-      for (int ib = 0; ib < 2; ib++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          y0[4 * ib + r] = ya[ib][r];
-          if (p == 0) y0s[16 * ib + 4 * r + g] = ya[ib][r];
-        }
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        yu0[r] = yu[r];
-        if (p == 0) yu0s[4 * r + g] = yu[r];
-      }
-    }
-    double qx0, qu0;  // cost_x(x), cost_u(u)
-    {
-      double px = 0, pu = 0;
-#pragma unroll
-      for (int k = 0; k < 8; k++) px = __builtin_fma(xb[k], y0[k], px);
-#pragma unroll
-      for (int k = 0; k < 4; k++) pu = __builtin_fma(ub[k], yu0[k], pu);
-      qx0 = group_sum(px);
-      qu0 = group_sum(pu);
+      const int r = lane & 31;
+      const bool tr = lane >= 32;
+      const double* qrow = Qc + (tr ? r * LQ : r);
+      const int step = tr ? 1 : LQ;
+      double acc = 0;
+#pragma unroll 8
+      for (int c = 0; c < GN; c++) acc = __builtin_fma(qrow[c * step], xk[c], acc);
+      (tr ? zxs : y0s)[r] = acc;
+      const int ru = lane & 15;
+      const bool tu = (lane & 16) != 0;
+      const double* rrow = Rc + (tu ? ru * LR : ru);
+      const int stepu = tu ? 1 : LR;
+      double accu = 0;
+#pragma unroll 8
+      for (int c = 0; c < GM; c++) accu = __builtin_fma(rrow[c * stepu], uk[c], accu);
+      if (lane < 32) (tu ? zus : yu0s)[ru] = accu;
     }
     sync();
-
-    // x'Qx at the knot with component i1 += d1, then component i2 += d2 (index < 0: none; i2 == i1: both on that component)
-    auto form_x = [&](int i1, double d1, int i2, double d2) __attribute__((always_inline)) {
-      const int c1 = (i1 >= 0) ? i1 : 0, c2 = (i2 >= 0) ? i2 : 0;
-      const double x1 = xk[c1], x2 = xk[c2];
-      double p1 = x1 + d1;
-      if (i2 == i1) p1 = p1 + d2;  // finite_diff.h:67-86: one perturbation after the other
-      const double del1 = (i1 >= 0) ? p1 - x1 : 0.0;
-      const double del2 = (i2 >= 0 && i2 != i1) ? (x2 + d2) - x2 : 0.0;
-      const double2_t* q1 = reinterpret_cast<const double2_t*>(&Qc[c1 * GN + 8 * g]);
-      const double2_t* q2 = reinterpret_cast<const double2_t*>(&Qc[c2 * GN + 8 * g]);
-      double part = 0;
+    double qx0, qu0;  // cost_x(x), cost_u(u)
+    {
+      double part = (lane < 32) ? xk[lane & 31] * y0s[lane & 31] : ((lane < 48) ? uk[lane & 15] * yu0s[lane & 15] : 0.0);
 #pragma unroll
-      for (int k2 = 0; k2 < 4; k2++) {
-        const double2_t a = q1[k2], c = q2[k2];
-#pragma unroll
-        for (int h2 = 0; h2 < 2; h2++) {
-          const int k = 2 * k2 + h2;  // row 16 (k >> 2) + 4 (k & 3) + g = this lane's component xb[k]
-          const double y = __builtin_fma(del2, c[h2], __builtin_fma(del1, a[h2], y0[k]));
-          part = __builtin_fma(xb[k], y, part);
-        }
-      }
-      part = group_sum(part);
-      const int m1 = permq(c1), m2 = permq(c2);
-      const double Y1 = __builtin_fma(del2, Qc[c2 * GN + m1], __builtin_fma(del1, Qc[c1 * GN + m1], y0s[c1]));  // (Q p)[i1]
-      const double Y2 = __builtin_fma(del2, Qc[c2 * GN + m2], __builtin_fma(del1, Qc[c1 * GN + m2], y0s[c2]));  // (Q p)[i2]
-      return __builtin_fma(del2, Y2, __builtin_fma(del1, Y1, part));
-    };
-    auto form_u = [&](int i1, double d1, int i2, double d2) __attribute__((always_inline)) {
-      const int c1 = (i1 >= 0) ? i1 : 0, c2 = (i2 >= 0) ? i2 : 0;
-      const double x1 = uk[c1], x2 = uk[c2];
-      double p1 = x1 + d1;
-      if (i2 == i1) p1 = p1 + d2;
-      const double del1 = (i1 >= 0) ? p1 - x1 : 0.0;
-      const double del2 = (i2 >= 0 && i2 != i1) ? (x2 + d2) - x2 : 0.0;
-      const double2_t* q1 = reinterpret_cast<const double2_t*>(&Rc[c1 * GM + 4 * g]);
-      const double2_t* q2 = reinterpret_cast<const double2_t*>(&Rc[c2 * GM + 4 * g]);
-      double part = 0;
-#pragma unroll
-      for (int k2 = 0; k2 < 2; k2++) {
-        const double2_t a = q1[k2], c = q2[k2];
-#pragma unroll
-        for (int h2 = 0; h2 < 2; h2++) {
-          const int k = 2 * k2 + h2;  // row 4 k + g = this lane's component ub[k]
-          const double y = __builtin_fma(del2, c[h2], __builtin_fma(del1, a[h2], yu0[k]));
-          part = __builtin_fma(ub[k], y, part);
-        }
-      }
-      part = group_sum(part);
-      const int m1 = permr(c1), m2 = permr(c2);
-      const double Y1 = __builtin_fma(del2, Rc[c2 * GM + m1], __builtin_fma(del1, Rc[c1 * GM + m1], yu0s[c1]));
-      const double Y2 = __builtin_fma(del2, Rc[c2 * GM + m2], __builtin_fma(del1, Rc[c1 * GM + m2], yu0s[c2]));
-      return __builtin_fma(del2, Y2, __builtin_fma(del1, Y1, part));
-    };
-
-    // ---- single perturbations: cost_x(x +- eps e_i), cost_u(u +- eps e_j) ----
-    for (int base = 0; base < 2 * nx; base += 16) {
-      const int e = base + p;
-      const double f = form_x(e < 2 * nx ? (e >> 1) : -1, (e & 1) ? -kEps : kEps, -1, 0.0);
-      if (g == 0 && e < 2 * nx) sx[e] = f;
+      for (int sh = 1; sh < 32; sh <<= 1) part += __shfl_xor(part, sh, 64);
+      qx0 = __shfl(part, 0, 64);
+      qu0 = __shfl(part, 32, 64);
     }
-    for (int base = 0; base < 2 * nu; base += 16) {
-      const int e = base + p;
-      const double f = form_u(e < 2 * nu ? (e >> 1) : -1, (e & 1) ? -kEps : kEps, -1, 0.0);
-      if (g == 0 && e < 2 * nu) su[e] = f;
+
+    // ---- single perturbations: cost_x(x +- eps e_i) on lane 2 i (+ 1), cost_u(u +- eps e_j) ----
+    {
+      const int i = lane >> 1;
+      const double d = (lane & 1) ? -kEps : kEps;
+      if (i < nx) {
+        const double x1 = xk[i];
+        const double del = (x1 + d) - x1;
+        const double Y = __builtin_fma(del, Qc[i * LQ + i], y0s[i]);              // (Q p)[i]
+        sx[lane] = __builtin_fma(del, Y, __builtin_fma(del, zxs[i], qx0));
+      }
+      if (i < nu) {
+        const double u1 = uk[i];
+        const double del = (u1 + d) - u1;
+        const double Y = __builtin_fma(del, Rc[i * LR + i], yu0s[i]);
+        su[lane] = __builtin_fma(del, Y, __builtin_fma(del, zus[i], qu0));
+      }
     }
     sync();
     // cx, cu (derivatives.cpp:44-47)
@@ -1468,77 +1388,55 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       D[oCX + i] = (LqModel::cost_from_parts(sx[2 * i], qu0) - LqModel::cost_from_parts(sx[2 * i + 1], qu0)) / (2 * kEps);
     for (int j = lane; j < nu; j += 64)
       D[oCU + j] = (LqModel::cost_from_parts(qx0, su[2 * j]) - LqModel::cost_from_parts(qx0, su[2 * j + 1])) / (2 * kEps);
-    // cxu (derivatives.cpp:114-144): c(px,pu) - c(mx,pu) - c(px,mu) + c(mx,mu)
+    // cxu (derivatives.cpp:114-144): c(px,pu) - c(mx,pu) - c(px,mu) + c(mx,mu); consecutive lanes write consecutive rows of a column
     for (int q = lane; q < nx * nu; q += 64) {
-      const int i = q / nu, j = q - i * nu;
+      const int j = q / nx, i = q - j * nx;
       const double v4 = LqModel::cost_from_parts(sx[2 * i], su[2 * j]) - LqModel::cost_from_parts(sx[2 * i + 1], su[2 * j]) -
                         LqModel::cost_from_parts(sx[2 * i], su[2 * j + 1]) + LqModel::cost_from_parts(sx[2 * i + 1], su[2 * j + 1]);
       D[oCXU + i + nx * j] = v4 / (4 * kEps * kEps);
     }
-    // ---- cxx, cuu: the upper triangle, four sign combinations per pair (finite_diff.h:67-86).  A pass = 16 PAIRS: lane (g, p) evaluates its
-    // eight (four) rows of Q p for all four points of pair p -- the two columns of Q are fetched once for the four --, pp, mp, pm, mm ----
-    auto hessian = [&](auto on_x, int n, int oH, double other) __attribute__((always_inline)) {
+    // ---- cxx, cuu: the upper triangle, four sign combinations per pair (finite_diff.h:67-86): pp, mp, pm, mm on the pair's lane ----
+    auto hessian = [&](auto on_x, int n, int oH, double other, double q0) __attribute__((always_inline)) {
       constexpr bool X = decltype(on_x)::value;
-      constexpr int NR = X ? 8 : 4;           // rows per lane
-      constexpr int LD = X ? GN : GM;
+      constexpr int LD = X ? LQ : LR;
       const double* Mc = X ? Qc : Rc;
       const double* zk = X ? xk : uk;
-      const double* y0k = X ? y0s : yu0s;
-      const unsigned short* tab = X ? pair_x : pair_u;
-      const int npairs = n * (n + 1) / 2;
+      const double* yk = X ? y0s : yu0s;
+      const double* zz = X ? zxs : zus;
       constexpr double inv4e2 = 1.0 / (4 * kEps * kEps);  // (the quotient of finite_diff.h:84 as a product: <= 1 ulp of an entry, as derivatives.hpp does)
-      for (int base = 0; base < npairs; base += 16) {
-        const int q = base + p;
-        const bool valid = q < npairs;
-        const unsigned ij = tab[valid ? q : 0];
-        const int i = ij & 0xff, j = ij >> 8;
-        const bool diag = i == j;
-        const double x1 = zk[i], x2 = zk[j];
-        // the perturbations as they are applied: +-eps on component i, then +-eps on component j (the same component on the diagonal)
-        const double p1p = x1 + kEps, p1m = x1 - kEps;
-        double del1[4], del2[4];
+      const int nb = (n + 7) >> 3;
+      for (int bi = 0; bi < nb; bi++)
+        for (int bj = bi; bj < nb; bj++) {
+          const int i = 8 * bi + (lane & 7), j = 8 * bj + (lane >> 3);
+          const bool valid = (i <= j) & (j < n);
+          const int ii = valid ? i : 0, jj = valid ? j : 0;
+          const bool diag = ii == jj;
+          const double x1 = zk[ii], x2 = zk[jj];
+          // the perturbations as they are applied: +-eps on component i, then +-eps on component j (the same component on the diagonal)
+          const double p1p = x1 + kEps, p1m = x1 - kEps;
+          const double Mii = Mc[ii * LD + ii], Mij = Mc[jj * LD + ii], Mji = Mc[ii * LD + jj], Mjj = Mc[jj * LD + jj];
+          const double yi = yk[ii], yj = yk[jj], zi = zz[ii], zj = zz[jj];
+          double fv[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const double first = (c & 1) ? p1m : p1p, d2 = (c & 2) ? -kEps : kEps;
-          del1[c] = (diag ? first + d2 : first) - x1;
-          del2[c] = diag ? 0.0 : (x2 + d2) - x2;
-        }
-        const double2_t* q1 = reinterpret_cast<const double2_t*>(&Mc[i * LD + NR * g]);
-        const double2_t* q2 = reinterpret_cast<const double2_t*>(&Mc[j * LD + NR * g]);
-        double part[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int k2 = 0; k2 < NR / 2; k2++) {
-          const double2_t a = q1[k2], cc = q2[k2];
-#pragma unroll
-          for (int h2 = 0; h2 < 2; h2++) {
-            const int k = 2 * k2 + h2;
-            const double zb = X ? xb[k] : ub[k & 3], yk = X ? y0[k] : yu0[k & 3];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-              const double y = __builtin_fma(del2[c], cc[h2], __builtin_fma(del1[c], a[h2], yk));
-              part[c] = __builtin_fma(zb, y, part[c]);
-            }
+          for (int c = 0; c < 4; c++) {
+            const double first = (c & 1) ? p1m : p1p, d2 = (c & 2) ? -kEps : kEps;
+            const double del1 = (diag ? first + d2 : first) - x1;
+            const double del2 = diag ? 0.0 : (x2 + d2) - x2;
+            const double Y1 = __builtin_fma(del2, Mij, __builtin_fma(del1, Mii, yi));   // (M p)[i]
+            const double Y2 = __builtin_fma(del2, Mjj, __builtin_fma(del1, Mji, yj));   // (M p)[j]
+            const double xy = __builtin_fma(del2, zj, __builtin_fma(del1, zi, q0));      // z . (M p)
+            const double f = __builtin_fma(del2, Y2, __builtin_fma(del1, Y1, xy));
+            fv[c] = X ? LqModel::cost_from_parts(f, other) : LqModel::cost_from_parts(other, f);
+          }
+          if (valid) {
+            const double val = (fv[0] - fv[1] - fv[2] + fv[3]) * inv4e2;
+            D[oH + ii + n * jj] = val;
+            D[oH + jj + n * ii] = val;
           }
         }
-        const int m1 = X ? permq(i) : permr(i), m2 = X ? permq(j) : permr(j);
-        const double Mii = Mc[i * LD + m1], Mij = Mc[j * LD + m1], Mji = Mc[i * LD + m2], Mjj = Mc[j * LD + m2], yi = y0k[i], yj = y0k[j];
-        double fv[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const double Y1 = __builtin_fma(del2[c], Mij, __builtin_fma(del1[c], Mii, yi));  // (M p)[i]
-          const double Y2 = __builtin_fma(del2[c], Mjj, __builtin_fma(del1[c], Mji, yj));  // (M p)[j]
-          const double f = __builtin_fma(del2[c], Y2, __builtin_fma(del1[c], Y1, group_sum(part[c])));
-          fv[c] = X ? LqModel::cost_from_parts(f, other) : LqModel::cost_from_parts(other, f);
-        }
-        if (valid && g == 0) {
-          const double val = (fv[0] - fv[1] - fv[2] + fv[3]) * inv4e2;
-          D[oH + i + n * j] = val;
-          D[oH + j + n * i] = val;
-        }
-      }
     };
-    hessian(std::true_type{}, nx, oCXX, qu0);
-    hessian(std::false_type{}, nu, oCUU, qx0);
+    hessian(std::true_type{}, nx, oCXX, qu0, qx0);
+    hessian(std::false_type{}, nu, oCUU, qx0, qu0);
   }
 }
 
