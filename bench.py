@@ -555,8 +555,7 @@ def main():
 
     if not args.no_extra_configs and world == 1:
         # a user's own device twin with dimensions of its own (examples/user_model_linear6.hpp: n = 6, m = 2, compiled in from outside the
-        # library): the generic kernels on something other than 32 / 16 -- thread-per-rollout forward passes, a finite-difference sweep that
-        # evaluates every perturbed point through the model's dynamics() / cost(), k_backward_w3<1> (one 16 x 16 tile per matrix)
+        # library), on both routes such a small twin has
         from ilqr_amd import _build
         if os.path.exists(_build.USER_EXAMPLE6_LIB):
             nu6, mu6, Tu, Bu, itu = 6, 2, 200, 4096, 5
@@ -564,29 +563,43 @@ def main():
             A6 = -np.eye(nu6) + 0.3 * ru.normal(size=(nu6, nu6)) / np.sqrt(nu6)
             B6 = ru.normal(size=(nu6, mu6)) / np.sqrt(nu6)
             mats6 = (A6, B6, np.eye(nu6), 0.1 * np.eye(mu6), np.eye(nu6))
-            gu = BatchILQR("user", Bu, Tu, dt, u_min=-0.5, u_max=0.5, lib=_build.USER_EXAMPLE6_LIB, nx=nu6, nu=mu6, device=local_rank, stream=stream,
-                           user_params=np.concatenate([np.ascontiguousarray(a).ravel() for a in mats6]), flags=capi.FLAG_FIXED_WORK, params=dict(max_iter=itu + 2))
-            gu.init_traj(ru.uniform(-1, 1, (Bu, nu6)), np.zeros((Bu, Tu, mu6)))
-            gu.iterate(1)
-            gu.profile(True)
-            gu.profile_reset()
-            barrier()
-            t0 = time.perf_counter()
-            gu.iterate(itu)
-            barrier()
-            elu = time.perf_counter() - t0
-            pu_ = gu.profile_read()
-            assert gu.count_running() == Bu
-            namu = {i: gu.lib.ilqr_stage_kernel_name(gu.h, i).decode() for i in range(capi.NUM_STAGES)}
-            stu = {k: {"kernel": namu[capi.STAGE_NAMES.index(k)], "ms_per_launch": ms / ln, "launches": ln} for k, (ms, ln) in pu_.items() if ln}
-            gu.close()
+            x06 = ru.uniform(-1, 1, (Bu, nu6))
+
+            def run6(route):
+                gu = BatchILQR("user", Bu, Tu, dt, u_min=-0.5, u_max=0.5, lib=_build.USER_EXAMPLE6_LIB, nx=nu6, nu=mu6, device=local_rank, stream=stream, route=route,
+                               user_params=np.concatenate([np.ascontiguousarray(a).ravel() for a in mats6]), flags=capi.FLAG_FIXED_WORK, params=dict(max_iter=itu + 2))
+                gu.init_traj(x06, np.zeros((Bu, Tu, mu6)))
+                gu.iterate(1)
+                gu.profile(True)
+                gu.profile_reset()
+                barrier()
+                t0 = time.perf_counter()
+                gu.iterate(itu)
+                barrier()
+                elu = time.perf_counter() - t0
+                pu_ = gu.profile_read()
+                assert gu.count_running() == Bu
+                namu = {i: gu.lib.ilqr_stage_kernel_name(gu.h, i).decode() for i in range(capi.NUM_STAGES)}
+                stu = {k: {"kernel": namu[capi.STAGE_NAMES.index(k)], "ms_per_launch": ms / ln, "launches": ln} for k, (ms, ln) in pu_.items() if ln}
+                gu.close()
+                return elu, stu
             flop6 = 4 * nu6 ** 3 + 10 * nu6 * nu6 * mu6 + 6 * nu6 * mu6 * mu6 + mu6 ** 3
-            bwu = stu["backward"]["ms_per_launch"] * 1e-3
+            # default route of a small twin (even nx <= 8, nu <= 4): the tiled thread kernels -- a thread per knot / trajectory / rollout
+            elu, stu = run6(0)
             extra["user_linear6_n6_m2_T200_B4096_fd"] = {
                 "workload": "a user's device twin (examples/user_model_linear6.hpp, n=6 m=2, ILQR_MODEL_USER) T=200 B=4096, u in [-0.5,0.5], fp64, "
-                            "finite differences point by point through the model's own functions, fixed-work iterations",
+                            "finite differences point by point through the model's own functions, fixed-work iterations; the tiled thread kernels "
+                            "(k_derivatives, k_backward_t, k_rollout): the default route of a small twin",
                 "value": Bu * Tu * itu / elu, "unit": "trajectory-timesteps/s", "ms_per_step": elu / itu * 1e3, "stages": stu,
-                "roofline": {"bound": "fp64 flops", "kernel": stu["backward"]["kernel"], "achieved": flop6 * Bu * Tu / bwu / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
+                "note": "B = 4096 trajectories are 64 wavefronts of k_backward_t on 1024 SIMDs: the backward pass is a latency-bound chain of T steps; the route scales with B up to ~64 K trajectories"}
+            # the same workload on the generic kernels every larger twin runs in (ILQR_ROUTE_WAVE_PER_TRAJECTORY)
+            elw, stw = run6(capi.ROUTE_WAVE_PER_TRAJECTORY)
+            bwu = stw["backward"]["ms_per_launch"] * 1e-3
+            extra["user_linear6_n6_m2_T200_B4096_fd_wave_per_trajectory"] = {
+                "workload": "the same twin and workload on the generic kernels (ILQR_ROUTE_WAVE_PER_TRAJECTORY): wavefront-per-knot finite differences, k_backward_w3<1> "
+                            "(one 16 x 16 tile per matrix), thread-per-rollout forward passes",
+                "value": Bu * Tu * itu / elw, "unit": "trajectory-timesteps/s", "ms_per_step": elw / itu * 1e3, "stages": stw,
+                "roofline": {"bound": "fp64 flops", "kernel": stw["backward"]["kernel"], "achieved": flop6 * Bu * Tu / bwu / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": flop6 * Bu * Tu / bwu / 1e12 / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_timestep": flop6,
                              "avg_launch_ms": bwu * 1e3,
                              "note": "one wavefront per trajectory and every matrix padded to a 16 x 16 tile: (6/16)^2 of each matrix instruction is this model's"}}

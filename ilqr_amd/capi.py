@@ -11,6 +11,7 @@ DTYPE_F64, DTYPE_F32 = 0, 1
 # enum ilqr_route (include/ilqr_amd.h): which of several equivalent kernels a handle uses; 0 = by batch size
 ROUTE_TILE_PER_CU, ROUTE_TWO_TILES_PER_CU, ROUTE_WIDE_TILES = 1, 2, 3
 ROUTE_WIDE_ONE_PER_CU, ROUTE_WIDE_TWO_PER_CU, ROUTE_NO_COMPACTION, ROUTE_FULL_RECORDS, ROUTE_LQ_THREAD_ROLLOUT, ROUTE_BACKWARD_LDS, ROUTE_QUAD_CHAIN, ROUTE_LQ_RECOMMIT, ROUTE_BACKWARD_W2, ROUTE_LQ_DENSE_FD = 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048
+ROUTE_WAVE_PER_TRAJECTORY = 4096
 NUM_STAGES = 5
 STAGE_NAMES = ("derivatives", "backward", "rollout", "accept", "solve")
 

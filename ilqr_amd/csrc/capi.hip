@@ -169,7 +169,8 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     REQUIRE(d->nx == UM::NX && d->nu == UM::NU, "this build's user model is nx=%d nu=%d, got %d/%d", UM::NX, UM::NU, d->nx, d->nu);
     REQUIRE(d->u_min && d->u_max, "ILQR_MODEL_USER needs u_min/u_max (Model::u_min/u_max, include/model.h:17)");
     REQUIRE(!(d->flags & ILQR_FLAG_ANALYTIC_DERIVATIVES) || has_analytic_record<UM>::value, "this user model has no analytic_record()");
-    if (!kUserTiled) {  // not a tiled nx = 4 shape: the generic kernels (fp64), trajectory-contiguous layout like the LQ model's
+    // not a tiled shape -- or a small one asked to take the generic route: the generic kernels (fp64), trajectory-contiguous layout like the LQ model's
+    if (!kUserTiled || (kUserSmall && (d->route & ILQR_ROUTE_WAVE_PER_TRAJECTORY))) {
       REQUIRE(d->dtype == ILQR_DTYPE_F64, "the generic nx <= 32 path is fp64");
       h->aos = true;
     }

@@ -38,7 +38,7 @@ template <class F>
 static int with_generic_model(ilqr_batch* h, F&& f) {
   if (h->model == ILQR_MODEL_LQ) return f(h->lq);
 #ifdef ILQR_HAVE_USER_MODEL
-  if constexpr (!kUserTiled)
+  if constexpr (kUserGeneric)
     if (h->model == ILQR_MODEL_USER) return f(h->user_g);
 #endif
   return fail(ILQR_ERR_UNSUPPORTED, "model %d has no generic device kernels", h->model);
@@ -229,7 +229,8 @@ static int launch_backward(ilqr_batch* h, int mode) {
   } else if (use_quad_backward(h)) {
     dim3 grid(h->ntiles), block(64);  // one wavefront = one tile of 16 trajectories x 4 lanes
     if (int rc = with_model(h, [&](auto& v, auto& m, auto&) {
-          hipLaunchKernelGGL((k_backward_q<std::decay_t<decltype(m)>>), grid, block, 0, h->stream, v, m, h->sp, mode);
+          if constexpr (std::decay_t<decltype(m)>::NX == 4)
+            hipLaunchKernelGGL((k_backward_q<std::decay_t<decltype(m)>>), grid, block, 0, h->stream, v, m, h->sp, mode);
           return 0;
         }))
       return rc;
@@ -285,7 +286,7 @@ static int launch_sweep_backward(ilqr_batch* h, int mode, int force) {
   const int variant = fused_variant(h);
   const int* ci = h->commit_pending ? h->commit_idx : nullptr;
   if (int rc = with_model(h, [&](auto& v, auto& m, auto& fdm) {
-        launch_sweep_backward_t(h, v, m, fdm, variant, mode, force, ci);
+        if constexpr (std::decay_t<decltype(m)>::NX == 4) launch_sweep_backward_t(h, v, m, fdm, variant, mode, force, ci);
         return 0;
       }))
     return rc;
@@ -325,6 +326,9 @@ static int launch_solve_tiles(ilqr_batch* h, int n_iters) {
   if (int rc = with_model(h, [&](auto& v, auto& m, auto& fdm) {
         using MM = std::decay_t<decltype(m)>;
         using MF = std::decay_t<decltype(fdm)>;
+        if constexpr (MM::NX != 4) {
+          return fail(ILQR_ERR_STATE, "persistent tiles are nx = 4 kernels");
+        } else
         if (occ == 3) {
           if constexpr (MM::NU == 1)
           {

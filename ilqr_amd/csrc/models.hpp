@@ -344,7 +344,10 @@ struct has_analytic_record<M, std::void_t<decltype(std::declval<const M&>().anal
 // their finite differences in UserModelT<double>) -- examples/user_model_acrobot.hpp.  Any other NX <= 32, NU <= 16 runs in
 // the generic kernels (generic.hpp: thread-per-rollout k_rollout_g, wavefront-per-knot finite differences k_derivatives_g,
 // the matrix-core backward pass k_backward_w3; fp64; an analytic_record, if the model has one, is called by one lane per knot under
-// ILQR_FLAG_ANALYTIC_DERIVATIVES) -- examples/user_model_linear6.hpp.
+// ILQR_FLAG_ANALYTIC_DERIVATIVES) -- examples/user_model_linear6.hpp.  A SMALL twin (even NX <= 8, NU <= 4) is compiled into both and
+// runs, unless ILQR_ROUTE_WAVE_PER_TRAJECTORY asks for the generic kernels, in the tiled thread kernels: one thread per knot
+// (k_derivatives), per trajectory (k_backward_t) and per rollout (k_rollout) with the whole 6 x 6 algebra in registers -- a 16 x 16
+// matrix-core tile is (6 / 16)^2 full at n = 6 --, in fp64 or fp32.
 // ------------------------------------------------------------------------------------------
 #ifdef ILQR_USER_MODEL_HEADER
 namespace ilqr {
@@ -352,7 +355,10 @@ namespace ilqr {
 static_assert(UserModelT<double>::NX >= 1 && UserModelT<double>::NX <= MAXN && UserModelT<double>::NU >= 1 && UserModelT<double>::NU <= MAXM,
               "user device models: 1 <= NX <= 32, 1 <= NU <= 16");
 // which kernels the build's user model runs in
-constexpr bool kUserTiled = UserModelT<double>::NX == 4 && (UserModelT<double>::NU == 1 || UserModelT<double>::NU == 2);
+constexpr bool kUserQuad = UserModelT<double>::NX == 4 && (UserModelT<double>::NU == 1 || UserModelT<double>::NU == 2);  // lane-quad kernels, persistent routes
+constexpr bool kUserSmall = !kUserQuad && UserModelT<double>::NX % 2 == 0 && UserModelT<double>::NX <= 8 && UserModelT<double>::NU <= 4;  // tiled thread kernels
+constexpr bool kUserTiled = kUserQuad || kUserSmall;   // has tiled kernels (trajectory-interleaved layout)
+constexpr bool kUserGeneric = !kUserQuad;              // has generic kernels (trajectory-contiguous layout, wavefront per trajectory)
 }  // namespace ilqr
 #define ILQR_HAVE_USER_MODEL 1
 #endif

@@ -178,6 +178,8 @@ enum ilqr_route {
   ILQR_ROUTE_LQ_RECOMMIT = 512,     /* LQ model: no candidate buffers (11 x the nominal trajectory); the accepted rollout is run again to commit it */
   ILQR_ROUTE_LQ_DENSE_FD = 2048,    /* LQ model, finite differences: every perturbed point's quadratic forms evaluated densely on the matrix cores
                                        (k_derivatives_g) instead of by what moved (k_derivatives_lq: Q p = Q x + delta_i Q[:,i] + delta_j Q[:,j]) */
+  ILQR_ROUTE_WAVE_PER_TRAJECTORY = 4096, /* a small user twin (even nx <= 8, nu <= 4): the generic wavefront-per-trajectory kernels instead of the tiled
+                                            thread-per-trajectory ones it runs in by default (cross-check; fp64 only) */
   ILQR_ROUTE_BACKWARD_W2 = 1024     /* generic path: round 2's register kernel k_backward_w2 (literal Cholesky in every box-QP, per-knot cx / cu records)
                                        instead of k_backward_w3 (matrix-core refinement of the previous knot's inverse; LQ model with exact
                                        derivatives: no record array at all) */

@@ -91,9 +91,29 @@ def user6_lib():
     return _build.build_user(_build.USER_EXAMPLE6_HEADER, _build.USER_EXAMPLE6_LIB)
 
 
-def test_user_model_with_dimensions_of_its_own(user6_lib, oracle):
+ROUTES6 = ["thread", "wave"]  # a small twin's default (tiled thread kernels) and ILQR_ROUTE_WAVE_PER_TRAJECTORY (the generic kernels)
+
+
+def _route6(route):
+    from ilqr_amd import capi
+    return 0 if route == "thread" else capi.ROUTE_WAVE_PER_TRAJECTORY
+
+
+def _kernels6(g, route):
+    from ilqr_amd import capi
+    name = lambda st: g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index(st))
+    if route == "thread":
+        assert (name("derivatives"), name("backward"), name("rollout")) == (b"k_derivatives", b"k_backward_t", b"k_rollout")
+    else:
+        assert (name("derivatives"), name("rollout")) == (b"k_derivatives_g", b"k_rollout_g")
+
+
+@pytest.mark.parametrize("route", ROUTES6)
+def test_user_model_with_dimensions_of_its_own(user6_lib, oracle, route):
     """A user twin that is not an nx = 4 shape (examples/user_model_linear6.hpp: n = 6, m = 2, written as plain loops over
-    its own matrices) runs in the generic kernels: thread-per-rollout forward passes, wavefront-per-knot finite differences
+    its own matrices).  Small as it is (even nx <= 8, nu <= 4) it runs by default in the tiled THREAD kernels -- a thread per knot,
+    per trajectory, per rollout, the 6 x 6 algebra in registers --, and under ILQR_ROUTE_WAVE_PER_TRAJECTORY in the generic kernels
+    every larger twin gets: thread-per-rollout forward passes, wavefront-per-knot finite differences
     through the model's own dynamics() / cost() / final_cost(), the matrix-core backward pass.  Every iteration of a
     free-running solve against the oracle's LQ model with the same matrices (tests/parity.py: device-driven walk, 1e-6 per
     knot or a proven tie), and against the SHIPPED LQ twin at n = 6, m = 2 (whose sums run in the matrix cores' order:
@@ -107,9 +127,8 @@ def test_user_model_with_dimensions_of_its_own(user6_lib, oracle):
     rng = np.random.default_rng(3)
     x0 = rng.uniform(-1, 1, (B, n))
     u0 = rng.normal(size=(B, T, m)) * 0.1
-    g = BatchILQR("user", B, T, DT, u_min=-lim, u_max=lim, lib=user6_lib, nx=n, nu=m, user_params=params)
-    assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("derivatives")) == b"k_derivatives_g"
-    assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("rollout")) == b"k_rollout_g"
+    g = BatchILQR("user", B, T, DT, u_min=-lim, u_max=lim, lib=user6_lib, nx=n, nu=m, user_params=params, route=_route6(route))
+    _kernels6(g, route)
     om = oracle.Model("lq", lq=mats, u_lim=lim)
     r = walk_iterations(oracle, om, g, x0, u0, DT, 6, drive="gpu")
     print("user n=6 m=2 walk:", {kk: v for kk, v in r.items() if kk not in ("per_iter", "tied")})
@@ -129,13 +148,22 @@ def test_user_model_with_dimensions_of_its_own(user6_lib, oracle):
     # getters, stage calls and the full solve work on this route like on any other
     g.generate_trajectory()
     assert g.count_running() == 0 and np.all(np.isfinite(g.cost())) and np.all(g.cost() <= c_user * (1 + 1e-9))
-    with pytest.raises(capi.ILQRError, match="fp64"):
-        BatchILQR("user", 4, 5, DT, u_min=-1.0, u_max=1.0, nx=n, nu=m, lib=user6_lib, user_params=params, dtype="f32")
+    if route == "wave":
+        with pytest.raises(capi.ILQRError, match="fp64"):
+            BatchILQR("user", 4, 5, DT, u_min=-1.0, u_max=1.0, nx=n, nu=m, lib=user6_lib, user_params=params, dtype="f32", route=_route6(route))
+    else:  # the tiled kernels have an fp32 mode: float storage and rollouts, the double chain, finite differences in the double twin
+        g32 = BatchILQR("user", B, T, DT, u_min=-lim, u_max=lim, lib=user6_lib, nx=n, nu=m, user_params=params, dtype="f32")
+        g32.init_traj(x0, u0)
+        g32.iterate(3)
+        rel = np.abs(g32.cost() - c_user) / np.abs(c_user)
+        assert np.median(rel) < 1e-4 and (rel < 1e-2).mean() > 0.9, rel
+        g32.close()
     g.close()
     g2.close()
 
 
-def test_generic_user_model_whose_cost_reads_its_own_limits(user6_lib, oracle):
+@pytest.mark.parametrize("route", ROUTES6)
+def test_generic_user_model_whose_cost_reads_its_own_limits(user6_lib, oracle, route):
     """A Model subclass may read its public u_min / u_max members in cost() (include/model.h:17).  The linear6 example's optional
     penalty wb sum_j (u_j / u_max_j)^2 does: the generic kernels' copy of the model must carry the limits (the rollout cost is
     checked against numpy), and the solve must be the oracle's LQ solve with R + 2 wb diag(1 / u_max^2)."""
@@ -149,7 +177,8 @@ def test_generic_user_model_whose_cost_reads_its_own_limits(user6_lib, oracle):
     rng = np.random.default_rng(4)
     x0 = rng.uniform(-1, 1, (B, n))
     u0 = rng.normal(size=(B, T, m)) * 0.1
-    g = BatchILQR("user", B, T, DT, u_min=-umax, u_max=umax, lib=user6_lib, nx=n, nu=m, user_params=params)
+    g = BatchILQR("user", B, T, DT, u_min=-umax, u_max=umax, lib=user6_lib, nx=n, nu=m, user_params=params, route=_route6(route))
+    _kernels6(g, route)
     c0 = g.init_traj(x0, u0)
     xs, us = g.trajectory()
     run = 0.5 * (np.einsum("bti,ij,btj->b", xs[:, :T], Q, xs[:, :T]) + np.einsum("bti,ij,btj->b", us, R, us)) + wb * ((us / umax) ** 2).sum(axis=(1, 2))
@@ -162,7 +191,8 @@ def test_generic_user_model_whose_cost_reads_its_own_limits(user6_lib, oracle):
     g.close()
 
 
-def test_generic_user_model_analytic_record(user6_lib):
+@pytest.mark.parametrize("route", ROUTES6)
+def test_generic_user_model_analytic_record(user6_lib, route):
     """A user twin's own analytic_record (examples/user_model_linear6.hpp) on the generic kernels (ILQR_FLAG_ANALYTIC_DERIVATIVES): its
     records against the finite-difference sweep's of the same model (second differences of a quadratic: exact value + rounding noise
     ~ 1e-16 f / eps^2), and the solve they drive against the finite-difference solve."""
@@ -177,8 +207,8 @@ def test_generic_user_model_analytic_record(user6_lib):
     u0 = rng.normal(size=(B, T, m)) * 0.2
     out = {}
     for name, fl in (("fd", 0), ("exact", capi.FLAG_ANALYTIC_DERIVATIVES)):
-        g = BatchILQR("user", B, T, DT, u_min=-umax, u_max=umax, lib=user6_lib, nx=n, nu=m, user_params=params, flags=fl)
-        assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("derivatives")) == b"k_derivatives_g"
+        g = BatchILQR("user", B, T, DT, u_min=-umax, u_max=umax, lib=user6_lib, nx=n, nu=m, user_params=params, flags=fl, route=_route6(route))
+        _kernels6(g, route)
         g.init_traj(x0, u0)
         g.compute_derivatives()
         d = g.derivatives()
