@@ -472,17 +472,19 @@ def main():
         # is its single-trajectory T=100 solve, a parity case): n=4, m=2 -- the generic m x m box-QP inside the quad kernel
         Bd, Td, goal = 4096, 100, [1.0, 0.5, 0.0, 0.0]
         gd = BatchILQR("integrator", Bd, Td, dt, u_min=-0.5, u_max=0.5, goal=goal, device=local_rank, stream=stream,
-                       flags=capi.FLAG_FIXED_WORK, params=dict(max_iter=args.warmup + steps + 1))
+                       flags=capi.FLAG_FIXED_WORK, params=dict(max_iter=args.warmup + 2 * steps + 1))
         rd = np.random.default_rng(4321)
         gd.init_traj(rd.uniform(-1, 1, size=(Bd, 4)) * np.array([1.5, 1.5, 0.5, 0.5]), np.zeros((Bd, Td, 2)))
         gd.iterate(args.warmup)
         gd.profile(True)
-        gd.profile_reset()
-        barrier()
-        t0 = time.perf_counter()
-        gd.iterate(steps)
-        barrier()
-        eld = time.perf_counter() - t0
+        eld = None
+        for _ in range(2):  # (a 4 ms region right after the host-side CPU baseline: the second of two runs is the one with the clocks up)
+            gd.profile_reset()
+            barrier()
+            t0 = time.perf_counter()
+            gd.iterate(steps)
+            barrier()
+            eld = time.perf_counter() - t0
         pd_ = gd.profile_read()
         assert gd.count_running() == Bd
         named = {i: gd.lib.ilqr_stage_kernel_name(gd.h, i).decode() for i in range(capi.NUM_STAGES)}

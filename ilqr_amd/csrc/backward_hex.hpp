@@ -525,6 +525,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int kShareReals = 4 * ((2 * M::NU + M::NU * M::NX + M::NX + 3) / 4) * TW;
   static_assert(kShareReals <= (int)(sizeof(pairs[0].ring) / sizeof(real)), "a pair's ring holds a wavefront's rollout rows");
   long long t_sweep = 0, t_roll = 0, t0 = 0;
+#ifdef ILQR_HEX_SECTIONS
+  long long t_sweep_last = 0;
+#endif
   const bool timing = (phase_ticks != nullptr) & (threadIdx.x == 0);
   const long long c_begin = timing ? clock64() : 0, w_begin = timing ? wall_clock64() : 0;
   if (commit_pending) {  // accepts of an earlier launch that nobody has copied yet
@@ -538,11 +541,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     phase_barrier();  // the tile's gains, lambda, status are in memory for its rollout wavefronts
     if (timing) {
       const long long t1 = wall_clock64();
+#ifdef ILQR_HEX_SECTIONS
+      t_sweep_last = t1 - t0;
+#endif
       t_sweep += t1 - t0;
       t0 = t1;
     }
     rollout_tile<M, true, true, kDeepPrefetch<M>, true, true, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, commit_idx, tile, lds_cost, /*count_running=*/it == n_iters - 1, rwave,
                                                pairs[role & 3].ring);
+#ifdef ILQR_HEX_SECTIONS  // experiment build (scripts/hex_sections.sh): "backward" = rollouts + accept, "rollout" = commit + barriers
+    if (timing) {
+      const long long t1 = wall_clock64();
+      t_sweep = t_sweep - t_sweep_last + (t1 - t0);
+      t0 = t1;
+    }
+#endif
     // (accept_one ran in threads 0 .. TW-1 at the end of rollout_tile: each hands its trajectory's accepted alpha on through LDS;
     //  the candidates themselves were stored by this block's rollout wavefronts and are waited for)
     if (threadIdx.x < TW) lds_commit[threadIdx.x] = commit_idx[tile * TW + threadIdx.x];

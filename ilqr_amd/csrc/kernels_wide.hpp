@@ -571,6 +571,12 @@ struct WideCfg {
   // tiles per CU depth 8 is 7.35e9/s against 6.96e9/s at B = 32768, with one tile per CU depth 4 is 6.21e9/s against 5.97e9/s at
   // B = 16384 -- in both cases through phase 1 (the register allocation of the whole kernel moves), not through the rollouts.
   static constexpr int kPrefetch = (OCC == 1) ? 4 : 8;
+  // alpha groups a rollout wavefront carries per lane (rollout.hpp, NG): with four wavefronts per tile each takes one 16-trajectory
+  // tile whole; eight wavefronts keep the twelve (tile, alpha group) units
+#ifndef ILQR_WIDE_ROLL_GROUPS
+#define ILQR_WIDE_ROLL_GROUPS 3
+#endif
+  static constexpr int kRollGroups = (OCC == 1) ? 1 : ILQR_WIDE_ROLL_GROUPS;
 };
 
 // Whole iterations for ONE wide tile (see k_solve_tile).  grid = ntiles / 4, block = 64 x kWaves.
@@ -622,8 +628,15 @@ __global__ __launch_bounds__(64 * WideCfg<OCC>::kWaves) __attribute__((amdgpu_wa
     }
     // 12 rollout units (tile of the wide tile, alpha group) over the wavefronts that roll out.  (Handing units out
     // dynamically, as wavefronts become free, measured 3 % slower than this fixed assignment.)
-    for (int u = rwave; u < (WT / TW) * 3; u += roll_waves)
-      rollout_tile<M, true, true, Cfg::kPrefetch, false, true, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, nullptr, wtile * (WT / TW) + u / 3, nullptr, false, u % 3, roll_share);
+    if constexpr (Cfg::kRollGroups == 3) {
+      // four wavefronts, four 16-trajectory tiles: a wavefront rolls out ALL eleven alphas of its tile, three alpha groups per lane
+      // (rollout.hpp, NG): the tile's nominal rows are fetched once instead of by three units at three different times
+      for (int u = rwave; u < WT / TW; u += roll_waves)
+        rollout_tile<M, true, true, Cfg::kPrefetch, false, true, true, 3>(v, model, alphas, NALPHA, v.cost_c, 1, sp, nullptr, wtile * (WT / TW) + u, nullptr, false, 0, roll_share);
+    } else {
+      for (int u = rwave; u < (WT / TW) * 3; u += roll_waves)
+        rollout_tile<M, true, true, Cfg::kPrefetch, false, true, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, nullptr, wtile * (WT / TW) + u / 3, nullptr, false, u % 3, roll_share);
+    }
     phase_barrier();  // the candidates' costs are in memory
     if (threadIdx.x < WT)
       accept_one(v, sp, wtile * WT + (int)threadIdx.x, [&](int a) { return v.cost_c[(size_t)a * v.Bp + wtile * WT + threadIdx.x]; }, commit_idx,

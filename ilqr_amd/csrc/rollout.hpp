@@ -108,34 +108,53 @@ constexpr int kDeepPrefetch = (M::NU * M::NX + M::NX + 2 * M::NU <= 10) ? 8 : 4;
 // no LDS to spare a priori, keeps the per-lane loads.
 // NOFIX: the caller's route is never taken with the opt-in fixes (sp.fixes == 0: the persistent matrix-core and wide kernels) --
 // the clamp of ilqr_core.cpp:327-329's "right way" and its selects leave the step (4 of its ~170 instructions).
-template <class M, bool GAINS, bool CAND, int PD, bool ACCEPT, bool SHARE = false, bool NOFIX = false>
+template <class M, bool GAINS, bool CAND, int PD, bool ACCEPT, bool SHARE = false, bool NOFIX = false, int NG = 1>
 __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>& v, const M& model, const AlphaSet& alphas, int n_alpha,
                                              double* __restrict__ cost_out, int mode, const SolverParams& sp,
                                              int* __restrict__ commit_idx, int tile, double* lds_cost, bool count_running = true, int rwave = -1,
                                              typename M::real* share = nullptr) {
   using real = typename M::real;
   constexpr int NX = M::NX, NU = M::NU;
+  static_assert(NG == 1 || (SHARE && GAINS && !ACCEPT), "several alpha groups per wavefront: the shared-row rollout of the wide tiles");
   const int wave = (rwave >= 0) ? rwave : (int)(threadIdx.x >> 6);  // which four alphas this wavefront rolls out (>= 3: none)
   const int lane = threadIdx.x & 63;
   const int l = lane & (TW - 1);
   const int a_sub = lane >> 4;
-  const int a = wave * 4 + a_sub;
   const int b = tile * TW + l;
-  bool active = (b < v.B) && (a < n_alpha);
-  if (active && mode == 1) active = (v.status[b] == 0 && v.backpass_done[b]);
+  // NG alpha groups per wavefront (the wide tiles' NG = 3: every lane carries the rollouts of alphas a_sub, 4 + a_sub, 8 + a_sub of its
+  // trajectory, step by step side by side): the nominal rows of a step are fetched and passed through LDS once for the three, and three
+  // independent chains per lane fill each other's dependent-issue gaps.  Each rollout is the expression sequence of NG = 1: same bits.
+  int a[NG];
+  bool active[NG];
+  bool any_active = false;
+  const bool eligible = (b < v.B) && (mode != 1 || (v.status[b < v.B ? b : 0] == 0 && v.backpass_done[b < v.B ? b : 0]));
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    a[g] = (wave + g) * 4 + a_sub;
+    active[g] = eligible && (a[g] < n_alpha);
+    any_active = any_active || active[g];
+  }
   // SHARE: every lane of a wavefront with work fetches its rows and runs the steps (an alpha group without an alpha, the
   // lanes of a finished trajectory: their arithmetic is discarded); `active` only decides who stores
-  const bool run = (SHARE && GAINS) ? (__ballot(active) != 0ull) : active;
+  const bool run = (SHARE && GAINS) ? (__ballot(any_active) != 0ull) : any_active;
   if (!ACCEPT && !run) return;
   if (run) {
   const int T = v.T;
-  const real alpha = (real)alphas.a[a < NALPHA ? a : NALPHA - 1];
+  real alpha[NG];
+#pragma unroll
+  for (int g = 0; g < NG; g++) alpha[g] = (real)alphas.a[a[g] < NALPHA ? a[g] : NALPHA - 1];
   const real dt = (real)v.dt;
 
-  real x[NX];
+  real x[NG][NX];
 #pragma unroll
-  for (int i = 0; i < NX; i++) x[i] = v.x0[tidx(tile, 0, i, l, 1, NX)];
-  double total = 0;  // (the sum over the horizon is a per-trajectory accumulator: double in both modes, common.hpp)
+  for (int i = 0; i < NX; i++) {
+    const real x0i = v.x0[tidx(tile, 0, i, l, 1, NX)];
+#pragma unroll
+    for (int g = 0; g < NG; g++) x[g][i] = x0i;
+  }
+  double total[NG];  // (the sum over the horizon is a per-trajectory accumulator: double in both modes, common.hpp)
+#pragma unroll
+  for (int g = 0; g < NG; g++) total[g] = 0;
 
   // The nominal controls / gains / states of step t do not depend on the rollout's own state,
   // and one step of arithmetic (~600 cycles) is far shorter than an HBM round trip under load
@@ -163,12 +182,14 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
   };
   // SHARE && CAND: a lane without a rollout of its own (an alpha group beyond the last alpha, a finished trajectory) stores too,
   // into the spare plane behind the last alpha's (the buffers hold NALPHA + 1): no predicate around the stores of every step
-  const int ta_store = ((SHARE && CAND && !active) ? NALPHA : a) * v.ntiles + tile;
+  int ta_store[NG];
+#pragma unroll
+  for (int g = 0; g < NG; g++) ta_store[g] = ((SHARE && CAND && !active[g]) ? NALPHA : a[g]) * v.ntiles + tile;
   // knot t = (x_t, u_t); with_u: a step's call (t < T by construction: no test in the step), false for the final state
-  auto emit_knot = [&](int t, const real* xx, const real* uu, auto with_u) __attribute__((always_inline)) {
-    if (SHARE && !CAND && !active) return;
+  auto emit_knot = [&](int g, int t, const real* xx, const real* uu, auto with_u) __attribute__((always_inline)) {
+    if (SHARE && !CAND && !active[g]) return;
     if (CAND) {
-      const int ta = ta_store;
+      const int ta = ta_store[g];
       if (with_u) {
 #pragma unroll
         for (int q = 0; q < NU; q++) v.cand_u[tidx(ta, t, q, l, T, NU)] = uu[q];
@@ -187,29 +208,32 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
     }
   };
   auto do_step = [&](int t, const StepIn& d) __attribute__((always_inline)) {
-    real u[NU];
 #pragma unroll
-    for (int j = 0; j < NU; j++) u[j] = d.u[j];
-    if (GAINS) {
+    for (int g = 0; g < NG; g++) {
+      real u[NU];
 #pragma unroll
-      for (int j = 0; j < NU; j++) {
-        u[j] += d.k[j] * alpha;  // :190
-        real acc = 0;
+      for (int j = 0; j < NU; j++) u[j] = d.u[j];
+      if (GAINS) {
 #pragma unroll
-        for (int i = 0; i < NX; i++) acc += d.K[j + NU * i] * (x[i] - d.xnom[i]);
-        u[j] += acc;  // :316
+        for (int j = 0; j < NU; j++) {
+          u[j] += d.k[j] * alpha[g];  // :190
+          real acc = 0;
+#pragma unroll
+          for (int i = 0; i < NX; i++) acc += d.K[j + NU * i] * (x[g][i] - d.xnom[i]);
+          u[j] += acc;  // :316
+        }
       }
-    }
-    if (!NOFIX && (sp.fixes & 1)) {  // opt-in fix: "the right way" of ilqr_core.cpp:327-329 -- the clamped control is stored and integrated
+      if (!NOFIX && (sp.fixes & 1)) {  // opt-in fix: "the right way" of ilqr_core.cpp:327-329 -- the clamped control is stored and integrated
 #pragma unroll
-      for (int j = 0; j < NU; j++) u[j] = min_of(max_of(u[j], model.u_min[j]), model.u_max[j]);
-    }
-    emit_knot(t, x, u, std::true_type());
-    total += (double)model.cost(x, u);  // :324
-    real x1[NX];
-    integrate_dynamics(model, x, u, dt, x1);  // :325
+        for (int j = 0; j < NU; j++) u[j] = min_of(max_of(u[j], model.u_min[j]), model.u_max[j]);
+      }
+      emit_knot(g, t, x[g], u, std::true_type());
+      total[g] += (double)model.cost(x[g], u);  // :324
+      real x1[NX];
+      integrate_dynamics(model, x[g], u, dt, x1);  // :325
 #pragma unroll
-    for (int i = 0; i < NX; i++) x[i] = x1[i];
+      for (int i = 0; i < NX; i++) x[g][i] = x1[i];
+    }
   };
   if constexpr (SHARE && GAINS) {
     static_assert(PD % 2 == 0 || PD == 1, "static ring indices");
@@ -301,16 +325,19 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
     do_step(t, cur);
   }
   }
-  {  // knot T: the final state (no control)
-    real uz[NU];
 #pragma unroll
-    for (int q = 0; q < NU; q++) uz[q] = 0;
-    emit_knot(T, x, uz, std::false_type());
-  }
-  total += (double)model.final_cost(x);  // :335
-  if (active) {
-    cost_out[(size_t)a * v.Bp + b] = total;
-    if (ACCEPT) lds_cost[a * TW + l] = total;
+  for (int g = 0; g < NG; g++) {
+    {  // knot T: the final state (no control)
+      real uz[NU];
+#pragma unroll
+      for (int q = 0; q < NU; q++) uz[q] = 0;
+      emit_knot(g, T, x[g], uz, std::false_type());
+    }
+    total[g] += (double)model.final_cost(x[g]);  // :335
+    if (active[g]) {
+      cost_out[(size_t)a[g] * v.Bp + b] = total[g];
+      if (ACCEPT) lds_cost[a[g] * TW + l] = total[g];
+    }
   }
   }  // if (run)
   if constexpr (ACCEPT) {
