@@ -26,6 +26,10 @@
 
 namespace ilqr {
 
+#ifndef ILQR_COMMIT_ROLLED
+#define ILQR_COMMIT_ROLLED 1
+#endif
+
 constexpr int HT = 4;  // trajectories per sub-tile (= per chain wavefront)
 
 // One pair's ring: a slot holds one knot of the sub-tile's 4 trajectories, pair-interleaved like the HBM records:
@@ -469,6 +473,32 @@ __device__ __forceinline__ void commit_tile_chunks(const BatchViewT<typename M::
 #pragma unroll
       for (int jj = 0; jj < NU; jj++) uq[q][jj] = v.cand_u[tidx(ta, tq, jj, l, T, NU)];
     }
+#if ILQR_COMMIT_ROLLED
+    // ONE copy of the step in the instruction stream (a rolled loop; the chunk's controls move down a register per trip so that
+    // every index stays static): 1 KB instead of 7 KB of code that runs once per iteration between two long loops.  Same time as the
+    // unrolled form (measured; the commit's 17 us are two rounds of HBM latency + 7 Euler steps + 52 memory instructions per wavefront).
+#pragma unroll 1
+    for (int q = 0; q < CT; q++) {
+      const int t = c * CT + q;
+      if (t > T) break;
+#pragma unroll
+      for (int i = 0; i < NX; i++) v.xs[tidx(tile, t, i, l, T + 1, NX)] = x[i];
+      if (t < T) {
+#pragma unroll
+        for (int jj = 0; jj < NU; jj++) v.us[tidx(tile, t, jj, l, T, NU)] = uq[0][jj];
+        if (q + 1 < CT) {
+          real x1[NX];
+          integrate_dynamics(model, x, uq[0], dt, x1);
+#pragma unroll
+          for (int i = 0; i < NX; i++) x[i] = x1[i];
+        }
+      }
+#pragma unroll
+      for (int qq = 0; qq + 1 < CT; qq++)
+#pragma unroll
+        for (int jj = 0; jj < NU; jj++) uq[qq][jj] = uq[qq + 1][jj];
+    }
+#else
 #pragma unroll
     for (int q = 0; q < CT; q++) {  // (no early exit: the loop must unroll for uq to stay in registers)
       const int t = c * CT + q;
@@ -487,6 +517,7 @@ __device__ __forceinline__ void commit_tile_chunks(const BatchViewT<typename M::
         }
       }
     }
+#endif
   }
 }
 
@@ -549,19 +580,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     rollout_tile<M, true, true, kDeepPrefetch<M>, true, true, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, commit_idx, tile, lds_cost, /*count_running=*/it == n_iters - 1, rwave,
                                                pairs[role & 3].ring);
-#ifdef ILQR_HEX_SECTIONS  // experiment build (scripts/hex_sections.sh): "backward" = rollouts + accept, "rollout" = commit + barriers
-    if (timing) {
-      const long long t1 = wall_clock64();
-      t_sweep = t_sweep - t_sweep_last + (t1 - t0);
-      t0 = t1;
+#ifdef ILQR_HEX_SECTIONS  // experiment builds (scripts/hex_sections.sh): the "backward" clock runs up to mark ILQR_HEX_SECTIONS, the "rollout" clock from there
+#define ILQR_HEX_MARK(n)                                   \
+    if (ILQR_HEX_SECTIONS == n && timing) {                \
+      const long long t1 = wall_clock64();                 \
+      t_sweep = t_sweep - t_sweep_last + (t1 - t0);        \
+      t0 = t1;                                             \
     }
+#else
+#define ILQR_HEX_MARK(n)
 #endif
+    ILQR_HEX_MARK(1)  // rollouts + accept
     // (accept_one ran in threads 0 .. TW-1 at the end of rollout_tile: each hands its trajectory's accepted alpha on through LDS;
     //  the candidates themselves were stored by this block's rollout wavefronts and are waited for)
     if (threadIdx.x < TW) lds_commit[threadIdx.x] = commit_idx[tile * TW + threadIdx.x];
     if (threadIdx.x == 0) tile_running = 0;
     phase_barrier();  // candidates, costs, status are in memory
+    ILQR_HEX_MARK(2)
     commit_tile_chunks<M>(v, model, lds_commit, tile);
+    ILQR_HEX_MARK(3)
     phase_barrier();  // the nominal trajectory is the accepted one
     if (timing) t_roll += wall_clock64() - t0;
     if (!sp.fixed_work) {  // has every trajectory of the tile left its loop?

@@ -576,7 +576,10 @@ struct WideCfg {
 #ifndef ILQR_WIDE_ROLL_GROUPS
 #define ILQR_WIDE_ROLL_GROUPS 3
 #endif
-  static constexpr int kRollGroups = (OCC == 1) ? 1 : ILQR_WIDE_ROLL_GROUPS;
+#ifndef ILQR_WIDE1_ROLL_GROUPS
+#define ILQR_WIDE1_ROLL_GROUPS 2
+#endif
+  static constexpr int kRollGroups = (OCC == 1) ? ILQR_WIDE1_ROLL_GROUPS : ILQR_WIDE_ROLL_GROUPS;
 };
 
 // Whole iterations for ONE wide tile (see k_solve_tile).  grid = ntiles / 4, block = 64 x kWaves.
@@ -633,6 +636,15 @@ __global__ __launch_bounds__(64 * WideCfg<OCC>::kWaves) __attribute__((amdgpu_wa
       // (rollout.hpp, NG): the tile's nominal rows are fetched once instead of by three units at three different times
       for (int u = rwave; u < WT / TW; u += roll_waves)
         rollout_tile<M, true, true, Cfg::kPrefetch, false, true, true, 3>(v, model, alphas, NALPHA, v.cost_c, 1, sp, nullptr, wtile * (WT / TW) + u, nullptr, false, 0, roll_share);
+    } else if constexpr (Cfg::kRollGroups == 2) {
+      // eight wavefronts: wavefront u < 4 carries alpha groups 0 and 1 of tile u per lane, wavefront 4 + u alpha group 2 of tile u
+      // (a SIMD holds one of each: the same three chains per SIMD as twelve single units, two of them in one instruction stream)
+      for (int u = rwave; u < 2 * (WT / TW); u += roll_waves) {
+        if (u < WT / TW)
+          rollout_tile<M, true, true, Cfg::kPrefetch, false, true, true, 2>(v, model, alphas, NALPHA, v.cost_c, 1, sp, nullptr, wtile * (WT / TW) + u, nullptr, false, 0, roll_share);
+        else
+          rollout_tile<M, true, true, Cfg::kPrefetch, false, true, true, 1>(v, model, alphas, NALPHA, v.cost_c, 1, sp, nullptr, wtile * (WT / TW) + u - WT / TW, nullptr, false, 2, roll_share);
+      }
     } else {
       for (int u = rwave; u < (WT / TW) * 3; u += roll_waves)
         rollout_tile<M, true, true, Cfg::kPrefetch, false, true, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, nullptr, wtile * (WT / TW) + u / 3, nullptr, false, u % 3, roll_share);
