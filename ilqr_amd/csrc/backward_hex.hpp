@@ -52,7 +52,7 @@ static_assert(kHexSlots > kHexLead + kHexKnotsPerRound - 1, "a round must not re
 template <class real, int NX, int NU>
 struct HexPair {  // LDS of one (chain, producer) pair
   using RS = HexRing<NX, NU, real, kHexSlots>;
-  real ring[RS::SLOTS * RS::ELEMS];
+  alignas(16) real ring[RS::SLOTS * RS::ELEMS];  // (16-byte aligned: the rollouts read it in row pairs, rollout.hpp)
   int rounds_done;                    // rounds (counted across passes) whose records are in the ring
   int consumer_at;                    // running index of the knot the chain waits for (everything below is consumed)
   int passes_started;                 // backward passes begun; -1 once the chain is through

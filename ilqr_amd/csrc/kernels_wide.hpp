@@ -39,7 +39,7 @@ template <class real, int NX, int NU, int kProd, int RING_KB = 148>
 struct WideShared {
   using RS = WideRing<NX, NU, real, RING_KB>;
   double steps[104];  // (the chain runs in double for every handle, backward_quad.hpp)
-  real ring[RS::SLOTS * RS::ELEMS];
+  alignas(16) real ring[RS::SLOTS * RS::ELEMS];
   int rounds_done[kProd];
   int consumer_at;
   int passes_started;

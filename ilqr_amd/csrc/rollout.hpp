@@ -267,21 +267,32 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
 #pragma unroll
       for (int j = 0; j < NLD; j++) d.r[j] = rbase[j][(size_t)tt * rstride[j]];
     };
-    real* const mine = share + (a_sub * TW + l);
+    // LDS layout of a step's rows: [row pair][trajectory][2] -- a lane reads rows 2 q and 2 q + 1 of its trajectory with ONE 16-byte
+    // (fp32: 8-byte) LDS instruction, five per step for the acrobot's ten rows instead of ten
+    typedef real real2_t __attribute__((ext_vector_type(2)));
+    constexpr int NPAIR = (NROWS + 1) / 2;
+    real* const mine = share + (((a_sub >> 1) * TW + l) * 2 + (a_sub & 1));  // row a_sub + 4 j: 4 j TW further on
     auto put = [&](const Raw& d) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < NLD; j++) mine[4 * j * TW] = d.r[j];
     };
-    const real* const row0 = share + l;
+    const real2_t* const row0 = reinterpret_cast<const real2_t*>(share + 2 * l);
     auto get = [&](StepIn& d) __attribute__((always_inline)) {
+      real rows[2 * NPAIR];
 #pragma unroll
-      for (int j = 0; j < NU; j++) d.u[j] = row0[j * TW];
+      for (int q = 0; q < NPAIR; q++) {
+        const real2_t pr = row0[q * TW];
+        rows[2 * q] = pr.x;
+        rows[2 * q + 1] = pr.y;
+      }
 #pragma unroll
-      for (int j = 0; j < NU; j++) d.k[j] = row0[(NU + j) * TW];
+      for (int j = 0; j < NU; j++) d.u[j] = rows[j];
 #pragma unroll
-      for (int e = 0; e < NU * NX; e++) d.K[e] = row0[(2 * NU + e) * TW];
+      for (int j = 0; j < NU; j++) d.k[j] = rows[NU + j];
 #pragma unroll
-      for (int i = 0; i < NX; i++) d.xnom[i] = row0[(2 * NU + NU * NX + i) * TW];
+      for (int e = 0; e < NU * NX; e++) d.K[e] = rows[2 * NU + e];
+#pragma unroll
+      for (int i = 0; i < NX; i++) d.xnom[i] = rows[2 * NU + NU * NX + i];
     };
     Raw ring[PD];
 #pragma unroll

@@ -18,7 +18,7 @@ template <class real, int NX, int NU, int kProd, int RING_KB, int PAD = 0>
 struct SweepShared {
   using RS = RingSlot<NX, NU, real, RING_KB, PAD>;
   double steps[104];                  // backtracking step sizes, in the chain's arithmetic (double for every handle) (per-lane indexed -> LDS, not constant cache)
-  real ring[RS::SLOTS * RS::ELEMS];   // knot with running index G lives in slot G % SLOTS
+  alignas(16) real ring[RS::SLOTS * RS::ELEMS];   // knot with running index G lives in slot G % SLOTS
   int rounds_done[kProd];             // rounds (counted across passes) whose records are in the ring
   int consumer_at;                    // running index of the knot the backward pass waits for (everything below is consumed)
   int passes_started;                 // backward passes begun; -1 once the tile's backward wavefront is through
