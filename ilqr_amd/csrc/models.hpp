@@ -38,14 +38,30 @@ __device__ __forceinline__ double vreg_const(double c) {
   asm("" : "+v"(c));
   return c;
 }
-__device__ __forceinline__ void sincos_shared(double x, double& s_out, double& c_out) {
+// The six constants sincos_shared keeps in vector registers.  vreg_const inside a loop body is a copy per trip (the asm's operand is
+// read-write: the hoisted constant is copied into a fresh register every time, six v_mov_b64 of a rollout step's ~135 instructions);
+// a loop that evaluates the model every trip takes them ONCE, before the loop (TrigConsts k = trig_consts(), WithTrigConsts below).
+struct TrigConsts {
+  double two_over_pi, pio2_1, pio2_2, pio2_3, s5, c5;
+};
+__device__ __forceinline__ TrigConsts trig_consts() {
+  TrigConsts k;
+  k.two_over_pi = vreg_const(6.36619772367581382433e-01);  // 2/pi
+  k.pio2_1 = vreg_const(1.57079632679489655800e+00);       // pi/2, leading 53 bits
+  k.pio2_2 = vreg_const(6.12323399573676603587e-17);       // next 53 bits
+  k.pio2_3 = vreg_const(-1.49738490485916983294e-33);      // and the rest
+  k.s5 = vreg_const(-2.50507602534068634195e-08);
+  k.c5 = vreg_const(2.08757232129817482790e-09);
+  return k;
+}
+__device__ __forceinline__ void sincos_shared(double x, double& s_out, double& c_out, const TrigConsts& k) {
   // contraction by the source, not by the optimiser: every inlined copy of this function (rollout kernels, the
   // persistent kernel, the commit / getter re-integration, the finite differences) must round identically
 #pragma clang fp contract(on)
-  const double j = __builtin_rint(x * vreg_const(6.36619772367581382433e-01));  // 2/pi
-  double r = __builtin_fma(-j, vreg_const(1.57079632679489655800e+00), x);      // pi/2, leading 53 bits
-  r = __builtin_fma(-j, vreg_const(6.12323399573676603587e-17), r);             // next 53 bits
-  r = __builtin_fma(-j, vreg_const(-1.49738490485916983294e-33), r);            // and the rest
+  const double j = __builtin_rint(x * k.two_over_pi);
+  double r = __builtin_fma(-j, k.pio2_1, x);
+  r = __builtin_fma(-j, k.pio2_2, r);
+  r = __builtin_fma(-j, k.pio2_3, r);
   // quadrant q = j mod 4: (sin, cos) = (sr, cr), (cr, -sr), (-sr, -cr), (-cr, sr).  The sine kernel is odd, every operation in it
   // symmetric under negation: its sign goes in with r (quadrants 1 and 2), the cosine kernel's is applied to its result
   // (quadrants 2 and 3), both as XORs of the sign bit; then one swap.  14 instead of 18 instructions; the same bits as
@@ -59,14 +75,14 @@ __device__ __forceinline__ void sincos_shared(double x, double& s_out, double& c
   // sin(r) = r + r^3 (S1 + z (S2 + ... ))
   const double ps = 8.33333333332248946124e-03 +
                     z * (-1.98412698298579493134e-04 +
-                         z * (2.75573137070700676789e-06 + z * (vreg_const(-2.50507602534068634195e-08) + z * 1.58969099521155010221e-10)));
+                         z * (2.75573137070700676789e-06 + z * (k.s5 + z * 1.58969099521155010221e-10)));
   const double sr = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
   // cos(r) = 1 - z/2 + z^2 (C1 + z (C2 + ... )), summed so that the 1 - z/2 rounding is compensated
   const double pc = z * (4.16666666666666019037e-02 +
                          z * (-1.38888888888741095749e-03 +
                               z * (2.48015872894767294178e-05 +
                                    z * (-2.75573143513906633035e-07 +
-                                        z * (vreg_const(2.08757232129817482790e-09) + z * -1.13596475577881948265e-11)))));
+                                        z * (k.c5 + z * -1.13596475577881948265e-11)))));
   const double hz = 0.5 * z;
   const double w = 1.0 - hz;
   double cr = w + (((1.0 - w) - hz) + z * pc);
@@ -74,6 +90,10 @@ __device__ __forceinline__ void sincos_shared(double x, double& s_out, double& c
   s_out = (q & 1u) ? cr : sr;
   c_out = (q & 1u) ? sr : cr;
 }
+
+__device__ __forceinline__ void sincos_shared(double x, double& s_out, double& c_out) { sincos_shared(x, s_out, c_out, trig_consts()); }
+struct NoTrigConsts {};  // (the float kernels' constants are literals of VOP2 / VOP3 instructions)
+__device__ __forceinline__ void sincos_shared(float x, float& s_out, float& c_out, const NoTrigConsts&);
 
 // fp32 flavour of the above.  The range reduction runs in DOUBLE (conversion, product, rint, one FMA against a 53-bit pi/2:
 // the same six instructions as a three-term float Cody-Waite reduction, whose exactness ends at |x| ~ 3.2e3): r = x - j pi/2
@@ -95,6 +115,10 @@ __device__ __forceinline__ void sincos_shared(float x, float& s_out, float& c_ou
   c_out = (q & 1u) ? sr : cr;
 }
 
+__device__ __forceinline__ void sincos_shared(float x, float& s_out, float& c_out, const NoTrigConsts&) { sincos_shared(x, s_out, c_out); }
+template <class real> struct TrigConstsOf { using type = NoTrigConsts; static __device__ __forceinline__ type get() { return type(); } };
+template <> struct TrigConstsOf<double> { using type = TrigConsts; static __device__ __forceinline__ type get() { return trig_consts(); } };
+
 // include/acrobot.h  (n=4, m=1).  I1=I2=l1=l2=m1=m2=1, lc1=lc2=.5, g=9.81 (:19-25).
 template <class real_>
 struct AcrobotModelT {
@@ -104,7 +128,10 @@ struct AcrobotModelT {
   real goal[4];  // acrobot.h:21  (3.1415, 0, 0, 0)
   real u_min[1], u_max[1];
 
-  __device__ __forceinline__ void dynamics(const real* x, const real* u, real* dx) const {
+  using trig_consts_t = typename TrigConstsOf<real>::type;
+  __device__ __forceinline__ void dynamics(const real* x, const real* u, real* dx) const { dynamics_k(x, u, dx, TrigConstsOf<real>::get()); }
+  // (the same function with sincos_shared's register constants handed in: WithTrigConsts)
+  __device__ __forceinline__ void dynamics_k(const real* x, const real* u, real* dx, const trig_consts_t& tk) const {
     // contraction by the source, not by the optimiser: every inlined copy of this function (rollout kernels, the
     // persistent kernel, the commit / getter re-integration, the finite differences) must round identically
 #pragma clang fp contract(on)
@@ -114,8 +141,8 @@ struct AcrobotModelT {
     // the four trig values of acrobot.h:44,55,65,66 from two shared-reduction evaluations;
     // sin(q0+q1) by the angle-sum identity (about 2e-16 absolute)
     real s1, c1, s2, c2;
-    sincos_shared(q0, s1, c1);
-    sincos_shared(q1, s2, c2);
+    sincos_shared(q0, s1, c1, tk);
+    sincos_shared(q1, s2, c2, tk);
     const real s12 = s1 * c2 + c1 * s2;
     // H(q), acrobot.h:43-51
     const real H00 = I1 + I2 + m2 * l1 * l1 + 2 * m2 * l1 * lc2 * c2;
@@ -293,6 +320,21 @@ struct DoubleIntegratorModelT {
   }
   // double_integrator.h:45-48
   __device__ __forceinline__ real final_cost(const real* x) const { return quad(x, real(10.0)); }
+};
+
+// A model whose dynamics() takes sincos_shared's register constants from the object instead of materialising them per call: built
+// once before a loop that evaluates the model every trip (rollout_tile).  Same expressions, same constants: the same bits.  Models
+// without dynamics_k (the double integrator, user twins) pass through unchanged.
+template <class M, class = void>
+struct WithTrigConsts : M {
+  __device__ __forceinline__ explicit WithTrigConsts(const M& m) : M(m) {}
+};
+template <class M>
+struct WithTrigConsts<M, std::void_t<typename M::trig_consts_t>> : M {
+  using real = typename M::real;
+  typename M::trig_consts_t tk;
+  __device__ __forceinline__ explicit WithTrigConsts(const M& m) : M(m), tk(TrigConstsOf<real>::get()) {}
+  __device__ __forceinline__ void dynamics(const real* x, const real* u, real* dx) const { M::dynamics_k(x, u, dx, tk); }
 };
 
 // include/model.h:12-15  x1 = x + dynamics(x,u)*dt

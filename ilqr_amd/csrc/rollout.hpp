@@ -207,6 +207,7 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
       }
     }
   };
+  const WithTrigConsts<M> rmodel(model);  // (models.hpp: the trig constants of the dynamics in registers once, not once per step)
   auto do_step = [&](int t, const StepIn& d) __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < NG; g++) {
@@ -230,7 +231,7 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
       emit_knot(g, t, x[g], u, std::true_type());
       total[g] += (double)model.cost(x[g], u);  // :324
       real x1[NX];
-      integrate_dynamics(model, x[g], u, dt, x1);  // :325
+      integrate_dynamics(rmodel, x[g], u, dt, x1);  // :325
 #pragma unroll
       for (int i = 0; i < NX; i++) x[g][i] = x1[i];
     }
