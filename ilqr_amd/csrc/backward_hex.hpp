@@ -222,6 +222,10 @@ __device__ __forceinline__ void backward_hex(const BatchViewT<typename M::real>&
       V = (creal)r[((R::CXX + r_ + 4 * c_) >> 1) * RS::ROW + ((R::CXX + r_ + 4 * c_) & 1)];    // :354
     }
     kprev = (creal)kt[(unsigned)((T - 1) * TW)];
+    // (gfx950 counts stores in vmcnt too: with this load still "in flight" at the loop header the compiler made every step wait for
+    //  vmcnt(0) before its first use of kprev -- i.e. for the previous step's gain stores to be acknowledged by the L2, a few hundred
+    //  cycles of a 1500-cycle step.  Waited for here, once per pass, no step waits for memory at all.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     dV0 = dV1 = 0;
     diverge = 0;
     gacc = 0;
