@@ -18,6 +18,7 @@
 #include "backward_wave3.hpp"
 #include "generic.hpp"
 #include "kernels_wide.hpp"
+#include "kernels_wide2.hpp"
 #include "kernels.hpp"
 
 using namespace ilqr;

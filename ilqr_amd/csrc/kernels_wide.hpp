@@ -501,6 +501,10 @@ __device__ __forceinline__ void commit_chunks_wide(const BatchViewT<typename M::
   }
 }
 
+template <class M, class Gate, class RS>  // (kernels_wide2.hpp: the chain for two controls)
+__device__ __forceinline__ void backward_wide2(const BatchViewT<typename M::real>& v, const M& model, const SolverParams& sp, int mode, int wtile,
+                                               int lane, Gate& gate, const typename M::real* __restrict__ ring);
+
 // STEP 1 + STEP 2 of one iteration for one wide tile (see sweep_backward_tile): wavefront 0 the chain, 1..kProd producers
 // (one knot x 64 trajectories per producer and round), wavefront kProd + 1 the pending commit, the rest of the block idle
 // in this phase.
@@ -522,7 +526,10 @@ __device__ __forceinline__ void sweep_backward_wide(const BatchViewT<typename M:
   if (wave == 0) {
     __builtin_amdgcn_s_setprio(3);
     WideGate<SH, kProd> gate(sh, T);
-    backward_wide<M, decltype(gate), RS>(v, model, sp, mode, wtile, lane, sh.steps, gate, sh.ring);
+    if constexpr (M::NU == 1)
+      backward_wide<M, decltype(gate), RS>(v, model, sp, mode, wtile, lane, sh.steps, gate, sh.ring);
+    else
+      backward_wide2<M, decltype(gate), RS>(v, model, sp, mode, wtile, lane, gate, sh.ring);
     gate.finish();
     __builtin_amdgcn_s_setprio(0);
   } else if (wave <= kProd) {
@@ -566,15 +573,17 @@ __device__ __forceinline__ void sweep_backward_wide(const BatchViewT<typename M:
 // OCC = 1: one wide tile per CU -- 8 wavefronts, three producers, a 148 KB ring.
 // OCC = 2: TWO wide tiles per CU, so that one tile's rollouts (12 units, the bulk of the instructions) run beside the other's
 //          chain: 4 wavefronts each, two producers, a 74 KB ring (three slots in fp64), roles by SIMD as in k_solve_tile<.., 2>.
+// OCC = 3: the two-control tile (kernels_wide2.hpp): one per CU, FOUR wavefronts (one per SIMD: 512 registers for the chain), two
+//          producers, a 148 KB ring (four 30 KB slots in fp64).
 template <int OCC>
 struct WideCfg {
   static constexpr int kWaves = (OCC == 1) ? 8 : 4;
   static constexpr int kProd = (OCC == 1) ? 3 : 2;
-  static constexpr int kRingKb = (OCC == 1) ? 148 : 74;
+  static constexpr int kRingKb = (OCC == 2) ? 74 : 148;
   // rollout prefetch depth (steps of nominal rows in flight per wavefront).  Measured, alternating builds on one box: with two
   // tiles per CU depth 8 is 7.35e9/s against 6.96e9/s at B = 32768, with one tile per CU depth 4 is 6.21e9/s against 5.97e9/s at
   // B = 16384 -- in both cases through phase 1 (the register allocation of the whole kernel moves), not through the rollouts.
-  static constexpr int kPrefetch = (OCC == 1) ? 4 : 8;
+  static constexpr int kPrefetch = (OCC == 2) ? 8 : 4;
   // alpha groups a rollout wavefront carries per lane (rollout.hpp, NG): with four wavefronts per tile each takes one 16-trajectory
   // tile whole; eight wavefronts keep the twelve (tile, alpha group) units
 #ifndef ILQR_WIDE_ROLL_GROUPS

@@ -260,8 +260,8 @@ static int launch_backward(ilqr_batch* h, int mode) {
 static int fused_variant(const ilqr_batch* h) {  // 0: two kernels, 1: one tile per CU, 2: two tiles per CU, 3: wide tiles (64 trajectories, one per CU), 4: one tile per CU, matrix-core chains
   if (!use_quad_backward(h) || h->aos || (h->flags & ILQR_FLAG_UNFUSED) || h->route.unfused) return 0;
   const bool staged = (h->flags & ILQR_FLAG_STAGED) || h->route.staged;
-  const bool wide_ok = !staged && h->nu == 1 && h->sp.fixes == 0;  // wide tiles (kernels_wide.hpp): persistent route, m = 1, no opt-in fixes
-  const int one_per_cu = (wide_ok && !h->route.quad_chain) ? 4 : 1;  // k_solve_hex (backward_hex.hpp) shares the wide tiles' conditions
+  const bool wide_ok = !staged && h->nu <= 2 && h->sp.fixes == 0;  // wide tiles (kernels_wide.hpp, kernels_wide2.hpp): persistent route, m <= 2, no opt-in fixes
+  const int one_per_cu = (wide_ok && h->nu == 1 && !h->route.quad_chain) ? 4 : 1;  // k_solve_hex (backward_hex.hpp): the wide tiles' conditions and m = 1
   if (h->route.fused) return (h->route.fused == 3 && !wide_ok) ? 2 : (h->route.fused == 1 ? one_per_cu : h->route.fused);
   if (h->ntiles <= h->num_cus) return one_per_cu;
   // beyond two 16-trajectory tiles per CU: 64-trajectory wide tiles, the thread-per-trajectory chain (one per CU up to 64 #CU
@@ -337,6 +337,8 @@ static int launch_solve_tiles(ilqr_batch* h, int n_iters) {
             else
               hipLaunchKernelGGL((k_solve_wide<MM, MF, 2>), dim3((grid_tiles + 3) / 4), dim3(256), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
           }
+          else if constexpr (MM::NU == 2)
+            hipLaunchKernelGGL((k_solve_wide2<MM, MF>), dim3((grid_tiles + 3) / 4), dim3(256), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);
         } else if (occ == 4) {
           if constexpr (MM::NU == 1)
             hipLaunchKernelGGL((k_solve_hex<MM, MF>), dim3(grid_tiles), dim3(512), 0, h->stream, v, m, fdm, al, h->sp, n_iters, h->sp.fixed_work, h->commit_idx, pending, ticks);

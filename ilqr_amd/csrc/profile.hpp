@@ -73,7 +73,7 @@ const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
       return (h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t";
     case ILQR_STAGE_ROLLOUT: return (h && h->aos) ? ((h->route.lq_thread_rollout || h->model != ILQR_MODEL_LQ) ? "k_rollout_g" : "k_rollout_lq") : "k_rollout";
     case ILQR_STAGE_ACCEPT: return "k_accept";
-    case ILQR_STAGE_SOLVE: return (h && use_persistent(h)) ? (fused_variant(h) == 1 ? "k_solve_tile" : fused_variant(h) == 3 ? "k_solve_wide" : fused_variant(h) == 4 ? "k_solve_hex" : "k_solve_tile<2>") : "";
+    case ILQR_STAGE_SOLVE: return (h && use_persistent(h)) ? (fused_variant(h) == 1 ? "k_solve_tile" : fused_variant(h) == 3 ? (h->nu == 2 ? "k_solve_wide2" : "k_solve_wide") : fused_variant(h) == 4 ? "k_solve_hex" : "k_solve_tile<2>") : "";
     default: return "";
   }
 }

@@ -167,7 +167,7 @@ enum ilqr_route {
   ILQR_ROUTE_AUTO = 0,
   ILQR_ROUTE_TILE_PER_CU = 1,       /* ilqr_iterate: persistent 16-trajectory tiles, one per CU (k_solve_hex for m = 1 without opt-in fixes, else k_solve_tile<..,1>) */
   ILQR_ROUTE_TWO_TILES_PER_CU = 2,  /* ... two per CU (k_solve_tile<..,2>; with ILQR_FLAG_STAGED the one-producer k_sweep_backward) */
-  ILQR_ROUTE_WIDE_TILES = 3,        /* ... 64-trajectory wide tiles (k_solve_wide; m = 1 without opt-in fixes, else as 2) */
+  ILQR_ROUTE_WIDE_TILES = 3,        /* ... 64-trajectory wide tiles (k_solve_wide / k_solve_wide2; m <= 2 without opt-in fixes, else as 2) */
   ILQR_ROUTE_WIDE_ONE_PER_CU = 4,   /* wide tiles: one per CU whatever the batch size */
   ILQR_ROUTE_WIDE_TWO_PER_CU = 8,   /* wide tiles: two per CU whatever the batch size */
   ILQR_ROUTE_NO_COMPACTION = 16,    /* ilqr_generate_trajectory without re-packing running trajectories between chunks */

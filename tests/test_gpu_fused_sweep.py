@@ -159,6 +159,32 @@ def test_wide_tiles_equal_unfused(B, T, dtype, occ, monkeypatch):
     _same(out[0], out[1])
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("B,T", [(64, 40), (130, 99), (37, 3), (300, 100)])
+def test_wide_tiles_two_controls_equal_unfused(B, T, dtype):
+    """k_solve_wide2 (kernels_wide2.hpp: the 64-trajectory tile with the thread-per-trajectory chain for m = 2, the 2 x 2 box-QP
+    per thread, four wavefronts per tile) forced on small double-integrator batches -- ragged tiles, horizons shorter than the ring
+    -- in fixed-iteration and in normal mode until every trajectory has left its loop, against the two-kernel route (the quad
+    kernel): every array and scalar bit-identical."""
+    from ilqr_amd import BatchILQR, capi
+    x0 = integrator_x0(B)
+    u0 = np.zeros((B, T, 2))
+    kw = dict(u_min=-0.5, u_max=0.5, goal=[1.0, 0.5, 0.0, 0.0], params=dict(max_iter=14), dtype=dtype)
+    sv = capi.STAGE_NAMES.index("solve")
+    out = []
+    for fl, route in ((0, capi.ROUTE_WIDE_TILES), (capi.FLAG_UNFUSED, 0)):
+        g = BatchILQR("integrator", B, T, DT, flags=fl, route=route, **kw)
+        if route:
+            assert g.lib.ilqr_stage_kernel_name(g.h, sv) == b"k_solve_wide2"
+        g.init_traj(x0, u0)
+        g.iterate(3)
+        s3 = _state(g)
+        g.generate_trajectory()
+        out.append(dict(_state(g), **{"i3_" + n: a for n, a in s3.items()}))
+        g.close()
+    _same(out[0], out[1])
+
+
 def test_route_selection_by_batch_size(monkeypatch):
     """Route selection by batch size (ilqr_desc.assume_cus scales the thresholds down to test sizes): up to one tile per CU
     the persistent kernel with a CU per tile, up to two per CU the persistent kernel with two tiles per CU, beyond that -- at ANY
