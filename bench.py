@@ -470,32 +470,42 @@ def main():
             extra["acrobot_T500_B1024_lim5_f64"]["cpu_baseline"] = cpu_baseline(1024, T, dt, 5.0, target_wall_s=2.0, backward_only=False)
         # the reference's other shipped model, batched (north_star: "acrobot/double-integrator problems"; BASELINE configs[0]
         # is its single-trajectory T=100 solve, a parity case): n=4, m=2 -- the generic m x m box-QP inside the quad kernel
-        Bd, Td, goal = 4096, 100, [1.0, 0.5, 0.0, 0.0]
-        gd = BatchILQR("integrator", Bd, Td, dt, u_min=-0.5, u_max=0.5, goal=goal, device=local_rank, stream=stream,
-                       flags=capi.FLAG_FIXED_WORK, params=dict(max_iter=args.warmup + 2 * steps + 1))
-        rd = np.random.default_rng(4321)
-        gd.init_traj(rd.uniform(-1, 1, size=(Bd, 4)) * np.array([1.5, 1.5, 0.5, 0.5]), np.zeros((Bd, Td, 2)))
-        gd.iterate(args.warmup)
-        gd.profile(True)
-        eld = None
-        for _ in range(2):  # (a 4 ms region right after the host-side CPU baseline: the second of two runs is the one with the clocks up)
-            gd.profile_reset()
-            barrier()
-            t0 = time.perf_counter()
-            gd.iterate(steps)
-            barrier()
-            eld = time.perf_counter() - t0
-        pd_ = gd.profile_read()
-        assert gd.count_running() == Bd
-        named = {i: gd.lib.ilqr_stage_kernel_name(gd.h, i).decode() for i in range(capi.NUM_STAGES)}
-        extra["integrator_T100_B4096_lim0.5_f64"] = {
-            "workload": "double integrator (n=4, m=2) T=100 B=4096, u in [-0.5,0.5]^2, goal (1, 0.5, 0, 0), fp64, fixed-work iterations",
-            "value": Bd * Td * steps / eld, "unit": "trajectory-timesteps/s", "ms_per_step": eld / steps * 1e3,
-            "stages": {k: {"kernel": "k_solve_tile" if k in ("backward", "rollout", "solve") else named[capi.STAGE_NAMES.index(k)],
-                           "ms_per_launch": ms / ln, "launches": ln} for k, (ms, ln) in pd_.items() if ln}}
-        if not args.no_cpu_baseline:
-            extra["integrator_T100_B4096_lim0.5_f64"]["cpu_baseline"] = cpu_baseline_other("integrator", Td, dt)
-        gd.close()
+        Td, goal = 100, [1.0, 0.5, 0.0, 0.0]
+        for Bd in (4096, 32768):  # one 16-trajectory tile per CU (the quad chain); the saturated regime (k_solve_wide2: 64-trajectory tiles)
+            gd = BatchILQR("integrator", Bd, Td, dt, u_min=-0.5, u_max=0.5, goal=goal, device=local_rank, stream=stream,
+                           flags=capi.FLAG_FIXED_WORK, params=dict(max_iter=args.warmup + 2 * steps + 1))
+            rd = np.random.default_rng(4321)
+            gd.init_traj(rd.uniform(-1, 1, size=(Bd, 4)) * np.array([1.5, 1.5, 0.5, 0.5]), np.zeros((Bd, Td, 2)))
+            gd.iterate(args.warmup)
+            gd.profile(True)
+            eld = None
+            for _ in range(2):  # (a few ms right after the host-side CPU baseline: the second of two runs is the one with the clocks up)
+                gd.profile_reset()
+                barrier()
+                t0 = time.perf_counter()
+                gd.iterate(steps)
+                barrier()
+                eld = time.perf_counter() - t0
+            pd_ = gd.profile_read()
+            assert gd.count_running() == Bd
+            named = {i: gd.lib.ilqr_stage_kernel_name(gd.h, i).decode() for i in range(capi.NUM_STAGES)}
+            solve_kernel = named[capi.STAGE_NAMES.index("solve")]
+            key = "integrator_T100_B%d_lim0.5_f64" % Bd
+            extra[key] = {
+                "workload": "double integrator (n=4, m=2) T=100 B=%d, u in [-0.5,0.5]^2, goal (1, 0.5, 0, 0), fp64, fixed-work iterations" % Bd,
+                "value": Bd * Td * steps / eld, "unit": "trajectory-timesteps/s", "ms_per_step": eld / steps * 1e3,
+                "stages": {k: {"kernel": solve_kernel if k in ("backward", "rollout", "solve") else named[capi.STAGE_NAMES.index(k)],
+                               "ms_per_launch": ms / ln, "launches": ln} for k, (ms, ln) in pd_.items() if ln}}
+            # the contract's HBM figure for this line: Rec<4,2> sweep + backward + 11-alpha rollouts, algorithmic bytes per trajectory-timestep
+            # (records stay in LDS: xs, us read by the producers 6 doubles; gains written 10; rollouts read 16 rows and write 11 x (2 controls + 4/8 states))
+            bts = 8 * (6 + 10 + 16 + 11 * 2.5)
+            extra[key]["roofline"] = {"bound": "valu_issue", "contract_bound": "hbm", "kernel": solve_kernel, "achieved": bts * Bd * Td / (eld / steps) / 1e9,
+                                      "peak": 8000.0, "unit": "GB/s", "frac": bts * Bd * Td / (eld / steps) / 1e9 / 8000.0,
+                                      "algorithmic_bytes_per_timestep": bts, "traffic": None,
+                                      "limiter": "one dependent chain per tile (instruction issue and latency), as the acrobot lines"}
+            if not args.no_cpu_baseline and Bd == 4096:
+                extra[key]["cpu_baseline"] = cpu_baseline_other("integrator", Td, dt)
+            gd.close()
         # BASELINE configs[4]: synthetic LQ n=32 m=16 T=200 B=8192, limits +-1: the generic wave-per-trajectory path
         nq, mq, Tq, Bq = 32, 16, 200, 8192
         flop_ts = 4 * nq ** 3 + 10 * nq * nq * mq + 6 * nq * mq * mq + mq ** 3   # backward flops / timestep
