@@ -70,6 +70,13 @@ timeout 600 rocprofv3 --pmc MeanOccupancyPerCU MeanOccupancyPerActiveCU --kernel
 # ... and with every perturbed point's forms evaluated densely on the matrix cores (ILQR_ROUTE_LQ_DENSE_FD = 2048: k_derivatives_g, the sweep of rounds 1-4)
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/lqfd_dense_stats -o $R -- $LQFD 2048 > $OUT/lqfd_dense_bench.txt 2> $OUT/lqfd_dense_stats.err
 timeout 600 rocprofv3 --pmc $SQLQ --kernel-trace -d $OUT/lqfd_dense_pmc_sq -o $R -- $LQFD 2048 > /dev/null 2> $OUT/lqfd_dense_pmc_sq.err
+# the double integrator (m = 2) in the saturated regime: k_solve_wide2 (64-trajectory tiles, thread-per-trajectory chain with the 2 x 2 box-QP)
+INT="python $ROOT/scripts/bench_integrator.py"
+B=32768 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/int_stats -o $R -- $INT > $OUT/int_bench.txt 2> $OUT/int_stats.err
+for C in FETCH_SIZE WRITE_SIZE; do
+  B=32768 timeout 300 rocprofv3 --pmc $C --kernel-trace -d $OUT/int_pmc_$C -o $R -- $INT > /dev/null 2> $OUT/int_pmc_$C.err
+done
+B=32768 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace -d $OUT/int_pmc_sq1 -o $R -- $INT > /dev/null 2> $OUT/int_pmc_sq1.err
 cd $ROOT
 for U in lat ldsmix; do  # microbenchmarks quoted in DESIGN.md, re-run on this box
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $OUT/$U scripts/ubench/$U.hip 2> /dev/null && $OUT/$U > $OUT/ubench_$U.txt 2>/dev/null
@@ -77,7 +84,7 @@ for U in lat ldsmix; do  # microbenchmarks quoted in DESIGN.md, re-run on this b
 done
 for d in stats stats5 quad_stats5 pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq1 pmc_sq2 pmc_sq3 pmc_sq4 sat_stats5 sat_pmc_FETCH_SIZE sat_pmc_WRITE_SIZE sat_pmc_sq1 sat_pmc_sq2 sat_pmc_sq3 \
          f32_stats5 f32_pmc_FETCH_SIZE f32_pmc_WRITE_SIZE f32_pmc_sq1 f32_pmc_sq2 f32_pmc_sq3 f32sat_stats5 f32sat_pmc_FETCH_SIZE f32sat_pmc_WRITE_SIZE f32sat_pmc_sq1 f32sat_pmc_sq2 f32sat_pmc_sq3 \
-         staged_pmc_FETCH_SIZE staged_pmc_WRITE_SIZE staged_stats lq_stats lq_pmc_sq lq_pmc_occ lq_pmc_FETCH_SIZE lq_pmc_WRITE_SIZE lq_w2_pmc_sq lq_w1_pmc_sq lq_w1_pmc_occ lqfd_stats lqfd_pmc_sq lqfd_pmc_occ lqfd_dense_stats lqfd_dense_pmc_sq; do
+         staged_pmc_FETCH_SIZE staged_pmc_WRITE_SIZE staged_stats lq_stats lq_pmc_sq lq_pmc_occ lq_pmc_FETCH_SIZE lq_pmc_WRITE_SIZE lq_w2_pmc_sq lq_w1_pmc_sq lq_w1_pmc_occ lqfd_stats lqfd_pmc_sq lqfd_pmc_occ lqfd_dense_stats lqfd_dense_pmc_sq int_stats int_pmc_FETCH_SIZE int_pmc_WRITE_SIZE int_pmc_sq1; do
   f=$(find $OUT/$d -name "*.db" | head -1)
   [ -n "$f" ] && python scripts/prof_summary.py $f > $OUT/$d.txt 2>&1
 done
