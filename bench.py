@@ -503,6 +503,14 @@ def main():
                                       "peak": 8000.0, "unit": "GB/s", "frac": bts * Bd * Td / (eld / steps) / 1e9 / 8000.0,
                                       "algorithmic_bytes_per_timestep": bts, "traffic": None,
                                       "limiter": "one dependent chain per tile (instruction issue and latency), as the acrobot lines"}
+            if solve_kernel == "k_solve_wide2" and Bd == 32768:  # the counter passes of this kernel were taken at this batch (collect_profiles.sh: int_*)
+                tr, src = pmc_traffic(solve_kernel, steps)
+                extra[key]["roofline"]["traffic"] = tr
+                extra[key]["roofline"]["traffic_source"] = src
+                extra[key]["roofline"]["algorithmic_bytes_per_launch"] = bts * Bd * Td * steps
+                iss = issue_roofline(solve_kernel, eld / steps * 1e3, gd.shader_clock_mhz() if pd_.get("solve", (0, 0))[1] else None, Bd * Td)
+                extra[key]["roofline"]["bound_frac"] = iss.get("frac")
+                extra[key]["roofline_issue"] = iss
             if not args.no_cpu_baseline and Bd == 4096:
                 extra[key]["cpu_baseline"] = cpu_baseline_other("integrator", Td, dt)
             gd.close()

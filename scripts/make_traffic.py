@@ -47,16 +47,17 @@ def durations(path):
     return out
 
 
-def solve_entry(d, prefix, key, B, T, f, w):
+def solve_entry(d, prefix, key, B, T, f, w, WARMUP=WARMUP, STEPS=STEPS, stats="stats5"):
     """the persistent kernel of one counter-run set (prefix "" = headline batch, "sat_" = saturated batch): per-iteration figures"""
-    valu = read("%s/%spmc_sq1.txt" % (d, prefix), "SQ_INSTS_VALU")
-    wavecyc = read("%s/%spmc_sq3.txt" % (d, prefix), "SQ_WAVE_CYCLES")
-    waitany = read("%s/%spmc_sq3.txt" % (d, prefix), "SQ_WAIT_ANY")
     import os
+    valu = read("%s/%spmc_sq1.txt" % (d, prefix), "SQ_INSTS_VALU")
+    have_sq3 = os.path.exists("%s/%spmc_sq3.txt" % (d, prefix))
+    wavecyc = read("%s/%spmc_sq3.txt" % (d, prefix), "SQ_WAVE_CYCLES") if have_sq3 else {}
+    waitany = read("%s/%spmc_sq3.txt" % (d, prefix), "SQ_WAIT_ANY") if have_sq3 else {}
     have_sq2 = os.path.exists("%s/%spmc_sq2.txt" % (d, prefix))
     bank = read("%s/%spmc_sq2.txt" % (d, prefix), "SQ_LDS_BANK_CONFLICT") if have_sq2 else {}
     ldsact = read("%s/%spmc_sq2.txt" % (d, prefix), "SQ_LDS_IDX_ACTIVE") if have_sq2 else {}
-    dur = durations("%s/%sstats5.txt" % (d, prefix))
+    dur = durations("%s/%s%s.txt" % (d, prefix, stats))
     fr, wr = f.get(key, (0.0, 1))[0], w.get(key, (0.0, 1))[0]
     e = {"fetch_size_kb": fr, "write_size_kb": wr, "hbm_read_bytes": 2 * fr * 1024, "hbm_write_bytes": wr * 1024,
          "hbm_bytes_per_launch": 2 * fr * 1024 + wr * 1024}
@@ -112,6 +113,13 @@ def main(d, tag):
             if key in ff or key in wf:
                 kernels[key] = solve_entry(d, prefix, key, Bk, T, ff, wf)
                 kernels[key]["workload"] = "acrobot T=499 B=%d fp32 limits +-5" % Bk
+    # the double integrator (m = 2) in the saturated regime: scripts/bench_integrator.py at B = 32768 (3 + 20 iterations, T = 100)
+    if os.path.exists("%s/int_pmc_FETCH_SIZE.txt" % d):
+        ff, wf = read("%s/int_pmc_FETCH_SIZE.txt" % d, "FETCH_SIZE"), read("%s/int_pmc_WRITE_SIZE.txt" % d, "WRITE_SIZE")
+        for key in ("k_solve_wide2", "k_solve_wide2_f32"):
+            if key in ff or key in wf:
+                kernels[key] = solve_entry(d, "int_", key, 32768, 100, ff, wf, WARMUP=3, STEPS=20, stats="stats")
+                kernels[key]["workload"] = "double integrator T=100 B=32768 %s limits +-0.5 (scripts/bench_integrator.py)" % ("fp32" if key.endswith("f32") else "fp64")
     json.dump({"source": "rocprofv3 passes of `bench.py --no-cpu-baseline --no-extra-configs --steps 5 --warmup 3` on MI355X, one counter "
                          "set per run with --kernel-trace only (scripts/collect_profiles.sh; summaries profiles/%s_*.txt): FETCH_SIZE x 2.000, WRITE_SIZE x 1.000 "
                          "as calibrated on 8-byte row loads / stores of known size (profiles/r04_fetch_calibration.txt), KB = 1024 B; k_sweep_backward / "
