@@ -329,7 +329,10 @@ __device__ __forceinline__ int w3_box_qp_small(int m, LDS& L, int lane, int& nfR
 
 // n <= 16 NT, m <= 16.  Arguments as k_backward_w2; LQF: const_rec holds TWO records (the constant blocks of the knots t < T,
 // then knot T's) and v.D is not touched.
-template <int NT, bool FULL, bool LQF>
+// REGV (ILQR_FLAG_REGULARIZE_VXX, opt-in): lambda regularises Vxx' ([Tassa 2012] eq. 10) instead of Quu -- QuuF = Quu + lambda fu'fu and the
+// gains' Qux_reg = Qux + lambda fu'fx, two more transposed products per 16-column block on the operands the step holds anyway; the value
+// update keeps Quu, Qux (backward_thread.hpp, oracle/orc_bw.inc).  Instantiated without FULL / LQF.
+template <int NT, bool FULL, bool LQF, bool REGV = false>
 __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w3(BatchView v, int n, int m, const double* __restrict__ u_min,
                                                                     const double* __restrict__ u_max, SolverParams sp, int mode,
                                                                     const double* __restrict__ const_rec) {
@@ -502,6 +505,7 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w3(BatchView v
       // :361 Qxx = cxx + A1 fx ; :362 Qux = cxu' + A2 fx ; :363/:367 Quu, QuuF = cuu (+ lambda I) + A2 fu
       ILQR_W2MARK(1)
       double Qxx[NT][NT][4], Qux[NT][4], quu_nat[4];
+      double Quxr[REGV ? NT : 1][4];  // REGV: Qux + lambda fu'fx, what the gains are solved from
 #pragma unroll
       for (int tj = 0; tj < NT; tj++) {  // one 16-column block of the outputs at a time (registers)
         __builtin_amdgcn_sched_barrier(0);
@@ -558,6 +562,17 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w3(BatchView v
           Qux[tj][rr] = (FULL || (mrow_in(rr) && col_in(tj))) ? val : 0.0;
           asm volatile("" : "+v"(Qux[tj][rr]));
         }
+        double4_t fufu = zero4;
+        if constexpr (REGV) {  // fu'fx, fu'fu: rows and columns outside the model are zero in fu, fx already
+          double4_t fufx = zero4;
+#pragma unroll
+          for (int ks = 0; ks < 4 * NT; ks++) {
+            fufx = mfma(fu[ks >> 2][ks & 3], fx[ks >> 2][tj][ks & 3], fufx);
+            if (tj == 0) fufu = mfma(fu[ks >> 2][ks & 3], fu[ks >> 2][ks & 3], fufu);
+          }
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) Quxr[tj][rr] = Qux[tj][rr] + lambda * fufx[rr];
+        }
         if (tj == 0) {
 #pragma unroll
           for (int rr = 0; rr < 4; rr++) {
@@ -566,7 +581,10 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w3(BatchView v
             const double cu2 = in ? cuu[rr] : 0.0;
             quu_nat[rr] = in ? cu2 + quu[rr] : 0.0;
             L.Quu()[a + LDM * c] = quu_nat[rr];
-            L.QuuF()[a + LDM * c] = in ? (cu2 + ((a == c) ? lambda : 0.0)) + quu[rr] : 0.0;
+            if constexpr (REGV)
+              L.QuuF()[a + LDM * c] = in ? quu_nat[rr] + lambda * fufu[rr] : 0.0;
+            else
+              L.QuuF()[a + LDM * c] = in ? (cu2 + ((a == c) ? lambda : 0.0)) + quu[rr] : 0.0;
           }
         }
       }
@@ -611,6 +629,9 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w3(BatchView v
       // :373-385  K rows of free dims, natural registers K[tj][r] = K(4 r + g, 16 tj + p)
       double K[NT][4];
       const int nf = __popc(free_mask);
+      auto quxk = [&](int tj, int rr) -> double {  // what the gains are solved from
+        if constexpr (REGV) return Quxr[tj][rr]; else return Qux[tj][rr];
+      };
       if (!slow) {
         // K = -(masked inverse) Qux: clamped rows of the inverse are zero, so those rows of K are, and its zero columns add
         // exact zeros to the k-ordered sums over the free dims
@@ -618,7 +639,7 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w3(BatchView v
         for (int tj = 0; tj < NT; tj++) {
           double4_t acc = zero4;
 #pragma unroll
-          for (int ks = 0; ks < WM / 4; ks++) acc = mfma(Xm[ks], Qux[tj][ks], acc);
+          for (int ks = 0; ks < WM / 4; ks++) acc = mfma(Xm[ks], quxk(tj, ks), acc);
 #pragma unroll
           for (int rr = 0; rr < 4; rr++) K[tj][rr] = -acc[rr];
         }
@@ -644,7 +665,7 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w3(BatchView v
           for (int tj = 0; tj < NT; tj++) {
             double4_t acc = zero4;
 #pragma unroll
-            for (int ks = 0; ks < WM / 4; ks++) acc = mfma(aM[ks], Qux[tj][ks], acc);
+            for (int ks = 0; ks < WM / 4; ks++) acc = mfma(aM[ks], quxk(tj, ks), acc);
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) K[tj][rr] = -acc[rr];
           }
@@ -654,7 +675,7 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w3(BatchView v
 #pragma unroll
           for (int tj = 0; tj < NT; tj++)
 #pragma unroll
-            for (int rr = 0; rr < 4; rr++) L.Tbuf[(4 * rr + g) + LDM * (16 * tj + p)] = Qux[tj][rr];
+            for (int rr = 0; rr < 4; rr++) L.Tbuf[(4 * rr + g) + LDM * (16 * tj + p)] = quxk(tj, rr);
           lds_sync();
           if (nf > 0) {
             const int nuse = (nf < nfR) ? nf : nfR;

@@ -323,14 +323,15 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   h->sp.fixed_work = (h->flags & ILQR_FLAG_FIXED_WORK) ? 1 : 0;
   h->sp.fixes = ((h->flags & ILQR_FLAG_REFERENCE_FIXES) ? 3 : 0) | ((h->flags & ILQR_FLAG_REGULARIZE_VXX) ? 4 : 0);
   // generic handles: ILQR_FLAG_REFERENCE_FIXES on the models with a device twin (their rollouts clamp, their box-QP reports a failed factorisation); the
-  // host-evaluated route's rollouts belong to the caller, and lambda on Vxx would be two more products per step of the matrix-core kernels
-  if ((h->sp.fixes & 4) && h->aos) return fail(ILQR_ERR_UNSUPPORTED, "ILQR_FLAG_REGULARIZE_VXX is implemented for the nx = 4 device models");
-  if (h->sp.fixes && h->model == ILQR_MODEL_HOST) return fail(ILQR_ERR_UNSUPPORTED, "ILQR_FLAG_REFERENCE_FIXES on a host-evaluated model: its rollouts are the caller's (clamp there); the flag is implemented for the models with a device twin");
+  // host-evaluated route's rollouts belong to the caller.  ILQR_FLAG_REGULARIZE_VXX is the backward pass's alone (k_backward_w3<.., REGV>), on any model
+  if ((h->sp.fixes & 4) && h->aos && (h->route.backward_w1 || h->route.backward_w2))
+    return fail(ILQR_ERR_UNSUPPORTED, "ILQR_FLAG_REGULARIZE_VXX on the generic path is implemented in k_backward_w3: drop ILQR_ROUTE_BACKWARD_LDS / ILQR_ROUTE_BACKWARD_W2");
+  if ((h->sp.fixes & 3) && h->model == ILQR_MODEL_HOST) return fail(ILQR_ERR_UNSUPPORTED, "ILQR_FLAG_REFERENCE_FIXES on a host-evaluated model: its rollouts are the caller's (clamp there); the flag is implemented for the models with a device twin");
 
   hipLaunchKernelGGL(k_reset_state<double>, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
                      h->params.dlambda_init);
   HIPCHK(hipGetLastError());
-  h->lq_fused = h->model == ILQR_MODEL_LQ && v.analytic && !h->route.full_records && !h->route.backward_w1 && !h->route.backward_w2;
+  h->lq_fused = h->model == ILQR_MODEL_LQ && v.analytic && !h->route.full_records && !h->route.backward_w1 && !h->route.backward_w2 && !(h->sp.fixes & 4);
   if (h->lq_fused) {  // both constant records, once (what = 3)
     hipLaunchKernelGGL(k_analytic_lq, dim3(1), dim3(64), 0, h->stream, h->v, h->lq, 1, 3, h->const_rec, kAnalyticChunk);
     HIPCHK(hipGetLastError());

@@ -219,7 +219,12 @@ static int launch_backward(ilqr_batch* h, int mode) {
       hipLaunchKernelGGL(k_backward_w2<2>, grid, block, 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
     else if (h->route.backward_w2)
       hipLaunchKernelGGL(k_backward_w2<1>, grid, block, 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
-    else if (h->nx > 16) {
+    else if (h->sp.fixes & 4) {  // ILQR_FLAG_REGULARIZE_VXX: the bounds-checked instantiations on whole records (ilqr_create keeps lq_fused off)
+      if (h->nx > 16)
+        hipLaunchKernelGGL((k_backward_w3<2, false, false, true>), grid, block, 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
+      else
+        hipLaunchKernelGGL((k_backward_w3<1, false, false, true>), grid, block, 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
+    } else if (h->nx > 16) {
       if (fused) { if (full) ILQR_W3(2, true, true); else ILQR_W3(2, false, true); }
       else { if (full) ILQR_W3(2, true, false); else ILQR_W3(2, false, false); }
     } else {

@@ -121,7 +121,9 @@ enum ilqr_flags {
   /* Opt-in, OFF by default (third part of SURVEY.md 8f-4): lambda regularises the value Hessian instead of Quu --
    * [Tassa 2012] eq. 10a/10b, Quu_reg = cuu + fu'(Vxx' + lambda I) fu, Qux_reg = cxu' + fu'(Vxx' + lambda I) fx --
    * where the reference adds lambda I to Quu and notes "regularization is different" (src/ilqr_core.cpp:365-367).
-   * The value update keeps the unregularised Quu, Qux as in the reference.  nx = 4 device models. */
+   * The value update keeps the unregularised Quu, Qux as in the reference.  Every model: the nx = 4 kernels, the
+   * tiled kernels of a small twin, and k_backward_w3 on the generic path (n <= 32, m <= 16; host-evaluated models
+   * included: the backward pass is what they run on the device) -- not with ILQR_ROUTE_BACKWARD_LDS / _W2. */
   ILQR_FLAG_REGULARIZE_VXX = 128
 };
 

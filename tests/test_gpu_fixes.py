@@ -91,8 +91,8 @@ def test_the_flag_is_off_by_default_and_rejected_where_not_implemented():
     with pytest.raises(ILQRError, match="host-evaluated"):
         BatchILQR("host", 2, 5, DT, nx=3, nu=2, u_min=[-1, -1], u_max=[1, 1], flags=capi.FLAG_REFERENCE_FIXES)
     from tests.test_gpu_lq_end_to_end import dense_mats
-    with pytest.raises(ILQRError, match="REGULARIZE_VXX"):
-        BatchILQR("lq", 2, 5, DT, lq=dense_mats(6, 3), u_min=-1.0, u_max=1.0, flags=capi.FLAG_REGULARIZE_VXX)
+    with pytest.raises(ILQRError, match="REGULARIZE_VXX"):  # (the generic path has it in k_backward_w3 only)
+        BatchILQR("lq", 2, 5, DT, lq=dense_mats(6, 3), u_min=-1.0, u_max=1.0, flags=capi.FLAG_REGULARIZE_VXX, route=capi.ROUTE_BACKWARD_W2)
 
 
 @pytest.mark.parametrize("n,m,B,T,lim,route", [(6, 3, 30, 40, 0.15, 0), (32, 16, 5, 20, 0.1, 0), (6, 3, 30, 40, 0.15, "thread")])
@@ -180,6 +180,102 @@ def test_vxx_regularisation_matches_the_oracle(oracle, name, B, T, lim):
             assert np.abs(mat(r0["K"]) - mat(ro["K"])).max() > 1e-3 * np.abs(mat(ro["K"])).max()
         r = walk_iterations(oracle, om, g, x0, np.zeros((B, T, om.nu)), DT, 4)
         assert r["checked"] >= 2 * B and len(r["tied"]) <= max(2, r["checked"] // 10), r
+        g.close()
+    finally:
+        oracle.set_fixes(0)
+
+
+@pytest.mark.parametrize("n,m,B,T,lim", [(6, 3, 30, 40, 0.15), (32, 16, 5, 20, 0.1), (5, 2, 20, 30, 0.15), (20, 7, 6, 25, 0.1)])
+def test_generic_path_vxx_regularisation_matches_the_oracle(oracle, n, m, B, T, lim):
+    """ILQR_FLAG_REGULARIZE_VXX on the generic path (k_backward_w3<.., REGV>: fu'fu and fu'fx as two more transposed products on the
+    matrix cores): teacher-forced backward passes at lambda in {1, 10} against the oracle with orc_set_fixes(4) -- one 16 x 16 tile and
+    two, the scalar box-QPs of m <= 2, sizes that are not multiples of a tile -- and whole iterations."""
+    from ilqr_amd import BatchILQR, capi
+    from tests.test_gpu_lq_end_to_end import dense_mats
+    oracle.set_fixes(4)
+    try:
+        mats = dense_mats(n, m)
+        om = oracle.Model("lq", lq=mats, u_lim=lim)
+        g = BatchILQR("lq", B, T, DT, u_min=-lim, u_max=lim, lq=mats, flags=capi.FLAG_REGULARIZE_VXX)
+        rng = np.random.default_rng(8)
+        x0 = rng.uniform(-1, 1, (B, n))
+        u0 = rng.normal(size=(B, T, m)) * 0.1
+        xs, us, cost = oracle.batch_rollout(om, x0, u0, DT)
+        do = oracle.batch_derivatives(om, xs, us, DT)
+        for lam in (1.0, 10.0):
+            ro = oracle.batch_backward(om, us, do, lam=lam)
+            g.set_trajectory(x0=x0, xs=xs, us=us, cost=cost)
+            g.set_derivatives(**{k: (do[k] if k in ("cx", "cu") else mat(do[k])) for k in do})
+            g.set_gains(k=np.zeros((B, T, m)), K=np.zeros((B, T, m, n)))
+            g.set_lambda(lam, 1.0)
+            div = g.backward_pass()
+            k, K = g.gains()
+            check_backward(oracle, om, us, do, np.zeros((B, T, m)), lam, k, K, g.dV(), div, ro, max_ties=max(1, B // 8), max_over10=max(1, B // 10))
+            oracle.set_fixes(0)  # ... and it is another regularisation than lambda I on Quu
+            r0 = oracle.batch_backward(om, us, do, lam=lam)
+            oracle.set_fixes(4)
+            assert np.abs(mat(r0["K"]) - mat(ro["K"])).max() > 1e-3 * np.abs(mat(ro["K"])).max()
+        r = walk_iterations(oracle, om, g, x0, u0, DT, 4)
+        assert r["checked"] >= 2 * B and len(r["tied"]) <= max(2, r["checked"] // 10), r
+        g.close()
+    finally:
+        oracle.set_fixes(0)
+
+
+def test_generic_path_vxx_regularisation_with_exact_derivatives(oracle):
+    """With ILQR_FLAG_ANALYTIC_DERIVATIVES the LQ handle leaves its record-free route under the flag (per-knot cx / cu records + the
+    constant blocks): the backward pass over the handle's own sweep against the oracle's over the same records."""
+    from ilqr_amd import BatchILQR, capi
+    from tests.test_gpu_lq_end_to_end import dense_mats
+    n, m, B, T, lim = 32, 16, 5, 20, 0.1
+    oracle.set_fixes(4)
+    try:
+        mats = dense_mats(n, m)
+        om = oracle.Model("lq", lq=mats, u_lim=lim)
+        g = BatchILQR("lq", B, T, DT, u_min=-lim, u_max=lim, lq=mats, flags=capi.FLAG_REGULARIZE_VXX | capi.FLAG_ANALYTIC_DERIVATIVES)
+        rng = np.random.default_rng(10)
+        x0 = rng.uniform(-1, 1, (B, n))
+        u0 = rng.normal(size=(B, T, m)) * 0.1
+        g.init_traj(x0, u0)
+        g.compute_derivatives()
+        g.set_lambda(3.0, 1.0)
+        div = g.backward_pass()
+        k, K = g.gains()
+        d = g.derivatives()
+        _, us = g.trajectory()
+        do = {kk: np.ascontiguousarray(vv if kk in ("cx", "cu") else np.swapaxes(vv, -1, -2)) for kk, vv in d.items()}
+        ro = oracle.batch_backward(om, us, do, lam=3.0)
+        check_backward(oracle, om, us, do, np.zeros((B, T, m)), 3.0, k, K, g.dV(), div, ro, max_ties=1, max_over10=1)
+        g.iterate(3)
+        assert np.all(np.isfinite(g.cost()))
+        g.close()
+    finally:
+        oracle.set_fixes(0)
+
+
+def test_host_model_backward_pass_with_vxx_regularisation(oracle):
+    """A host-evaluated model's handle runs only the backward pass on the device: ILQR_FLAG_REGULARIZE_VXX applies to it as to any model."""
+    from ilqr_amd import BatchILQR, capi
+    from tests.test_gpu_lq_end_to_end import dense_mats
+    n, m, B, T, lim = 7, 3, 12, 30, 0.2
+    oracle.set_fixes(4)
+    try:
+        mats = dense_mats(n, m)
+        om = oracle.Model("lq", lq=mats, u_lim=lim)
+        g = BatchILQR("host", B, T, DT, nx=n, nu=m, u_min=[-lim] * m, u_max=[lim] * m, flags=capi.FLAG_REGULARIZE_VXX)
+        rng = np.random.default_rng(9)
+        x0 = rng.uniform(-1, 1, (B, n))
+        u0 = rng.normal(size=(B, T, m)) * 0.1
+        xs, us, cost = oracle.batch_rollout(om, x0, u0, DT)
+        do = oracle.batch_derivatives(om, xs, us, DT)
+        ro = oracle.batch_backward(om, us, do, lam=2.0)
+        g.set_trajectory(x0=x0, xs=xs, us=us, cost=cost)
+        g.set_derivatives(**{k: (do[k] if k in ("cx", "cu") else mat(do[k])) for k in do})
+        g.set_gains(k=np.zeros((B, T, m)), K=np.zeros((B, T, m, n)))
+        g.set_lambda(2.0, 1.0)
+        div = g.backward_pass()
+        k, K = g.gains()
+        check_backward(oracle, om, us, do, np.zeros((B, T, m)), 2.0, k, K, g.dV(), div, ro, max_ties=2, max_over10=2)
         g.close()
     finally:
         oracle.set_fixes(0)
