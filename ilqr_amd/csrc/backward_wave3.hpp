@@ -331,7 +331,7 @@ __device__ __forceinline__ int w3_box_qp_small(int m, LDS& L, int lane, int& nfR
 // then knot T's) and v.D is not touched.
 // REGV (ILQR_FLAG_REGULARIZE_VXX, opt-in): lambda regularises Vxx' ([Tassa 2012] eq. 10) instead of Quu -- QuuF = Quu + lambda fu'fu and the
 // gains' Qux_reg = Qux + lambda fu'fx, two more transposed products per 16-column block on the operands the step holds anyway; the value
-// update keeps Quu, Qux (backward_thread.hpp, oracle/orc_bw.inc).  Instantiated without FULL / LQF.
+// update keeps Quu, Qux (as backward_thread.hpp does for the tiled kernels).  Instantiated without FULL / LQF.
 template <int NT, bool FULL, bool LQF, bool REGV = false>
 __global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w3(BatchView v, int n, int m, const double* __restrict__ u_min,
                                                                     const double* __restrict__ u_max, SolverParams sp, int mode,

@@ -118,6 +118,7 @@ def build(force=False):
 
 
 _libs = {}
+_fixes = 0
 
 
 def lib():
@@ -131,6 +132,7 @@ def lib():
         for name in ("orc_forward_pass", "orc_init_traj", "orc_gradient_norm"):
             getattr(L, name).restype = _ac()
         L.orc_quad_cost.restype = _rc()
+        L.orc_set_fixes(int(_fixes))  # (a flavour loaded after set_fixes -- the fp80 yardstick, lazily -- carries the same switch)
         _libs[_cur] = L
     return _libs[_cur]
 
@@ -169,6 +171,8 @@ def _pa(a):
 
 def set_fixes(bits=0):
     """Opt-in fixes (ILQR_FLAG_REFERENCE_FIXES on the product side): 1 = clamped rollout, 2 = Cholesky failure ends the box-QP, 3 = both."""
+    global _fixes
+    _fixes = int(bits)
     for name in list(_libs) or ["f64"]:
         with flavour(name):
             lib().orc_set_fixes(int(bits))
