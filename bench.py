@@ -13,7 +13,10 @@ a..d ~ U(-1,1), u0 = 0.  Inputs are resident in HBM before the timed region.
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (see README/DESIGN.md for the field contract).
+Rank 0 prints ONE JSON line on stdout: a COMPACT record (< 2 KB: metric, value, config, roofline, cpu_baseline -- what the
+driver parses).  Everything else this script can measure (per-stage table, the issue roofline with its sources, the
+backward-only figure, and -- with --extra-configs -- the other BASELINE configurations, each with a CPU baseline of its own)
+goes to a side file (--extras-out, default gpurun_out/bench_extras.json), never to stdout.
 """
 import argparse
 import json
@@ -48,17 +51,22 @@ def algorithmic_bytes_per_timestep(n, m, s=8):
     }
 
 
-def cpu_baseline(B_total, T, dt, lim, target_wall_s=4.0, flavour="f64", backward_only=True):
+def cpu_baseline(B_total, T, dt, lim, target_wall_s=4.0, flavour="f64", backward_only=True, reps=3):
     """The CPU oracle (plain-C restatement of the reference, OpenMP over trajectories) on a
     bounded sample of the same workload, on this box's host cores: the same fixed-work
     iterations over as many of the bench's own trajectories as fit the time budget.
-    flavour "f32": the oracle's float twin (what an fp32 handle is compared with)."""
+    flavour "f32": the oracle's float twin (what an fp32 handle is compared with).
+
+    Sample length: one 1.6-2 s run moved +-25 % between boxes and runs (rounds 4/5: thread start-up, page first-touch
+    and host clocks inside the sample).  The figure is now the MEDIAN of `reps` runs of about `target_wall_s` seconds
+    each after an untimed run of the same size (threads and pages warm), and the line carries the spread
+    (max - min) / median of those runs -- within +-5 % at 3 x 4 s on the boxes this was tried on."""
     from oracle import oracle as O
     with O.flavour(flavour):
-        return _cpu_baseline_acrobot(O, B_total, T, dt, lim, target_wall_s, flavour, backward_only)
+        return _cpu_baseline_acrobot(O, B_total, T, dt, lim, target_wall_s, flavour, backward_only, reps)
 
 
-def _cpu_baseline_acrobot(O, B_total, T, dt, lim, target_wall_s, flavour, backward_only):
+def _cpu_baseline_acrobot(O, B_total, T, dt, lim, target_wall_s, flavour, backward_only, reps):
     from tests.util import acrobot_x0
     cores = os.cpu_count() or 1
     om = O.Model("acrobot", u_lim=lim)
@@ -72,6 +80,7 @@ def _cpu_baseline_acrobot(O, B_total, T, dt, lim, target_wall_s, flavour, backwa
         return time.perf_counter() - t0
 
     nb = min(B_total, 4 * cores)
+    run(nb, 1)                          # threads up, code paged in
     t = run(nb, 1)                      # calibration
     rate = nb * T / t
     iters = 4
@@ -79,27 +88,28 @@ def _cpu_baseline_acrobot(O, B_total, T, dt, lim, target_wall_s, flavour, backwa
     nb2 = max(cores, (nb2 // cores) * cores) if nb2 >= cores else nb2
     if nb2 == B_total:                  # the whole batch is still too quick: run more iterations
         iters = int(min(40, max(iters, target_wall_s * rate / (T * nb2))))
-    t2 = run(nb2, iters)
+    run(nb2, 1)                         # first touch of this sample's pages, untimed
+    ts = sorted(run(nb2, iters) for _ in range(max(1, reps)))
+    t2 = ts[len(ts) // 2]
     lib_name = {"f64": "liboracle_ilqr.so", "f32": "liboracle_ilqr_f32.so"}.get(flavour, flavour)
+    res = {"value": nb2 * T * iters / t2, "unit": "trajectory-timesteps/s", "cores": cores, "kind": "port",
+           "spread": (ts[-1] - ts[0]) / t2,
+           "sample": "median of %d runs of %d trajectories x %d fixed-work iterations of this workload (%.1f s each), oracle/%s, OpenMP on all host threads"
+                     % (len(ts), nb2, iters, t2, lib_name)}
     if not backward_only:
-        return {"value": nb2 * T * iters / t2, "unit": "trajectory-timesteps/s", "cores": cores, "kind": "port",
-                "sample": "%d trajectories x %d fixed-work iterations of the same acrobot workload (u in [-%g,%g], %s), %.1f s wall, oracle/%s "
-                          "with OpenMP over trajectories on all host threads" % (nb2, iters, lim, lim, flavour, t2, lib_name)}
+        return res
     # backward pass alone on fixed derivatives (the north star's backward-only figure), same threads
     nb3 = min(B_total, 8 * cores)
     u3 = np.zeros((nb3, T, 1))
     xs3, us3, _ = O.batch_rollout(om, x0_all[:nb3], u3, dt, nthreads=cores)
     dv3 = O.batch_derivatives(om, xs3, us3, dt, nthreads=cores)
-    reps = 3
+    nrep = 3
     t0 = time.perf_counter()
-    for _ in range(reps):
+    for _ in range(nrep):
         O.batch_backward(om, us3, dv3, lam=1.0, nthreads=cores)
-    t3 = (time.perf_counter() - t0) / reps
-    return {"value": nb2 * T * iters / t2, "unit": "trajectory-timesteps/s", "cores": cores, "kind": "port",
-            "backward_only_value": nb3 * T / t3,
-            "sample": "%d trajectories x %d fixed-work iterations of the same acrobot workload, %.1f s wall "
-                      "(%.0f core-seconds), oracle/liboracle_ilqr.so with OpenMP over trajectories on all host "
-                      "threads" % (nb2, iters, t2, t2 * cores)}
+    t3 = (time.perf_counter() - t0) / nrep
+    res["backward_only_value"] = nb3 * T / t3
+    return res
 
 
 def cpu_baseline_other(kind, T, dt, target_wall_s=3.0):
@@ -217,6 +227,36 @@ def issue_roofline(kernel, iteration_ms, sclk_mhz, timesteps, n_simds=1024):
             "lds_bank_conflict_fraction": e.get("lds_bank_conflict_fraction"), "source": note}
 
 
+COMPACT_LIMIT = 2048  # bytes: the driver keeps the last 8 KB of stdout; round 1's 2.3 KB line parsed, round 5's 27 KB line did not
+
+
+def _r(x, sig=6):
+    """Round floats to `sig` significant digits (the line is a record, not a dump)."""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x))
+    return x
+
+
+def compact_record(full):
+    """The ONE stdout line: the contract's fields + roofline + cpu_baseline, short strings, numbers to 6 digits.
+    `full` is the complete result dict (what goes to the extras file)."""
+    roof, cpu = full.get("roofline") or {}, full.get("cpu_baseline")
+    rec = {k: _r(full[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data") if k in full}
+    cfg = full.get("config") or {}
+    rec["config"] = {k: cfg[k] for k in ("workload", "batch_per_gpu", "global_batch", "T", "u_limit", "parallelism") if k in cfg}
+    rec["roofline"] = {k: _r(roof.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                     "algorithmic_bytes_per_launch", "avg_launch_ms", "limiter", "bound_frac")}
+    if cpu:
+        rec["cpu_baseline"] = {k: _r(cpu.get(k)) for k in ("value", "unit", "cores", "kind", "sample", "spread")}
+    for k in ("rccl_ranks", "backward_only_timesteps_per_s", "extras"):
+        if k in full:
+            rec[k] = _r(full[k])
+    line = json.dumps(rec, separators=(",", ":"))
+    assert len(line) < COMPACT_LIMIT, "bench.py's stdout record grew to %d bytes (limit %d): move detail to the extras file" % (len(line), COMPACT_LIMIT)
+    return line
+
+
 def lq_mats(n, m, seed=7):
     """SURVEY.md 8(d) cfg 5: A = -I + 0.1 N(0,1)/sqrt(n), B = N(0,1)/sqrt(n), Q = I, R = 0.1 I."""
     rng = np.random.default_rng(seed)
@@ -238,10 +278,15 @@ def main():
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64", help="arithmetic of the HEADLINE run (the other "
                     "one is reported under configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-configs", action="store_true", help="only the headline workload")
+    ap.add_argument("--extra-configs", action="store_true", help="also run the other BASELINE configurations (saturated batch, configs[1], [3], [4], the "
+                    "double integrator, a user twin), each with a CPU baseline of its own: minutes; their records go to the extras file")
+    ap.add_argument("--no-extra-configs", action="store_true", help="(the default since round 6; accepted for the scripts that pass it)")
+    ap.add_argument("--extras-out", default=os.path.join(ROOT, "gpurun_out", "bench_extras.json"),
+                    help="where the full record (stages, issue roofline, sources, --extra-configs results) is written; '' = nowhere")
     ap.add_argument("--flags", type=int, default=0, help="extra ilqr_flags (kernel variant selection)")
     ap.add_argument("--route", type=int, default=0, help="enum ilqr_route for the headline handle (A/B runs of equivalent kernels)")
     args = ap.parse_args()
+    args.no_extra_configs = not args.extra_configs
 
     import torch
     import torch.distributed as dist
@@ -356,16 +401,15 @@ def main():
         achieved = stages[dom]["algorithmic_GBps"]
         # (the counter passes are of the fp64 workloads: a float instantiation has an entry of its own in traffic.json, or none)
         traffic, traffic_src = pmc_traffic(kern + ("_f32" if dtype == "f32" else ""), stages[dom].get("iterations_per_launch", 1))
-        # `bound` names the limiter this build claims for the kernel.  achieved / peak / unit / frac stay the figures of the
-        # contract's roofline for the path (HBM: algorithmic bytes over the launch duration) -- repeated as
-        # contract_bound / contract_frac so that nobody reads 0.11 as "11 % of the limiter"; the limiter's own fraction is
-        # bound_frac (filled in from roofline_issue when counters of THIS code exist).
-        return {"bound": "valu_issue", "contract_bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "contract_frac": achieved / HBM_PEAK_GBS, "bound_frac": None,
+        # `bound` is the contract's roofline for this byte-light path (HBM: algorithmic bytes over the launch duration);
+        # `limiter` names what the counters say actually bounds the kernel and `bound_frac` is the fraction of THAT limit
+        # (filled in from roofline_issue when counters of THIS code exist), so nobody reads 0.14 as "14 % of the limiter".
+        return {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "limiter": "valu_issue", "bound_frac": None,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_ts[dom] * B * T, "avg_launch_ms": stages[dom]["ms_per_launch"],
-                "limiter": "VALU issue + latency of dependent chains (the Riccati chains of a tile -- four on the matrix cores at one tile per CU --, then its rollout wavefronts), not "
-                           "bytes: see roofline_issue; HBM is the contract's nominal bound for this byte-light path"}
+                "limiter_note": "VALU issue + latency of dependent chains (the Riccati chains of a tile -- four on the matrix cores at one tile per CU --, then its "
+                                "rollout wavefronts), not bytes: see roofline_issue; HBM is the contract's nominal bound for this byte-light path"}
 
 
     # ---------------- headline: BASELINE.json metric, configs[2] ----------------
@@ -499,10 +543,10 @@ def main():
             # the contract's HBM figure for this line: Rec<4,2> sweep + backward + 11-alpha rollouts, algorithmic bytes per trajectory-timestep
             # (records stay in LDS: xs, us read by the producers 6 doubles; gains written 10; rollouts read 16 rows and write 11 x (2 controls + 4/8 states))
             bts = 8 * (6 + 10 + 16 + 11 * 2.5)
-            extra[key]["roofline"] = {"bound": "valu_issue", "contract_bound": "hbm", "kernel": solve_kernel, "achieved": bts * Bd * Td / (eld / steps) / 1e9,
+            extra[key]["roofline"] = {"bound": "hbm", "limiter": "valu_issue", "kernel": solve_kernel, "achieved": bts * Bd * Td / (eld / steps) / 1e9,
                                       "peak": 8000.0, "unit": "GB/s", "frac": bts * Bd * Td / (eld / steps) / 1e9 / 8000.0,
                                       "algorithmic_bytes_per_timestep": bts, "traffic": None,
-                                      "limiter": "one dependent chain per tile (instruction issue and latency), as the acrobot lines"}
+                                      "limiter_note": "one dependent chain per tile (instruction issue and latency), as the acrobot lines"}
             if solve_kernel == "k_solve_wide2" and Bd == 32768:  # the counter passes of this kernel were taken at this batch (collect_profiles.sh: int_*)
                 tr, src = pmc_traffic(solve_kernel, steps)
                 extra[key]["roofline"]["traffic"] = tr
@@ -643,18 +687,16 @@ def main():
         value = world * B * T * steps / elapsed
         bytes_bw = algorithmic_bytes_per_timestep(n, m, s_bytes)["backward"]
         roof = roofline_of(stages, bytes_ts, B, args.dtype)
-        roof_issue = issue_roofline(roof["kernel"], elapsed / steps * 1e3, headline_sclk, B * T)
+        roof_issue = issue_roofline(roof["kernel"] + ("_f32" if args.dtype == "f32" else ""), elapsed / steps * 1e3, headline_sclk, B * T)
         roof["bound_frac"] = roof_issue["frac"]
         out = {
             "metric": "iLQR iterations/sec (batch x T timesteps/sec), acrobot T=500 batch=4096",
             "value": value, "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": steps,
             "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "acrobot n=4 m=1 T=499 transitions (500 knots) B=%d per GPU, u in [-%.1f,%.1f] "
-                                   "(box-QP clamps active), %s, full iteration = FD derivatives + backward/box-QP "
-                                   "+ 11-alpha rollouts + accept, fixed work" % (B, lim, lim, args.dtype),
-                       "batch_per_gpu": B, "global_batch": world * B, "T": T, "parallelism": "batch-sharded x%d (%s), no data-path collective; "
-                       "one all_gather of per-trajectory costs at the end" % (world, "a fixed global batch split over the ranks" if args.global_batch else "a fixed batch per rank")},
+            "config": {"workload": "acrobot n=4 m=1 T=499 (500 knots), box-QP limits active, FD derivatives + backward/box-QP + 11-alpha search + accept, fixed work",
+                       "batch_per_gpu": B, "global_batch": world * B, "T": T, "u_limit": lim,
+                       "parallelism": "batch shards x%d, one all_gather of costs" % world},
             "roofline": roof,
             "roofline_issue": roof_issue,
             # how many ranks ran and what carried their one collective (the driver's scaling run reads this)
@@ -665,12 +707,21 @@ def main():
                               "timesteps_per_s": B * T / (bw_ms * 1e-3) * world,
                               "algorithmic_GBps": bytes_bw * B * T / (bw_ms * 1e-3) / 1e9,
                               "frac_of_hbm_peak": bytes_bw * B * T / (bw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "backward_only_timesteps_per_s": B * T / (bw_ms * 1e-3) * world,
             "final_cost_mean": float(np.mean(costs)),
             "configs": extra,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, T, dt, lim)
-        print(json.dumps(out))
+        if args.extras_out:
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(args.extras_out)), exist_ok=True)
+                with open(args.extras_out, "w") as f:
+                    json.dump(out, f, indent=1)
+                out["extras"] = os.path.relpath(args.extras_out, ROOT)
+            except OSError as e:  # a read-only checkout: the record on stdout is what counts
+                print("bench.py: extras not written (%s)" % e, file=sys.stderr)
+        print(compact_record(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
