@@ -31,6 +31,12 @@ namespace ilqr {
 #endif
 
 constexpr int HT = 4;  // trajectories per sub-tile (= per chain wavefront)
+#ifndef ILQR_HEX_SLOT_PAD
+#define ILQR_HEX_SLOT_PAD 8
+#endif
+#ifndef ILQR_HEX_PAIR_PERM
+#define ILQR_HEX_PAIR_PERM 1
+#endif
 
 // One pair's ring: a slot holds one knot of the sub-tile's 4 trajectories, pair-interleaved like the HBM records:
 // [pair][trajectory lp][2].
@@ -40,8 +46,13 @@ struct HexRing {
   static constexpr int PAIRS = (Rec<NX, NU>::SIZE + NU + 1) / 2;
   static constexpr int ROW = 2 * HT;             // `real`s from one element pair to the next
   static constexpr int PAD = ROW - 2 * TW;       // what derivatives_of_knot adds to its 16-trajectory row (negative: a narrower row)
-  static constexpr int ELEMS = PAIRS * ROW;
+  // SLOT_PAD: a producer round writes 16 knots = 16 consecutive slots with one store instruction per pair row; unpadded the slot
+  // stride (1536 bytes in double) is a whole number of bank rows and the knots of a lane group land on the same banks (a 2-way
+  // conflict on every one of a round's 24 stores); 8 `real`s further on each, the two (fp32: four) knots of a group sit side by side.
+  static constexpr int ELEMS = PAIRS * ROW + ILQR_HEX_SLOT_PAD;
   static constexpr int SLOTS = SLOTS_;
+  static constexpr bool PERM = (ILQR_HEX_PAIR_PERM != 0) && NX == 4 && NU == 1;
+  static constexpr int pos(int pair) { return PERM ? hex_pair_pos(pair) : pair; }
 };
 
 constexpr int kHexKnotsPerRound = 64 / HT;       // a producer round: 16 knots x 4 trajectories
@@ -160,6 +171,10 @@ __device__ __forceinline__ void qp1_search_hex(QP1StateT<double>& q, int j, int 
   }
 }
 
+// RS::pos for a pair index that depends on the lane (computed once per wavefront: the addresses are loop invariants)
+template <class RS>
+__device__ __forceinline__ int hex_pos_rt(int pair) { return RS::PERM ? hex_pair_pos(pair) : pair; }
+
 template <class real>
 struct HexStep {  // what lane (r, t, c) needs of one derivative record, as loaded (widened to the chain's arithmetic when used)
   typedef real pair_t __attribute__((ext_vector_type(2)));
@@ -195,8 +210,8 @@ __device__ __forceinline__ void backward_hex(const BatchViewT<typename M::real>&
   auto load = [&](int t, HexStep<real>& d) __attribute__((always_inline)) {
     gate.wait(t);
     lds_cd* r = (lds_cd*)(ring + gate.slot(t) * RS::ELEMS + t_ * 2);
-    auto pair = [&](int e) { return *(lds_cd2*)(r + (e >> 1) * RS::ROW); };
-    auto one = [&](int e) { return r[(e >> 1) * RS::ROW + (e & 1)]; };
+    auto pair = [&](int e) { return *(lds_cd2*)(r + RS::pos(e >> 1) * RS::ROW); };   // (constant e)
+    auto one = [&](int e) { return r[hex_pos_rt<RS>(e >> 1) * RS::ROW + (e & 1)]; };  // (e depends on the lane)
     d.F = one(R::FX + r_ + 4 * c_);
     d.cxx_rc = one(R::CXX + r_ + 4 * c_);
     d.cxx_cr = one(R::CXX + c_ + 4 * r_);
@@ -218,8 +233,8 @@ __device__ __forceinline__ void backward_hex(const BatchViewT<typename M::real>&
     {
       gate.wait(T);
       lds_cd* r = (lds_cd*)(ring + gate.slot(T) * RS::ELEMS + t_ * 2);
-      RVx = (creal)r[((R::CX + r_) >> 1) * RS::ROW + ((R::CX + r_) & 1)];                        // :353
-      V = (creal)r[((R::CXX + r_ + 4 * c_) >> 1) * RS::ROW + ((R::CXX + r_ + 4 * c_) & 1)];    // :354
+      RVx = (creal)r[hex_pos_rt<RS>((R::CX + r_) >> 1) * RS::ROW + ((R::CX + r_) & 1)];                        // :353
+      V = (creal)r[hex_pos_rt<RS>((R::CXX + r_ + 4 * c_) >> 1) * RS::ROW + ((R::CXX + r_ + 4 * c_) & 1)];    // :354
     }
     kprev = (creal)kt[(unsigned)((T - 1) * TW)];
     // (gfx950 counts stores in vmcnt too: with this load still "in flight" at the loop header the compiler made every step wait for
@@ -443,7 +458,7 @@ __device__ __forceinline__ void sweep_backward_hex(const BatchViewT<typename M::
         if ((started < 0) | (started > pass + 1)) break;  // the chain has left this pass behind
         const int t = T - (j0 + ks);
         if (t >= 0 && (pass == 0 || mine))
-          derivatives_of_knot<M, true, MFD, RS::PAD>(v, model, fdm, force, nullptr, tile, t, l, sh.ring + ((G0 + ks) % RS::SLOTS) * RS::ELEMS + lp * 2, true);
+          derivatives_of_knot<M, true, MFD, RS::PAD, RS::PERM>(v, model, fdm, force, nullptr, tile, t, l, sh.ring + ((G0 + ks) % RS::SLOTS) * RS::ELEMS + lp * 2, true);
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the round's LDS writes are done
         if (lane == 0) __hip_atomic_store(&sh.rounds_done, pass * nrounds + r + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }

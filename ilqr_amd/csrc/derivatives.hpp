@@ -76,7 +76,19 @@ struct RingSlot {
 // the knot (float) is widened, the sweep below runs in double exactly as for an fp64 handle, and the record
 // is rounded to float when stored.  Rollouts, the commit and the analytic route stay in the handle's own
 // arithmetic (`model`).
-template <class M, bool RING = false, class MFD = M, int RING_PAD = 0>
+// PERM: the pair rows of the slot are stored in the order hex_pair_pos gives them (the matrix-core chain's ring, backward_hex.hpp).
+__host__ __device__ constexpr int hex_pair_pos(int p) {
+  // fx (pairs 0..7) and cxx (pairs 12..19) are read by the 16-lanes-per-trajectory chain as element (r, c) = pair 2 c + (r >> 1)
+  // -- and cxx also as (c, r) = pair 2 r + (c >> 1) -- by 32 lanes at a time (ds_read_b64: r in {0, 1} or {2, 3}): four pair rows per
+  // access, 64 bytes each, and the LDS has four 64-byte bank groups.  In record order the rows 0, 2, 4, 6 fall on two groups (a
+  // 2-way bank conflict on two of the step's nine reads); with q = 4 a + 2 b + c stored at 4 a + 2 b + (a ^ c) the four rows of
+  // every one of those accesses ({c fixed}, {a fixed}) land on the four groups.
+  const int q = (p < 8) ? p : p - 12;
+  if (p >= 8 && (p < 12 || p >= 20)) return p;
+  const int a = (q >> 2) & 1, b = (q >> 1) & 1, c = q & 1;
+  return (p - q) + 4 * a + 2 * b + (a ^ c);
+}
+template <class M, bool RING = false, class MFD = M, int RING_PAD = 0, bool PERM = false>
 __device__ __forceinline__ void derivatives_of_knot(const BatchViewT<typename M::real>& v, const M& model, const MFD& fdm, int force,
                                                     const int* __restrict__ commit_idx, int tile, int t, int l,
                                                     typename M::real* rs = nullptr, bool records = true) {
@@ -124,7 +136,7 @@ __device__ __forceinline__ void derivatives_of_knot(const BatchViewT<typename M:
   auto put = [&](int e, fdr val_) {
     const real val = (real)val_;
     if (RING)
-      rs[(e >> 1) * (2 * TW + RING_PAD) + (e & 1)] = val;
+      rs[(PERM ? hex_pair_pos(e >> 1) : (e >> 1)) * (2 * TW + RING_PAD) + (e & 1)] = val;
     else
       D[(size_t)(e >> 1) * (2 * TW) + (e & 1)] = val;
   };
@@ -133,7 +145,7 @@ __device__ __forceinline__ void derivatives_of_knot(const BatchViewT<typename M:
     w.x = (real)v0;
     w.y = (real)v1;
     if (RING)
-      *reinterpret_cast<real2_t*>(rs + (e >> 1) * (2 * TW + RING_PAD)) = w;
+      *reinterpret_cast<real2_t*>(rs + (PERM ? hex_pair_pos(e >> 1) : (e >> 1)) * (2 * TW + RING_PAD)) = w;
     else
       *reinterpret_cast<real2_t*>(D + (size_t)(e >> 1) * (2 * TW)) = w;
   };

@@ -499,12 +499,12 @@ def _candidate_costs(g, x0, st, b):
 
 
 def publish(name, r, **meta):
-    """Adds the per-iteration bins of a walk to the tracked statistics file (copied to profiles/parity_r05.json from the GPU
+    """Adds the per-iteration bins of a walk to the tracked statistics file (copied to profiles/parity_r06.json from the GPU
     run): which share of the checked trajectory-iterations met the plain 1e-6 criterion and which went through which proof."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.environ.get("ILQR_PARITY_JSON", os.path.join(root, "gpurun_out", "parity_r05.json"))
+    path = os.environ.get("ILQR_PARITY_JSON", os.path.join(root, "gpurun_out", "parity_r06.json"))
     os.makedirs(os.path.dirname(path), exist_ok=True)
     doc = json.load(open(path)) if os.path.exists(path) else {}
     tot = {kk: sum(p[kk] for p in r["per_iter"]) for kk in r["per_iter"][0] if kk != "iteration"} if r["per_iter"] else {}
