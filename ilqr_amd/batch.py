@@ -87,6 +87,10 @@ class BatchILQR:
 
     def close(self):
         if getattr(self, "h", None):
+            self.lib.ilqr_synchronize(self.h)
+            for a in getattr(self, "_pinned", []):
+                self.lib.ilqr_host_unregister(a.ctypes.data)
+            self._pinned = []
             self.lib.ilqr_destroy(self.h)
             self.h = None
 
@@ -197,6 +201,31 @@ class BatchILQR:
         K = np.zeros((self.B, self.T, self.nx, self.nu))  # memory: column-major nu x nx
         self._check(self.lib.ilqr_get_gains(self.h, _p(k), _p(K)))
         return k, np.swapaxes(K, -1, -2)
+
+    def result_buffers(self, pinned=True, K=True):
+        """Result arrays a caller keeps across solves, in the ABI's memory layouts: dict(xs, us, k, K, cost) (K [B][T][nx][nu] in memory =
+        column-major nu x nx per knot; K=False: without the gains).  pinned: page-locked with ilqr_host_register, so that results_async's
+        copies are DMA transfers that the call does not wait for."""
+        bufs = dict(xs=np.zeros((self.B, self.T + 1, self.nx)), us=np.zeros((self.B, self.T, self.nu)), cost=np.zeros(self.B))
+        if K:
+            bufs.update(k=np.zeros((self.B, self.T, self.nu)), K=np.zeros((self.B, self.T, self.nx, self.nu)))
+        if pinned:
+            for a in bufs.values():
+                self._check(self.lib.ilqr_host_register(a.ctypes.data, a.nbytes))
+            self._pinned = getattr(self, "_pinned", []) + [a for a in bufs.values()]
+        return bufs
+
+    def results_async(self, bufs):
+        """ilqr_get_results_async into `bufs` (result_buffers()): every array in one call, nothing waited for -- valid after synchronize()."""
+        self._check(self.lib.ilqr_get_results_async(self.h, _p(bufs.get("xs")), _p(bufs.get("us")), _p(bufs.get("k")), _p(bufs.get("K")), _p(bufs.get("cost"))))
+
+    def copy_trajectory_to_device(self, xs_ptr=None, us_ptr=None):
+        """canonical xs [B][T+1][nx] / us [B][T][nu] (double) into caller-owned device memory (raw pointers, e.g. torch.Tensor.data_ptr());
+        enqueued on the handle's stream."""
+        self._check(self.lib.ilqr_copy_trajectory_to_device(self.h, xs_ptr, us_ptr))
+
+    def copy_gains_to_device(self, k_ptr=None, K_ptr=None):
+        self._check(self.lib.ilqr_copy_gains_to_device(self.h, k_ptr, K_ptr))
 
     def derivatives(self):
         n, m, B, T1 = self.nx, self.nu, self.B, self.T + 1

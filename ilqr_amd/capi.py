@@ -4,13 +4,13 @@ import os
 
 from . import _build
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MODEL_ACROBOT, MODEL_DOUBLE_INTEGRATOR, MODEL_LQ, MODEL_HOST, MODEL_USER = 0, 1, 2, 3, 4
 FLAG_FIXED_WORK, FLAG_BACKWARD_THREAD_PER_TRAJ, _FLAG_RESERVED_4, FLAG_UNFUSED, FLAG_ANALYTIC_DERIVATIVES, FLAG_STAGED, FLAG_REFERENCE_FIXES, FLAG_REGULARIZE_VXX = 1, 2, 4, 8, 16, 32, 64, 128
 DTYPE_F64, DTYPE_F32 = 0, 1
 # enum ilqr_route (include/ilqr_amd.h): which of several equivalent kernels a handle uses; 0 = by batch size
 ROUTE_TILE_PER_CU, ROUTE_TWO_TILES_PER_CU, ROUTE_WIDE_TILES = 1, 2, 3
-ROUTE_WIDE_ONE_PER_CU, ROUTE_WIDE_TWO_PER_CU, ROUTE_NO_COMPACTION, ROUTE_FULL_RECORDS, ROUTE_LQ_THREAD_ROLLOUT, ROUTE_BACKWARD_LDS, ROUTE_QUAD_CHAIN, ROUTE_LQ_RECOMMIT, ROUTE_BACKWARD_W2, ROUTE_LQ_DENSE_FD = 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048
+ROUTE_WIDE_ONE_PER_CU, ROUTE_WIDE_TWO_PER_CU, ROUTE_NO_COMPACTION, ROUTE_FULL_RECORDS, ROUTE_LQ_THREAD_ROLLOUT, ROUTE_QUAD_CHAIN, ROUTE_LQ_RECOMMIT, ROUTE_BACKWARD_W2, ROUTE_LQ_DENSE_FD = 4, 8, 16, 32, 64, 256, 512, 1024, 2048  # (128: retired in ABI 5)
 ROUTE_WAVE_PER_TRAJECTORY = 4096
 NUM_STAGES = 5
 STAGE_NAMES = ("derivatives", "backward", "rollout", "accept", "solve")
@@ -73,6 +73,11 @@ SYMBOLS = {
     "ilqr_get_candidate": (C.c_int, [_H, C.c_int, _dp, _dp]),
     "ilqr_count_running": (C.c_int, [_H, _ip]),
     "ilqr_copy_cost_to_device": (C.c_int, [_H, C.c_void_p]),
+    "ilqr_copy_trajectory_to_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    "ilqr_copy_gains_to_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    "ilqr_get_results_async": (C.c_int, [_H, _dp, _dp, _dp, _dp, _dp]),
+    "ilqr_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "ilqr_host_unregister": (C.c_int, [C.c_void_p]),
     "ilqr_group_create": (C.c_int, [C.POINTER(_H), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "ilqr_group_destroy": (None, [C.c_void_p]),
     "ilqr_group_gather_costs": (C.c_int, [C.c_void_p, _dp]),

@@ -1,5 +1,7 @@
-// backward_wave.hpp -- generic backward pass, ONE WAVEFRONT PER TRAJECTORY, runtime nx <= 32,
-// nu <= 16, every matrix of the step held in LDS.
+// backward_wave.hpp -- what the generic backward kernels (ONE WAVEFRONT PER TRAJECTORY, runtime nx <= 32, nu <= 16: backward_wave2.hpp,
+// backward_wave3.hpp) share: the box-QP's LDS block, matrix-core tile helpers, wave reductions and the literal box-QP w_box_qp.
+// (Round 1's kernel k_backward_w, which held every matrix of the step in LDS, was retired in ABI 5; the notes below on its layout
+// still describe WaveLds, which the register kernels use in part.)
 //
 // This is the path for (a) models that exist only as host virtuals -- their finite differences
 // are taken on the host and uploaded with ilqr_set_derivatives -- and (b) the synthetic LQ
@@ -477,460 +479,10 @@ __device__ int w_box_qp(int m, LDS& L, int lane, int& nfR_out ILQR_W2CLOCK_ARG, 
   return result;
 }
 
-// One wavefront per trajectory.  mode as in the quad kernel (0: one pass, all trajectories;
-// 1: STEP 2 with the lambda retry and the gradient-norm test for running trajectories).
-// const_rec != nullptr: the matrix blocks (fx, fu, cxx, cxu, cuu) of every knot t < T are those of this one
-// record (a model whose exact derivatives do not depend on the knot, k_analytic_lq); cx, cu and knot T come
-// from the per-knot records as always.
-__global__ __launch_bounds__(64) void k_backward_w(BatchView v, int n, int m, const double* __restrict__ u_min,
-                                                   const double* __restrict__ u_max, SolverParams sp, int mode,
-                                                   const double* __restrict__ const_rec) {
-  __shared__ WaveLds L;
-  const int lane = threadIdx.x;
-  const int b = blockIdx.x;
-  if (b >= v.B) return;
-  if (mode == 1 && v.status[b] != 0) return;
-  const int T = v.T;
-  const int REC = 2 * n * n + 2 * n * m + n + m + m * m;
-  const int oFX = 0, oFU = oFX + n * n, oCX = oFU + n * m, oCXX = oCX + n, oCXU = oCXX + n * n, oCU = oCXU + n * m,
-            oCUU = oCU + m;
-  const double* __restrict__ Db = v.D + (size_t)b * (T + 1) * REC;
-  const double* __restrict__ usb = v.us + (size_t)b * T * m;
-  double* __restrict__ kb = v.kff + (size_t)b * T * m;
-  double* __restrict__ Kb = v.Kfb + (size_t)b * T * m * n;
-  double lambda = v.lambda[b], dlambda = v.dlambda[b];
-  const int NT = (n + 15) / 16;              // 16-row tiles covering n
-  const int KN = (n + 3) / 4, KM = (m + 3) / 4;  // MFMA k-steps covering n, m
-  const int orow = lane >> 4, ocol = lane & 15;  // this lane's rows (orow + 4 r) and column in an output tile
-  // zero every LDS matrix once: the padding up to whole tiles must read as 0 in the products
-  {
-    double* z = reinterpret_cast<double*>(&L);
-    const int nz = (int)(sizeof(WaveLds) / sizeof(double));  // (the vectors too: dot_padded relies on zeros beyond m)
-    for (int e = lane; e < nz; e += 64) z[e] = 0.0;
-  }
-  lds_sync();
-
-  // One step's record goes through registers in two halves, every load of a half issued back to
-  // back (one HBM round trip, not one per loop iteration):
-  //   RecA  fx, fu (row-contiguous, for the copy into LDS), cx, cu, u: fetched one step AHEAD, right
-  //         after the products that need the most registers, and in flight during the box-QP;
-  //   RecB  cxx, cxu, cuu in the MFMA output mapping (this lane's rows orow+4r, column ocol of each
-  //         tile) where they are added: fetched at the top of their own step, consumed two product
-  //         phases later.
-  // (Holding a whole record a step ahead, as a first version did, spilled once the products kept all
-  // their operand sets in registers.)
-  struct RecA {
-    double fx[16], fu[8], cx, cu, us;
-  };
-  struct RecB {
-    double cxx[16], cxu[8], cuu[4];
-  };
-  // guarded load without a branch: padding lanes read element 0 of the record and drop it
-  auto ld0 = [](const double* r, bool in, int off) __attribute__((always_inline)) {
-    const double val = r[in ? off : 0];
-    return in ? val : 0.0;
-  };
-  auto load_rec_a = [&](int i, RecA& q) __attribute__((always_inline)) {
-    const double* r = Db + (size_t)i * REC;
-    const double* rm = const_rec ? const_rec : r;
-    const int a32 = lane & 31, chalf = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const int c = 2 * j + chalf;
-      q.fx[j] = ld0(rm, a32 < n && c < n, oFX + a32 + n * c);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int c = 2 * j + chalf;
-      q.fu[j] = ld0(rm, a32 < n && c < m, oFU + a32 + n * c);
-    }
-    q.cx = ld0(r, lane < n, oCX + lane);
-    q.cu = ld0(r, lane >= WN && lane - WN < m, oCU + lane - WN);  // (lanes 32.. : where Qu is computed)
-    q.us = (lane < m) ? usb[(size_t)i * m + lane] : 0.0;
-  };
-  auto load_rec_b = [&](int i, RecB& q) __attribute__((always_inline)) {
-    const double* r = const_rec ? const_rec : Db + (size_t)i * REC;
-#pragma unroll
-    for (int t2 = 0; t2 < 16; t2++) {
-      const int a = (t2 >> 3) * 16 + orow + 4 * (t2 & 3), c = ((t2 >> 2) & 1) * 16 + ocol;
-      q.cxx[t2] = ld0(r, a < n && c < n, oCXX + a + n * c);
-    }
-#pragma unroll
-    for (int t2 = 0; t2 < 8; t2++) {
-      const int a = orow + 4 * (t2 & 3), c = (t2 >> 2) * 16 + ocol;
-      q.cxu[t2] = ld0(r, a < m && c < n, oCXU + c + n * a);
-    }
-#pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-      const int a = orow + 4 * rr;
-      q.cuu[rr] = ld0(r, a < m && ocol < m, oCUU + a + m * ocol);
-    }
-  };
-
-  int diverge = 0;
-  bool done = false;
-  double dV0 = 0, dV1 = 0;
-  while (true) {
-    // :353-354
-    {
-      const double* r = Db + (size_t)T * REC;
-      for (int e = lane; e < n; e += 64) L.Vx[e] = r[oCX + e];
-      for (int c = 0; c < n; c++)
-        for (int a = lane; a < n; a += 64) L.Vxx[a + LDN * c] = r[oCXX + a + n * c];
-      if (lane < m) L.kprev[lane] = kb[(size_t)(T - 1) * m + lane];
-    }
-    dV0 = dV1 = 0;
-    diverge = 0;
-    lds_sync();
-#define ILQR_WMARK(k)
-#ifdef ILQR_W2_TIMING
-    W2Clock clk;
-    clk.start();
-#endif
-    RecA cur;
-    load_rec_a(T - 1, cur);
-    for (int i = T - 1; i >= 0; i--) {
-      ILQR_WMARK(7)
-      {  // fx, fu -> LDS (rows along lanes 0..31, two columns per pass)
-        const int a32 = lane & 31, chalf = lane >> 5;
-#pragma unroll
-        for (int j = 0; j < 16; j++) L.fx[a32 + LDN * (2 * j + chalf)] = cur.fx[j];
-#pragma unroll
-        for (int j = 0; j < 8; j++) L.fu[a32 + LDN * (2 * j + chalf)] = cur.fu[j];
-      }
-      if (lane < m) {
-        L.lo[lane] = u_min[lane] - cur.us;  // :369
-        L.hi[lane] = u_max[lane] - cur.us;
-      }
-      const double rec_cx = cur.cx, rec_cu = cur.cu;
-      RecB rec;
-      load_rec_b(i, rec);
-      ILQR_WMARK(0)
-      lds_sync();
-      // :359-360
-      {  // (lanes 0..31: Qx, lanes 32..47: Qu -- one batch of LDS reads for both)
-        const bool isx = lane < WN;
-        const int col = isx ? lane : ((lane - WN) & (WM - 1));
-        const double* colp = isx ? &L.fx[LDN * col] : &L.fu[LDN * col];
-        const double acc = dot_masked<WN>(0, n, [&](int q) { return colp[q]; }, [&](int q) { return L.Vx[q]; });
-        if (isx && lane < n) L.Qx[lane] = rec_cx + acc;
-        if (!isx && lane - WN < m) L.Qu[lane - WN] = rec_cu + acc;
-      }
-      // A1 = fx' Vxx ; A2 = fu' Vxx      (matrix cores; LDS operands are zero-padded to whole tiles)
-      if (NT == 2) {
-        // all six output tiles at once: each operand set is read from LDS once (40 reads instead of
-        // 96) and the six independent accumulation chains interleave, so no MFMA waits for the one
-        // before it.  Per tile the k order is unchanged.
-        double aFx[2][WN / 4], aFu[WN / 4], bV[2][WN / 4];
-#pragma unroll
-        for (int t2 = 0; t2 < 2; t2++) {
-          ld_operand<WN / 4>([&](int i2, int k) { return L.fx[k + LDN * (t2 * 16 + i2)]; }, lane, aFx[t2]);
-          ld_operand<WN / 4>([&](int j, int k) { return L.Vxx[k + LDN * (t2 * 16 + j)]; }, lane, bV[t2]);
-        }
-        ld_operand<WN / 4>([&](int i2, int k) { return L.fu[k + LDN * i2]; }, lane, aFu);
-        double4_t acc[6];
-#pragma unroll
-        for (int q = 0; q < 6; q++) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < WN / 4; ks++) {
-#pragma unroll
-          for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-            for (int tj = 0; tj < 2; tj++)
-              acc[ti * 2 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aFx[ti][ks], bV[tj][ks], acc[ti * 2 + tj], 0, 0, 0);
-#pragma unroll
-          for (int tj = 0; tj < 2; tj++) acc[4 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aFu[ks], bV[tj][ks], acc[4 + tj], 0, 0, 0);
-        }
-#pragma unroll
-        for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-          for (int tj = 0; tj < 2; tj++)
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++) L.A1[(ti * 16 + orow + 4 * rr) + LDN * (tj * 16 + ocol)] = acc[ti * 2 + tj][rr];
-#pragma unroll
-        for (int tj = 0; tj < 2; tj++)
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++) L.A2[(orow + 4 * rr) + LDM * (tj * 16 + ocol)] = acc[4 + tj][rr];
-      } else {
-#pragma unroll
-      for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-        for (int tj = 0; tj < 2; tj++) {
-          if (ti >= NT || tj >= NT) continue;
-          const double4_t acc = mfma_tile<WN / 4>(
-              [&](int i2, int k) { return L.fx[k + LDN * (ti * 16 + i2)]; },
-              [&](int k, int j) { return L.Vxx[k + LDN * (tj * 16 + j)]; }, lane);
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++) L.A1[(ti * 16 + orow + 4 * rr) + LDN * (tj * 16 + ocol)] = acc[rr];
-        }
-#pragma unroll
-      for (int tj = 0; tj < 2; tj++) {
-        if (tj >= NT) continue;
-        const double4_t acc = mfma_tile<WN / 4>(
-            [&](int i2, int k) { return L.fu[k + LDN * i2]; },
-            [&](int k, int j) { return L.Vxx[k + LDN * (tj * 16 + j)]; }, lane);
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) L.A2[(orow + 4 * rr) + LDM * (tj * 16 + ocol)] = acc[rr];
-      }
-      }
-      lds_sync();
-      ILQR_WMARK(1)
-      // :361 Qxx = cxx + A1 fx ; :362 Qux = cxu' + A2 fx ; :363/:367 Quu, QuuF = cuu (+ lambda I) + A2 fu
-      if (NT == 2) {  // seven tiles, six operand sets (as above)
-        double aA1[2][WN / 4], aA2[WN / 4], bFx[2][WN / 4], bFu[WN / 4];
-#pragma unroll
-        for (int t2 = 0; t2 < 2; t2++) {
-          ld_operand<WN / 4>([&](int i2, int k) { return L.A1[(t2 * 16 + i2) + LDN * k]; }, lane, aA1[t2]);
-          ld_operand<WN / 4>([&](int j, int k) { return L.fx[k + LDN * (t2 * 16 + j)]; }, lane, bFx[t2]);
-        }
-        ld_operand<WN / 4>([&](int i2, int k) { return L.A2[i2 + LDM * k]; }, lane, aA2);
-        ld_operand<WN / 4>([&](int j, int k) { return L.fu[k + LDN * j]; }, lane, bFu);
-        double4_t acc[7];
-#pragma unroll
-        for (int q = 0; q < 7; q++) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < WN / 4; ks++) {
-#pragma unroll
-          for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-            for (int tj = 0; tj < 2; tj++)
-              acc[ti * 2 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA1[ti][ks], bFx[tj][ks], acc[ti * 2 + tj], 0, 0, 0);
-#pragma unroll
-          for (int tj = 0; tj < 2; tj++) acc[4 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA2[ks], bFx[tj][ks], acc[4 + tj], 0, 0, 0);
-          acc[6] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA2[ks], bFu[ks], acc[6], 0, 0, 0);
-        }
-#pragma unroll
-        for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-          for (int tj = 0; tj < 2; tj++)
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++) {
-              const int a = ti * 16 + orow + 4 * rr, c = tj * 16 + ocol;
-              L.Qxx()[a + LDN * c] = (a < n && c < n) ? rec.cxx[(ti * 2 + tj) * 4 + rr] + acc[ti * 2 + tj][rr] : 0.0;
-            }
-#pragma unroll
-        for (int tj = 0; tj < 2; tj++)
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++) {
-            const int a = orow + 4 * rr, c = tj * 16 + ocol;
-            L.Qux[a + LDM * c] = (a < m && c < n) ? rec.cxu[tj * 4 + rr] + acc[4 + tj][rr] : 0.0;
-          }
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-          const int a = orow + 4 * rr, c = ocol;
-          const bool in = (a < m && c < m);
-          const double cuu = in ? rec.cuu[rr] : 0.0;
-          L.Quu()[a + LDM * c] = in ? cuu + acc[6][rr] : 0.0;
-          L.QuuF()[a + LDM * c] = in ? (cuu + ((a == c) ? lambda : 0.0)) + acc[6][rr] : 0.0;
-        }
-      } else {
-#pragma unroll
-      for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-        for (int tj = 0; tj < 2; tj++) {
-          if (ti >= NT || tj >= NT) continue;
-          const double4_t acc = mfma_tile<WN / 4>(
-              [&](int i2, int k) { return L.A1[(ti * 16 + i2) + LDN * k]; },
-              [&](int k, int j) { return L.fx[k + LDN * (tj * 16 + j)]; }, lane);
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++) {
-            const int a = ti * 16 + orow + 4 * rr, c = tj * 16 + ocol;
-            L.Qxx()[a + LDN * c] = (a < n && c < n) ? rec.cxx[(ti * 2 + tj) * 4 + rr] + acc[rr] : 0.0;
-          }
-        }
-#pragma unroll
-      for (int tj = 0; tj < 2; tj++) {
-        if (tj >= NT) continue;
-        const double4_t acc = mfma_tile<WN / 4>(
-            [&](int i2, int k) { return L.A2[i2 + LDM * k]; },
-            [&](int k, int j) { return L.fx[k + LDN * (tj * 16 + j)]; }, lane);
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-          const int a = orow + 4 * rr, c = tj * 16 + ocol;
-          L.Qux[a + LDM * c] = (a < m && c < n) ? rec.cxu[tj * 4 + rr] + acc[rr] : 0.0;
-        }
-      }
-      {
-        const double4_t acc = mfma_tile<WN / 4>(
-            [&](int i2, int k) { return L.A2[i2 + LDM * k]; }, [&](int k, int j) { return L.fu[k + LDN * j]; }, lane);
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-          const int a = orow + 4 * rr, c = ocol;
-          const bool in = (a < m && c < m);
-          const double cuu = in ? rec.cuu[rr] : 0.0;
-          L.Quu()[a + LDM * c] = in ? cuu + acc[rr] : 0.0;
-          L.QuuF()[a + LDM * c] = in ? (cuu + ((a == c) ? lambda : 0.0)) + acc[rr] : 0.0;
-        }
-      }
-      }
-      if (i > 0) load_rec_a(i - 1, cur);  // next step's fx, fu, ...: in flight during the box-QP
-      lds_sync();
-      ILQR_WMARK(2)
-      int nfR = 0;
-      const int result = w_box_qp(m, L, lane, nfR ILQR_W2CLOCK_PASS, nullptr, sp.fixes);
-      ILQR_WMARK(3)
-      if (result < 1) {  // :371
-        diverge = i;
-        break;
-      }
-      // :373-385  K rows of free dims
-      const unsigned long long free_mask = __ballot(lane < m && L.vfree[lane]);
-      const int nf = __popcll(free_mask);
-      if (lane < m && L.vfree[lane]) L.idx[__popcll(free_mask & ((1ull << lane) - 1ull))] = lane;
-      if (nf == 0 || nf != nfR)  // (the matrix-core route below writes every entry of K itself)
-        for (int c = lane >> 4; c < n; c += 4) L.K()[(lane & 15) + LDM * c] = 0;
-      lds_sync();
-      if (nf > 0) {
-        // (L.Minv = R^-1 R^-T of the factor the box-QP returned, :379, left there by w_box_qp)
-        const int nuse = (nf < nfR) ? nf : nfR;
-        if (nf == nfR) {
-          // K = -(Minv scattered to the free rows / columns of an m x m matrix) Qux on the matrix
-          // cores: clamped rows of the scattered matrix are zero, so those rows of K come out zero,
-          // and the zero columns add exact zeros to the k-ordered sums over the free dims.
-          double* MF = L.Qf();  // (the Cholesky work copy / Ri: dead until the next factorisation)
-          if (nf == m) {
-            MF = L.Minv();  // nothing clamped: the scatter is the identity
-          } else {
-            for (int e = lane; e < LDM * WM; e += 64) MF[e] = 0.0;
-            lds_sync();
-            for (int e = lane; e < nf * nf; e += 64) {
-              const int a = e % nf, b2 = e / nf;
-              MF[L.idx[a] + LDM * L.idx[b2]] = L.Minv()[a + LDM * b2];
-            }
-            lds_sync();
-          }
-#pragma unroll
-          for (int tj = 0; tj < 2; tj++) {
-            if (tj >= NT) continue;
-            const double4_t acc = mfma_tile<WM / 4>(
-                [&](int i2, int k) { return MF[i2 + LDM * k]; },
-                [&](int k, int j) { return L.Qux[k + LDM * (tj * 16 + j)]; }, lane);
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++) L.K()[(orow + 4 * rr) + LDM * (tj * 16 + ocol)] = -acc[rr];
-          }
-        } else {  // a stale factor of another size (:80): the literal sums over its leading block
-          for (int e = lane; e < nuse * n; e += 64) {
-            const int rr = e % nuse, c = e / nuse;
-            double acc = 0;
-            for (int l2 = 0; l2 < nuse; l2++) acc += -L.Minv()[rr + LDM * l2] * L.Qux[L.idx[l2] + LDM * c];
-            L.K()[L.idx[rr] + LDM * c] = acc;
-          }
-        }
-      }
-      lds_sync();
-      ILQR_WMARK(4)
-      // :388-389
-      {
-        const double d0 = wave_sum_row0(lane < m ? L.x[lane] * L.Qu[lane] : 0.0);
-        double part = 0;
-        if (lane < m) {
-          const double rr = dot_padded([&](int a) { return 0.5 * L.x[a]; }, [&](int a) { return L.Quu()[a + LDM * lane]; });
-          part = rr * L.x[lane];
-        }
-        dV0 += d0;
-        dV1 += wave_sum_row0(part);
-      }
-      // T1 = K' Quu (n x m)
-#pragma unroll
-      for (int ti = 0; ti < 2; ti++) {
-        if (ti >= NT) continue;
-        const double4_t acc = mfma_tile<WM / 4>(
-            [&](int i2, int k) { return L.K()[k + LDM * (ti * 16 + i2)]; }, [&](int k, int j) { return L.Quu()[k + LDM * j]; },
-            lane);
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) L.T1()[(ti * 16 + orow + 4 * rr) + LDN * ocol] = acc[rr];
-      }
-      lds_sync();
-      // :391 Vx ; :392 Vn = ((Qxx + T1 K) + K'Qux) + Qux'K into A1 ; :393 symmetrise into Vxx
-      for (int a = lane; a < n; a += 64) {
-        const double t1 = dot_masked(0, m, [&](int c) { return L.T1()[a + LDN * c]; }, [&](int c) { return L.x[c]; });
-        const double t2 = dot_masked(0, m, [&](int c) { return L.K()[c + LDM * a]; }, [&](int c) { return L.Qu[c]; });
-        const double t3 = dot_masked(0, m, [&](int c) { return L.Qux[c + LDM * a]; }, [&](int c) { return L.x[c]; });
-        L.Vxn[a] = ((L.Qx[a] + t1) + t2) + t3;
-      }
-#pragma unroll
-      for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-        for (int tj = 0; tj < 2; tj++) {
-          if (ti >= NT || tj >= NT) continue;
-          const double4_t t1 = mfma_tile<WM / 4>(
-              [&](int i2, int k) { return L.T1()[(ti * 16 + i2) + LDN * k]; },
-              [&](int k, int j) { return L.K()[k + LDM * (tj * 16 + j)]; }, lane);
-          const double4_t t2 = mfma_tile<WM / 4>(
-              [&](int i2, int k) { return L.K()[k + LDM * (ti * 16 + i2)]; },
-              [&](int k, int j) { return L.Qux[k + LDM * (tj * 16 + j)]; }, lane);
-          const double4_t t3 = mfma_tile<WM / 4>(
-              [&](int i2, int k) { return L.Qux[k + LDM * (ti * 16 + i2)]; },
-              [&](int k, int j) { return L.K()[k + LDM * (tj * 16 + j)]; }, lane);
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++) {
-            const int a = ti * 16 + orow + 4 * rr, c = tj * 16 + ocol;
-            L.A1[a + LDN * c] = ((L.Qxx()[a + LDN * c] + t1[rr]) + t2[rr]) + t3[rr];
-          }
-        }
-      lds_sync();
-      ILQR_WMARK(5)
-#pragma unroll
-      for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-        for (int tj = 0; tj < 2; tj++)
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++) {
-            if (ti >= NT || tj >= NT) continue;
-            const int a = ti * 16 + orow + 4 * rr, c = tj * 16 + ocol;
-            L.Vxx[a + LDN * c] = 0.5 * (L.A1[a + LDN * c] + L.A1[c + LDN * a]);
-          }
-      for (int a = lane; a < n; a += 64) L.Vx[a] = L.Vxn[a];
-      // :396-397
-      if (lane < m) {
-        kb[(size_t)i * m + lane] = L.x[lane];
-        L.kprev[lane] = L.x[lane];
-      }
-      for (int c = lane >> 4; c < n; c += 4)
-        if ((lane & 15) < m) Kb[(size_t)i * m * n + (lane & 15) + m * c] = L.K()[(lane & 15) + LDM * c];
-      lds_sync();
-    }
-    if (mode == 0) {
-      done = (diverge == 0);
-      break;
-    }
-    if (diverge != 0) {  // :142-148
-      dlambda = fmax(dlambda * sp.lambda_factor, sp.lambda_factor);
-      lambda = fmax(lambda * dlambda, sp.lambda_min);
-      if (lambda > sp.lambda_max) break;
-      continue;
-    }
-    done = true;
-    break;
-  }
-  // :153 / :405-412 gradient norm: mean_t max_j |k_j| / (|u_j| + 1), ascending t
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_waitcnt(0);
-  double acc = 0;
-  for (int t = 0; t < T; t++) {
-    double val = -1.0;
-    if (lane < m) val = fabs(kb[(size_t)t * m + lane]) / (fabs(usb[(size_t)t * m + lane]) + 1);
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) val = fmax(val, __shfl_xor(val, off, 64));
-    acc += __shfl(val, 0, 64);
-  }
-  const double gnorm = acc / T;
-  if (lane == 0) {
-    v.dV[b] = dV0;
-    v.dV[v.Bp + b] = dV1;
-    v.diverge[b] = diverge;
-    v.backpass_done[b] = done ? 1 : 0;
-    v.gnorm[b] = gnorm;
-    if (mode == 1) {
-      v.lambda[b] = lambda;
-      v.dlambda[b] = dlambda;
-      if (!sp.fixed_work && gnorm < sp.tol_grad && lambda < 1e-5) {
-        v.status[b] = 1;
-        v.iters[b] += 1;
-      }
-    }
-  }
-}
+// (Round 1's kernel k_backward_w -- every matrix of a step in LDS, 39.6 KB per wavefront -- lived here until ABI 5.  k_backward_w2
+//  (backward_wave2.hpp) reproduces its bits with the matrices in registers and is the literal-order kernel the product keeps behind
+//  ILQR_ROUTE_BACKWARD_W2; what remains in this file is what the register kernels share: the LDS block of the box-QP, the matrix-core
+//  tile helpers, reductions, and w_box_qp -- boxqp.cpp:26-139 as written.)
 
 // canonical [B][S][len] block  <->  AoS record slot [b][s][off .. off+len)
 __global__ void k_rec_aos(double* __restrict__ D, double* __restrict__ host_layout, int B, int S, int REC, int off, int len,

@@ -98,7 +98,6 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   // route choices come with the descriptor (ilqr_desc.route, include/ilqr_amd.h): the library reads no environment
   h->route.staged = false;
   h->route.unfused = false;
-  h->route.backward_w1 = (d->route & ILQR_ROUTE_BACKWARD_LDS) != 0;
   h->route.backward_w2 = (d->route & ILQR_ROUTE_BACKWARD_W2) != 0;
   h->route.lq_dense_fd = (d->route & ILQR_ROUTE_LQ_DENSE_FD) != 0;
   h->route.lq_thread_rollout = (d->route & ILQR_ROUTE_LQ_THREAD_ROLLOUT) != 0;
@@ -324,14 +323,14 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   h->sp.fixes = ((h->flags & ILQR_FLAG_REFERENCE_FIXES) ? 3 : 0) | ((h->flags & ILQR_FLAG_REGULARIZE_VXX) ? 4 : 0);
   // generic handles: ILQR_FLAG_REFERENCE_FIXES on the models with a device twin (their rollouts clamp, their box-QP reports a failed factorisation); the
   // host-evaluated route's rollouts belong to the caller.  ILQR_FLAG_REGULARIZE_VXX is the backward pass's alone (k_backward_w3<.., REGV>), on any model
-  if ((h->sp.fixes & 4) && h->aos && (h->route.backward_w1 || h->route.backward_w2))
-    return fail(ILQR_ERR_UNSUPPORTED, "ILQR_FLAG_REGULARIZE_VXX on the generic path is implemented in k_backward_w3: drop ILQR_ROUTE_BACKWARD_LDS / ILQR_ROUTE_BACKWARD_W2");
+  if ((h->sp.fixes & 4) && h->aos && h->route.backward_w2)
+    return fail(ILQR_ERR_UNSUPPORTED, "ILQR_FLAG_REGULARIZE_VXX on the generic path is implemented in k_backward_w3: drop ILQR_ROUTE_BACKWARD_W2");
   if ((h->sp.fixes & 3) && h->model == ILQR_MODEL_HOST) return fail(ILQR_ERR_UNSUPPORTED, "ILQR_FLAG_REFERENCE_FIXES on a host-evaluated model: its rollouts are the caller's (clamp there); the flag is implemented for the models with a device twin");
 
   hipLaunchKernelGGL(k_reset_state<double>, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
                      h->params.dlambda_init);
   HIPCHK(hipGetLastError());
-  h->lq_fused = h->model == ILQR_MODEL_LQ && v.analytic && !h->route.full_records && !h->route.backward_w1 && !h->route.backward_w2 && !(h->sp.fixes & 4);
+  h->lq_fused = h->model == ILQR_MODEL_LQ && v.analytic && !h->route.full_records && !h->route.backward_w2 && !(h->sp.fixes & 4);
   if (h->lq_fused) {  // both constant records, once (what = 3)
     hipLaunchKernelGGL(k_analytic_lq, dim3(1), dim3(64), 0, h->stream, h->v, h->lq, 1, 3, h->const_rec, kAnalyticChunk);
     HIPCHK(hipGetLastError());
@@ -347,6 +346,10 @@ int ilqr_create(const ilqr_desc* d, ilqr_batch** out) {
   REQUIRE(d->B >= 1 && d->T >= 1 && d->nx >= 1 && d->nu >= 1, "B, T, nx, nu must be positive");
   REQUIRE(d->nx <= MAXN && d->nu <= MAXM, "nx <= %d and nu <= %d", MAXN, MAXM);
   REQUIRE(d->dt > 0, "dt must be positive");
+  if (d->route & 128)  // (ILQR_ROUTE_BACKWARD_LDS of ABI <= 4)
+    return fail(ILQR_ERR_UNSUPPORTED, "route bit 128 (round 1's LDS kernel k_backward_w) was retired in ABI 5: ILQR_ROUTE_BACKWARD_W2 gives the same bits");
+  if ((d->route & ILQR_ROUTE_WIDE_TWO_PER_CU) && d->nu == 2 && d->nx == 4)
+    return fail(ILQR_ERR_UNSUPPORTED, "ILQR_ROUTE_WIDE_TWO_PER_CU: the m = 2 wide tiles (k_solve_wide2) run one tile per CU (four wavefronts at <= 512 registers); the bit applies to k_solve_wide (m = 1)");
   ilqr_batch* h = new ilqr_batch();
   const int rc = create_impl(d, h);
   if (rc) {
@@ -855,6 +858,73 @@ int ilqr_copy_cost_to_device(ilqr_batch* h, void* dst) {
   if (!h || !dst) return fail(ILQR_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpyAsync(dst, h->v.cost, (size_t)h->B * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  return 0;
+}
+// the handle's (tiled, possibly float) array -> canonical double [B][S][E] in device memory `dst`; enqueued, not waited for
+static int unpack_to_device(ilqr_batch* h, const void* src, double* dst, int S, int E) {
+  const size_t n = (size_t)h->B * S * E;
+  if (h->aos) {  // generic handles: the canonical layout IS the device layout
+    HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+  }
+  if (h->dtype == ILQR_DTYPE_F32)
+    hipLaunchKernelGGL(k_unpack<float>, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, (const float*)src, dst, h->B, S, E);
+  else
+    hipLaunchKernelGGL(k_unpack<double>, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, (const double*)src, dst, h->B, S, E);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int ilqr_copy_trajectory_to_device(ilqr_batch* h, void* xs_dev, void* us_dev) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (xs_dev) if (int rc = unpack_to_device(h, h->v.xs, (double*)xs_dev, h->T + 1, h->nx)) return rc;
+  if (us_dev) if (int rc = unpack_to_device(h, h->v.us, (double*)us_dev, h->T, h->nu)) return rc;
+  return 0;
+}
+int ilqr_copy_gains_to_device(ilqr_batch* h, void* k_dev, void* K_dev) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (k_dev) if (int rc = unpack_to_device(h, h->v.kff, (double*)k_dev, h->T, h->nu)) return rc;
+  if (K_dev) if (int rc = unpack_to_device(h, h->v.Kfb, (double*)K_dev, h->T, h->nu * h->nx)) return rc;
+  return 0;
+}
+int ilqr_get_results_async(ilqr_batch* h, double* xs, double* us, double* k, double* K, double* cost) {
+  if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  struct Item { const void* src; double* dst; int S, E; };
+  const Item items[4] = {{h->v.xs, xs, h->T + 1, h->nx}, {h->v.us, us, h->T, h->nu}, {h->v.kff, k, h->T, h->nu}, {h->v.Kfb, K, h->T, h->nu * h->nx}};
+  if (h->aos) {
+    for (const Item& it : items)
+      if (it.dst) HIPCHK(hipMemcpyAsync(it.dst, it.src, (size_t)h->B * it.S * it.E * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  } else {
+    // every array gets its own stretch of the staging buffer: the unpack kernels and the copies follow each other on the stream without a
+    // host synchronisation in between (the staging buffer is only ever touched by work enqueued on this stream: a later upload is ordered
+    // behind these copies)
+    size_t total = 0;
+    for (const Item& it : items)
+      if (it.dst) total += (size_t)h->B * it.S * it.E;
+    if (total)
+      if (int rc = ensure_staging(h, total)) return rc;
+    size_t off = 0;
+    for (const Item& it : items) {
+      if (!it.dst) continue;
+      const size_t n = (size_t)h->B * it.S * it.E;
+      if (int rc = unpack_to_device(h, it.src, h->staging + off, it.S, it.E)) return rc;
+      HIPCHK(hipMemcpyAsync(it.dst, h->staging + off, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      off += n;
+    }
+  }
+  if (cost) HIPCHK(hipMemcpyAsync(cost, h->v.cost, (size_t)h->B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  return 0;
+}
+int ilqr_host_register(void* ptr, size_t bytes) {
+  if (!ptr || !bytes) return fail(ILQR_ERR_INVALID, "null argument");
+  HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return 0;
+}
+int ilqr_host_unregister(void* ptr) {
+  if (!ptr) return fail(ILQR_ERR_INVALID, "null argument");
+  HIPCHK(hipHostUnregister(ptr));
   return 0;
 }
 

@@ -98,7 +98,7 @@ struct ilqr_batch {
   // Route choices for A/B runs and the bit-identity tests: ilqr_desc.route, fixed at ilqr_create -- a handle never changes
   // kernels between calls, and nothing is read from the environment
   struct {
-    bool staged = false, unfused = false, backward_w1 = false, backward_w2 = false, lq_dense_fd = false, lq_thread_rollout = false, full_records = false, no_compaction = false, quad_chain = false;
+    bool staged = false, unfused = false, backward_w2 = false, lq_dense_fd = false, lq_thread_rollout = false, full_records = false, no_compaction = false, quad_chain = false;
     int fused = 0;  // 0 = by batch size
     int wide_occ = 0;  // wide tiles per CU: 0 = by batch size
   } route;

@@ -204,8 +204,8 @@ static int launch_backward(ilqr_batch* h, int mode) {
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (int rc = timer_begin(h, ILQR_STAGE_BACKWARD, &ev)) return rc;
   if (h->aos) {
-    // the register-resident kernel, two (nx > 16) or more (nx <= 16) wavefronts per SIMD; ILQR_ROUTE_BACKWARD_LDS forces round
-    // 1's LDS kernel -- the two give bit-identical results (tests/test_gpu_generic_backward.py)
+    // the register-resident kernels, two (nx > 16) or more (nx <= 16) wavefronts per SIMD: k_backward_w3, or with ILQR_ROUTE_BACKWARD_W2 the
+    // literal-order k_backward_w2 (round 1's LDS kernel k_backward_w, whose bits k_backward_w2 reproduces, was retired in ABI 5)
     const bool fused = h->lq_fused && !h->lq_caller_records;  // cx, cu from the knot, the matrices from const_rec: D untouched
     if (!fused)
       if (int rc = ensure_records(h)) return rc;
@@ -213,9 +213,7 @@ static int launch_backward(ilqr_batch* h, int mode) {
     const dim3 grid(h->B), block(64);
     const bool full = h->nu == WM && (h->nx == 16 || h->nx == 32);
 #define ILQR_W3(NT_, FULL_, LQF_) hipLaunchKernelGGL((k_backward_w3<NT_, FULL_, LQF_>), grid, block, 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec)
-    if (h->route.backward_w1)
-      hipLaunchKernelGGL(k_backward_w, grid, block, 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
-    else if (h->route.backward_w2 && h->nx > 16)
+    if (h->route.backward_w2 && h->nx > 16)
       hipLaunchKernelGGL(k_backward_w2<2>, grid, block, 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);
     else if (h->route.backward_w2)
       hipLaunchKernelGGL(k_backward_w2<1>, grid, block, 0, h->stream, h->v, h->nx, h->nu, h->d_umin, h->d_umax, h->sp, mode, crec);

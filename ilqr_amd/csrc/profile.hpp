@@ -68,7 +68,7 @@ const char* ilqr_stage_kernel_name(ilqr_batch* h, int stage) {
   switch (stage) {
     case ILQR_STAGE_DERIVATIVES: return (h && h->aos) ? (h->lq_fused ? "" : (h->v.analytic && h->model == ILQR_MODEL_LQ) ? "k_analytic_lq" : (h->model == ILQR_MODEL_LQ && !h->route.lq_dense_fd) ? "k_derivatives_lq" : "k_derivatives_g") : "k_derivatives";
     case ILQR_STAGE_BACKWARD:
-      if (h && h->aos) return h->route.backward_w1 ? "k_backward_w" : h->route.backward_w2 ? "k_backward_w2" : "k_backward_w3";
+      if (h && h->aos) return h->route.backward_w2 ? "k_backward_w2" : "k_backward_w3";
       if (h && use_fused_sweep(h)) return "k_sweep_backward";  // what ilqr_iterate launches
       return (h && use_quad_backward(h)) ? "k_backward_q" : "k_backward_t";
     case ILQR_STAGE_ROLLOUT: return (h && h->aos) ? ((h->route.lq_thread_rollout || h->model != ILQR_MODEL_LQ) ? "k_rollout_g" : "k_rollout_lq") : "k_rollout";

@@ -37,7 +37,9 @@
 extern "C" {
 #endif
 
-#define ILQR_AMD_ABI_VERSION 4 /* 2: ilqr_desc.dtype; 3: ILQR_MODEL_USER, ilqr_desc.user_params; 4: ilqr_desc.route, assume_cus (the library reads no environment) */
+#define ILQR_AMD_ABI_VERSION 5 /* 2: ilqr_desc.dtype; 3: ILQR_MODEL_USER, ilqr_desc.user_params; 4: ilqr_desc.route, assume_cus (the library reads no environment);
+                                  5: results into device memory / in one asynchronous call (ilqr_copy_trajectory_to_device, ilqr_copy_gains_to_device,
+                                     ilqr_get_results_async, ilqr_host_register); route bit 128 (ILQR_ROUTE_BACKWARD_LDS, round 1's LDS kernel) retired */
 
 typedef struct ilqr_batch ilqr_batch; /* opaque: owns all device memory of one batch */
 
@@ -123,7 +125,7 @@ enum ilqr_flags {
    * where the reference adds lambda I to Quu and notes "regularization is different" (src/ilqr_core.cpp:365-367).
    * The value update keeps the unregularised Quu, Qux as in the reference.  Every model: the nx = 4 kernels, the
    * tiled kernels of a small twin, and k_backward_w3 on the generic path (n <= 32, m <= 16; host-evaluated models
-   * included: the backward pass is what they run on the device) -- not with ILQR_ROUTE_BACKWARD_LDS / _W2. */
+   * included: the backward pass is what they run on the device) -- not with ILQR_ROUTE_BACKWARD_W2. */
   ILQR_FLAG_REGULARIZE_VXX = 128
 };
 
@@ -166,16 +168,26 @@ typedef struct ilqr_desc {
 /* Which of several equivalent kernels a handle uses.  Every choice leaves the same bits (tests/test_gpu_fused_sweep.py,
  * scripts/soak.py): these exist for A/B measurements and for those tests.  The library reads NO environment variables. */
 enum ilqr_route {
+  /* What ILQR_ROUTE_AUTO means for the arithmetic: on the nx = 4 path every route computes every element by the same expression in the
+   * same order (bit-identical, tests/test_gpu_fused_sweep.py).  On the GENERIC path (n <= 32, m <= 16: LQ model, larger user twins,
+   * host-evaluated models) the default backward kernel k_backward_w3 does NOT follow the reference's operation order: the box-QP's
+   * inverse comes from a Newton-Schulz refinement of the previous knot's inverse (the literal Cholesky of src/boxqp.cpp:80-119 is its
+   * fallback), the upper Vxx tile is the transpose of the lower one, matrix-vector products are per-lane sums.  Its gains equal the
+   * reference-order kernel's and the oracle's to rounding (1e-9 on well-conditioned steps; the 1e-6 per-knot tolerance is what is
+   * tested), and where fp64 itself does not determine a pass (an indefinite Quu) only its discrete outcome.  The kernel that keeps
+   * the reference's order of operations, bit for bit what round 1's LDS kernel computed, is opt-in: ILQR_ROUTE_BACKWARD_W2. */
   ILQR_ROUTE_AUTO = 0,
   ILQR_ROUTE_TILE_PER_CU = 1,       /* ilqr_iterate: persistent 16-trajectory tiles, one per CU (k_solve_hex for m = 1 without opt-in fixes, else k_solve_tile<..,1>) */
   ILQR_ROUTE_TWO_TILES_PER_CU = 2,  /* ... two per CU (k_solve_tile<..,2>; with ILQR_FLAG_STAGED the one-producer k_sweep_backward) */
   ILQR_ROUTE_WIDE_TILES = 3,        /* ... 64-trajectory wide tiles (k_solve_wide / k_solve_wide2; m <= 2 without opt-in fixes, else as 2) */
   ILQR_ROUTE_WIDE_ONE_PER_CU = 4,   /* wide tiles: one per CU whatever the batch size */
-  ILQR_ROUTE_WIDE_TWO_PER_CU = 8,   /* wide tiles: two per CU whatever the batch size */
+  ILQR_ROUTE_WIDE_TWO_PER_CU = 8,   /* wide tiles (m = 1, k_solve_wide): two per CU whatever the batch size.  The m = 2 wide tiles (k_solve_wide2) always run
+                                       one per CU: ilqr_create answers ILQR_ERR_UNSUPPORTED to this bit on an nx = 4, nu = 2 handle */
   ILQR_ROUTE_NO_COMPACTION = 16,    /* ilqr_generate_trajectory without re-packing running trajectories between chunks */
   ILQR_ROUTE_FULL_RECORDS = 32,     /* LQ model, exact derivatives: whole per-knot records instead of one shared copy of the constant blocks */
   ILQR_ROUTE_LQ_THREAD_ROLLOUT = 64,/* LQ model: thread-per-rollout k_rollout_g instead of the matrix-core k_rollout_lq */
-  ILQR_ROUTE_BACKWARD_LDS = 128,    /* generic path: round 1's LDS kernel k_backward_w instead of the register kernels */
+  /* (128 was ILQR_ROUTE_BACKWARD_LDS, round 1's LDS kernel k_backward_w: retired in ABI 5 -- ILQR_ROUTE_BACKWARD_W2 gives the same bits;
+   *  ilqr_create answers ILQR_ERR_UNSUPPORTED to the bit) */
   ILQR_ROUTE_QUAD_CHAIN = 256,      /* one tile per CU: the 4-lane DPP chain (k_solve_tile<..,1>) also where the matrix-core chains (k_solve_hex: m = 1, no opt-in fixes) would run */
   ILQR_ROUTE_LQ_RECOMMIT = 512,     /* LQ model: no candidate buffers (11 x the nominal trajectory); the accepted rollout is run again to commit it */
   ILQR_ROUTE_LQ_DENSE_FD = 2048,    /* LQ model, finite differences: every perturbed point's quadratic forms evaluated densely on the matrix cores
@@ -254,6 +266,16 @@ int ilqr_set_lambda(ilqr_batch* h, const double* lambda, const double* dlambda);
 
 int ilqr_get_trajectory(ilqr_batch* h, double* xs, double* us); /* either may be NULL */
 int ilqr_get_gains(ilqr_batch* h, double* k, double* K);
+/* The derivative records.  WHICH trajectory they describe depends on the route, as the reference's members do on where its loop stands
+ * (src/ilqr_core.cpp:115-120 refreshes fx ... cuu at the top of an iteration, :210-213 accepts a new trajectory at its end):
+ *   - after a stage call (ilqr_compute_derivatives, ilqr_set_derivatives): the records that call left;
+ *   - nx = 4 handles after ilqr_iterate: the persistent kernels keep no records in memory; the getter computes those of the CURRENT
+ *     nominal trajectory on demand (zeros after ilqr_init_traj, as ilqr_core.cpp:39-45 leaves them);
+ *   - LQ model with exact derivatives on the default route: likewise recomputed for the current nominal trajectory (k_analytic_lq);
+ *   - generic handles on the record-keeping routes (finite differences, ILQR_ROUTE_BACKWARD_W2, ILQR_ROUTE_FULL_RECORDS, user twins,
+ *     host-evaluated models): what the LAST sweep left, i.e. the records of the trajectory the last iteration STARTED from -- one
+ *     accepted step behind the nominal trajectory, exactly as the reference's members are after generate_trajectory().
+ * A caller that needs one definite meaning calls ilqr_compute_derivatives first: then every route returns the current trajectory's. */
 int ilqr_get_derivatives(ilqr_batch* h, double* fx, double* fu, double* cx, double* cu,
                          double* cxx, double* cxu, double* cuu);
 int ilqr_get_cost(ilqr_batch* h, double* cost);                     /* [B] cost_s */
@@ -271,6 +293,23 @@ int ilqr_count_running(ilqr_batch* h, int* n_running);
  * (the payload of the multi-GPU gather).  Enqueued on the handle's stream:
  * ilqr_synchronize before handing the buffer to work on another stream (a collective). */
 int ilqr_copy_cost_to_device(ilqr_batch* h, void* dst_device);
+/* ---- results without a host round trip per array (ABI 5) ------------------------------------------------------------------------
+ * The reference hands its caller xs / us / K / k as members (include/ilqr.h:48-56); a batched caller of the getters above pays one
+ * unpack kernel + one device-to-host copy + one stream synchronisation per array, and for an 11 ms job (B = 4096, 20 iterations)
+ * 164 MB of results are 3-10 ms of that.  Two ways around it:
+ * (1) Callers that stay on the GPU (MPC: the next warm start, src/ilqr_core.cpp:65-76, a learned policy's loss, ...): the canonical
+ *     layouts of the top of this file as double, written into CALLER-OWNED DEVICE memory on this handle's device.  Enqueued on the handle's
+ *     stream, not waited for (ilqr_synchronize, or stream order, before another stream reads them).  Any pointer may be NULL. */
+int ilqr_copy_trajectory_to_device(ilqr_batch* h, void* xs_device, void* us_device);
+int ilqr_copy_gains_to_device(ilqr_batch* h, void* k_device, void* K_device);
+/* (2) Host callers: every requested array (NULL = skip) in ONE call -- the unpack kernels and the device-to-host copies follow each
+ *     other on the handle's stream with NO synchronisation; the arrays are valid after ilqr_synchronize.  With page-locked destinations
+ *     (ilqr_host_register once per buffer a caller reuses, or hipHostMalloc) the copies are DMA at PCIe rate and the call returns at
+ *     once; with pageable memory the runtime stages them and the call may block, the result is the same. */
+int ilqr_get_results_async(ilqr_batch* h, double* xs, double* us, double* k, double* K, double* cost);
+/* hipHostRegister / hipHostUnregister for callers that do not link the HIP runtime themselves */
+int ilqr_host_register(void* ptr, size_t bytes);
+int ilqr_host_unregister(void* ptr);
 
 /* ---- several shards of one batch, one process ----------------------------------
  * The path partitions by trajectory: shard i = a handle of its own (any device, ilqr_desc.device) holding the contiguous block

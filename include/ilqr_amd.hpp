@@ -366,6 +366,16 @@ class BatchILQR {
     check(ilqr_get_cost(h_, c.data()), "ilqr_get_cost");
     return c;
   }
+  // Every result in one call (ABI 5): the device-to-host copies are enqueued back to back, nothing is waited for until synchronize().
+  // The buffers belong to the caller (sizes as the getters above; nullptr = skip); page-lock buffers that are reused across solves once
+  // with ilqr_host_register so that the copies are DMA transfers.
+  void results_async(double* xs, double* us, double* k, double* K, double* cost) {
+    check(ilqr_get_results_async(h_, xs, us, k, K, cost), "ilqr_get_results_async");
+  }
+  // ... or keep them on the GPU: canonical layouts into caller-owned device memory (the next warm start, ilqr_core.cpp:65-76, of an MPC loop)
+  void copy_trajectory_to_device(void* xs_device, void* us_device) { check(ilqr_copy_trajectory_to_device(h_, xs_device, us_device), "ilqr_copy_trajectory_to_device"); }
+  void copy_gains_to_device(void* k_device, void* K_device) { check(ilqr_copy_gains_to_device(h_, k_device, K_device), "ilqr_copy_gains_to_device"); }
+  void synchronize() { check(ilqr_synchronize(h_), "ilqr_synchronize"); }
   std::vector<int> status() {
     std::vector<int> s(B_);
     check(ilqr_get_status(h_, s.data(), nullptr, nullptr), "ilqr_get_status");

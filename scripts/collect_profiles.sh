@@ -9,10 +9,10 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --extras-out $OUT/bench_extras_under_rocprof.json"
 SHORT="$BENCH --no-extra-configs --steps 5 --warmup 3"
 # the whole default record (headline + configs) under the tracer
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o $R -- $BENCH --steps 20 --warmup 3 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o $R -- $BENCH --extra-configs --steps 20 --warmup 3 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 # the headline alone, 5 iterations per launch: durations in the units of the counter passes below
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats5 -o $R -- $SHORT > /dev/null 2> $OUT/stats5.err
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -51,7 +51,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/staged_stats -o $R -- $SHORT --flags 32 > /dev/null 2> $OUT/staged_stats.err
 # the generic path (configs[4]: LQ n=32, m=16, T=200, B=8192, exact derivatives): k_backward_w3 (fused: no sweep, no record array); forced, round 2's
-# k_backward_w2 (route 1024) and round 1's k_backward_w (route 128); and the finite-difference mode (k_derivatives_g + k_backward_w3 on per-knot records)
+# k_backward_w2 (route 1024); and the finite-difference mode (k_derivatives_g + k_backward_w3 on per-knot records)
 LQ="python $ROOT/scripts/bench_lq.py 8192 2 16"
 SQLQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/lq_stats -o $R -- $LQ > $OUT/lq_bench.txt 2> $OUT/lq_stats.err
@@ -61,8 +61,6 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $C --kernel-trace -d $OUT/lq_pmc_$C -o $R -- $LQ > /dev/null 2> $OUT/lq_pmc_$C.err
 done
 timeout 300 rocprofv3 --pmc $SQLQ --kernel-trace -d $OUT/lq_w2_pmc_sq -o $R -- $LQ 1024 > /dev/null 2> $OUT/lq_w2_pmc_sq.err
-timeout 300 rocprofv3 --pmc $SQLQ --kernel-trace -d $OUT/lq_w1_pmc_sq -o $R -- $LQ 128 > /dev/null 2> $OUT/lq_w1_pmc_sq.err
-timeout 300 rocprofv3 --pmc MeanOccupancyPerCU MeanOccupancyPerActiveCU --kernel-trace -d $OUT/lq_w1_pmc_occ -o $R -- $LQ 128 > /dev/null 2> $OUT/lq_w1_pmc_occ.err
 LQFD="python $ROOT/scripts/bench_lq.py 8192 1 0"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/lqfd_stats -o $R -- $LQFD > $OUT/lqfd_bench.txt 2> $OUT/lqfd_stats.err
 timeout 600 rocprofv3 --pmc $SQLQ --kernel-trace -d $OUT/lqfd_pmc_sq -o $R -- $LQFD > /dev/null 2> $OUT/lqfd_pmc_sq.err
@@ -84,12 +82,13 @@ for U in lat ldsmix; do  # microbenchmarks quoted in DESIGN.md, re-run on this b
 done
 for d in stats stats5 quad_stats5 pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq1 pmc_sq2 pmc_sq3 pmc_sq4 sat_stats5 sat_pmc_FETCH_SIZE sat_pmc_WRITE_SIZE sat_pmc_sq1 sat_pmc_sq2 sat_pmc_sq3 \
          f32_stats5 f32_pmc_FETCH_SIZE f32_pmc_WRITE_SIZE f32_pmc_sq1 f32_pmc_sq2 f32_pmc_sq3 f32sat_stats5 f32sat_pmc_FETCH_SIZE f32sat_pmc_WRITE_SIZE f32sat_pmc_sq1 f32sat_pmc_sq2 f32sat_pmc_sq3 \
-         staged_pmc_FETCH_SIZE staged_pmc_WRITE_SIZE staged_stats lq_stats lq_pmc_sq lq_pmc_occ lq_pmc_FETCH_SIZE lq_pmc_WRITE_SIZE lq_w2_pmc_sq lq_w1_pmc_sq lq_w1_pmc_occ lqfd_stats lqfd_pmc_sq lqfd_pmc_occ lqfd_dense_stats lqfd_dense_pmc_sq int_stats int_pmc_FETCH_SIZE int_pmc_WRITE_SIZE int_pmc_sq1; do
+         staged_pmc_FETCH_SIZE staged_pmc_WRITE_SIZE staged_stats lq_stats lq_pmc_sq lq_pmc_occ lq_pmc_FETCH_SIZE lq_pmc_WRITE_SIZE lq_w2_pmc_sq lqfd_stats lqfd_pmc_sq lqfd_pmc_occ lqfd_dense_stats lqfd_dense_pmc_sq int_stats int_pmc_FETCH_SIZE int_pmc_WRITE_SIZE int_pmc_sq1; do
   f=$(find $OUT/$d -name "*.db" | head -1)
   [ -n "$f" ] && python scripts/prof_summary.py $f > $OUT/$d.txt 2>&1
 done
 python scripts/make_traffic.py $OUT $R > $OUT/traffic.json 2> $OUT/traffic.err
 cp $OUT/traffic.json profiles/traffic.json   # (on the GPU box only; the caller copies $OUT/traffic.json back)
-python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err   # the default record, now quoting counters of THIS code
+python bench.py --extras-out $OUT/bench_default_extras.json > $OUT/bench_default.json 2> $OUT/bench_default.err   # the default record, now quoting counters of THIS code
+timeout 1200 python bench.py --extra-configs --extras-out $OUT/bench_extra_configs.json > $OUT/bench_extra_configs_line.json 2> $OUT/bench_extra_configs.err   # the other configurations, each with its CPU baseline
 find $OUT -name "*.db" -delete
 ls -la $OUT

@@ -34,7 +34,7 @@ for case in range(100000):
     om = O.Model("lq", lq=mats, u_lim=lim)
     ro = O.batch_solve(om, x0, u0, DT)
     res = []
-    for route, name in ((0, "fused w3"), (capi.ROUTE_BACKWARD_W2, "w2"), (capi.ROUTE_BACKWARD_LDS, "lds")):
+    for route, name in ((0, "fused w3"), (capi.ROUTE_BACKWARD_W2, "w2")):
         g = BatchILQR("lq", B, T, DT, u_min=-lim, u_max=lim, lq=mats, flags=capi.FLAG_ANALYTIC_DERIVATIVES, route=route)
         g.init_traj(x0, u0)
         g.iterate(iters)

@@ -2,8 +2,7 @@
 
 Every case draws dimensions n <= 32, m <= 16, a batch, a horizon, limits, lambda and (sometimes) a negative shift
 of one diagonal entry of cuu (indefinite Quu: partial factors, stale factors, aborted passes), then checks
-  * k_backward_w2 (matrices in registers, ILQR_ROUTE_BACKWARD_W2) == k_backward_w (matrices in LDS, ILQR_ROUTE_BACKWARD_LDS), bit for bit:
-    gains, dV, divergence index, gradient norm;
+  * (through round 5: k_backward_w2 == round 1's LDS kernel k_backward_w, bit for bit; the LDS kernel was retired in ABI 5)
   * k_backward_w2 AND k_backward_w3 (the default: per-lane matrix-vector sums, the box-QP's inverse refined on the matrix cores where the
     free set is the previous knot's, the literal path elsewhere) against the oracle's backward_pass per knot (tests/parity.check_backward:
     1e-6, deviations must be clamp knife edges or fp64-conditioning-limited against the fp80 oracle); where the indefinite shift makes the
@@ -56,7 +55,7 @@ def main():
         k_prev = rng.normal(size=(B, T, m)) * 0.1
         desc = "n=%d m=%d B=%d T=%d lim=%g lam=%g shifted=%s seed=%d" % (n, m, B, T, lim, lam, shifted, seed)
         outs = []
-        for route in (capi.ROUTE_BACKWARD_W2, capi.ROUTE_BACKWARD_LDS, 0):
+        for route in (capi.ROUTE_BACKWARD_W2, 0):
             try:
                 g = BatchILQR("host", B, T, DT, nx=n, nu=m, u_min=om.u_min, u_max=om.u_max, route=route)
                 g.set_trajectory(x0=x0, xs=xs, us=us, cost=cost)
@@ -69,25 +68,21 @@ def main():
                 g.close()
             finally:
                 pass
-        for key in outs[0]:
-            if not np.array_equal(outs[0][key], outs[1][key], equal_nan=True):
-                print("FAIL register kernel != LDS kernel:", key, desc)
-                return 1
-        if not np.array_equal(outs[0]["div"], outs[2]["div"]):
-            print("FAIL k_backward_w3 diverge knots:", desc, outs[0]["div"], outs[2]["div"])
+        if not np.array_equal(outs[0]["div"], outs[1]["div"]):
+            print("FAIL k_backward_w3 diverge knots:", desc, outs[0]["div"], outs[1]["div"])
             return 1
         if not shifted:  # the two register kernels against each other: 1e-9, or a clamp knife edge (a component inside the 1e-4 band of a bound
             # that one of them reads as clamped: tests/parity.py) -- bounded like the ties against the oracle
             lo_b, hi_b = om.u_min[None, None, :] - us, om.u_max[None, None, :] - us
             n_edge = 0
             for bb in range(B):
-                close = all(np.abs(outs[0][key][bb] - outs[2][key][bb]).max() <= 1e-9 * max(1.0, np.abs(outs[0][key][bb]).max()) for key in ("k", "K", "dV", "gnorm"))
+                close = all(np.abs(outs[0][key][bb] - outs[1][key][bb]).max() <= 1e-9 * max(1.0, np.abs(outs[0][key][bb]).max()) for key in ("k", "K", "dV", "gnorm"))
                 if close:
                     continue
-                if first_gain_mismatch_is_knife_edge(outs[2]["k"][bb], outs[2]["K"][bb], outs[0]["k"][bb], outs[0]["K"][bb], us[bb], lo_b[bb], hi_b[bb], 1e-9):
+                if first_gain_mismatch_is_knife_edge(outs[1]["k"][bb], outs[1]["K"][bb], outs[0]["k"][bb], outs[0]["K"][bb], us[bb], lo_b[bb], hi_b[bb], 1e-9):
                     n_edge += 1
                     continue
-                print("FAIL k_backward_w3 vs k_backward_w2 (not a clamp knife edge): trajectory", bb, np.abs(outs[0]["k"][bb] - outs[2]["k"][bb]).max(), desc)
+                print("FAIL k_backward_w3 vs k_backward_w2 (not a clamp knife edge): trajectory", bb, np.abs(outs[0]["k"][bb] - outs[1]["k"][bb]).max(), desc)
                 return 1
             if n_edge > max(1, B // 4):
                 print("FAIL too many knife edges between the two kernels:", n_edge, desc)
@@ -117,8 +112,8 @@ def main():
         try:
             r = check_backward(O, om, sub(us), {kk: v[sane] for kk, v in dv.items()}, sub(k_prev), lam, sub(outs[0]["k"]), sub(outs[0]["K"]),
                                sub(outs[0]["dV"]), sub(outs[0]["div"]), ro_s, max_ties=max(1, B // 4), max_over10=max(1, B // 16))
-            r3 = check_backward(O, om, sub(us), {kk: v[sane] for kk, v in dv.items()}, sub(k_prev), lam, sub(outs[2]["k"]), sub(outs[2]["K"]),
-                                sub(outs[2]["dV"]), sub(outs[2]["div"]), ro_s, max_ties=max(1, B // 4), max_over10=max(1, B // 16),
+            r3 = check_backward(O, om, sub(us), {kk: v[sane] for kk, v in dv.items()}, sub(k_prev), lam, sub(outs[1]["k"]), sub(outs[1]["K"]),
+                                sub(outs[1]["dV"]), sub(outs[1]["div"]), ro_s, max_ties=max(1, B // 4), max_over10=max(1, B // 16),
                                 max_unpinned=(B if shifted else 0))
         except AssertionError as e:
             print("FAIL oracle parity:", desc, str(e)[:300])

@@ -171,7 +171,7 @@ def test_full_size_properties(oracle):
     #  the ones whose line search then also branched differently, or whose gains float cannot resolve at all)
     # mixed arithmetic (the backward pass in double on float records): the gains are held to 1e-5 per knot, costs to 1e-4; what is
     # not plain is a float ROLLOUT whose 499 steps amplified its rounding ("amplified": judged against the fp64 rollout)
-    assert_walk(r, NIT, min_plain_it0=0.8, min_plain=0.78)  # (recorded: 0.86)
+    assert_walk(r, NIT, min_plain_it0=0.8, min_plain=0.78, max_amplified=r["checked"] // 8)  # (recorded: 0.86 plain, 0.06 amplified)
     assert r["unresolved"] == 0, r["unresolved"]
     x0[1] = x0[0]
     x0[B - 1] = x0[0]

@@ -108,11 +108,12 @@ def test_non_positive_definite_quu(oracle, n, m, where, kernel):
                                            (32, 16, 0.3, "middle"), (20, 16, 0.5, "first"),
                                            (6, 2, 0.2, None), (16, 4, 0.3, None), (12, 16, 0.2, None), (3, 1, 0.5, None),
                                            (12, 16, 0.3, "middle"), (6, 2, 0.5, "first")])
-def test_register_kernel_equals_lds_kernel(oracle, n, m, lim, shift):
-    """k_backward_w2 (matrices in MFMA-layout registers; <2>: 16 < nx <= 32, two wavefronts per SIMD; <1>: nx <= 16, three) is a re-arrangement of
-    k_backward_w (matrices in LDS): transposed products, the same k-ordered FMA chains.  Gains, value terms, divergence
-    indices and gradient norms must be IDENTICAL, bit for bit -- mixed clamp sets, partial factors and stale
-    factors included (the non-positive-definite cases)."""
+def test_default_kernel_against_the_literal_order_kernel(oracle, n, m, lim, shift):
+    """k_backward_w2 (ILQR_ROUTE_BACKWARD_W2: matrices in MFMA-layout registers; <2>: 16 < nx <= 32, two wavefronts per SIMD; <1>: nx <= 16, three) keeps
+    the reference's order of operations -- the same k-ordered FMA chains round 1's LDS kernel k_backward_w ran (retired in ABI 5; the two were held
+    bit-identical by this test and scripts/soak_lq.py through round 5).  The default k_backward_w3 must leave the same divergence indices and, on
+    well-conditioned steps, the same gains, value terms and gradient norms to 1e-9 -- mixed clamp sets, partial factors and stale factors included
+    (the non-positive-definite cases)."""
     import os
     from ilqr_amd import BatchILQR
     om = lq_model(oracle, n, m, lim=lim)
@@ -129,9 +130,9 @@ def test_register_kernel_equals_lds_kernel(oracle, n, m, lim, shift):
     k_prev = rng.normal(size=(B, T, m)) * 0.1
     outs = []
     from ilqr_amd import capi
-    for route in (capi.ROUTE_BACKWARD_W2, capi.ROUTE_BACKWARD_LDS, 0):
+    for route in (capi.ROUTE_BACKWARD_W2, 0):
         g = BatchILQR("host", B, T, DT, nx=n, nu=m, u_min=om.u_min, u_max=om.u_max, route=route)
-        assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("backward")) == {capi.ROUTE_BACKWARD_W2: b"k_backward_w2", capi.ROUTE_BACKWARD_LDS: b"k_backward_w", 0: b"k_backward_w3"}[route]
+        assert g.lib.ilqr_stage_kernel_name(g.h, capi.STAGE_NAMES.index("backward")) == {capi.ROUTE_BACKWARD_W2: b"k_backward_w2", 0: b"k_backward_w3"}[route]
         g.set_trajectory(x0=x0, xs=xs, us=us, cost=cost)
         g.set_derivatives(**{k: (dv[k] if k in ("cx", "cu") else mat(dv[k])) for k in dv})
         g.set_gains(k=k_prev, K=np.zeros((B, T, m, n)))
@@ -140,14 +141,60 @@ def test_register_kernel_equals_lds_kernel(oracle, n, m, lim, shift):
         k, K = g.gains()
         outs.append(dict(div=np.asarray(div), k=k, K=K, dV=g.dV(), gnorm=g.gnorm()))
         g.close()
-    for key in outs[0]:
-        assert np.array_equal(outs[0][key], outs[1][key], equal_nan=True), key
     # k_backward_w3 (the default): the same step with the matrix-vector products as per-lane sums and, where the free set is the
     # previous knot's, the box-QP's inverse refined on the matrix cores instead of factored -- equal to rounding on the well-conditioned
     # cases; with an indefinite Quu every box-QP takes the literal path and only the sums' order differs, which the 1e15 amplification
     # of a failed first pivot (test_non_positive_definite_quu) does not let through a tight bound: there the discrete outcome is compared
-    assert np.array_equal(outs[0]["div"], outs[2]["div"])
+    assert np.array_equal(outs[0]["div"], outs[1]["div"])
     if shift is None:
         for key in ("k", "K", "dV", "gnorm"):
             scale = max(1.0, np.abs(outs[0][key]).max())
-            assert np.abs(outs[0][key] - outs[2][key]).max() <= 1e-9 * scale, (key, np.abs(outs[0][key] - outs[2][key]).max(), scale)
+            assert np.abs(outs[0][key] - outs[1][key]).max() <= 1e-9 * scale, (key, np.abs(outs[0][key] - outs[1][key]).max(), scale)
+
+
+@pytest.mark.parametrize("n,m,lim", [(32, 16, 0.05), (32, 16, 0.2), (16, 8, 0.1)])
+def test_default_kernel_against_the_literal_order_kernel_long_horizon(oracle, n, m, lim):
+    """The same comparison over a LONG horizon with tight limits: T = 200, noisy controls of the size of the box, so the free set changes at
+    most knots and k_backward_w3 alternates between its refinement (free set unchanged) and the literal path / the re-seed of the inverse
+    (free set changed) hundreds of times per pass.  Per trajectory the two kernels agree to 1e-8 on k, K, dV and the gradient norm, or the first
+    knot where they part is a clamp knife edge (a component inside the 1e-4 band of a bound: tests/parity.py) -- bounded; the divergence indices
+    are equal.  This is the test the test-suite keeps so that the loosened bounds of the indefinite cases cannot hide a regression of the
+    fast path (round 5's advice)."""
+    from ilqr_amd import BatchILQR, capi
+    from tests.parity import first_gain_mismatch_is_knife_edge
+    om = lq_model(oracle, n, m, lim=lim)
+    B, T = 12, 200
+    rng = np.random.default_rng(11)
+    x0 = rng.uniform(-1, 1, (B, n))
+    u0 = np.clip(rng.normal(size=(B, T, m)) * lim, -1.5 * lim, 1.5 * lim)
+    xs, us, cost = oracle.batch_rollout(om, x0, u0, DT)
+    dv = oracle.batch_derivatives(om, xs, us, DT)
+    k_prev = rng.normal(size=(B, T, m)) * 0.1 * lim
+    outs = []
+    for route in (capi.ROUTE_BACKWARD_W2, 0):
+        g = BatchILQR("host", B, T, DT, nx=n, nu=m, u_min=om.u_min, u_max=om.u_max, route=route)
+        g.set_trajectory(x0=x0, xs=xs, us=us, cost=cost)
+        g.set_derivatives(**{k: (dv[k] if k in ("cx", "cu") else mat(dv[k])) for k in dv})
+        g.set_gains(k=k_prev, K=np.zeros((B, T, m, n)))
+        g.set_lambda(1e-3, 1.0)
+        div = g.backward_pass()
+        k, K = g.gains()
+        outs.append(dict(div=np.asarray(div), k=k, K=K, dV=g.dV(), gnorm=g.gnorm()))
+        g.close()
+    assert np.array_equal(outs[0]["div"], outs[1]["div"]) and np.all(outs[0]["div"] == 0)
+    # the free set does change along the horizon (else this test would not exercise what it is for)
+    clamped = (np.abs(outs[0]["K"]).reshape(B, T, m, n).max(axis=3) == 0)
+    changes = (clamped[:, 1:] != clamped[:, :-1]).any(axis=2).mean()
+    assert changes > 0.05, changes
+    lo_b, hi_b = om.u_min[None, None, :] - us, om.u_max[None, None, :] - us
+    edges = 0
+    for b in range(B):
+        close = all(np.abs(outs[0][key][b] - outs[1][key][b]).max() <= 1e-8 * max(1.0, np.abs(outs[0][key][b]).max()) for key in ("k", "K", "dV", "gnorm"))
+        if close:
+            continue
+        assert first_gain_mismatch_is_knife_edge(outs[1]["k"][b], outs[1]["K"][b], outs[0]["k"][b], outs[0]["K"][b], us[b], lo_b[b], hi_b[b], 1e-8), b
+        edges += 1
+    # (a clamp knife edge is no rare event here: 16 controls x 200 knots per trajectory, each with a chance of 2e-4 / |box| of landing inside the
+    #  1e-4 band -- at +-0.05 several per trajectory are expected; what the check above proves is that nothing ELSE separates the two kernels
+    #  before the first of them)
+    assert edges <= (B if lim < 0.1 else B // 2), edges

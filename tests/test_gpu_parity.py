@@ -409,6 +409,7 @@ def test_bench_saturated_batch_two_wide_tiles_per_cu_10_iterations(oracle, dtype
                                                     r, B=B, T=T, u_lim=lim, n_sample=len(r["sel"]), precision=dtype))
     # (10 iterations: the first, where 60 % of the fp64 trajectories need the stage-by-stage argument, weighs 2.5 x what it does in a 25-iteration
     #  walk.  Recorded: fp64 0.67 plain / 0.31 on the device's records)
-    assert_walk(r, NIT, min_plain_it0=0.95 if dtype == "f64" else 0.8, min_plain=0.58 if dtype == "f64" else 0.75, max_on_records=0.42)
+    assert_walk(r, NIT, min_plain_it0=0.95 if dtype == "f64" else 0.8, min_plain=0.58 if dtype == "f64" else 0.75, max_on_records=0.42,
+                max_amplified=None if dtype == "f64" else r["checked"] // 8)  # (recorded amplified share: fp64 0.003, fp32 0.083)
     assert r["unresolved"] == 0, r["unresolved"]
     g.close()
