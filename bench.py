@@ -681,6 +681,63 @@ def main():
                     "sample": "%d trajectories x 4 fixed-work iterations of the same model as the oracle's LQ model, %.1f s wall, oracle/liboracle_ilqr.so with OpenMP over "
                               "trajectories on all host threads" % (nb6, t6)}
 
+    if not args.no_extra_configs and world == 1:
+        # a user's twin that is neither small nor linear-quadratic (examples/user_model_pendulum_chain.hpp: n = 16, m = 4, trigonometric dynamics,
+        # a non-quadratic cost): the generic path measured on a model that can take none of the LQ twin's shortcuts -- finite differences point by
+        # point through the model's own functions (40 Euler maps + 880 cost evaluations per knot), k_backward_w3<1>, thread-per-rollout forward passes
+        from ilqr_amd import _build
+        if os.path.exists(_build.USER_CHAIN_LIB):
+            NLc, Tc, Bc, itc, limc = 8, 200, 4096, 5, 2.0
+            nc, mc = 2 * NLc, NLc // 2
+            prm = np.array([9.81, 0.1, 2.0, 10.0, 1.0, 0.1, 50.0, 0.0])
+            rc_ = np.random.default_rng(3)
+            x0c = np.concatenate([rc_.uniform(-1, 1, (Bc, NLc)), rc_.uniform(-1, 1, (Bc, NLc)) * 0.5], axis=1)
+            gc = BatchILQR("user", Bc, Tc, dt, u_min=-limc, u_max=limc, lib=_build.USER_CHAIN_LIB, nx=nc, nu=mc, device=local_rank, stream=stream,
+                           user_params=prm, flags=capi.FLAG_FIXED_WORK, params=dict(max_iter=itc + 2))
+            gc.init_traj(x0c, np.zeros((Bc, Tc, mc)))
+            gc.iterate(1)
+            gc.profile(True)
+            gc.profile_reset()
+            barrier()
+            t0 = time.perf_counter()
+            gc.iterate(itc)
+            barrier()
+            elc = time.perf_counter() - t0
+            pc_ = gc.profile_read()
+            assert gc.count_running() == Bc
+            namc = {i: gc.lib.ilqr_stage_kernel_name(gc.h, i).decode() for i in range(capi.NUM_STAGES)}
+            stc = {k: {"kernel": namc[capi.STAGE_NAMES.index(k)], "ms_per_launch": ms / ln, "launches": ln} for k, (ms, ln) in pc_.items() if ln}
+            gc.close()
+            flopc = 4 * nc ** 3 + 10 * nc * nc * mc + 6 * nc * mc * mc + mc ** 3
+            bwc = stc["backward"]["ms_per_launch"] * 1e-3
+            recc = 2 * nc * nc + 2 * nc * mc + mc * mc + nc + mc   # doubles per knot record
+            key = "user_pendulum_chain_n16_m4_T200_B4096_fd"
+            extra[key] = {
+                "workload": "a user's device twin (examples/user_model_pendulum_chain.hpp: 8 coupled pendulums, n=16 m=4, trigonometric dynamics, non-quadratic cost; "
+                            "ILQR_MODEL_USER) T=200 B=4096, u in [-2,2], fp64, finite differences point by point through the model's own functions, fixed-work "
+                            "iterations: the generic kernels (k_derivatives_g, k_backward_w3<1>, k_rollout_g)",
+                "value": Bc * Tc * itc / elc, "unit": "trajectory-timesteps/s", "ms_per_step": elc / itc * 1e3, "stages": stc,
+                "roofline": {"bound": "mfma", "kernel": stc["backward"]["kernel"], "achieved": flopc * Bc * Tc / bwc / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": flopc * Bc * Tc / bwc / 1e12 / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_timestep": flopc,
+                             "avg_launch_ms": bwc * 1e3, "traffic": None,
+                             "note": "one 16 x 16 tile per matrix at n = 16 (m = 4: a quarter of the control tiles' columns is this model's)"},
+                "roofline_records": {"bound": "hbm", "what": "the record array between the sweep and the backward pass (%d doubles per knot, written once and read once per iteration)" % recc,
+                                     "bytes_per_iteration": 2 * 8 * recc * Bc * (Tc + 1),
+                                     "sweep_GBps": 8 * recc * Bc * (Tc + 1) / (stc["derivatives"]["ms_per_launch"] * 1e-3) / 1e9 if "derivatives" in stc else None,
+                                     "backward_GBps": 8 * recc * Bc * (Tc + 1) / bwc / 1e9, "peak": HBM_PEAK_GBS}}
+            if not args.no_cpu_baseline:
+                from oracle import oracle as O
+                cores = os.cpu_count() or 1
+                omc = O.Model("chain", chain=(NLc, prm), u_lim=limc)
+                nbc = min(Bc, 4 * cores)
+                O.batch_solve(omc, x0c[:nbc], np.zeros((nbc, Tc, mc)), dt, max_iters=1, fixed_work=True, nthreads=cores)
+                t0 = time.perf_counter()
+                O.batch_solve(omc, x0c[:nbc], np.zeros((nbc, Tc, mc)), dt, max_iters=4, fixed_work=True, nthreads=cores)
+                tcb = time.perf_counter() - t0
+                extra[key]["cpu_baseline"] = {"value": nbc * Tc * 4 / tcb, "unit": "trajectory-timesteps/s", "cores": cores, "kind": "port",
+                                              "sample": "%d trajectories x 4 fixed-work iterations of the same model (oracle/orc_models.inc: chain_*), %.1f s wall, "
+                                                        "oracle/liboracle_ilqr.so with OpenMP over trajectories on all host threads" % (nbc, tcb)}
+
     if rank == 0:
         costs = gathered.cpu().numpy()
         assert np.all(np.isfinite(costs)), "non-finite cost in the gathered result"

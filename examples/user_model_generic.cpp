@@ -75,7 +75,25 @@ int main() {
     std::printf("user twin / host virtuals / shipped LQ twin: cost[0] %.12g %.12g %.12g, worst relative difference %.3g\n", cost[0][0], cost[1][0],
                 cost[2][0], worst);
     std::printf("agree %d\n", worst < 1e-6 ? 1 : 0);
-    return worst < 1e-6 ? 0 : 1;
+    // ILQR_FLAG_REFERENCE_FIXES (opt-in: the clamped rollout of src/ilqr_core.cpp:327-329, "the right way"): the device twins clamp in their rollout
+    // kernels, the host-evaluated route in the facade's host rollouts -- the same problems again, tight limits so that the clamp matters
+    std::vector<double> fixed[3], us_host;
+    for (int route = 0; route < 3; route++) {
+      BatchILQR solver(std::make_shared<MyLinear6>(route, A, Bm, Q, R, Qf, 0.05), B, T, 0.02, 0, ILQR_FLAG_REFERENCE_FIXES);
+      solver.init_traj(x0, u0);
+      solver.iterate(3);
+      fixed[route] = solver.cost();
+      if (route == 1) us_host = solver.controls();
+    }
+    double worst_fixed = 0, umax = 0;
+    for (int b = 0; b < B; b++)
+      for (int r = 1; r < 3; r++) worst_fixed = std::fmax(worst_fixed, std::fabs(fixed[0][b] - fixed[r][b]) / std::fabs(fixed[0][b]));
+    for (double v : us_host) umax = std::fmax(umax, std::fabs(v));
+    std::printf("with ILQR_FLAG_REFERENCE_FIXES: cost[0] %.12g %.12g %.12g, worst relative difference %.3g, max |u| of the host-evaluated route %.6g (limit 0.05)\n",
+                fixed[0][0], fixed[1][0], fixed[2][0], worst_fixed, umax);
+    const bool fixes_ok = worst_fixed < 1e-6 && umax <= 0.05;
+    std::printf("fixes agree %d\n", fixes_ok ? 1 : 0);
+    return (worst < 1e-6 && fixes_ok) ? 0 : 1;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 2;

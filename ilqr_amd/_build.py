@@ -87,6 +87,18 @@ USER_EXAMPLE_LIB = os.path.join(PKG, "lib", "libilqr_amd_user_example.so")
 # a user twin with dimensions of its own (n = 6, m = 2): the generic kernels
 USER_EXAMPLE6_HEADER = os.path.join(os.path.dirname(PKG), "examples", "user_model_linear6.hpp")
 USER_EXAMPLE6_LIB = os.path.join(PKG, "lib", "libilqr_amd_user_linear6.so")
+# a user twin that is neither small nor linear-quadratic (n = 16, m = 4: a chain of coupled pendulums): the generic kernels, point-by-point finite differences
+USER_CHAIN_HEADER = os.path.join(os.path.dirname(PKG), "examples", "user_model_pendulum_chain.hpp")
+USER_CHAIN_LIB = os.path.join(PKG, "lib", "libilqr_amd_user_chain.so")
+USER_BUILDS = ((USER_EXAMPLE_HEADER, USER_EXAMPLE_LIB), (USER_EXAMPLE6_HEADER, USER_EXAMPLE6_LIB), (USER_CHAIN_HEADER, USER_CHAIN_LIB))
+
+
+def build_all(verbose=False):
+    """The stock library and every example twin, compiled side by side (each is one translation unit of about two minutes)."""
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = [lambda: build(force=True, verbose=verbose)] + [(lambda h=h, o=o: build_user(h, o, verbose=verbose)) for h, o in USER_BUILDS]
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        return [f.result() for f in [ex.submit(j) for j in jobs]]
 
 
 if __name__ == "__main__":

@@ -131,7 +131,11 @@ __device__ __forceinline__ void qp1_search_hex(QP1StateT<double>& q, int j, int 
   const int pp = hex_first(__ballot(t_pass), t4);
   const bool success = pp < 52;            // a set bit
   const int jw = success ? (((pp >> 4) << 2) | (pp & 3)) : 0;
+#ifdef ILQR_EXP_NO_STEP_LDS  // timing experiment (wrong results for jw >= 2): what the step table's LDS round trip costs the chain
+  q.step = jw == 0 ? 1.0 : 0.6;
+#else
   q.step = lds_steps[jw];
+#endif
   q.x1 = clamp_of(q.x + q.step * q.search, q.lo, q.hi);   // the winner's trial point and value, by the winner's expressions
   q.v1 = qp1_value(q, q.x1);
   bool more = p_and(!success, !q.early);

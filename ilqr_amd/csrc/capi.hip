@@ -321,11 +321,12 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   h->sp.z_min = h->params.z_min;
   h->sp.fixed_work = (h->flags & ILQR_FLAG_FIXED_WORK) ? 1 : 0;
   h->sp.fixes = ((h->flags & ILQR_FLAG_REFERENCE_FIXES) ? 3 : 0) | ((h->flags & ILQR_FLAG_REGULARIZE_VXX) ? 4 : 0);
-  // generic handles: ILQR_FLAG_REFERENCE_FIXES on the models with a device twin (their rollouts clamp, their box-QP reports a failed factorisation); the
-  // host-evaluated route's rollouts belong to the caller.  ILQR_FLAG_REGULARIZE_VXX is the backward pass's alone (k_backward_w3<.., REGV>), on any model
+  // generic handles: ILQR_FLAG_REFERENCE_FIXES -- models with a device twin: their rollouts clamp, their box-QP reports a failed factorisation; the
+  // host-evaluated route: the box-QP likewise, the rollouts belong to the caller (the facade clamps).  ILQR_FLAG_REGULARIZE_VXX is the backward pass's alone (k_backward_w3<.., REGV>), on any model
   if ((h->sp.fixes & 4) && h->aos && h->route.backward_w2)
     return fail(ILQR_ERR_UNSUPPORTED, "ILQR_FLAG_REGULARIZE_VXX on the generic path is implemented in k_backward_w3: drop ILQR_ROUTE_BACKWARD_W2");
-  if ((h->sp.fixes & 3) && h->model == ILQR_MODEL_HOST) return fail(ILQR_ERR_UNSUPPORTED, "ILQR_FLAG_REFERENCE_FIXES on a host-evaluated model: its rollouts are the caller's (clamp there); the flag is implemented for the models with a device twin");
+  // (a host-evaluated model under ILQR_FLAG_REFERENCE_FIXES: part (2), the failed factorisation that ends the box-QP, is the device's -- k_backward_w3 /
+  //  k_backward_w2 honour sp.fixes & 2 --; part (1), the clamped rollout, belongs to whoever rolls out: the C++ facade's host_forward does it)
 
   hipLaunchKernelGGL(k_reset_state<double>, dim3((h->Bp + 255) / 256), dim3(256), 0, h->stream, h->v, h->params.lambda_init,
                      h->params.dlambda_init);

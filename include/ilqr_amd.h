@@ -118,7 +118,9 @@ enum ilqr_flags {
    * box-QP's clamped feed-forward without re-clamping, README.md:9 "control-limited part not working").
    * (2) A failed Cholesky factorisation of Quu on the free subspace ends the box-QP with result -1 and the
    * backward pass reports divergence at that step (lambda is raised) -- src/boxqp.cpp:85-88 never looks at
-   * info() and goes on with the partial factor.  nx = 4 device models; the CPU oracle has the same switch. */
+   * info() and goes on with the partial factor.  Every model: the nx = 4 device models, the generic twins, and host-evaluated
+   * models (ILQR_MODEL_HOST: (2) on the device; (1) is applied by whoever rolls out -- the C++ facade's host rollouts clamp
+   * under this flag).  The CPU oracle has the same switch. */
   ILQR_FLAG_REFERENCE_FIXES = 64,
   /* Opt-in, OFF by default (third part of SURVEY.md 8f-4): lambda regularises the value Hessian instead of Quu --
    * [Tassa 2012] eq. 10a/10b, Quu_reg = cuu + fu'(Vxx' + lambda I) fu, Qux_reg = cxu' + fu'(Vxx' + lambda I) fx --

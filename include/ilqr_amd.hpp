@@ -258,7 +258,7 @@ inline void check(int rc, const char* what) {
 class BatchILQR {
  public:
   BatchILQR(std::shared_ptr<Model> model, int B, int T, double dt, int device = 0, int flags = 0)
-      : model_(model), B_(B), T_(T), n_(model->x_dims), m_(model->u_dims), dt_(dt), h_(nullptr) {
+      : model_(model), B_(B), T_(T), n_(model->x_dims), m_(model->u_dims), dt_(dt), h_(nullptr), flags_(flags) {
     // A Model without a device twin exists only as host virtuals, which no kernel can call: its
     // rollouts and finite differences are evaluated HERE by calling those virtuals (that is the
     // plugin, not a substitute for a kernel), and everything that does not need the model --
@@ -412,8 +412,10 @@ class BatchILQR {
           u(a) += acc;
         }
       }
+      if (flags_ & ILQR_FLAG_REFERENCE_FIXES)  // opt-in: "the right way" of :327-329 -- the clamped control is stored and integrated
+        for (int a = 0; a < m_; a++) u(a) = std::min(std::max(u(a), model_->u_min(a)), model_->u_max(a));
       for (int i = 0; i < n_; i++) xs_out[(size_t)t * n_ + i] = x(i);
-      for (int a = 0; a < m_; a++) us_out[(size_t)t * m_ + a] = u(a);  // :323 (no clamping)
+      for (int a = 0; a < m_; a++) us_out[(size_t)t * m_ + a] = u(a);  // :323 (no clamping unless the flag asks for it)
       total += model_->cost(x, u);
       x = model_->integrate_dynamics(x, u, dt_);
     }
@@ -609,6 +611,7 @@ class BatchILQR {
   int B_, T_, n_, m_;
   double dt_;
   ilqr_batch* h_;
+  int flags_ = 0;
   bool host_ = false;
   int host_threads_ = 1;
   std::vector<double> hx0_, hxs_, hus_, d_fx_, d_fu_, d_cx_, d_cu_, d_cxx_, d_cxu_, d_cuu_;

@@ -78,6 +78,9 @@ static const int qp_maxIter = 100;
 #define lq_dynamics_fd lq_dynamics
 #define lq_cost_fd lq_cost
 #define lq_final_cost_fd lq_final_cost
+#define chain_dynamics_fd chain_dynamics
+#define chain_cost_fd chain_cost
+#define chain_final_cost_fd chain_final_cost
 #endif
 
 void orc_model_init_acrobot(orc_model* m) {
@@ -134,6 +137,25 @@ void orc_model_init_lq(orc_model* m, int nx, int nu, const orc_real* A, const or
   m->dynamics_fd = lq_dynamics_fd;
   m->cost_fd = lq_cost_fd;
   m->final_cost_fd = lq_final_cost_fd;
+}
+
+/* the pendulum chain (orc_models.inc): N links, params[8] = g/l, damping, coupling, w_theta, w_omega, w_u, final scale, target angle */
+void orc_model_init_chain(orc_model* m, int N, const orc_f64* params, orc_f64 umin, orc_f64 umax) {
+  memset(m, 0, sizeof(*m));
+  m->id = ORC_MODEL_CHAIN;
+  m->nx = 2 * N;
+  m->nu = N / 2;
+  for (int i = 0; i < 8; i++) m->goal[i] = (orc_real)params[i];
+  for (int i = 0; i < m->nu; i++) {
+    m->u_min[i] = umin;
+    m->u_max[i] = umax;
+  }
+  m->dynamics = chain_dynamics;
+  m->cost = chain_cost;
+  m->final_cost = chain_final_cost;
+  m->dynamics_fd = chain_dynamics_fd;
+  m->cost_fd = chain_cost_fd;
+  m->final_cost_fd = chain_final_cost_fd;
 }
 
 /* include/model.h:12-15: x1 = x + dynamics(x,u)*dt */

@@ -71,7 +71,7 @@ void orc_set_params(orc_f64 tol_fun, orc_f64 tol_grad, orc_f64 lambda_factor, or
 /* opt-in fixes (process-wide; 0 = the reference as it is): bit 0 clamped rollout, bit 1 Cholesky failure ends the box-QP */
 void orc_set_fixes(int bits);
 
-enum { ORC_MODEL_ACROBOT = 0, ORC_MODEL_DOUBLE_INTEGRATOR = 1, ORC_MODEL_LQ = 2 };
+enum { ORC_MODEL_ACROBOT = 0, ORC_MODEL_DOUBLE_INTEGRATOR = 1, ORC_MODEL_LQ = 2, ORC_MODEL_CHAIN = 3 };
 
 /* status of a solve (where the outer loop of src/ilqr_core.cpp:103-288 left) */
 enum {
@@ -105,6 +105,8 @@ void orc_model_init_double_integrator(orc_model* m, const orc_real* goal); /* in
 void orc_model_init_lq(orc_model* m, int nx, int nu, const orc_real* A, const orc_real* Bm,
                        const orc_real* Q, const orc_real* R, const orc_real* Qf, orc_f64 umin,
                        orc_f64 umax);
+/* a chain of N coupled pendulums (nx = 2 N <= 32, nu = N / 2): the oracle-side twin of examples/user_model_pendulum_chain.hpp */
+void orc_model_init_chain(orc_model* m, int N, const orc_f64* params, orc_f64 umin, orc_f64 umax);
 void orc_integrate_dynamics(const orc_model* m, const orc_real* x, const orc_real* u, orc_f64 dt,
                             orc_real* x1); /* include/model.h:12-15 */
 

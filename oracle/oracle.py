@@ -190,7 +190,7 @@ def _pi(a):
 class Model:
     """A Model plugin instance (include/model.h) on the oracle side, in the flavour current at construction."""
 
-    def __init__(self, kind, goal=None, lq=None, u_lim=None):
+    def __init__(self, kind, goal=None, lq=None, u_lim=None, chain=None):
         self.flavour = _cur
         _Model, _ = _structs()
         self.m = _Model()
@@ -209,8 +209,15 @@ class Model:
             L.orc_model_init_lq(C.byref(self.m), nx, nu, _p(A), _p(Bm), _p(Q), _p(R), _p(Qf),
                                 C.c_double(-lim), C.c_double(lim))
             u_lim = None
+        elif kind == "chain":  # chain = (N, params[8]): the pendulum chain of orc_models.inc / examples/user_model_pendulum_chain.hpp
+            N, prm = int(chain[0]), np.ascontiguousarray(chain[1], dtype=np.float64)
+            assert prm.shape == (8,) and 2 <= N <= 16 and N % 2 == 0
+            lim = 1.0 if u_lim is None else float(u_lim)
+            L.orc_model_init_chain(C.byref(self.m), N, prm.ctypes.data_as(C.POINTER(C.c_double)), C.c_double(-lim), C.c_double(lim))
+            u_lim = None
         else:
             raise ValueError(kind)
+        self.chain_arg = chain
         self.kind, self.goal_arg, self.lq_arg, self.lim_arg = kind, goal, lq, u_lim
         if u_lim is not None:
             self.set_limits(-abs(u_lim), abs(u_lim))
@@ -219,8 +226,8 @@ class Model:
         """The same model in another arithmetic flavour (constructed there from the same arguments)."""
         with flavour(name):
             m = Model(self.kind, goal=self.goal_arg, lq=[np.asarray(a, dtype=np.float64) for a in self.lq_arg] if self.lq_arg is not None else None,
-                      u_lim=self.lim_arg)
-            if self.kind in ("lq", MODEL_LQ):
+                      u_lim=self.lim_arg, chain=self.chain_arg)
+            if self.kind in ("lq", MODEL_LQ, "chain"):
                 m.set_limits(np.asarray(self.u_min, dtype=np.float64), np.asarray(self.u_max, dtype=np.float64))
         return m
 

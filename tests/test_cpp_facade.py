@@ -238,3 +238,5 @@ def test_user_twin_with_its_own_dimensions_against_host_virtuals(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "agree 1" in r.stdout
+    # ... and under ILQR_FLAG_REFERENCE_FIXES: the host-evaluated route's rollouts (the facade's) clamp as the device twins' do
+    assert "fixes agree 1" in r.stdout, r.stdout
