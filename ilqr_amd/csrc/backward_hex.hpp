@@ -37,6 +37,10 @@ constexpr int HT = 4;  // trajectories per sub-tile (= per chain wavefront)
 #ifndef ILQR_HEX_PAIR_PERM
 #define ILQR_HEX_PAIR_PERM 1
 #endif
+#ifndef ILQR_HEX_CAND_T
+#define ILQR_HEX_CAND_T 1   // the kernel's candidates in groups per trajectory (rollout.hpp: CANDT); 0: one element per trajectory, the stage kernels' layout (A/B)
+#endif
+constexpr bool kHexCandT = ILQR_HEX_CAND_T != 0;
 
 // One pair's ring: a slot holds one knot of the sub-tile's 4 trajectories, pair-interleaved like the HBM records:
 // [pair][trajectory lp][2].
@@ -474,10 +478,14 @@ __device__ __forceinline__ void sweep_backward_hex(const BatchViewT<typename M::
 // a candidate is stored as its controls and every CT-th state (common.hpp); every chunk of CT knots is integrated forward
 // once from its checkpoint -- the steps candidate_knot takes, in its order: the same bits -- and written to xs / us.
 // 16 trajectories x (T / CT + 1) chunks over the block's threads: a few microseconds per iteration.
-template <class M>
+// CANDT: the candidates were left by this kernel's own rollouts, in groups per trajectory (rollout.hpp): a task reads its checkpoint as one
+// 32-byte piece and its eight controls as two -- whole memory sectors of what it needs.  (false: the plane
+// layout of every other producer of candidates -- the accepts of an earlier launch or of a stage call that this kernel finds pending.)
+template <class M, bool CANDT = false>
 __device__ __forceinline__ void commit_tile_chunks(const BatchViewT<typename M::real>& v, const M& model, const int* commit_of_lane /* [TW], LDS or global */, int tile) {
   using real = typename M::real;
   constexpr int NX = M::NX, NU = M::NU;
+  static_assert(!CANDT || (NX == 4 && NU == 1 && CT == 8 && CG == 4), "grouped candidates: nx = 4, nu = 1");
   const int T = v.T;
   const real dt = (real)v.dt;
   const int ntask = v.nch * TW;
@@ -488,6 +496,26 @@ __device__ __forceinline__ void commit_tile_chunks(const BatchViewT<typename M::
     if (ci < 0) continue;
     const int ta = ci * v.ntiles + tile;
     real x[NX], uq[CT][NU];  // the checkpoint and the chunk's controls: one memory round trip, then the steps
+    if constexpr (CANDT) {
+      typedef real real4v __attribute__((ext_vector_type(4)));
+      const real4v xv = *reinterpret_cast<const real4v*>(v.cand_x + cand_g_x(ta, c, l, v.nch, NX));
+      x[0] = xv.x;
+      x[1] = xv.y;
+      x[2] = xv.z;
+      x[3] = xv.w;
+      // (a plane row holds whole chunks past T - 1: the last chunk reads up to seven slots beyond it; they feed Euler steps whose
+      //  results are never stored)
+      const real4v u0 = *reinterpret_cast<const real4v*>(v.cand_u + cand_g_u(ta, 2 * c, l, T));
+      const real4v u1 = *reinterpret_cast<const real4v*>(v.cand_u + cand_g_u(ta, 2 * c + 1, l, T));
+      uq[0][0] = u0.x;
+      uq[1][0] = u0.y;
+      uq[2][0] = u0.z;
+      uq[3][0] = u0.w;
+      uq[4][0] = u1.x;
+      uq[5][0] = u1.y;
+      uq[6][0] = u1.z;
+      uq[7][0] = u1.w;
+    } else {
 #pragma unroll
     for (int i = 0; i < NX; i++) x[i] = v.cand_x[tidx(ta, c, i, l, v.nch, NX)];
 #pragma unroll
@@ -495,6 +523,7 @@ __device__ __forceinline__ void commit_tile_chunks(const BatchViewT<typename M::
       const int tq = (c * CT + q < T) ? c * CT + q : T - 1;
 #pragma unroll
       for (int jj = 0; jj < NU; jj++) uq[q][jj] = v.cand_u[tidx(ta, tq, jj, l, T, NU)];
+    }
     }
 #if ILQR_COMMIT_ROLLED
     // ONE copy of the step in the instruction stream (a rolled loop; the chunk's controls move down a register per trip so that
@@ -601,7 +630,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       t_sweep += t1 - t0;
       t0 = t1;
     }
-    rollout_tile<M, true, true, kDeepPrefetch<M>, true, true, true>(v, model, alphas, NALPHA, v.cost_c, 1, sp, commit_idx, tile, lds_cost, /*count_running=*/it == n_iters - 1, rwave,
+    rollout_tile<M, true, true, kDeepPrefetch<M>, true, true, true, 1, kHexCandT>(v, model, alphas, NALPHA, v.cost_c, 1, sp, commit_idx, tile, lds_cost, /*count_running=*/it == n_iters - 1, rwave,
                                                pairs[role & 3].ring);
 #ifdef ILQR_HEX_SECTIONS  // experiment builds (scripts/hex_sections.sh): the "backward" clock runs up to mark ILQR_HEX_SECTIONS, the "rollout" clock from there
 #define ILQR_HEX_MARK(n)                                   \
@@ -620,7 +649,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (threadIdx.x == 0) tile_running = 0;
     phase_barrier();  // candidates, costs, status are in memory
     ILQR_HEX_MARK(2)
-    commit_tile_chunks<M>(v, model, lds_commit, tile);
+    commit_tile_chunks<M, kHexCandT>(v, model, lds_commit, tile);
     ILQR_HEX_MARK(3)
     phase_barrier();  // the nominal trajectory is the accepted one
     if (timing) t_roll += wall_clock64() - t0;

@@ -290,7 +290,8 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
   v.D = nullptr;  // on first use (ensure_records)
   v.nch = h->T / CT + 1;
   // (one plane more than there are alphas: where the rollout lanes without a rollout of their own put their stores, rollout.hpp)
-  rc |= dev_alloc_real(h, &v.cand_u, (size_t)(NALPHA + 1) * nt * T * nu * TW);
+  // (the matrix-core kernel keeps its candidates in groups of CG controls, a plane row padded to whole chunks past T - 1: rollout.hpp, cand_g_u)
+  rc |= dev_alloc_real(h, &v.cand_u, (size_t)(NALPHA + 1) * nt * (size_t)(cand_groups(T) * CG) * nu * TW);
   rc |= dev_alloc_real(h, &v.cand_x, (size_t)(NALPHA + 1) * nt * v.nch * nx * TW);
   rc |= dev_alloc(h, &v.cost_c, (size_t)NALPHA * Bp);
   }
@@ -845,7 +846,14 @@ int ilqr_get_candidate(ilqr_batch* h, int a, double* xs, double* us) {
   double* dus = h->staging + nx_el;
   const dim3 grid(grid_for((size_t)h->B * (h->T + 1), 256)), block(256);
   if (int rc = with_model(h, [&](auto& v, auto& m, auto&) {
-        hipLaunchKernelGGL((k_unpack_cand<std::decay_t<decltype(m)>>), grid, block, 0, h->stream, v, m, a, dxs, dus);
+        using MM = std::decay_t<decltype(m)>;
+        if constexpr (MM::NX == 4 && MM::NU == 1) {
+          if (h->cands_grouped) {
+            hipLaunchKernelGGL((k_unpack_cand<MM, true>), grid, block, 0, h->stream, v, m, a, dxs, dus);
+            return 0;
+          }
+        }
+        hipLaunchKernelGGL((k_unpack_cand<MM>), grid, block, 0, h->stream, v, m, a, dxs, dus);
         return 0;
       }))
     return rc;

@@ -7,6 +7,7 @@
 // consecutive lanes to consecutive trajectories of a tile, so each vector memory instruction
 // touches whole 128-byte lines, and one tile's whole time series is one contiguous stream.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -74,6 +75,14 @@ inline void rec_offsets(int nx, int nu, int off[7], int len[7]) {
   for (int i = 0; i < 7; i++) {
     off[i] = o[i];
     len[i] = n[i];
+  }
+}
+// f(std::integral_constant<int, 0>()), ..., f(std::integral_constant<int, N - 1>()): an unrolled loop whose index is a compile-time value
+template <int N, int I = 0, class F>
+__host__ __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    static_for<N, I + 1>(f);
   }
 }
 // Derivative records are stored pair-interleaved: [tile][knot][REC/2][TW][2] -- element e of lane

@@ -84,6 +84,7 @@ struct ilqr_batch {
   // cand_u / cand_x / cost_c hold, slot for slot, the last rollouts of the trajectories now in those slots.  Compaction
   // (ilqr_generate_trajectory) moves trajectories without moving their candidates: after it they belong to nobody.
   bool cands_valid = false;
+  bool cands_grouped = false;  // ... and lie in k_solve_hex's grouped layout (rollout.hpp: CANDT) instead of one element per trajectory
   bool aos = false;             // host-model / generic handles: trajectory-contiguous layout, wave-per-trajectory backward
   double* d_umin = nullptr;     // [nu] device copies of the limits (generic kernel)
   double* d_umax = nullptr;

@@ -96,6 +96,7 @@ static int launch_rollout(ilqr_batch* h, bool gains, bool cand, const AlphaSet& 
   }
   rc = with_model(h, [&](auto& v, auto& m, auto&) { return launch_rollout_t(h, v, m, gains, cand, al, n_alpha, cost_out, mode, with_accept); });
   if (rc) return rc;
+  if (cand) h->cands_grouped = false;  // (the stage kernels write the alpha planes)
   return timer_end(h, ILQR_STAGE_ROLLOUT, ev);
 }
 
@@ -354,6 +355,7 @@ static int launch_solve_tiles(ilqr_batch* h, int n_iters) {
     return rc;
   HIPCHK(hipGetLastError());
   h->commit_pending = (occ != 4);   // the last iteration's accepts (flushed by the caller); k_solve_hex commits every iteration's itself
+  h->cands_grouped = (occ == 4) && kHexCandT;  // (what ilqr_get_candidate finds in the buffers)
   h->recs = ilqr_batch::REC_STALE;
   return timer_end(h, ILQR_STAGE_SOLVE, ev);
 }

@@ -108,7 +108,21 @@ constexpr int kDeepPrefetch = (M::NU * M::NX + M::NX + 2 * M::NU <= 10) ? 8 : 4;
 // no LDS to spare a priori, keeps the per-lane loads.
 // NOFIX: the caller's route is never taken with the opt-in fixes (sp.fixes == 0: the persistent matrix-core and wide kernels) --
 // the clamp of ilqr_core.cpp:327-329's "right way" and its selects leave the step (4 of its ~170 instructions).
-template <class M, bool GAINS, bool CAND, int PD, bool ACCEPT, bool SHARE = false, bool NOFIX = false, int NG = 1>
+// CANDT (k_solve_hex, nu = 1): the candidates in GROUPS of CG consecutive controls (and whole checkpoint states) per trajectory,
+//     cand_u [alpha plane][tile][t / CG][TW][CG]        cand_x [alpha plane][tile][chunk][TW][nx]
+// instead of one control (one state component) per trajectory.  In the plane layout the commit of the accepted candidates gathers 8
+// bytes per trajectory and step from up to eleven planes (the sixteen trajectories of a tile accept different alphas): a whole memory
+// sector fetched for every 8 bytes, 437 MB read per iteration at B = 4096 against 204 algorithmic.  Grouped, a task of the commit reads
+// its checkpoint as ONE 32-byte piece and its eight controls as two -- whole sectors of what it needs -- and a rollout lane stores four
+// controls every fourth step (16 lanes x 32 bytes: whole lines, a quarter of the store instructions).  (A time-innermost row per
+// trajectory reads as well but WRITES 16-byte pieces of 64 different lines per instruction: + 90 MB of write traffic per iteration and
+// + 1 % time, profiles/r06b_candidate_layouts.txt.)
+constexpr int CG = 4;
+static_assert(CT % CG == 0, "a chunk of the commit is a whole number of control groups");
+__host__ __device__ inline int cand_groups(int T) { return (T + CT + CG - 1) / CG; }   // groups per plane row: whole chunks past T - 1
+__host__ __device__ inline size_t cand_g_u(int ta, int grp, int l, int T) { return (((size_t)ta * cand_groups(T) + grp) * TW + l) * CG; }
+__host__ __device__ inline size_t cand_g_x(int ta, int c, int l, int nch, int NX) { return (((size_t)ta * nch + c) * TW + l) * NX; }
+template <class M, bool GAINS, bool CAND, int PD, bool ACCEPT, bool SHARE = false, bool NOFIX = false, int NG = 1, bool CANDT = false>
 __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>& v, const M& model, const AlphaSet& alphas, int n_alpha,
                                              double* __restrict__ cost_out, int mode, const SolverParams& sp,
                                              int* __restrict__ commit_idx, int tile, double* lds_cost, bool count_running = true, int rwave = -1,
@@ -116,6 +130,7 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
   using real = typename M::real;
   constexpr int NX = M::NX, NU = M::NU;
   static_assert(NG == 1 || (SHARE && GAINS && !ACCEPT), "several alpha groups per wavefront: the shared-row rollout of the wide tiles");
+  static_assert(!CANDT || (CAND && SHARE && GAINS && NU == 1 && NX == 4 && PD % CG == 0), "grouped candidates: the matrix-core kernel's rollouts (nx = 4, nu = 1)");
   const int wave = (rwave >= 0) ? rwave : (int)(threadIdx.x >> 6);  // which four alphas this wavefront rolls out (>= 3: none)
   const int lane = threadIdx.x & 63;
   const int l = lane & (TW - 1);
@@ -186,9 +201,40 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
 #pragma unroll
   for (int g = 0; g < NG; g++) ta_store[g] = ((SHARE && CAND && !active[g]) ? NALPHA : a[g]) * v.ntiles + tile;
   // knot t = (x_t, u_t); with_u: a step's call (t < T by construction: no test in the step), false for the final state
-  auto emit_knot = [&](int g, int t, const real* xx, const real* uu, auto with_u) __attribute__((always_inline)) {
+  // ph: t mod CG, a compile-time value in the unrolled loops (CANDT gathers the controls of CG steps into one store)
+  typedef real real4v __attribute__((ext_vector_type(4)));
+  real pend[NG][CG - 1];  // CANDT: the controls of the group's first steps, waiting for its last one
+#pragma unroll
+  for (int g = 0; g < NG; g++)
+#pragma unroll
+    for (int q = 0; q < CG - 1; q++) pend[g][q] = 0;
+  auto store_group = [&](int g, int t, real last) __attribute__((always_inline)) {  // the group of step t, its last slot = `last`
+    real4v w;
+    w.x = pend[g][0];
+    w.y = pend[g][1];
+    w.z = pend[g][2];
+    w.w = last;
+    *reinterpret_cast<real4v*>(v.cand_u + cand_g_u(ta_store[g], t / CG, l, T)) = w;
+  };
+  auto emit_knot = [&](int g, int t, const real* xx, const real* uu, auto with_u, auto ph) __attribute__((always_inline)) {
     if (SHARE && !CAND && !active[g]) return;
-    if (CAND) {
+    if constexpr (CANDT) {
+      constexpr int p = decltype(ph)::value;
+      if (with_u) {
+        if constexpr (p == CG - 1)
+          store_group(g, t, uu[0]);
+        else
+          pend[g][p] = uu[0];
+      }
+      if ((t & (CT - 1)) == 0) {
+        real4v w;
+        w.x = xx[0];
+        w.y = xx[1];
+        w.z = xx[2];
+        w.w = xx[3];
+        *reinterpret_cast<real4v*>(v.cand_x + cand_g_x(ta_store[g], t / CT, l, v.nch, NX)) = w;
+      }
+    } else if (CAND) {
       const int ta = ta_store[g];
       if (with_u) {
 #pragma unroll
@@ -208,7 +254,7 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
     }
   };
   const WithTrigConsts<M> rmodel(model);  // (models.hpp: the trig constants of the dynamics in registers once, not once per step)
-  auto do_step = [&](int t, const StepIn& d) __attribute__((always_inline)) {
+  auto do_step = [&](int t, const StepIn& d, auto ph) __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < NG; g++) {
       real u[NU];
@@ -228,7 +274,7 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
 #pragma unroll
         for (int j = 0; j < NU; j++) u[j] = min_of(max_of(u[j], model.u_min[j]), model.u_max[j]);
       }
-      emit_knot(g, t, x[g], u, std::true_type());
+      emit_knot(g, t, x[g], u, std::true_type(), ph);
       total[g] += (double)model.cost(x[g], u);  // :324
       real x1[NX];
       integrate_dynamics(rmodel, x[g], u, dt, x1);  // :325
@@ -304,21 +350,25 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
     // step s: pass step s + 1 through LDS (its rows are in ring[(s + 1) % PD]), refill ring[s % PD] -- free since step
     // s - 1 -- with step s + PD, compute step s from `cur`.  LDS executes a wavefront's operations in order: the reads
     // of step s + 1 follow its writes, and the next writes follow those reads.
-    auto one = [&](int s_, Raw& free_set, const Raw& next_set) __attribute__((always_inline)) {
+    auto one = [&](int s_, Raw& free_set, const Raw& next_set, auto ph) __attribute__((always_inline)) {
       put(next_set);
       get(nxt);
       fetch(s_ + PD, free_set);
-      do_step(s_, cur);
+      do_step(s_, cur, ph);
       cur = nxt;
     };
+    // (t stays a multiple of PD, and CANDT has PD a multiple of CG: (t + d) mod CG is d mod CG -- a compile-time value)
     int t = 0;
     for (; t + PD <= T; t += PD) {
-#pragma unroll
-      for (int d = 0; d < PD; d++) one(t + d, ring[d], ring[(d + 1) % PD]);
+      static_for<PD>([&](auto dc) __attribute__((always_inline)) {
+        constexpr int d = decltype(dc)::value;
+        one(t + d, ring[d], ring[(d + 1) % PD], std::integral_constant<int, d % CG>());
+      });
     }
-#pragma unroll
-    for (int d = 0; d < PD; d++)  // remainder (< PD steps; t is a multiple of PD)
-      if (t + d < T) one(t + d, ring[d], ring[(d + 1) % PD]);
+    static_for<PD>([&](auto dc) __attribute__((always_inline)) {  // remainder (< PD steps; t is a multiple of PD)
+      constexpr int d = decltype(dc)::value;
+      if (t + d < T) one(t + d, ring[d], ring[(d + 1) % PD], std::integral_constant<int, d % CG>());
+    });
   } else {
   StepIn ring[PD];
 #pragma unroll
@@ -327,14 +377,14 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
   for (; t + PD <= T; t += PD) {
 #pragma unroll
     for (int d = 0; d < PD; d++) {
-      do_step(t + d, ring[d]);          // (the set is consumed in place and refilled right after: copying it out first so
-      load_step(t + d + PD, ring[d]);   //  that the refill could be issued a step earlier cost ten register moves per step)
+      do_step(t + d, ring[d], std::integral_constant<int, 0>());   // (the set is consumed in place and refilled right after: copying it out first so
+      load_step(t + d + PD, ring[d]);               //  that the refill could be issued a step earlier cost ten register moves per step)
     }
   }
   for (; t < T; t++) {  // remainder (< PD steps)
     StepIn cur;
     load_step(t, cur);
-    do_step(t, cur);
+    do_step(t, cur, std::integral_constant<int, 0>());
   }
   }
 #pragma unroll
@@ -343,7 +393,10 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
       real uz[NU];
 #pragma unroll
       for (int q = 0; q < NU; q++) uz[q] = 0;
-      emit_knot(g, T, x[g], uz, std::false_type());
+      emit_knot(g, T, x[g], uz, std::false_type(), std::integral_constant<int, 0>());
+      if constexpr (CANDT) {
+        if (T % CG) store_group(g, T - 1, pend[g][CG - 2]);  // a last, partial group (its slots past T - 1 are never used for anything that is stored)
+      }
     }
     total[g] += (double)model.final_cost(x[g]);  // :335
     if (active[g]) {
@@ -370,20 +423,21 @@ __global__ __launch_bounds__(192) void k_rollout(BatchViewT<typename M::real> v,
 // Knot t of candidate `a` of trajectory (tile, l): the control as stored, the state re-integrated
 // from the checkpoint at knot (t/CT)*CT with the rollout's own step (include/model.h:12-15).  The
 // CT-1 controls of the chunk are fetched up front (one memory round trip), the steps run predicated.
-template <class M>
+// CANDT: the candidates lie in the grouped layout k_solve_hex's rollouts leave (cand_g_u / cand_g_x above; nu = 1)
+template <class M, bool CANDT = false>
 __device__ __forceinline__ void candidate_knot(const BatchViewT<typename M::real>& v, const M& model, int a, int tile, int t, int l,
                                                typename M::real* x, typename M::real* u) {
   using real = typename M::real;
   constexpr int NX = M::NX, NU = M::NU;
   const int T = v.T, ta = a * v.ntiles + tile, c = t / CT, off = t - c * CT;
 #pragma unroll
-  for (int i = 0; i < NX; i++) x[i] = v.cand_x[tidx(ta, c, i, l, v.nch, NX)];
+  for (int i = 0; i < NX; i++) x[i] = CANDT ? v.cand_x[cand_g_x(ta, c, l, v.nch, NX) + i] : v.cand_x[tidx(ta, c, i, l, v.nch, NX)];
   real uq[CT][NU];
 #pragma unroll
   for (int q = 0; q < CT; q++) {
     const int tq = (c * CT + q < T) ? c * CT + q : T - 1;
 #pragma unroll
-    for (int j = 0; j < NU; j++) uq[q][j] = v.cand_u[tidx(ta, tq, j, l, T, NU)];
+    for (int j = 0; j < NU; j++) uq[q][j] = CANDT ? v.cand_u[cand_g_u(ta, tq / CG, l, T) + tq % CG] : v.cand_u[tidx(ta, tq, j, l, T, NU)];
   }
 #pragma unroll
   for (int j = 0; j < NU; j++) u[j] = 0.0;  // knot T has no control
@@ -403,7 +457,7 @@ __device__ __forceinline__ void candidate_knot(const BatchViewT<typename M::real
 }
 
 // candidate `a` -> canonical xs [B][T+1][nx], us [B][T][nu]   (getter only)
-template <class M>
+template <class M, bool CANDT = false>
 __global__ void k_unpack_cand(BatchViewT<typename M::real> v, M model, int a, double* __restrict__ xs, double* __restrict__ us) {
   using real = typename M::real;
   constexpr int NX = M::NX, NU = M::NU;
@@ -413,7 +467,7 @@ __global__ void k_unpack_cand(BatchViewT<typename M::real> v, M model, int a, do
     const int t = (int)(i % (T + 1));
     const int b = (int)(i / (T + 1));
     real x[NX], u[NU];
-    candidate_knot(v, model, a, b / TW, t, b % TW, x, u);
+    candidate_knot<M, CANDT>(v, model, a, b / TW, t, b % TW, x, u);
     if (xs)
       for (int e = 0; e < NX; e++) xs[((size_t)b * (T + 1) + t) * NX + e] = (double)x[e];
     if (us && t < T)
