@@ -88,7 +88,8 @@ def _cpu_baseline_acrobot(O, B_total, T, dt, lim, target_wall_s, flavour, backwa
     nb2 = max(cores, (nb2 // cores) * cores) if nb2 >= cores else nb2
     if nb2 == B_total:                  # the whole batch is still too quick: run more iterations
         iters = int(min(40, max(iters, target_wall_s * rate / (T * nb2))))
-    run(nb2, 1)                         # first touch of this sample's pages, untimed
+    t1 = run(nb2, 1)                    # first touch of this sample's pages; also the better calibration (threads and pages warm, this sample)
+    iters = int(min(40, max(iters, round(target_wall_s / max(t1, 1e-9)))))
     ts = sorted(run(nb2, iters) for _ in range(max(1, reps)))
     t2 = ts[len(ts) // 2]
     lib_name = {"f64": "liboracle_ilqr.so", "f32": "liboracle_ilqr_f32.so"}.get(flavour, flavour)
