@@ -657,6 +657,14 @@ def main():
                             "(k_derivatives, k_backward_t, k_rollout): the default route of a small twin",
                 "value": Bu * Tu * itu / elu, "unit": "trajectory-timesteps/s", "ms_per_step": elu / itu * 1e3, "stages": stu,
                 "note": "B = 4096 trajectories are 64 wavefronts of k_backward_t on 1024 SIMDs: the backward pass is a latency-bound chain of T steps; the route scales with B up to ~64 K trajectories"}
+            # the contract's roofline for the dominant kernel of this line (k_backward_t: records in, gains out; SURVEY 8d's byte count at n = 6, m = 2)
+            bt6 = algorithmic_bytes_per_timestep(nu6, mu6, 8)["backward"]
+            bw6 = stu["backward"]["ms_per_launch"] * 1e-3
+            extra["user_linear6_n6_m2_T200_B4096_fd"]["roofline"] = {
+                "bound": "hbm", "kernel": stu["backward"]["kernel"], "achieved": bt6 * Bu * Tu / bw6 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": bt6 * Bu * Tu / bw6 / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_timestep": bt6, "algorithmic_bytes_per_launch": bt6 * Bu * Tu, "avg_launch_ms": bw6 * 1e3,
+                "traffic": None, "limiter": "latency", "limiter_note": "64 wavefronts, each a dependent chain of T = 200 steps with the 6 x 6 algebra and the 2 x 2 box-QP in one thread: "
+                "6 % of the chip's SIMDs have a wavefront at all; the figure rises with B, not with the kernel"}
             # the same workload on the generic kernels every larger twin runs in (ILQR_ROUTE_WAVE_PER_TRAJECTORY)
             elw, stw = run6(capi.ROUTE_WAVE_PER_TRAJECTORY)
             bwu = stw["backward"]["ms_per_launch"] * 1e-3

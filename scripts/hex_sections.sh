@@ -8,12 +8,13 @@
 mkdir -p gpurun_out
 for L in ilqr_amd/lib/libilqr_amd.so "$@"; do
   for rep in 1 2; do
-    ILQR_AMD_LIB=$PWD/$L timeout 200 python bench.py --no-cpu-baseline --no-extra-configs > /tmp/ab.json 2>/tmp/ab.err
+    ILQR_AMD_LIB=$PWD/$L timeout 200 python bench.py --no-cpu-baseline --extras-out /tmp/ab_extras.json > /tmp/ab.json 2>/tmp/ab.err
     python - "$L" <<PY
 import json,sys
 try:
     d=json.loads(open("/tmp/ab.json").read().strip().splitlines()[-1])
-    print(sys.argv[1], "%.4g ts/s"%d["value"], "%.4f ms"%d["ms_per_step"], {k:round(v["ms_per_launch"],4) for k,v in d["stages"].items()})
+    x=json.load(open("/tmp/ab_extras.json"))
+    print(sys.argv[1], "%.4g ts/s"%d["value"], "%.4f ms"%d["ms_per_step"], {k:round(v["ms_per_launch"],4) for k,v in x["stages"].items()})
 except Exception as e:
     print(sys.argv[1], "ERR", e, open("/tmp/ab.err").read()[-600:])
 PY
