@@ -285,6 +285,9 @@ def main():
     ap.add_argument("--extras-out", default=os.path.join(ROOT, "gpurun_out", "bench_extras.json"),
                     help="where the full record (stages, issue roofline, sources, --extra-configs results) is written; '' = nowhere")
     ap.add_argument("--flags", type=int, default=0, help="extra ilqr_flags (kernel variant selection)")
+    ap.add_argument("--test-backend", default="", help="TESTS ONLY (tests/test_bench_record.py): run the N-rank path on a box with fewer GPUs than ranks -- "
+                    "this torch.distributed backend (gloo) instead of nccl = RCCL, every rank on the device LOCAL_RANK modulo the visible ones, the one "
+                    "collective on host tensors.  A line produced this way says so (collective_backend) and is no measurement")
     ap.add_argument("--route", type=int, default=0, help="enum ilqr_route for the headline handle (A/B runs of equivalent kernels)")
     args = ap.parse_args()
     args.no_extra_configs = not args.extra_configs
@@ -321,18 +324,24 @@ def main():
         if args.global_batch % world:
             raise SystemExit("bench.py --global-batch %d is not a multiple of %d ranks" % (args.global_batch, world))
         args.batch = args.global_batch // world
-    if local_rank >= torch.cuda.device_count():
+    if local_rank >= torch.cuda.device_count() and not args.test_backend:
         raise SystemExit("rank %d: no HIP device %d (%d visible)" % (rank, local_rank, torch.cuda.device_count()))
+    if args.test_backend:  # (several ranks share a device: the N-rank code path on a one-GPU test box)
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    coll_device = "cpu" if args.test_backend else "cuda"  # where the tensors of the one collective live (RCCL: on the device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.test_backend:
+            dist.init_process_group(args.test_backend)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     T, dt, n, m = args.T, 0.02, 4, 1
     stream = torch.cuda.current_stream().cuda_stream
     cost_dev = torch.zeros(args.batch, dtype=torch.float64, device="cuda")
     if world > 1:  # warm-up of the one collective of the path: RCCL sets its rings up on the first call
-        D.gather_costs(cost_dev)
+        D.gather_costs(cost_dev.to(coll_device))
         torch.cuda.synchronize()
 
     def barrier():
@@ -362,9 +371,9 @@ def main():
             cd = cost_dev if B == args.batch else torch.zeros(B, dtype=torch.float64, device="cuda")
             capi.check(g.lib.ilqr_copy_cost_to_device(g.h, cd.data_ptr()))
             g.synchronize()  # the copy runs on the handle's stream, the collective on torch's: order them
-            gathered = D.gather_costs(cd)
+            gathered = D.gather_costs(cd.to(coll_device))
         barrier()
-        elapsed = D.max_over_ranks(time.perf_counter() - t0, device="cuda")
+        elapsed = D.max_over_ranks(time.perf_counter() - t0, device=coll_device)
         prof = g.profile_read()
         g.sclk_mhz = g.shader_clock_mhz() if prof.get("solve", (0, 0))[1] else None
         g.profile(False)

@@ -752,7 +752,14 @@ __global__ __launch_bounds__(256) void k_commit_lq(BatchView v, int nx, int nu, 
 // from cost(x_T, 0), the cxu[T] formula the reference itself marks wrong).
 template <class M>
 // t_only >= 0: one block per trajectory, knot t_only alone (the last knot behind k_derivatives_lq, which sweeps the knots t < T).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_derivatives_g(BatchView v, M model, int force, int t_only) {
+#ifndef ILQR_FD_G_WAVES_SMALL
+// Wavefronts per SIMD of k_derivatives_g: two at NX > 16 (186 registers for the LQ model's 32-vectors); THREE for a model of NX <= 16 (168
+// registers, 40 bytes of scratch): every lane of this kernel is a latency-bound chain through the user's cost function, and the third
+// wavefront hides more of it than the few spilled values cost -- the pendulum chain's sweep 17.2 -> 14.0 ms (four: 128 registers, 216
+// bytes of scratch, 18.7 ms).  Same instructions per lane: the same bits.
+#define ILQR_FD_G_WAVES_SMALL 3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((M::NX <= 16 ? ILQR_FD_G_WAVES_SMALL : 2), (M::NX <= 16 ? ILQR_FD_G_WAVES_SMALL : 2)))) void k_derivatives_g(BatchView v, M model, int force, int t_only) {
   constexpr int NX = M::NX, NU = M::NU;
   const int nx = model.nx, nu = model.nu, T = v.T;
   const int lane = threadIdx.x;

@@ -69,7 +69,8 @@ def main():
                                # CU; m = 2 falls back to two tiles per CU), and compaction of running trajectories between chunks
                                ("quad1", 0, dict(route=capi.ROUTE_QUAD_CHAIN)), ("occ2", 0, dict(route=capi.ROUTE_TWO_TILES_PER_CU)),
                                ("wide1", 0, dict(route=capi.ROUTE_WIDE_TILES | capi.ROUTE_WIDE_ONE_PER_CU)),
-                               ("wide2", 0, dict(route=capi.ROUTE_WIDE_TILES | capi.ROUTE_WIDE_TWO_PER_CU)),
+                               # (ABI 5: the m = 2 wide tiles run one per CU only -- ilqr_create rejects WIDE_TWO_PER_CU there)
+                               ("wide2", 0, dict(route=capi.ROUTE_WIDE_TILES | (capi.ROUTE_WIDE_TWO_PER_CU if nu == 1 else capi.ROUTE_WIDE_ONE_PER_CU))),
                                ("compact", 0, dict(assume_cus=2))):
             g = BatchILQR(name, B, T, DT, flags=fl, params=dict(max_iter=iters), **dict(kw, **env))
             g.init_traj(x0, u0)

@@ -97,3 +97,37 @@ def test_default_bench_invocation_prints_one_parsable_line(tmp_path):
     assert abs(rec["value"] - 4096 * 499 / (rec["ms_per_step"] * 1e-3)) / rec["value"] < 1e-4
     full = json.load(open(extras))
     assert "stages" in full and "roofline_issue" in full and full["configs"] == {}
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_invocation_as_the_driver_launches_it(tmp_path):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2 ...` -- the driver's command for N > 1 -- on the
+    one GPU of the test box: --test-backend gloo puts both ranks on device 0 and carries the one collective over gloo, everything else
+    is the code an 8-GPU node runs (env parsing, the shard of the global batch, barriers, max-over-ranks timing, rank 0 alone printing).
+    One compact line, n_gpus = 2, value = the whole job's timesteps over the slowest rank's time, no cpu_baseline (N = 1 only)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    extras = tmp_path / "extras.json"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "512", "--test-backend", "gloo", "--extras-out", str(extras)],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["scaling"] == "weak" and "cpu_baseline" not in rec
+    assert rec["config"]["batch_per_gpu"] == 512 and rec["config"]["global_batch"] == 1024
+    assert abs(rec["value"] - 2 * 512 * 499 / (rec["ms_per_step"] * 1e-3)) / rec["value"] < 1e-4
+    assert json.load(open(extras))["collective_backend"] == "gloo"
+
+
+def test_multi_gpu_request_on_a_box_without_them_fails_loudly():
+    """bench.py --gpus 8 started plainly on a box with fewer devices says so instead of measuring one GPU (no GPU at all: the no-fallback message)."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        return  # (an 8-GPU node would simply run the job)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and p.stdout.strip() == ""
+    assert ("HIP device(s) visible" in p.stderr) or ("needs a GPU" in p.stderr)
