@@ -332,8 +332,18 @@ __device__ __forceinline__ int w3_box_qp_small(int m, LDS& L, int lane, int& nfR
 // REGV (ILQR_FLAG_REGULARIZE_VXX, opt-in): lambda regularises Vxx' ([Tassa 2012] eq. 10) instead of Quu -- QuuF = Quu + lambda fu'fu and the
 // gains' Qux_reg = Qux + lambda fu'fx, two more transposed products per 16-column block on the operands the step holds anyway; the value
 // update keeps Quu, Qux (as backward_thread.hpp does for the tiled kernels).  Instantiated without FULL / LQF.
+// Wavefronts per SIMD.  n <= 16 (NT = 1): TWO since round 6 -- at three (168 registers) the kernel kept 308 bytes of scratch per lane and its
+// step went through memory: the pendulum chain's pass (n = 16, m = 4, B = 4096) 7.4 -> 4.8 ms with 254 registers and no scratch (four: the
+// compiler gives up on the bound).  n > 16 (NT = 2): two, 256 registers and 170-260 bytes of scratch; one wavefront per SIMD with the
+// accumulation registers as spill space was measured too (ILQR_W3_NT2_WAVES=1: profiles/README.md, round 6).
+#ifndef ILQR_W3_NT1_WAVES
+#define ILQR_W3_NT1_WAVES 2
+#endif
+#ifndef ILQR_W3_NT2_WAVES
+#define ILQR_W3_NT2_WAVES 2
+#endif
 template <int NT, bool FULL, bool LQF, bool REGV = false>
-__global__ __launch_bounds__(64, NT == 2 ? 2 : 3) void k_backward_w3(BatchView v, int n, int m, const double* __restrict__ u_min,
+__global__ __launch_bounds__(64, NT == 2 ? ILQR_W3_NT2_WAVES : ILQR_W3_NT1_WAVES) void k_backward_w3(BatchView v, int n, int m, const double* __restrict__ u_min,
                                                                     const double* __restrict__ u_max, SolverParams sp, int mode,
                                                                     const double* __restrict__ const_rec) {
   __shared__ Wave2Lds<NT> L;

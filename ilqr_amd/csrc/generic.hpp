@@ -514,8 +514,12 @@ __global__ __launch_bounds__(64) void k_analytic_lq(BatchView v, LqModel model, 
 // ACCEPT (RG_SEARCH with candidate buffers only): the wavefront also performs STEP 3/4 for its trajectory (accept_one: selection,
 // lambda schedule, termination -- k_accept's work); the copy of the accepted candidate stays k_commit_lq's.  An iteration of the LQ
 // path with exact derivatives is then three launches (backward pass, search + accept, commit) instead of five.  commit_idx is written, not read.
+#ifndef ILQR_ROLLOUT_LQ_WAVES
+#define ILQR_ROLLOUT_LQ_WAVES 1   // one wavefront per SIMD (312 registers incl. accumulators).  Two (256 registers, 160 bytes of scratch) was measured
+                                  // SLOWER at configs[4]: 4.5 -> 5.5 ms per search (round 6)
+#endif
 template <int MODE, bool ACCEPT = false>
-__global__ __launch_bounds__(64) void k_rollout_lq(BatchView v, LqModel model, AlphaSet alphas, double* __restrict__ cost_out,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ILQR_ROLLOUT_LQ_WAVES, ILQR_ROLLOUT_LQ_WAVES))) void k_rollout_lq(BatchView v, LqModel model, AlphaSet alphas, double* __restrict__ cost_out,
                                                    int* __restrict__ commit_idx, int mode, int write_cost, SolverParams sp) {
   static_assert(GN == 32 && GM == 16, "operand blocks below are written for a 32 x 16 model");
   static_assert(!ACCEPT || MODE == RG_SEARCH, "the accept epilogue belongs to the search");
