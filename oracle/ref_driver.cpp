@@ -13,7 +13,9 @@
 // src/derivatives.cpp:20-21,40-42,90-92,109 makes, re-made here so that the reference's own
 // finite-difference operators are exercised on the reference's own models.
 //
-// Only the oracle tests load this library; it never reaches the GPU box as source.
+// Only the oracle tests (CPU tests: tests/test_oracle_vs_ref.py, scripts/make_golden.py) load this library.  The BUILT file is git-ignored
+// and travels to the GPU box with the snapshot like every other built .so (it is not gpurun-ignored), where nothing loads it; the
+// reference's sources never leave /root/reference.
 #include <functional>
 #include <memory>
 
