@@ -283,10 +283,13 @@ static int create_impl(const ilqr_desc* d, ilqr_batch* h) {
     }
   } else {
   rc |= dev_alloc_real(h, &v.x0, nt * nx * TW);
-  rc |= dev_alloc_real(h, &v.xs, nt * T1 * nx * TW);
-  rc |= dev_alloc_real(h, &v.us, nt * T * nu * TW);
-  rc |= dev_alloc_real(h, &v.kff, nt * T * nu * TW);
-  rc |= dev_alloc_real(h, &v.Kfb, nt * T * nu * nx * TW);
+  // (+ kRolloutFetchSlack rows: the shared-row rollouts prefetch up to that many steps past T - 1 without clamping the row index -- rollout.hpp --
+  //  which for the last tile is past the array's end; what those loads return is never used)
+  const size_t slack = (size_t)kRolloutFetchSlack * nu * nx * TW;
+  rc |= dev_alloc_real(h, &v.xs, nt * T1 * nx * TW + slack);
+  rc |= dev_alloc_real(h, &v.us, nt * T * nu * TW + slack);
+  rc |= dev_alloc_real(h, &v.kff, nt * T * nu * TW + slack);
+  rc |= dev_alloc_real(h, &v.Kfb, nt * T * nu * nx * TW + slack);
   v.D = nullptr;  // on first use (ensure_records)
   v.nch = h->T / CT + 1;
   // (one plane more than there are alphas: where the rollout lanes without a rollout of their own put their stores, rollout.hpp)

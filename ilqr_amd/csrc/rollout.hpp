@@ -92,6 +92,10 @@ struct AlphaSet {
 // Prefetch depth of the rollout when a tile has a CU to itself: 8 steps for the acrobot (10 doubles per step: 160
 // registers of ring), 4 for the double integrator (16 per step: at depth 8 the ring alone is 256 registers, the
 // kernel spills -- and inside k_solve_tile the spilled build produced wrong rollouts from knot 59 on).
+#ifndef ILQR_ROLLOUT_UNCLAMPED_FETCH
+#define ILQR_ROLLOUT_UNCLAMPED_FETCH 1
+#endif
+constexpr int kRolloutFetchSlack = 8;  // >= every prefetch depth PD of the shared-row rollouts
 template <class M>
 constexpr int kDeepPrefetch = (M::NU * M::NX + M::NX + 2 * M::NU <= 10) ? 8 : 4;
 
@@ -284,6 +288,7 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
   };
   if constexpr (SHARE && GAINS) {
     static_assert(PD % 2 == 0 || PD == 1, "static ring indices");
+    static_assert(PD <= kRolloutFetchSlack, "the arrays end in kRolloutFetchSlack spare rows");
     constexpr int NROWS = 2 * NU + NU * NX + NX;  // u, k, K, xs
     constexpr int NLD = (NROWS + 3) / 4;          // rows per alpha group
     struct Raw {
@@ -310,7 +315,12 @@ __device__ __forceinline__ void rollout_tile(const BatchViewT<typename M::real>&
       }
     }
     auto fetch = [&](int tt, Raw& d) __attribute__((always_inline)) {
-      tt = (tt < T) ? tt : T - 1;  // tail: harmless re-load instead of a branch
+      // tail (tt >= T): rows that no step consumes.  Not clamped to T - 1: the arrays end in kRolloutFetchSlack spare rows (ilqr_create), and without
+      // the clamp the row addresses are plain induction variables -- three pointer increments per step instead of min / multiply / shift / add
+      // (seven instructions of a step's ~145)
+#if !ILQR_ROLLOUT_UNCLAMPED_FETCH
+      tt = (tt < T) ? tt : T - 1;
+#endif
 #pragma unroll
       for (int j = 0; j < NLD; j++) d.r[j] = rbase[j][(size_t)tt * rstride[j]];
     };
